@@ -1,0 +1,39 @@
+"""Host-side image normalisation (reference: empanada_napari/utils.py:153-201).
+
+``Preprocessor`` keeps the reference's contract: integer-typed 2-D numpy image
+in, ``{'image': FloatTensor (1,H,W)}`` out, float input rejected with the same
+exception.  The GPU engine can also take the raw integer tile and fuse the
+same arithmetic into its stem kernel (``normalize_params`` gives it the two
+constants), which is the path ``bench.py`` times.
+"""
+import numpy as np
+
+
+def normalize_params(mean, std, max_pixel_value):
+    """-> (sub, mul) fp32 such that out = (img - sub) * mul  (utils.py:153-165)."""
+    m = np.float32(np.array(mean, dtype=np.float32) * max_pixel_value)
+    s = np.float32(np.array(std, dtype=np.float32) * max_pixel_value)
+    return m, np.reciprocal(s, dtype=np.float32)
+
+
+def normalize(img, mean, std, max_pixel_value=255.0):
+    sub, mul = normalize_params(mean, std, max_pixel_value)
+    out = img.astype(np.float32)
+    out -= sub
+    out *= mul
+    return out
+
+
+class Preprocessor:
+    def __init__(self, mean=None, std=None):
+        self.mean = mean
+        self.std = std
+
+    def __call__(self, image=None):
+        import torch
+        assert image is not None
+        if np.issubdtype(image.dtype, np.floating):
+            raise Exception('Input image cannot be float type!')
+        max_value = np.iinfo(image.dtype).max
+        image = normalize(image, self.mean, self.std, max_pixel_value=max_value)
+        return {'image': torch.from_numpy(image[None])}

@@ -1,0 +1,119 @@
+"""Seeded synthetic inputs (no datasets or checkpoints are reachable offline).
+
+* ``em_tiles``     -- EM-like uint8 tiles: band-limited noise + dark ellipses
+                      (SURVEY.md section 8d, config 2).
+* ``blob_image`` / ``blob_volume`` -- Gaussian-blob images in the style of the
+  reference's sanity fixtures (tests/test_button_widgets.py:26-50,119-140).
+* ``head_outputs`` -- plausible network-head tensors (semantic logits, centre
+  heatmap, offsets) with a known number of objects, for post-processing tests.
+"""
+import numpy as np
+
+
+def _smooth(img, passes=2):
+    for _ in range(passes):
+        img = (img + np.roll(img, 1, 0) + np.roll(img, -1, 0) + np.roll(img, 1, 1) + np.roll(img, -1, 1)) / 5.0
+    return img
+
+
+def em_tiles(n, size, seed=1234, n_ellipses=150):
+    """(n, size, size) uint8."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    out = np.empty((n, size, size), dtype=np.uint8)
+    n_ell = max(1, int(n_ellipses * (size / 1024.0) ** 2))
+    for t in range(n):
+        img = _smooth(rng.standard_normal((size, size)).astype(np.float32), 3) * 60.0 + 150.0
+        for _ in range(n_ell):
+            cy, cx = rng.uniform(0, size, 2)
+            a, b = rng.uniform(8, 40, 2)
+            th = rng.uniform(0, np.pi)
+            r = max(a, b) + 2
+            y0, y1 = int(max(0, cy - r)), int(min(size, cy + r + 1))
+            x0, x1 = int(max(0, cx - r)), int(min(size, cx + r + 1))
+            if y0 >= y1 or x0 >= x1:
+                continue
+            dy = yy[y0:y1, x0:x1] - cy
+            dx = xx[y0:y1, x0:x1] - cx
+            u = (dx * np.cos(th) + dy * np.sin(th)) / a
+            v = (-dx * np.sin(th) + dy * np.cos(th)) / b
+            m = (u * u + v * v) < 1.0
+            img[y0:y1, x0:x1][m] -= rng.uniform(50, 90)
+        out[t] = np.clip(img, 0, 255).astype(np.uint8)
+    return out
+
+
+def blob_image(h, w, seed=0, n_blobs=8):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w), dtype=np.float32)
+    s = max(h, w) / 100.0
+    for _ in range(n_blobs):
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        sigma = rng.uniform(4, 10) * s
+        amp = rng.uniform(120, 255)
+        img += amp * np.exp(-((x - cx) ** 2 + (y - cy) ** 2) / (2 * sigma ** 2))
+    img += rng.normal(0, 10, size=img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def blob_volume(d, h, w, seed=0, n_blobs=8):
+    rng = np.random.default_rng(seed)
+    z, y, x = np.mgrid[0:d, 0:h, 0:w]
+    vol = np.zeros((d, h, w), dtype=np.float32)
+    s = max(d, h, w) / 100.0
+    for _ in range(n_blobs):
+        cx, cy, cz = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(0, d)
+        sigma = rng.uniform(4, 10) * s
+        amp = rng.uniform(120, 255)
+        vol += amp * np.exp(-((z - cz) ** 2 + (x - cx) ** 2 + (y - cy) ** 2) / (2 * sigma ** 2))
+    vol += rng.normal(0, 10, size=vol.shape)
+    return np.clip(vol, 0, 255).astype(np.uint8)
+
+
+def head_outputs(H, W, n_inst, seed=0, coarse=True, num_classes=1, plateau=False):
+    """Synthetic head tensors for an (H,W) slice.
+
+    Returns fp32 ``sem_logits (1,C,H,W)``, ``ctr_hmp (1,1,h,w)``,
+    ``offsets (1,2,h,w)`` with h,w = H/4,W/4 when ``coarse`` else H,W.
+    ``n_inst`` discs with a heat-map peak each; ``plateau`` makes a few peaks
+    flat 2x1 plateaus (equal values -> several centres).
+    """
+    rng = np.random.default_rng(seed)
+    s = 4 if coarse else 1
+    h, w = H // s, W // s
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    ctr = np.zeros((h, w), np.float32)
+    off = rng.standard_normal((2, h, w)).astype(np.float32) * 0.5
+    semq = np.full((h, w), -3.0, np.float32)
+    cls = np.zeros((h, w), np.int64)
+    nearest = np.full((h, w), np.inf, np.float32)
+    for i in range(n_inst):
+        cy, cx = rng.uniform(2, h - 2), rng.uniform(2, w - 2)
+        r = rng.uniform(2.5, max(3.0, min(h, w) / 10.0))
+        d2 = (yy - cy) ** 2 + (xx - cx) ** 2
+        ctr = np.maximum(ctr, rng.uniform(0.3, 1.0) * np.exp(-d2 / (2 * (r / 2.5) ** 2)).astype(np.float32))
+        inside = d2 < r * r
+        closer = inside & (d2 < nearest)
+        nearest[closer] = d2[closer]
+        off[0][closer] = ((cy - yy) * s)[closer] + off[0][closer] * 0.2
+        off[1][closer] = ((cx - xx) * s)[closer] + off[1][closer] * 0.2
+        semq[inside] = 3.0
+        cls[inside] = 1 + (i % max(1, num_classes - 1))
+        if plateau and i % 3 == 0:
+            iy, ix = int(round(cy)), int(round(cx))
+            if 0 <= iy < h and 0 <= ix + 1 < w:
+                ctr[iy, ix] = ctr[iy, ix + 1] = 1.5
+    ctr = ctr + rng.uniform(0, 0.02, (h, w)).astype(np.float32)
+    # full-resolution semantic logits: nearest-upsampled discs + noise
+    if num_classes == 1:
+        sem = np.repeat(np.repeat(semq, s, 0), s, 1)[None]
+        sem = sem + rng.standard_normal(sem.shape).astype(np.float32) * 1.5
+    else:
+        clsf = np.repeat(np.repeat(cls, s, 0), s, 1)
+        sem = rng.standard_normal((num_classes, H, W)).astype(np.float32)
+        for c in range(num_classes):
+            sem[c][clsf == c] += 3.0
+    return (np.ascontiguousarray(sem[None].astype(np.float32)),
+            np.ascontiguousarray(ctr[None, None].astype(np.float32)),
+            np.ascontiguousarray(off[None].astype(np.float32)))

@@ -1,0 +1,189 @@
+"""Parameter bookkeeping for the Panoptic-DeepLab(PointRend) hot path.
+
+Three jobs, all host side (numpy / torch CPU tensors only):
+
+* ``pdl_spec(cfg)``       -- the ordered list of learnable layers of
+  ``QuantizablePanopticDeepLabPR`` (reference:
+  empanada/models/quantization/panoptic_deeplab.py:35-98,148-168,
+  encoders/resnet.py:143-215, decoders/panoptic_deeplab.py:25-62,
+  decoders/aspp.py:51-94, heads.py:10-16, point_rend.py:146-176) with the
+  module paths the reference's ``state_dict()`` uses.
+* ``seeded_state_dict``   -- deterministic random-init weights in the
+  reference's *unfused* key layout (the real MitoNet weights live on Zenodo;
+  benchmarks and parity tests use these, the reference model can
+  ``load_state_dict`` them verbatim).
+* ``fold_state_dict``     -- accepts either the unfused layout or the layout
+  of the exported TorchScript model (``fuse_model()`` output,
+  empanada_napari/_train.py:59-73) and returns one folded fp32
+  ``(weight, bias)`` pair per convolution: BatchNorm (eval) is folded into the
+  preceding convolution, which is what the HIP engine consumes.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+BN_EPS = 1e-5
+
+# MitoNet_v1-class configuration (empanada_napari/training/pdl_model.yaml:1-20,
+# empanada_napari/configs/MitoNet_v1.yaml).
+MITONET_PDL_CFG = dict(
+    arch='PanopticDeepLabPR', encoder='resnet50', num_classes=1,
+    stage4_stride=16, decoder_channels=256, low_level_stages=[1],
+    low_level_channels_project=[32], atrous_rates=[2, 4, 6],
+    aspp_channels=None, ins_decoder=True, ins_ratio=0.5, num_fc=3,
+    subdivision_num_points=8192,
+)
+
+RESNET50_LAYERS = (3, 4, 6, 3)
+RESNET_PLANES = (64, 128, 256, 512)
+
+
+def _L(name, shape, bn=None, bias=False, kind='conv', gain=1.0, bn_gamma=1.0):
+    return dict(name=name, shape=tuple(shape), bn=bn, bias=bias, kind=kind,
+                gain=gain, bn_gamma=bn_gamma)
+
+
+def resnet50_spec(prefix='encoder', in_channels=1):
+    """Layers of the 1-channel ResNet50 (encoders/resnet.py:143-215)."""
+    layers = [_L(f'{prefix}.conv1', (64, in_channels, 7, 7), bn=f'{prefix}.bn1')]
+    inplanes = 64
+    for li, (nblocks, planes) in enumerate(zip(RESNET50_LAYERS, RESNET_PLANES), start=1):
+        for b in range(nblocks):
+            p = f'{prefix}.layer{li}.{b}'
+            layers.append(_L(f'{p}.conv1', (planes, inplanes, 1, 1), bn=f'{p}.bn1'))
+            layers.append(_L(f'{p}.conv2', (planes, planes, 3, 3), bn=f'{p}.bn2'))
+            # a small last-BN gamma keeps the residual stream of a random-init
+            # net O(1) (cf. zero_init_residual, resnet.py:184-192)
+            layers.append(_L(f'{p}.conv3', (planes * 4, planes, 1, 1), bn=f'{p}.bn3', bn_gamma=0.35))
+            if b == 0:
+                layers.append(_L(f'{p}.downsample.0', (planes * 4, inplanes, 1, 1),
+                                 bn=f'{p}.downsample.1', bn_gamma=0.7))
+            inplanes = planes * 4
+    return layers
+
+
+def pdl_decoder_spec(prefix, in_ch, dec_ch, low_level_channels, low_level_project, aspp_ch=None):
+    """decoders/panoptic_deeplab.py:25-62 + decoders/aspp.py:51-94."""
+    aspp_ch = aspp_ch or dec_ch
+    L = []
+    L.append(_L(f'{prefix}.aspp.convs.0.0', (aspp_ch, in_ch, 1, 1), bn=f'{prefix}.aspp.convs.0.1'))
+    for i in (1, 2, 3):
+        L.append(_L(f'{prefix}.aspp.convs.{i}.0', (aspp_ch, in_ch, 3, 3), bn=f'{prefix}.aspp.convs.{i}.1'))
+    L.append(_L(f'{prefix}.aspp.convs.4.aspp_pooling.1', (aspp_ch, in_ch, 1, 1)))
+    L.append(_L(f'{prefix}.aspp.project.0', (aspp_ch, 5 * aspp_ch, 1, 1), bn=f'{prefix}.aspp.project.1'))
+    for i, (lc, lp) in enumerate(zip(low_level_channels, low_level_project)):
+        L.append(_L(f'{prefix}.project.{i}.0', (lp, lc, 1, 1), bn=f'{prefix}.project.{i}.1'))
+    for i, lp in enumerate(low_level_project):
+        fin = (aspp_ch if i == 0 else dec_ch) + lp
+        L.append(_L(f'{prefix}.fuse.{i}.0.sepconv.0', (fin, 1, 5, 5), kind='dw'))
+        L.append(_L(f'{prefix}.fuse.{i}.0.sepconv.1', (dec_ch, fin, 1, 1), bn=f'{prefix}.fuse.{i}.1'))
+    return L
+
+
+def pdl_head_spec(prefix, nin, ncls, out_std=1.0):
+    """heads.py:10-16: 5x5 separable + BN + ReLU, then 1x1 conv with bias."""
+    return [
+        _L(f'{prefix}.head.0.0.sepconv.0', (nin, 1, 5, 5), kind='dw'),
+        _L(f'{prefix}.head.0.0.sepconv.1', (nin, nin, 1, 1), bn=f'{prefix}.head.0.1'),
+        _L(f'{prefix}.head.1', (ncls, nin, 1, 1), bias=True, gain=out_std),
+    ]
+
+
+def pdl_spec(cfg=None):
+    """Ordered layer list of QuantizablePanopticDeepLabPR for ``cfg``."""
+    cfg = dict(MITONET_PDL_CFG, **(cfg or {}))
+    assert cfg['encoder'] == 'resnet50', 'only the resnet50 encoder is built so far'
+    widths = [p * 4 for p in RESNET_PLANES]  # cfg.widths, resnet.py:207-208
+    stages = cfg['low_level_stages']
+    llc = [widths[s - 1] for s in stages]
+    dec = cfg['decoder_channels']
+    ncls = cfg['num_classes']
+    L = resnet50_spec()
+    L += pdl_decoder_spec('semantic_decoder', widths[-1], dec, llc,
+                          cfg['low_level_channels_project'], cfg['aspp_channels'])
+    if cfg['ins_decoder']:
+        L += pdl_decoder_spec('instance_decoder', widths[-1], dec, llc,
+                              [int(s * cfg['ins_ratio']) for s in cfg['low_level_channels_project']],
+                              cfg['aspp_channels'])
+    L += pdl_head_spec('semantic_head', dec, ncls, out_std=2.0)
+    L += pdl_head_spec('ins_center', dec, 1, out_std=1.0)
+    L += pdl_head_spec('ins_xy', dec, 2, out_std=6.0)
+    fin = dec + ncls
+    for k in range(cfg['num_fc']):
+        L.append(_L(f'semantic_pr.point_head.fc_layers.{k}.0', (dec, fin, 1), bias=True, kind='fc'))
+    L.append(_L('semantic_pr.point_head.predictor', (ncls, fin, 1), bias=True, kind='fc', gain=2.0))
+    return L
+
+
+def seeded_state_dict(cfg=None, seed=0):
+    """Deterministic random-init parameters in the reference's unfused
+    ``state_dict`` layout (numpy fp32 arrays; int64 for num_batches_tracked).
+
+    Scales are chosen so every activation of the network stays O(1) and the
+    three heads produce logits / heatmaps / offsets with a useful dynamic
+    range (the reference's own init gives ~0 outputs, heads.py:21-26).
+    """
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for L in pdl_spec(cfg):
+        shp = L['shape']
+        fan_in = int(np.prod(shp[1:]))
+        std = L['gain'] * (np.sqrt(2.0 / fan_in) if L['bn'] or L['kind'] == 'fc' or L['kind'] == 'dw'
+                           else np.sqrt(1.0 / fan_in))
+        if L['kind'] == 'dw':
+            std = np.sqrt(1.0 / fan_in) * 1.5
+        sd[L['name'] + '.weight'] = (rng.standard_normal(shp) * std).astype(np.float32)
+        if L['bias']:
+            sd[L['name'] + '.bias'] = (rng.standard_normal(shp[0]) * 0.1).astype(np.float32)
+        if L['bn']:
+            c = shp[0]
+            g = L['bn_gamma']
+            sd[L['bn'] + '.weight'] = (g * rng.uniform(0.8, 1.2, c)).astype(np.float32)
+            sd[L['bn'] + '.bias'] = (rng.standard_normal(c) * 0.05).astype(np.float32)
+            sd[L['bn'] + '.running_mean'] = (rng.standard_normal(c) * 0.05).astype(np.float32)
+            sd[L['bn'] + '.running_var'] = rng.uniform(0.8, 1.2, c).astype(np.float32)
+            sd[L['bn'] + '.num_batches_tracked'] = np.array(0, dtype=np.int64)
+    return sd
+
+
+def _np(x):
+    if hasattr(x, 'detach'):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def fold_state_dict(sd, cfg=None):
+    """-> OrderedDict name -> (w fp32 (Cout,Cin/g,kh,kw | Cout,Cin,1), b fp32 (Cout,)).
+
+    Works on the unfused layout and on the ``fuse_model()`` layout of the
+    exported TorchScript models (Conv+ReLU become ``<name>.0.weight/bias``,
+    Conv+BN become ``<name>.weight/bias``, BatchNorm keys disappear).
+    """
+    out = OrderedDict()
+    for L in pdl_spec(cfg):
+        n = L['name']
+        if n + '.weight' in sd:
+            w = _np(sd[n + '.weight']).astype(np.float32)
+            b = _np(sd[n + '.bias']).astype(np.float32) if n + '.bias' in sd else None
+        elif n + '.0.weight' in sd:  # ConvReLU2d / fused Sequential
+            w = _np(sd[n + '.0.weight']).astype(np.float32)
+            b = _np(sd[n + '.0.bias']).astype(np.float32) if n + '.0.bias' in sd else None
+        else:
+            raise KeyError(f'parameter for layer {n!r} not found in state dict')
+        if tuple(w.shape) != L['shape']:
+            raise ValueError(f'{n}: expected shape {L["shape"]}, got {tuple(w.shape)}')
+        if b is None:
+            b = np.zeros(w.shape[0], dtype=np.float32)
+        bn = L['bn']
+        if bn and bn + '.running_mean' in sd:
+            gamma = _np(sd[bn + '.weight']).astype(np.float32)
+            beta = _np(sd[bn + '.bias']).astype(np.float32)
+            mean = _np(sd[bn + '.running_mean']).astype(np.float32)
+            var = _np(sd[bn + '.running_var']).astype(np.float32)
+            # same arithmetic as torch.nn.utils.fusion.fuse_conv_bn_weights (fp32)
+            rstd = (1.0 / np.sqrt(var + np.float32(BN_EPS))).astype(np.float32)
+            scale = (gamma * rstd).astype(np.float32)
+            w = (w * scale.reshape((-1,) + (1,) * (w.ndim - 1))).astype(np.float32)
+            b = ((b - mean) * rstd * gamma + beta).astype(np.float32)
+        out[n] = (np.ascontiguousarray(w), np.ascontiguousarray(b))
+    return out

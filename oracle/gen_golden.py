@@ -1,0 +1,210 @@
+"""Generate tests/golden/*.npz by importing the REFERENCE (build container only).
+
+    python oracle/gen_golden.py            # needs /root/reference, CPU only
+
+The reference cannot travel to the GPU box, so its outputs on seeded inputs are
+committed as small fixtures; the inputs are either stored next to them or are
+re-derivable from a seed through ``empanada-napari_amd/synth.py`` /
+``weights.py`` (both deterministic numpy generators).  This script is the
+"generating script" the fixtures are committed with.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+import __graft_entry__ as graft  # noqa: E402
+
+graft.load_package()
+from empanada_napari_amd import synth, weights  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+# ----------------------------------------------------------------------------
+# A. network forward
+# ----------------------------------------------------------------------------
+def ref_model(cfg, sd):
+    from empanada.models.quantization.panoptic_deeplab import QuantizablePanopticDeepLabPR
+    kw = {k: v for k, v in cfg.items() if k != 'arch'}
+    m = QuantizablePanopticDeepLabPR(quantize=False, **kw)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m.eval()
+
+
+def norm_image(img_u8, mean=0.57571, std=0.12765):
+    from empanada_napari_amd.preprocess import normalize
+    return normalize(img_u8, mean, std)
+
+
+def gen_model():
+    cfg = dict(weights.MITONET_PDL_CFG)
+    sd = weights.seeded_state_dict(cfg, seed=0)
+    m = ref_model(cfg, sd)
+    cases = {
+        'a': (np.stack([synth.blob_image(64, 64, seed=1), synth.blob_image(64, 64, seed=2)]), 2, False),
+        'b': (np.stack([synth.blob_image(64, 64, seed=3)]), 3, True),
+        'c': (np.stack([synth.em_tiles(1, 128, seed=5)[0]]), 2, False),
+        'd': (np.stack([synth.blob_image(96, 160, seed=7)]), 2, True),
+    }
+    out = {}
+    with torch.no_grad():
+        for k, (img, rs, interp) in cases.items():
+            x = torch.from_numpy(norm_image(img))[:, None]
+            o = m(x, rs, interp)
+            out[f'{k}_image'] = img
+            out[f'{k}_render_steps'] = np.int64(rs)
+            out[f'{k}_interpolate_ins'] = np.int64(interp)
+            for name in ('sem_logits', 'ctr_hmp', 'offsets'):
+                out[f'{k}_{name}'] = o[name].numpy()
+        # fused model == unfused model, and fold() of both key layouts agree
+        x = torch.from_numpy(norm_image(cases['a'][0]))[:, None]
+        ref = m(x, 2, False)
+        m.fuse_model()
+        fo = m(x, 2, False)
+        for name in ('sem_logits', 'ctr_hmp', 'offsets'):
+            assert torch.allclose(ref[name], fo[name], atol=2e-4, rtol=1e-4), name
+        fsd = {k: v.numpy() for k, v in m.state_dict().items()}
+        A = weights.fold_state_dict(sd, cfg)
+        B = weights.fold_state_dict(fsd, cfg)
+        for n in A:
+            assert np.allclose(A[n][0], B[n][0], atol=1e-6, rtol=1e-5), n
+            assert np.allclose(A[n][1], B[n][1], atol=1e-5, rtol=1e-4), n
+        out['fused_keys'] = np.array(sorted(fsd.keys()))
+    save('pdl_forward', **out)
+
+
+# ----------------------------------------------------------------------------
+# B. post-processing on synthetic head tensors
+# ----------------------------------------------------------------------------
+def gen_postprocess():
+    from empanada.inference import postprocess as pp
+    from empanada.inference.engines import PanopticDeepLabRenderEngine
+
+    class Fake(torch.nn.Module):
+        def __init__(self, outs):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.outs = outs
+
+        def forward(self, x, render_steps: int = 2, interpolate_ins: bool = True):
+            return {k: v.clone() for k, v in self.outs.items()}
+
+    out = {}
+    specs = [  # (H, W, n_inst, coarse, num_classes, nms_kernel, thr, plateau)
+        (64, 64, 0, True, 1, 3, 0.1, False),
+        (64, 96, 1, True, 1, 3, 0.1, False),
+        (128, 128, 19, True, 1, 3, 0.1, False),
+        (128, 128, 20, True, 1, 7, 0.1, True),
+        (128, 160, 21, True, 1, 3, 0.1, True),
+        (256, 256, 200, True, 1, 3, 0.05, False),
+        (64, 64, 12, False, 1, 3, 0.1, True),
+        (96, 64, 30, False, 1, 4, 0.1, False),   # even NMS kernel (postprocess.py:63-65)
+        (128, 128, 25, True, 4, 3, 0.1, False),  # multi-class softmax / argmax / torch.mode
+    ]
+    for i, (H, W, n, coarse, ncls, k, thr, plat) in enumerate(specs):
+        sem_logits, ctr, off = synth.head_outputs(H, W, n, seed=100 + i, coarse=coarse,
+                                                  num_classes=ncls, plateau=plat)
+        tctr, toff = torch.from_numpy(ctr), torch.from_numpy(off)
+        centers = pp.find_instance_center(tctr.clone(), thr, k)
+        out[f'{i}_spec'] = np.array([H, W, n, int(coarse), ncls, k], dtype=np.int64)
+        out[f'{i}_thr'] = np.float64(thr)
+        out[f'{i}_centers'] = centers.numpy()
+        step = 4 if coarse else 1
+        if centers.size(0) > 0:
+            out[f'{i}_groups'] = pp.group_pixels(centers, toff, step=step).numpy()
+        thing_list = [1] if ncls == 1 else [1, 2]
+        for divisor, conf in ((1000, 0.5), (10000, 0.3)):
+            eng = PanopticDeepLabRenderEngine(
+                Fake({'sem_logits': torch.from_numpy(sem_logits), 'ctr_hmp': tctr, 'offsets': toff}),
+                thing_list=thing_list, label_divisor=divisor, stuff_area=64, void_label=0,
+                nms_threshold=thr, nms_kernel=k, confidence_thr=conf, padding_factor=16,
+                coarse_boundaries=coarse)
+            image = torch.zeros(1, 1, H, W)
+            pan = eng(image, (H - 3, W - 5), upsampling=1)
+            out[f'{i}_pan_{divisor}'] = pan.numpy()
+            cells = eng.get_instance_cells(tctr.clone(), toff, 1)
+            out[f'{i}_cells'] = cells.numpy().astype(np.int32)
+    save('postprocess', **out)
+
+
+# ----------------------------------------------------------------------------
+# C. recursive median queue / 3d engine traces
+# ----------------------------------------------------------------------------
+def gen_median():
+    from empanada.inference.engines import PanopticDeepLabRenderEngine3d
+
+    class Seq(torch.nn.Module):
+        def __init__(self, outs):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.outs = outs
+            self.i = 0
+
+        def forward(self, x, render_steps: int = 2, interpolate_ins: bool = True):
+            o = {k: v.clone() for k, v in self.outs[self.i].items()}
+            self.i += 1
+            return o
+
+    out = {}
+    H = W = 64
+    nslices = 9
+    rng = np.random.default_rng(7)
+    base = [synth.head_outputs(H, W, 6, seed=300 + (z // 3), coarse=True) for z in range(nslices)]
+    slices = []
+    for z, (sem, ctr, off) in enumerate(base):
+        sem = sem + rng.standard_normal(sem.shape).astype(np.float32) * 1.0
+        slices.append({'sem_logits': torch.from_numpy(sem.astype(np.float32)),
+                       'ctr_hmp': torch.from_numpy(ctr), 'offsets': torch.from_numpy(off)})
+    out['sem_logits'] = np.stack([s['sem_logits'].numpy() for s in slices])
+    out['ctr_hmp'] = np.stack([s['ctr_hmp'].numpy() for s in slices])
+    out['offsets'] = np.stack([s['offsets'].numpy() for s in slices])
+    for ks in (1, 3, 5, 7):
+        eng = PanopticDeepLabRenderEngine3d(
+            Seq(slices), thing_list=[1], label_divisor=1000, nms_threshold=0.1, nms_kernel=3,
+            confidence_thr=0.5, median_kernel_size=ks, padding_factor=16, coarse_boundaries=True)
+        segs = []
+        for z in range(nslices):
+            r = eng(torch.zeros(1, 1, H, W), (H, W), 1)
+            if r is not None:
+                segs.append(r.numpy())
+        segs += [s.numpy() for s in eng.end(1)]
+        assert len(segs) == nslices, (ks, len(segs))
+        out[f'pan_ks{ks}'] = np.stack(segs).astype(np.int32)
+    # scalar trace of the recursion
+    from empanada.inference.engines import _MedianQueue
+    q = _MedianQueue(3)
+    vals = [5, 1, 9, 0, 7, 2]
+    tr = []
+    for v in vals:
+        q.enqueue({'sem': torch.tensor([[float(v)]])})
+        o = q.get_next(['sem'])
+        if o is not None:
+            tr.append(float(o['sem']))
+    tr += [float(o['sem']) for o in q.end()]
+    out['scalar_in'] = np.array(vals, dtype=np.float32)
+    out['scalar_out'] = np.array(tr, dtype=np.float32)
+    save('median3d', **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['model', 'postprocess', 'median']
+    torch.manual_seed(0)
+    if 'model' in which:
+        gen_model()
+    if 'postprocess' in which:
+        gen_postprocess()
+    if 'median' in which:
+        gen_median()

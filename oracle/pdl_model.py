@@ -1,0 +1,165 @@
+"""torch-CPU fp32 restatement of the reference network forward (oracle, test only).
+
+Consumes the folded ``name -> (w, b)`` parameters of
+``empanada-napari_amd/weights.py::fold_state_dict`` and reproduces, op by op,
+``QuantizablePanopticDeepLabPR.forward`` in eval mode
+(reference: empanada/models/quantization/panoptic_deeplab.py:194-250).
+Pinned against the reference itself by ``oracle/gen_golden.py``
+(tests/golden/pdl_forward_*.npz).
+"""
+import torch
+import torch.nn.functional as F
+
+RESNET50_LAYERS = (3, 4, 6, 3)
+
+
+def _t(a):
+    return None if a is None else torch.from_numpy(a)
+
+
+def _conv(x, p, stride=1, padding=0, dilation=1, groups=1, relu=False):
+    w, b = p
+    y = F.conv2d(x, _t(w), _t(b), stride, padding, dilation, groups)
+    return F.relu(y) if relu else y
+
+
+def resnet50_forward(P, x, output_stride=16, taps=None):
+    """encoders/resnet.py:217-229 with Bottleneck blocks (:109-129); BN folded."""
+    x = _conv(x, P['encoder.conv1'], stride=2, padding=3, relu=True)
+    if taps is not None:
+        taps['stem'] = x
+    p1 = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    pyr = [p1]
+    x = p1
+    for li, nblocks in enumerate(RESNET50_LAYERS, start=1):
+        stride = 1 if li == 1 else 2
+        dilation = 1
+        if li == 4 and output_stride == 16:  # resnet.py:173-175
+            stride, dilation = 1, 2
+        for b in range(nblocks):
+            pre = f'encoder.layer{li}.{b}'
+            s = stride if b == 0 else 1
+            identity = x
+            out = _conv(x, P[f'{pre}.conv1'], relu=True)
+            out = _conv(out, P[f'{pre}.conv2'], stride=s, padding=dilation, dilation=dilation, relu=True)
+            out = _conv(out, P[f'{pre}.conv3'])
+            if b == 0:
+                identity = _conv(x, P[f'{pre}.downsample.0'], stride=s)
+            x = F.relu(out + identity)
+            if taps is not None:
+                taps[pre] = x
+        pyr.append(x)
+    return pyr  # [p1, p2, p3, p4, p5]
+
+
+def aspp_forward(P, pre, x, rates):
+    """decoders/aspp.py:96-102 (+ ASPPPooling.forward :45-48)."""
+    res = [_conv(x, P[f'{pre}.convs.0.0'], relu=True)]
+    for i, r in enumerate(rates, start=1):
+        res.append(_conv(x, P[f'{pre}.convs.{i}.0'], padding=r, dilation=r, relu=True))
+    size = x.shape[-2:]
+    pooled = F.adaptive_avg_pool2d(x, 1)
+    pooled = _conv(pooled, P[f'{pre}.convs.4.aspp_pooling.1'], relu=True)
+    res.append(F.interpolate(pooled, size=size, mode='bilinear', align_corners=True))
+    return _conv(torch.cat(res, dim=1), P[f'{pre}.project.0'], relu=True)
+
+
+def decoder_forward(P, pre, pyr, low_level_stages, rates, taps=None):
+    """decoders/panoptic_deeplab.py:68-80."""
+    x = aspp_forward(P, f'{pre}.aspp', pyr[-1], rates)
+    if taps is not None:
+        taps[f'{pre}.aspp'] = x
+    for i, stage in enumerate(low_level_stages):
+        l = _conv(pyr[stage], P[f'{pre}.project.{i}.0'], relu=True)
+        x = F.interpolate(x, size=l.shape[2:], mode='bilinear', align_corners=True)
+        x = torch.cat((x, l), dim=1)
+        x = _conv(x, (P[f'{pre}.fuse.{i}.0.sepconv.0'][0], None), padding=2, groups=x.shape[1])
+        x = _conv(x, P[f'{pre}.fuse.{i}.0.sepconv.1'], relu=True)
+    return x
+
+
+def head_forward(P, pre, x):
+    """heads.py:12-19."""
+    x = _conv(x, (P[f'{pre}.head.0.0.sepconv.0'][0], None), padding=2, groups=x.shape[1])
+    x = _conv(x, P[f'{pre}.head.0.0.sepconv.1'], relu=True)
+    return _conv(x, P[f'{pre}.head.1'])
+
+
+def calculate_uncertainty(logits):
+    """point_rend.py:11-31."""
+    if logits.size(1) == 1:
+        return -(torch.abs(logits))
+    top2 = torch.topk(logits, k=2, dim=1)[0]
+    return (top2[:, 1] - top2[:, 0]).unsqueeze(1)
+
+
+def point_sample(features, point_coords):
+    """point_rend.py:33-60 (bilinear, align_corners=False, zero padding)."""
+    out = F.grid_sample(features, 2.0 * point_coords.unsqueeze(2) - 1.0, mode='bilinear', align_corners=False)
+    return out.squeeze(3)
+
+
+def uncertain_points_on_grid(uncertainty_map, num_points):
+    """point_rend.py:108-137."""
+    R, _, H, W = uncertainty_map.shape
+    h_step = 1.0 / float(H)
+    w_step = 1.0 / float(W)
+    num_points = min(H * W, num_points)
+    idx = torch.topk(uncertainty_map.view(R, H * W), k=num_points, dim=1)[1]
+    coords = torch.zeros(R, num_points, 2, dtype=torch.float)
+    coords[:, :, 0] = 0.5 * w_step + w_step * (idx % W).float()
+    coords[:, :, 1] = 0.5 * h_step + h_step * torch.div(idx, W, rounding_mode='floor').float()
+    return idx, coords
+
+
+def point_head_forward(P, fine, coarse, num_fc):
+    """point_rend.py:181-188 (Conv1d k=1 MLP, coarse concatenated at every layer)."""
+    x = torch.cat([fine, coarse], dim=1)
+    for k in range(num_fc):
+        w, b = P[f'semantic_pr.point_head.fc_layers.{k}.0']
+        x = F.relu(F.conv1d(x, _t(w), _t(b)))
+        x = torch.cat([x, coarse], dim=1)
+    w, b = P['semantic_pr.point_head.predictor']
+    return F.conv1d(x, _t(w), _t(b))
+
+
+def point_rend_forward(P, coarse_logits, features, steps, num_points, num_fc, taps=None):
+    """point_rend.py:241-269 (eval branch)."""
+    sem = coarse_logits.clone()
+    for s in range(steps):
+        sem = F.interpolate(sem, scale_factor=2.0, mode='bilinear', align_corners=False)
+        unc = calculate_uncertainty(sem)
+        idx, coords = uncertain_points_on_grid(unc, num_points)
+        coarse_pts = point_sample(coarse_logits, coords)
+        fine_pts = point_sample(features, coords)
+        logits = point_head_forward(P, fine_pts, coarse_pts, num_fc)
+        N, C, H, W = sem.shape
+        if taps is not None:
+            taps[f'pr.step{s}.idx'] = idx
+            taps[f'pr.step{s}.point_logits'] = logits
+        sem = sem.reshape(N, C, H * W).scatter_(2, idx.unsqueeze(1).expand(-1, C, -1), logits).view(N, C, H, W)
+    return sem
+
+
+@torch.no_grad()
+def pdl_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None):
+    """QuantizablePanopticDeepLabPR.forward, eval (quantization/panoptic_deeplab.py:238-250).
+
+    P: folded params (numpy), x: (N,1,H,W) fp32 torch tensor, H,W % 16 == 0.
+    Returns dict(sem_logits, ctr_hmp, offsets) of fp32 torch tensors.
+    """
+    pyr = resnet50_forward(P, x, cfg['stage4_stride'], taps)
+    stages, rates = cfg['low_level_stages'], cfg['atrous_rates']
+    semantic_x = decoder_forward(P, 'semantic_decoder', pyr, stages, rates, taps)
+    instance_x = decoder_forward(P, 'instance_decoder', pyr, stages, rates, taps) if cfg['ins_decoder'] else semantic_x
+    sem = head_forward(P, 'semantic_head', semantic_x)
+    ctr = head_forward(P, 'ins_center', instance_x)
+    off = head_forward(P, 'ins_xy', instance_x)
+    if taps is not None:
+        taps.update(semantic_x=semantic_x, instance_x=instance_x, sem_coarse=sem)
+    sem_logits = point_rend_forward(P, sem, semantic_x, render_steps,
+                                    cfg['subdivision_num_points'], cfg['num_fc'], taps)
+    if interpolate_ins:  # Interpolate2d(4, bilinear, align_corners=True), panoptic_deeplab.py:89,233-234
+        ctr = F.interpolate(ctr, scale_factor=4.0, mode='bilinear', align_corners=True)
+        off = F.interpolate(off, scale_factor=4.0, mode='bilinear', align_corners=True)
+    return {'sem_logits': sem_logits, 'ctr_hmp': ctr, 'offsets': off}

@@ -1,0 +1,68 @@
+"""Oracle (torch-CPU restatement) vs golden vectors produced by the imported
+reference (oracle/gen_golden.py -> tests/golden/pdl_forward.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from empanada_napari_amd import weights
+from empanada_napari_amd.preprocess import normalize
+from oracle import pdl_model
+
+
+@pytest.fixture(scope='module')
+def folded():
+    cfg = dict(weights.MITONET_PDL_CFG)
+    return cfg, weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+
+
+@pytest.mark.parametrize('case', ['a', 'b', 'c', 'd'])
+def test_forward_matches_reference(golden_dir, folded, case):
+    g = np.load(os.path.join(golden_dir, 'pdl_forward.npz'))
+    cfg, P = folded
+    x = torch.from_numpy(normalize(g[f'{case}_image'], 0.57571, 0.12765))[:, None]
+    out = pdl_model.pdl_forward(P, x, cfg, int(g[f'{case}_render_steps']), bool(g[f'{case}_interpolate_ins']))
+    for name in ('sem_logits', 'ctr_hmp', 'offsets'):
+        ref = g[f'{case}_{name}']
+        got = out[name].numpy()
+        assert got.shape == ref.shape
+        # tolerance: BN folding re-associates fp32 products (fold vs unfused BN)
+        np.testing.assert_allclose(got, ref, atol=2e-4, rtol=2e-4, err_msg=f'{case}/{name}')
+    # the synthetic weights give heads a useful dynamic range (not ~0 everywhere)
+    assert np.abs(g[f'{case}_sem_logits']).max() > 0.5
+
+
+def test_fold_accepts_fused_layout(golden_dir, folded):
+    """fold_state_dict must understand the exported (fuse_model) key layout."""
+    g = np.load(os.path.join(golden_dir, 'pdl_forward.npz'))
+    cfg, P = folded
+    keys = set(str(k) for k in g['fused_keys'])
+    # build a fused-layout dict from the folded params and fold it again
+    fsd = {}
+    for L in weights.pdl_spec(cfg):
+        n = L['name']
+        w, b = P[n]
+        if n + '.0.weight' in keys:
+            fsd[n + '.0.weight'] = w
+            if n + '.0.bias' in keys:
+                fsd[n + '.0.bias'] = b
+        elif n + '.weight' in keys:
+            fsd[n + '.weight'] = w
+            if n + '.bias' in keys:
+                fsd[n + '.bias'] = b
+        else:
+            raise AssertionError(n)
+    # un-fused BN leftovers (separable conv blocks keep their BatchNorm)
+    leftover = [k for k in keys if k.endswith('running_mean')]
+    assert leftover, 'exported layout keeps BN after separable convs'
+    for k in leftover:
+        base = k[:-len('.running_mean')]
+        c = [L for L in weights.pdl_spec(cfg) if L['bn'] == base][0]['shape'][0]
+        fsd[base + '.weight'] = np.ones(c, np.float32)
+        fsd[base + '.bias'] = np.zeros(c, np.float32)
+        fsd[base + '.running_mean'] = np.zeros(c, np.float32)
+        fsd[base + '.running_var'] = np.ones(c, np.float32) - np.float32(weights.BN_EPS)
+    Q = weights.fold_state_dict(fsd, cfg)
+    for n in P:
+        np.testing.assert_allclose(Q[n][0], P[n][0], atol=1e-6, rtol=1e-5)
