@@ -38,9 +38,10 @@ RESNET50_LAYERS = (3, 4, 6, 3)
 RESNET_PLANES = (64, 128, 256, 512)
 
 
-def _L(name, shape, bn=None, bias=False, kind='conv', gain=1.0, bn_gamma=1.0):
+def _L(name, shape, bn=None, bias=False, kind='conv', gain=1.0, bn_gamma=1.0,
+       zero_mean=False, bias_mean=0.0):
     return dict(name=name, shape=tuple(shape), bn=bn, bias=bias, kind=kind,
-                gain=gain, bn_gamma=bn_gamma)
+                gain=gain, bn_gamma=bn_gamma, zero_mean=zero_mean, bias_mean=bias_mean)
 
 
 def resnet50_spec(prefix='encoder', in_channels=1):
@@ -80,12 +81,12 @@ def pdl_decoder_spec(prefix, in_ch, dec_ch, low_level_channels, low_level_projec
     return L
 
 
-def pdl_head_spec(prefix, nin, ncls, out_std=1.0):
+def pdl_head_spec(prefix, nin, ncls, out_std=1.0, bias_mean=0.0):
     """heads.py:10-16: 5x5 separable + BN + ReLU, then 1x1 conv with bias."""
     return [
         _L(f'{prefix}.head.0.0.sepconv.0', (nin, 1, 5, 5), kind='dw'),
         _L(f'{prefix}.head.0.0.sepconv.1', (nin, nin, 1, 1), bn=f'{prefix}.head.0.1'),
-        _L(f'{prefix}.head.1', (ncls, nin, 1, 1), bias=True, gain=out_std),
+        _L(f'{prefix}.head.1', (ncls, nin, 1, 1), bias=True, gain=out_std, zero_mean=True, bias_mean=bias_mean),
     ]
 
 
@@ -105,13 +106,13 @@ def pdl_spec(cfg=None):
         L += pdl_decoder_spec('instance_decoder', widths[-1], dec, llc,
                               [int(s * cfg['ins_ratio']) for s in cfg['low_level_channels_project']],
                               cfg['aspp_channels'])
-    L += pdl_head_spec('semantic_head', dec, ncls, out_std=2.0)
-    L += pdl_head_spec('ins_center', dec, 1, out_std=1.0)
-    L += pdl_head_spec('ins_xy', dec, 2, out_std=6.0)
+    L += pdl_head_spec('semantic_head', dec, ncls, out_std=0.8)
+    L += pdl_head_spec('ins_center', dec, 1, out_std=0.25, bias_mean=-0.5)
+    L += pdl_head_spec('ins_xy', dec, 2, out_std=3.0)
     fin = dec + ncls
     for k in range(cfg['num_fc']):
         L.append(_L(f'semantic_pr.point_head.fc_layers.{k}.0', (dec, fin, 1), bias=True, kind='fc'))
-    L.append(_L('semantic_pr.point_head.predictor', (ncls, fin, 1), bias=True, kind='fc', gain=2.0))
+    L.append(_L('semantic_pr.point_head.predictor', (ncls, fin, 1), bias=True, kind='fc', gain=0.8, zero_mean=True))
     return L
 
 
@@ -132,9 +133,12 @@ def seeded_state_dict(cfg=None, seed=0):
                            else np.sqrt(1.0 / fan_in))
         if L['kind'] == 'dw':
             std = np.sqrt(1.0 / fan_in) * 1.5
-        sd[L['name'] + '.weight'] = (rng.standard_normal(shp) * std).astype(np.float32)
+        w = rng.standard_normal(shp) * std
+        if L['zero_mean']:  # keeps the output of a post-ReLU input centred
+            w = w - w.mean(axis=1, keepdims=True)
+        sd[L['name'] + '.weight'] = w.astype(np.float32)
         if L['bias']:
-            sd[L['name'] + '.bias'] = (rng.standard_normal(shp[0]) * 0.1).astype(np.float32)
+            sd[L['name'] + '.bias'] = (L['bias_mean'] + rng.standard_normal(shp[0]) * 0.1).astype(np.float32)
         if L['bn']:
             c = shp[0]
             g = L['bn_gamma']
