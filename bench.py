@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py -- tiles/sec of the MitoNet-class 2D hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic EM tiles that
+is already resident in HBM as uint8: fused normalisation + Panoptic-DeepLab/
+PointRend forward (fp16 MFMA, fp32 accumulate) + sigmoid + centre NMS/voting +
+panoptic merge -> int64 label maps on the device (BASELINE.json configs[1]:
+1024x1024 tiles, batch 32).  Tiles are independent, so N GPUs shard tiles with
+no data-path collective ("weak" scaling: 32 tiles per GPU per step).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+PEAK_F16_TFLOPS = 2500.0  # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(cfg, P, tile_size, n_tiles, seed):
+    """Oracle (CPU restatement of the reference engine) on a bounded sample of the same workload."""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model, postprocess as opp
+    torch.set_num_threads(os.cpu_count() or 1)
+    tiles = synth.em_tiles(n_tiles, tile_size, seed=seed)
+
+    def model(x, rs, interp):
+        o = pdl_model.pdl_forward(P, torch.from_numpy(x), cfg, rs, interp)
+        return {k: v.numpy() for k, v in o.items()}
+
+    eng = opp.RenderEngine(model, [1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                           padding_factor=16, coarse_boundaries=True)
+    t0 = time.perf_counter()
+    for t in tiles:  # the reference asserts batch 1 (engines.py:306): sequential calls
+        eng(normalize(t, 0.57571, 0.12765)[None, None], t.shape, 1)
+    dt = time.perf_counter() - t0
+    return {'value': round(n_tiles / dt, 4), 'unit': 'tiles/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n_tiles} x {tile_size}x{tile_size} uint8 EM-like tiles, fp32, sequential batch-1 calls '
+                      f'({dt:.1f} s)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--micro-batch', type=int, default=0, help='forward in chunks of this many tiles (0 = whole batch)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-tiles', type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    graft.load_package()
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab, PanopticDeepLabRenderEngine
+    from empanada_napari_amd.preprocess import normalize_params
+
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    model = HipPanopticDeepLab(P, cfg, device=dev, folded=True)
+    eng = PanopticDeepLabRenderEngine(model, thing_list=[1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3,
+                                      confidence_thr=0.5, padding_factor=16, coarse_boundaries=True)
+    B, S = args.batch, args.size
+    mb = args.micro_batch or B
+    # synthetic tiles: a few distinct ones tiled to the batch (generation cost only), different per rank
+    base = synth.em_tiles(min(B, 4), S, seed=1234 + rank)
+    tiles = torch.from_numpy(np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B])[:, None].to(dev)
+    sub, mul = normalize_params(0.57571, 0.12765, 255)
+    model.reserve(mb, S, S)
+
+    fwd_ms = []
+
+    def step(timed):
+        outs = []
+        for i in range(0, B, mb):
+            x = tiles[i:i + mb]
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            o = model(x, 2, interpolate_ins=False, sub=float(sub), mul=float(mul))
+            if timed:
+                e1.record()
+                fwd_ms.append((e0, e1))
+            from empanada_napari_amd.engines import logits_to_prob
+            sem = logits_to_prob(o['sem_logits'])
+            cells, _, _, kmax = eng.instance_cells_int(o['ctr_hmp'], o['offsets'], 1)
+            outs.append(eng.panoptic_merge_int(sem, cells, kmax))
+        return outs
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    fwd_total_ms = sum(a.elapsed_time(b) for a, b in fwd_ms)
+    flops_fwd = model.last_flops() * (B / mb)  # per step (last_flops is per forward call of mb tiles)
+    ms_per_step = dt * 1e3 / args.steps
+    value = world * B * args.steps / dt
+
+    if rank == 0:
+        fwd_ms_per_step = fwd_total_ms / args.steps
+        achieved = flops_fwd / (fwd_ms_per_step * 1e-3) / 1e12
+        res = {
+            'metric': 'EM tiles/sec (1024^2 fp16)', 'value': round(value, 2), 'unit': 'tiles/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16',
+            'data': 'synthetic',
+            'config': {'workload': f'MitoNet-class PanopticDeepLabPR/resnet50 2D inference, {S}x{S} uint8 tiles, '
+                                   f'batch {B} per GPU, forward + instance post-processing to int64 label maps',
+                       'tile': S, 'batch_per_gpu': B, 'micro_batch': mb, 'weights': 'seeded random init (seed 0)',
+                       'parallelism': f'tile-sharded x{world}, no collective'},
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_F16_TFLOPS, 4), 'traffic': None,
+                         'kernel': 'network forward (all kernels; implicit-GEMM conv dominates)',
+                         'flops_per_tile': round(flops_fwd / B / 1e9, 2), 'forward_ms_per_step': round(fwd_ms_per_step, 3)},
+            'arena_gib': round(model.arena_bytes() / 2 ** 30, 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(cfg, P, S, args.cpu_tiles, 1234)
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

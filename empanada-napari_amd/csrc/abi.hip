@@ -1,0 +1,83 @@
+// C-ABI glue of libempanada_hip: error reporting, device query and the
+// operator-level entry points that are not tied to a network object.
+#include <stdarg.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace emp {
+
+static thread_local char g_err[1024] = "no error";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+const void* zero_page() {
+  static void* page = nullptr;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (hipMalloc(&page, 256) != hipSuccess) { page = nullptr; return; }
+    if (hipMemset(page, 0, 256) != hipSuccess) { (void)hipFree(page); page = nullptr; }
+  });
+  return page;
+}
+
+}  // namespace emp
+
+using namespace emp;
+
+extern "C" {
+
+const char* emp_last_error(void) { return g_err; }
+int emp_abi_version(void) { return 1; }
+
+int emp_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return EMP_ERR_HIP;
+  }
+  return n;
+}
+
+int emp_copy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream) {
+  EMP_REQUIRE(d_dst && d_src, "copy_d2d: null pointer");
+  EMP_CHECK_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return EMP_OK;
+}
+
+int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_ld, const void* d_w,
+                        const float* d_bias, const float* d_bias_n, const void* d_res, int res_ld, void* d_out,
+                        int out_ld, int Cout, int KH, int KW, int stride, int pad, int dil, int relu, int variant,
+                        void* stream) {
+  EMP_REQUIRE(d_in && d_w && d_out, "conv2d: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d: bad geometry");
+  EMP_REQUIRE(variant >= 0 && variant <= 2, "conv2d: variant must be 0 (auto), 1 (register staged) or 2 (LDS-DMA)");
+  ConvParams p{};
+  p.in = (const half_t*)d_in;
+  p.wgt = (const half_t*)d_w;
+  p.bias = d_bias;
+  p.bias_n = d_bias_n;
+  p.res = (const half_t*)d_res;
+  p.res_ld = res_ld;
+  p.out = (half_t*)d_out;
+  p.zero = (const half_t*)zero_page();
+  EMP_REQUIRE(p.zero != nullptr, "conv2d: could not allocate the zero page");
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.in_ld = in_ld;
+  p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  EMP_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d: empty output");
+  p.out_ld = out_ld;
+  p.relu = relu;
+  p.M = N * p.Ho * p.Wo;
+  return launch_conv_igemm(p, variant, (hipStream_t)stream);
+}
+
+}  // extern "C"

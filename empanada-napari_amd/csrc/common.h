@@ -1,0 +1,106 @@
+// Shared declarations of libempanada_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/empanada_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace emp {
+
+void set_error(const char* fmt, ...);
+
+#define EMP_CHECK_HIP(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      emp::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return EMP_ERR_HIP;                                                          \
+    }                                                                              \
+  } while (0)
+
+#define EMP_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      emp::set_error(__VA_ARGS__);      \
+      return EMP_ERR_INVALID;           \
+    }                                   \
+  } while (0)
+
+#define EMP_LAUNCH_CHECK() EMP_CHECK_HIP(hipGetLastError())
+
+// A 256-byte device buffer of zeros (source for out-of-bounds LDS-DMA lanes).
+const void* zero_page();
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+// implicit-GEMM convolution (conv_igemm.hip)
+// ---------------------------------------------------------------------------
+struct ConvParams {
+  const half_t* in;   // (N,H,W,in_ld)
+  const half_t* wgt;  // (Cout, KH*KW, Cin)
+  const float* bias;  // (Cout) or null
+  const float* bias_n;  // (N,Cout) or null
+  const half_t* res;  // (N,Ho,Wo,res_ld) or null
+  half_t* out;        // (N,Ho,Wo,out_ld)
+  const half_t* zero; // zero page
+  int N, H, W, Cin, in_ld;
+  int Cout, KH, KW, stride, pad, dil;
+  int Ho, Wo, out_ld, res_ld, relu;
+  int M;           // N*Ho*Wo
+  int mt, nt;      // tiles along pixels / couts
+  int mt_per_xcd;  // ceil(mt/8)
+};
+
+// variant: 0 = auto, 1 = register-staged, 2 = LDS-DMA staged
+int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream);
+
+// ---------------------------------------------------------------------------
+// element-wise / stencil kernels (layers.hip)
+// ---------------------------------------------------------------------------
+// img: (N,vh,vw) raw or normalised; pixels outside (vh,vw) read as 0.0 (factor_pad + conv padding)
+int launch_stem7x7(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
+                   const float* w /*49x64*/, const float* b /*64*/, half_t* out, hipStream_t s);
+int launch_maxpool3x3s2(const half_t* in, int N, int H, int W, int C, half_t* out, hipStream_t s);
+int launch_dwconv5x5(const half_t* in, int N, int H, int W, int C, int in_ld, const float* w /*25 x C*/,
+                     half_t* out, int out_ld, hipStream_t s);
+int launch_bilinear_ac(const half_t* in, int N, int h, int w, int C, int in_ld, half_t* out, int H, int W,
+                       int out_ld, hipStream_t s);
+int launch_avgpool(const half_t* in, int N, int HW, int C, int in_ld, float* out /*N x C*/, float* part,
+                   hipStream_t s);
+int avgpool_scratch_floats(int N, int C);
+// out[n][co] = act(sum_k in[n][k] * w[co][k] + b[co]); fp32, tiny shapes
+int launch_gemv(const float* in, int N, int K, const float* w, const float* b, int Cout, int relu,
+                float* out, hipStream_t s);
+// out[n][c][pix] = sum_k in[n][pix][k]*w[c][k] + b[c]; fp16 NHWC in -> fp32 NCHW planes out.
+// if scatter_idx != null: pix index of row r is scatter_idx[n*P + r] into a plane of plane_size.
+int launch_head1x1(const half_t* in, int N, int P, int K, int in_ld, const float* w, const float* b, int C,
+                   float* out, int64_t plane_size, const int32_t* scatter_idx, hipStream_t s);
+int launch_bilinear_ac_f32_nchw(const float* in, int NC, int h, int w, float* out, int scale, hipStream_t s);
+int launch_zero(void* p, size_t bytes, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// PointRend (pointrend.hip)
+// ---------------------------------------------------------------------------
+size_t topk_work_bytes(int N, int64_t plane);
+int launch_upsample2x_keys(const float* in, int N, int C, int h, int w, float* out, uint32_t* keys, hipStream_t s);
+int launch_topk_smallest(const uint32_t* keys, int N, int64_t plane, int k, void* work, size_t work_bytes,
+                         int32_t* idx_out, hipStream_t s);
+int launch_point_features(const half_t* feat, int N, int fh, int fw, int C, int feat_ld, const float* coarse,
+                          int ncls, const int32_t* idx, int P, int H2, int W2, half_t* x0, half_t* x1, int ld,
+                          hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// post-processing (postprocess.hip)
+// ---------------------------------------------------------------------------
+
+}  // namespace emp

@@ -1,0 +1,495 @@
+// Non-GEMM layers of the Panoptic-DeepLab forward for gfx950: stem conv
+// (Cin = 1, fused normalisation + zero padding), 3x3/2 max-pool, 5x5 depthwise
+// conv, bilinear (align_corners=True) resampling, global average pool, tiny
+// fp32 GEMV (ASPP image-pooling branch) and the small-Cout 1x1 head conv.
+// All of them are HBM/L2-bound byte movers: NHWC fp16, 16-byte accesses per
+// lane, consecutive lanes on consecutive channel groups (coalesced).
+#include "common.h"
+
+namespace emp {
+namespace {
+
+// ---------------------------------------------------------------------------
+// stem: 7x7 stride-2 pad-3 conv, 1 -> 64 channels, + bias + ReLU
+// reference: encoders/resnet.py:164-167,219-221 (conv1+bn1+relu, BN folded)
+// One block = 16x16 output pixels; thread = 16 channels x 4 pixels.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) stem7x7_kernel(const T* __restrict__ img, float sub, float mul, int N,
+                                                      int H, int W, int vh, int vw, const float* __restrict__ wgt,
+                                                      const float* __restrict__ bias, half_t* __restrict__ out,
+                                                      int normalise) {
+  constexpr int TO = 16, PI = TO * 2 + 5;  // 37
+  __shared__ float patch[PI][PI + 1];
+  __shared__ __attribute__((aligned(16))) float wl[49][64];
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int tiles_x = (Wo + TO - 1) / TO;
+  const int tiles_y = (Ho + TO - 1) / TO;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y; b /= tiles_y;
+  const int n = b;
+  const int oy0 = ty * TO, ox0 = tx * TO;
+  const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
+  const int tid = threadIdx.x;
+  const T* src = img + (size_t)n * vh * vw;
+  for (int i = tid; i < PI * PI; i += 256) {
+    int py = i / PI, px = i - py * PI;
+    int iy = iy0 + py, ix = ix0 + px;
+    float v = 0.f;
+    if (iy >= 0 && iy < vh && ix >= 0 && ix < vw) {
+      v = (float)src[(size_t)iy * vw + ix];
+      if (normalise) { v -= sub; v *= mul; }
+    }
+    patch[py][px] = v;
+  }
+  for (int i = tid; i < 49 * 64; i += 256) (&wl[0][0])[i] = wgt[i];
+  __syncthreads();
+
+  const int cg = tid & 3;    // 16-channel group
+  const int pl = tid >> 2;   // 0..63
+  float acc[4][16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[k][c] = 0.f;
+  int py[4], px[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int idx = pl + 64 * k;
+    py[k] = idx >> 4;
+    px[k] = idx & 15;
+  }
+  for (int ky = 0; ky < 7; ++ky) {
+    for (int kx = 0; kx < 7; ++kx) {
+      float wv[16];
+      const float4* wp = reinterpret_cast<const float4*>(&wl[ky * 7 + kx][cg * 16]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 t = wp[q];
+        wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float x = patch[py[k] * 2 + ky][px[k] * 2 + kx];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[k][c] = fmaf(x, wv[c], acc[k][c]);
+      }
+    }
+  }
+  float bv[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) bv[c] = bias[cg * 16 + c];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int oy = oy0 + py[k], ox = ox0 + px[k];
+    if (oy >= Ho || ox >= Wo) continue;
+    f16x8 o0, o1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float a = acc[k][c] + bv[c];
+      float d = acc[k][8 + c] + bv[8 + c];
+      o0[c] = (half_t)(a > 0.f ? a : 0.f);
+      o1[c] = (half_t)(d > 0.f ? d : 0.f);
+    }
+    half_t* dst = out + (((size_t)n * Ho + oy) * Wo + ox) * 64 + cg * 16;
+    *reinterpret_cast<f16x8*>(dst) = o0;
+    *reinterpret_cast<f16x8*>(dst + 8) = o1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 stride-2 pad-1 max-pool (encoders/resnet.py:168,222)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const half_t* __restrict__ in, int N, int H, int W, int C,
+                                                           half_t* __restrict__ out, int64_t total) {
+  const int CG = C >> 3;
+  const int Ho = H >> 1, Wo = W >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int cg = (int)(i % CG);
+    int64_t p = i / CG;
+    int ox = (int)(p % Wo); p /= Wo;
+    int oy = (int)(p % Ho);
+    int n = (int)(p / Ho);
+    float m[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) m[c] = -INFINITY;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      int iy = oy * 2 + dy;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        int ix = ox * 2 + dx;
+        if (ix < 0 || ix >= W) continue;
+        f16x8 v = *reinterpret_cast<const f16x8*>(in + (((size_t)n * H + iy) * W + ix) * C + cg * 8);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) m[c] = fmaxf(m[c], (float)v[c]);
+      }
+    }
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (half_t)m[c];
+    *reinterpret_cast<f16x8*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + cg * 8) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// 5x5 depthwise conv, stride 1, pad 2, no bias (blocks.py:24-29, first conv of
+// SeparableConv2d).  thread = 8 channels x 4 consecutive output columns.
+// weights fp32 [25][C].
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dwconv5x5_kernel(const half_t* __restrict__ in, int N, int H, int W, int C,
+                                                        int in_ld, const float* __restrict__ wgt,
+                                                        half_t* __restrict__ out, int out_ld, int64_t total) {
+  const int CG = C >> 3;
+  const int WQ = (W + 3) >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int cg = (int)(i % CG);
+    int64_t p = i / CG;
+    int xq = (int)(p % WQ); p /= WQ;
+    int oy = (int)(p % H);
+    int n = (int)(p / H);
+    const int ox0 = xq * 4;
+    float acc[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      int iy = oy + ky - 2;
+      if (iy < 0 || iy >= H) continue;
+      const half_t* rowp = in + ((size_t)n * H + iy) * W * in_ld + cg * 8;
+      float xv[8][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int ix = ox0 + j - 2;
+        if (ix >= 0 && ix < W) {
+          f16x8 v = *reinterpret_cast<const f16x8*>(rowp + (size_t)ix * in_ld);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) xv[j][c] = (float)v[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) xv[j][c] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        const float4* wp = reinterpret_cast<const float4*>(wgt + (size_t)(ky * 5 + kx) * C + cg * 8);
+        float4 w0 = wp[0], w1 = wp[1];
+        float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[k][c] = fmaf(xv[k + kx][c], wv[c], acc[k][c]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int ox = ox0 + k;
+      if (ox >= W) continue;
+      f16x8 o;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = (half_t)acc[k][c];
+      *reinterpret_cast<f16x8*>(out + (((size_t)n * H + oy) * W + ox) * out_ld + cg * 8) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// bilinear resize, align_corners=True, NHWC fp16 (decoders/panoptic_deeplab.py:75)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bilinear_ac_kernel(const half_t* __restrict__ in, int N, int h, int w, int C,
+                                                          int in_ld, half_t* __restrict__ out, int H, int W,
+                                                          int out_ld, float sy, float sx, int64_t total) {
+  const int CG = C >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int cg = (int)(i % CG);
+    int64_t p = i / CG;
+    int ox = (int)(p % W); p /= W;
+    int oy = (int)(p % H);
+    int n = (int)(p / H);
+    float fy = sy * (float)oy, fx = sx * (float)ox;
+    int y0 = (int)fy, x0 = (int)fx;
+    int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    float ly = fy - (float)y0, lx = fx - (float)x0;
+    float hy = 1.f - ly, hx = 1.f - lx;
+    const half_t* base = in + (size_t)n * h * w * in_ld + cg * 8;
+    f16x8 v00 = *reinterpret_cast<const f16x8*>(base + ((size_t)y0 * w + x0) * in_ld);
+    f16x8 v01 = *reinterpret_cast<const f16x8*>(base + ((size_t)y0 * w + x1) * in_ld);
+    f16x8 v10 = *reinterpret_cast<const f16x8*>(base + ((size_t)y1 * w + x0) * in_ld);
+    f16x8 v11 = *reinterpret_cast<const f16x8*>(base + ((size_t)y1 * w + x1) * in_ld);
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float r = hy * (hx * (float)v00[c] + lx * (float)v01[c]) + ly * (hx * (float)v10[c] + lx * (float)v11[c]);
+      o[c] = (half_t)r;
+    }
+    *reinterpret_cast<f16x8*>(out + (((size_t)n * H + oy) * W + ox) * out_ld + cg * 8) = o;
+  }
+}
+
+// fp32 NCHW planes, integer scale, align_corners=True (Interpolate2d(4), panoptic_deeplab.py:89)
+__global__ void __launch_bounds__(256) bilinear_ac_f32_kernel(const float* __restrict__ in, int NC, int h, int w,
+                                                              float* __restrict__ out, int H, int W, float sy,
+                                                              float sx, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int ox = (int)(i % W);
+    int64_t p = i / W;
+    int oy = (int)(p % H);
+    int nc = (int)(p / H);
+    float fy = sy * (float)oy, fx = sx * (float)ox;
+    int y0 = (int)fy, x0 = (int)fx;
+    int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    float ly = fy - (float)y0, lx = fx - (float)x0;
+    float hy = 1.f - ly, hx = 1.f - lx;
+    const float* b = in + (size_t)nc * h * w;
+    out[i] = hy * (hx * b[y0 * w + x0] + lx * b[y0 * w + x1]) + ly * (hx * b[y1 * w + x0] + lx * b[y1 * w + x1]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// global average pool (decoders/aspp.py:33 AdaptiveAvgPool2d(1)): two stages,
+// fixed summation order (deterministic).
+// stage 1: grid (N, C/256, SEG): partial sums over a pixel segment
+// stage 2: sum SEG partials, scale by 1/HW
+// ---------------------------------------------------------------------------
+constexpr int AVG_SEG = 16;
+__global__ void __launch_bounds__(256) avgpool_partial_kernel(const half_t* __restrict__ in, int HW, int C, int in_ld,
+                                                              float* __restrict__ part) {
+  const int n = blockIdx.x, cb = blockIdx.y, seg = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int cg = tid & 31, pr = tid >> 5;  // 32 channel groups x 8 pixel lanes
+  const int c0 = cb * 256 + cg * 8;
+  const int per = (HW + AVG_SEG - 1) / AVG_SEG;
+  const int p0 = seg * per, p1 = min(HW, p0 + per);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < C) {
+    const half_t* base = in + (size_t)n * HW * in_ld + c0;
+    for (int p = p0 + pr; p < p1; p += 8) {
+      f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)p * in_ld);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s[c] += (float)v[c];
+    }
+  }
+  __shared__ float red[8][256 + 8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) red[pr][cg * 8 + c] = s[c];
+  __syncthreads();
+  if (tid < 256) {
+    int c = cb * 256 + tid;
+    if (c < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += red[r][tid];
+      part[((size_t)n * AVG_SEG + seg) * C + c] = t;
+    }
+  }
+}
+__global__ void avgpool_final_kernel(const float* __restrict__ part, int C, float inv, float* __restrict__ out,
+                                     int total) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int n = i / C, c = i - n * C;
+  float t = 0.f;
+  for (int s = 0; s < AVG_SEG; ++s) t += part[((size_t)n * AVG_SEG + s) * C + c];
+  out[i] = t * inv;
+}
+
+// one wave per output element
+__global__ void __launch_bounds__(256) gemv_kernel(const float* __restrict__ in, int N, int K,
+                                                   const float* __restrict__ w, const float* __restrict__ b, int Cout,
+                                                   int relu, float* __restrict__ out) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= N * Cout) return;
+  const int n = wave / Cout, co = wave - n * Cout;
+  const float* x = in + (size_t)n * K;
+  const float* wr = w + (size_t)co * K;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s = fmaf(x[k], wr[k], s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    if (b) s += b[co];
+    if (relu) s = s > 0.f ? s : 0.f;
+    out[wave] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// small-Cout 1x1 conv with bias, fp16 NHWC rows in -> fp32 NCHW planes out
+// (heads.py:14 final nn.Conv2d(nin, n_classes, 1); PointRend predictor
+// point_rend.py:162).  Half a wave (32 lanes x 8 channels) per row.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) head1x1_kernel(const half_t* __restrict__ in, int N, int P, int K, int in_ld,
+                                                      const float* __restrict__ w, const float* __restrict__ b, int C,
+                                                      float* __restrict__ out, int64_t plane,
+                                                      const int32_t* __restrict__ scatter_idx) {
+  const int lane = threadIdx.x & 63;
+  const int hl = lane & 31;
+  const int half_id = ((blockIdx.x * 256 + threadIdx.x) >> 5);
+  const int nhalf = (gridDim.x * 256) >> 5;
+  const int64_t rows = (int64_t)N * P;
+  const int KC = K >> 3;
+  for (int64_t r = half_id; r < rows; r += nhalf) {
+    float xv[2][8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int kc = hl + 32 * j;
+      if (kc < KC) {
+        f16x8 v = *reinterpret_cast<const f16x8*>(in + (size_t)r * in_ld + kc * 8);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xv[j][c] = (float)v[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xv[j][c] = 0.f;
+      }
+    }
+    const int n = (int)(r / P);
+    const int pr = (int)(r - (int64_t)n * P);
+    const int64_t pix = scatter_idx ? (int64_t)scatter_idx[r] : (int64_t)pr;
+    for (int c = 0; c < C; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int kc = hl + 32 * j;
+        if (kc < KC) {
+          const float4* wp = reinterpret_cast<const float4*>(w + (size_t)c * K + kc * 8);
+          float4 w0 = wp[0], w1 = wp[1];
+          s = fmaf(xv[j][0], w0.x, s); s = fmaf(xv[j][1], w0.y, s);
+          s = fmaf(xv[j][2], w0.z, s); s = fmaf(xv[j][3], w0.w, s);
+          s = fmaf(xv[j][4], w1.x, s); s = fmaf(xv[j][5], w1.y, s);
+          s = fmaf(xv[j][6], w1.z, s); s = fmaf(xv[j][7], w1.w, s);
+        }
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (hl == 0) out[((size_t)n * C + c) * plane + pix] = s + b[c];
+    }
+  }
+}
+
+__global__ void zero_kernel(uint4* p, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+    p[i] = uint4{0, 0, 0, 0};
+}
+
+inline int grid_for(int64_t total, int per_block = 256, int cap = 256 * 16) {
+  int64_t g = (total + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+int launch_stem7x7(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
+                   const float* w, const float* b, half_t* out, hipStream_t s) {
+  EMP_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H, W must be even");
+  const int Ho = H / 2, Wo = W / 2;
+  const int grid = N * cdiv(Ho, 16) * cdiv(Wo, 16);
+  switch (dtype) {
+    case EMP_IMG_F32:
+      hipLaunchKernelGGL(stem7x7_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)img, sub, mul, N, H, W, vh,
+                         vw, w, b, out, 0);
+      break;
+    case EMP_IMG_U8:
+      hipLaunchKernelGGL(stem7x7_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, (const uint8_t*)img, sub, mul, N, H, W,
+                         vh, vw, w, b, out, 1);
+      break;
+    case EMP_IMG_U16:
+      hipLaunchKernelGGL(stem7x7_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)img, sub, mul, N, H,
+                         W, vh, vw, w, b, out, 1);
+      break;
+    default:
+      EMP_REQUIRE(false, "stem: unknown image dtype %d", dtype);
+  }
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_maxpool3x3s2(const half_t* in, int N, int H, int W, int C, half_t* out, hipStream_t s) {
+  EMP_REQUIRE(C % 8 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: bad shape");
+  int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, N, H, W, C, out, total);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_dwconv5x5(const half_t* in, int N, int H, int W, int C, int in_ld, const float* w, half_t* out, int out_ld,
+                     hipStream_t s) {
+  EMP_REQUIRE(C % 8 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0, "dwconv: channels must be multiples of 8");
+  int64_t total = (int64_t)N * H * ((W + 3) / 4) * (C / 8);
+  hipLaunchKernelGGL(dwconv5x5_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, N, H, W, C, in_ld, w,
+                     out, out_ld, total);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_bilinear_ac(const half_t* in, int N, int h, int w, int C, int in_ld, half_t* out, int H, int W, int out_ld,
+                       hipStream_t s) {
+  EMP_REQUIRE(C % 8 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0, "bilinear: channels must be multiples of 8");
+  // area_pixel_compute_scale(align_corners=True): (in-1)/(out-1), 0 when out == 1
+  float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+  float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  int64_t total = (int64_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(bilinear_ac_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, N, h, w, C, in_ld,
+                     out, H, W, out_ld, sy, sx, total);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_bilinear_ac_f32_nchw(const float* in, int NC, int h, int w, float* out, int scale, hipStream_t s) {
+  const int H = h * scale, W = w * scale;
+  float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+  float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  int64_t total = (int64_t)NC * H * W;
+  hipLaunchKernelGGL(bilinear_ac_f32_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, NC, h, w, out, H, W, sy, sx,
+                     total);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+// part: scratch of N*AVG_SEG*C floats
+int launch_avgpool(const half_t* in, int N, int HW, int C, int in_ld, float* out, float* part, hipStream_t s) {
+  EMP_REQUIRE(C % 8 == 0, "avgpool: C must be a multiple of 8");
+  hipLaunchKernelGGL(avgpool_partial_kernel, dim3(N, cdiv(C, 256), AVG_SEG), dim3(256), 0, s, in, HW, C, in_ld, part);
+  EMP_LAUNCH_CHECK();
+  const int total = N * C;
+  hipLaunchKernelGGL(avgpool_final_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, part, C, 1.0f / (float)HW, out,
+                     total);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+int avgpool_scratch_floats(int N, int C) { return N * AVG_SEG * C; }
+
+int launch_gemv(const float* in, int N, int K, const float* w, const float* b, int Cout, int relu, float* out,
+                hipStream_t s) {
+  const int waves = N * Cout;
+  hipLaunchKernelGGL(gemv_kernel, dim3(cdiv(waves, 4)), dim3(256), 0, s, in, N, K, w, b, Cout, relu, out);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_head1x1(const half_t* in, int N, int P, int K, int in_ld, const float* w, const float* b, int C, float* out,
+                   int64_t plane_size, const int32_t* scatter_idx, hipStream_t s) {
+  EMP_REQUIRE(K % 8 == 0 && K <= 512, "head1x1: K=%d must be a multiple of 8 and <= 512", K);
+  int64_t rows = (int64_t)N * P;
+  hipLaunchKernelGGL(head1x1_kernel, dim3(grid_for(rows, 8, 256 * 8)), dim3(256), 0, s, in, N, P, K, in_ld, w, b, C,
+                     out, plane_size, scatter_idx);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_zero(void* p, size_t bytes, hipStream_t s) {
+  EMP_REQUIRE(bytes % 16 == 0 && ((uintptr_t)p % 16) == 0, "zero: 16-byte granularity");
+  if (bytes == 0) return EMP_OK;
+  size_t n16 = bytes / 16;
+  hipLaunchKernelGGL(zero_kernel, dim3(grid_for((int64_t)n16)), dim3(256), 0, s, (uint4*)p, n16);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+}  // namespace emp

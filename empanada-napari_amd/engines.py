@@ -1,0 +1,363 @@
+"""MI355X mirror of ``empanada.inference.engines`` (Render engines + median queue).
+
+Same class names, constructor arguments, attributes and error behaviour as the
+reference (empanada/inference/engines.py:223-394) so callers such as
+``empanada_napari.inference.Engine2d/Engine3d`` can swap the import.  All
+arithmetic runs in libempanada_hip.so through the C ABI (``_abi``); torch is
+used for device memory and streams only.  There is no CPU path: constructing
+an engine without a HIP device raises.
+
+``HipPanopticDeepLab`` plays the role of the TorchScript model
+(``model(image, render_steps, interpolate_ins) -> dict``, engines.py:250).
+"""
+import ctypes as C
+import math
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _abi, weights
+
+__all__ = ['HipPanopticDeepLab', 'PanopticDeepLabRenderEngine', 'PanopticDeepLabRenderEngine3d',
+           'factor_pad', 'logits_to_prob']
+
+IMG_DTYPES = {torch.float32: 0, torch.uint8: 1, torch.int16: 2, torch.uint16: 2}
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise RuntimeError('empanada_napari_amd needs a HIP device (MI355X); there is no CPU fallback')
+    return torch.device(device)
+
+
+def factor_pad(tensor, factor=16):
+    """postprocess.py:25-36."""
+    h, w = tensor.size()[2:]
+    pad_bottom = factor - h % factor if h % factor != 0 else 0
+    pad_right = factor - w % factor if w % factor != 0 else 0
+    if pad_bottom == 0 and pad_right == 0:
+        return tensor
+    return F.pad(tensor, (0, pad_right, 0, pad_bottom))
+
+
+class HipPanopticDeepLab:
+    """Panoptic-DeepLab(+PointRend) forward on the HIP engine.
+
+    ``state_dict``: reference-layout parameters (unfused or ``fuse_model()``
+    layout; torch tensors or numpy arrays), or an already folded dict from
+    ``weights.fold_state_dict``.
+    """
+
+    def __init__(self, state_dict, cfg=None, device='cuda:0', folded=False):
+        self.device = _require_gpu(device)
+        self.cfg = dict(weights.MITONET_PDL_CFG, **(cfg or {}))
+        self.lib = _abi.load()
+        c = _abi.PdlConfig()
+        cfgd = self.cfg
+        c.num_classes = cfgd['num_classes']
+        c.stage4_stride = cfgd['stage4_stride']
+        c.decoder_channels = cfgd['decoder_channels']
+        c.aspp_channels = cfgd['aspp_channels'] or 0
+        stages = cfgd['low_level_stages']
+        c.n_stages = len(stages)
+        for i, s in enumerate(stages):
+            c.low_level_stages[i] = s
+            c.low_level_proj_sem[i] = cfgd['low_level_channels_project'][i]
+            c.low_level_proj_ins[i] = int(cfgd['low_level_channels_project'][i] * cfgd['ins_ratio'])
+        for i, r in enumerate(cfgd['atrous_rates']):
+            c.atrous_rates[i] = r
+        c.ins_decoder = int(bool(cfgd['ins_decoder']))
+        c.num_fc = cfgd['num_fc']
+        c.subdivision_num_points = cfgd['subdivision_num_points']
+        self._h = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        _abi.check(self.lib.emp_pdl_create(C.byref(c), C.byref(self._h)), 'emp_pdl_create')
+        P = state_dict if folded else weights.fold_state_dict(state_dict, self.cfg)
+        n = self.lib.emp_pdl_num_params(self._h)
+        names = [self.lib.emp_pdl_param_name(self._h, i).decode() for i in range(n)]
+        missing = [k for k in names if k not in P]
+        if missing:
+            raise KeyError(f'missing parameters: {missing[:5]}...')
+        for k in names:
+            w, b = P[k]
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            shape = (C.c_int64 * w.ndim)(*w.shape)
+            _abi.check(self.lib.emp_pdl_set_param(self._h, k.encode(), w.ctypes.data_as(C.c_void_p), shape, w.ndim,
+                                                  b.ctypes.data_as(C.c_void_p)), f'set_param({k})')
+        _abi.check(self.lib.emp_pdl_finalize(self._h), 'emp_pdl_finalize')
+        self._dummy = torch.zeros(1, device=self.device)
+        self.num_classes = cfgd['num_classes']
+
+    # --- the reference's model contract (engines.py:34,41,250) ---
+    def eval(self):
+        return self
+
+    def parameters(self):
+        yield self._dummy
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.emp_pdl_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def reserve(self, N, H, W):
+        _abi.check(self.lib.emp_pdl_reserve(self._h, N, H, W), 'emp_pdl_reserve')
+
+    def arena_bytes(self):
+        return int(self.lib.emp_pdl_arena_bytes(self._h))
+
+    def last_flops(self):
+        return float(self.lib.emp_pdl_flops(self._h, 0, 0, 0, 0))
+
+    @torch.no_grad()
+    def __call__(self, image, render_steps=2, interpolate_ins=True, sub=0.0, mul=1.0, out=None):
+        """image: (N,1,H,W) cuda tensor, float32 (normalised) or uint8/uint16 (raw; then
+        ``sub``/``mul`` are the normalisation constants).  Returns the reference's dict."""
+        assert image.ndim == 4 and image.size(1) == 1, 'expected (N,1,H,W)'
+        if image.device != self.device:
+            image = image.to(self.device, non_blocking=True)
+        image = image.contiguous()
+        dt = IMG_DTYPES.get(image.dtype)
+        if dt is None:
+            raise TypeError(f'unsupported image dtype {image.dtype}')
+        N, _, H, W = image.shape
+        up = 2 ** (render_steps - 2) if render_steps >= 2 else 1.0 / (2 ** (2 - render_steps))
+        Hs, Ws = int(H * up), int(W * up)
+        hq, wq = (H, W) if interpolate_ins else (H // 4, W // 4)
+        if out is None:
+            sem = torch.empty((N, self.num_classes, Hs, Ws), dtype=torch.float32, device=self.device)
+            ctr = torch.empty((N, 1, hq, wq), dtype=torch.float32, device=self.device)
+            off = torch.empty((N, 2, hq, wq), dtype=torch.float32, device=self.device)
+        else:
+            sem, ctr, off = out
+        _abi.check(self.lib.emp_pdl_forward(self._h, _abi.ptr(image), dt, float(sub), float(mul), N, H, W,
+                                            int(render_steps), int(bool(interpolate_ins)), _abi.ptr(sem),
+                                            _abi.ptr(ctr), _abi.ptr(off), _abi.stream_ptr(self.device)),
+                   'emp_pdl_forward')
+        return {'sem_logits': sem, 'ctr_hmp': ctr, 'offsets': off}
+
+    def tap(self, name):
+        """fp16 NHWC activation of the last forward, as a (N,H,W,C) torch view (parity tests)."""
+        p = C.c_void_p()
+        shp = (C.c_int64 * 5)()
+        _abi.check(self.lib.emp_pdl_tap(self._h, name.encode(), C.byref(p), shp), f'tap({name})')
+        N, H, W, Cc, ld = [int(v) for v in shp]
+        t = torch.empty((N, H, W, ld), dtype=torch.float16, device=self.device)
+        _abi.check(self.lib.emp_copy_d2d(_abi.ptr(t), p, t.numel() * 2, _abi.stream_ptr(self.device)), 'emp_copy_d2d')
+        return t[..., :Cc]
+
+    def tap_names(self):
+        n = self.lib.emp_pdl_num_taps(self._h)
+        return [self.lib.emp_pdl_tap_name(self._h, i).decode() for i in range(n)]
+
+
+@torch.no_grad()
+def logits_to_prob(logits):
+    """engines.py:22-30 on the device."""
+    lib = _abi.load()
+    logits = logits.contiguous()
+    out = torch.empty_like(logits)
+    N, Cc, H, W = logits.shape
+    _abi.check(lib.emp_logits_to_prob(_abi.ptr(logits), _abi.ptr(out), N, Cc, H, W, _abi.stream_ptr(logits.device)),
+               'emp_logits_to_prob')
+    return out
+
+
+class _Engine:
+    def __init__(self, model):
+        self.model = model.eval()
+
+    def to_model_device(self, tensor):
+        device = next(self.model.parameters()).device
+        return tensor.to(device, non_blocking=True)
+
+
+class _MedianQueue:
+    """engines.py:47-90; the median runs as one HIP kernel over the queued maps
+    and overwrites the middle item's ``sem`` in place (recursive filter, :76-84)."""
+
+    def __init__(self, median_kernel_size, **kwargs):
+        super().__init__(**kwargs)
+        assert median_kernel_size % 2 == 1, 'Kernel size must be odd integer!'
+        self.ks = median_kernel_size
+        self.mid_idx = (median_kernel_size - 1) // 2
+        self.median_queue = deque(maxlen=median_kernel_size)
+
+    def reset(self):
+        self.median_queue = deque(maxlen=self.ks)
+
+    @torch.no_grad()
+    def get_median(self, key):
+        lib = _abi.load()
+        maps = [o[key].contiguous() for o in self.median_queue]
+        ks = len(maps)
+        out = torch.empty_like(maps[0])
+        ptrs = (C.c_void_p * ks)(*[m.data_ptr() for m in maps])
+        _abi.check(lib.emp_median_slices(ptrs, ks, _abi.ptr(out), maps[0].numel(), _abi.stream_ptr(out.device)),
+                   'emp_median_slices')
+        return out
+
+    def get_next(self, keys):
+        nq = len(self.median_queue)
+        if nq <= self.mid_idx:
+            output = self.median_queue[-1]
+        elif nq > self.mid_idx and nq < self.ks:
+            return None
+        elif nq == self.ks:
+            output = self.median_queue[self.mid_idx]
+            for key in keys:
+                output[key] = self.get_median(key)
+        return output
+
+    def enqueue(self, item):
+        self.median_queue.append(item)
+
+    def end(self):
+        return list(self.median_queue)[self.mid_idx + 1:]
+
+
+class PanopticDeepLabRenderEngine(_Engine):
+    """engines.py:223-325."""
+    MAX_CENTERS = 4096
+
+    def __init__(self, model, thing_list, label_divisor=1000, stuff_area=64, void_label=0, nms_threshold=0.1,
+                 nms_kernel=7, confidence_thr=0.5, padding_factor=16, coarse_boundaries=True, **kwargs):
+        super().__init__(model=model)
+        self.thing_list = thing_list
+        self.label_divisor = label_divisor
+        self.stuff_area = stuff_area
+        self.void_label = void_label
+        self.nms_threshold = nms_threshold
+        self.nms_kernel = nms_kernel
+        self.confidence_thr = confidence_thr
+        self.padding_factor = padding_factor
+        self.coarse_boundaries = coarse_boundaries
+        self.lib = _abi.load()
+
+    @torch.no_grad()
+    def infer(self, image, render_steps=2):
+        model_out = self.model(image, render_steps, interpolate_ins=not self.coarse_boundaries)
+        model_out['sem'] = logits_to_prob(model_out['sem_logits'])
+        return model_out
+
+    # ---- batched building blocks (N images per launch group) ----
+    @torch.no_grad()
+    def instance_cells_int(self, ctr_hmp, offsets, upsampling=1):
+        """-> (cells (N,H,W) int32, centers (N,MAX,2) int32, num_centers (N,) int32)."""
+        ctr_hmp = ctr_hmp.contiguous().float()
+        offsets = offsets.contiguous().float()
+        N, _, h, w = ctr_hmp.shape
+        step = 4 if self.coarse_boundaries else 1
+        up = int(upsampling * step)
+        dev = ctr_hmp.device
+        cells = torch.empty((N, h * up, w * up), dtype=torch.int32, device=dev)
+        max_c = self.MAX_CENTERS
+        while True:
+            centers = torch.empty((N, max_c, 2), dtype=torch.int32, device=dev)
+            num = torch.empty((N,), dtype=torch.int32, device=dev)
+            work = torch.empty((int(self.lib.emp_instance_cells_work_bytes(N, h, w)),), dtype=torch.uint8, device=dev)
+            _abi.check(self.lib.emp_instance_cells(_abi.ptr(ctr_hmp), _abi.ptr(offsets), N, h, w,
+                                                   float(self.nms_threshold), int(self.nms_kernel), step, up,
+                                                   _abi.ptr(cells), _abi.ptr(centers), _abi.ptr(num), max_c,
+                                                   _abi.ptr(work), _abi.stream_ptr(dev)), 'emp_instance_cells')
+            kmax = int(num.max().item())
+            if kmax <= max_c:
+                return cells, centers, num, kmax
+            max_c = 1 << (kmax - 1).bit_length()  # rare: more centres than the default bound, redo exactly
+
+    @torch.no_grad()
+    def panoptic_merge_int(self, sem, cells, max_ids):
+        """sem (N,C,H,W) probabilities, cells (N,H,W) int32 -> pan (N,H,W) int64."""
+        sem = sem.contiguous().float()
+        N, Cc, H, W = sem.shape
+        assert cells.shape == (N, H, W), f'{cells.shape} vs {(N, H, W)}'
+        dev = sem.device
+        pan = torch.empty((N, H, W), dtype=torch.int64, device=dev)
+        work = torch.empty((int(self.lib.emp_panoptic_merge_work_bytes(N, Cc, max_ids)),), dtype=torch.uint8, device=dev)
+        tl = (C.c_int32 * max(1, len(self.thing_list)))(*self.thing_list)
+        _abi.check(self.lib.emp_panoptic_merge(_abi.ptr(sem), _abi.ptr(cells.contiguous()), N, Cc, H, W,
+                                               float(self.confidence_thr), tl, len(self.thing_list),
+                                               int(self.label_divisor), int(self.stuff_area), int(self.void_label),
+                                               int(max_ids), _abi.ptr(pan), _abi.ptr(work), _abi.stream_ptr(dev)),
+                   'emp_panoptic_merge')
+        return pan
+
+    # ---- the reference's single-image API ----
+    @torch.no_grad()
+    def get_instance_cells(self, ctr_hmp, offsets, upsampling=1):
+        cells, _, _, _ = self.instance_cells_int(ctr_hmp, offsets, upsampling)
+        return cells.float()[:, None]  # (1,1,H,W) float, as engines.py:271-275
+
+    @torch.no_grad()
+    def get_panoptic_seg(self, sem, instance_cells):
+        raise NotImplementedError('use postprocess(sem, instance_cells)')
+
+    @torch.no_grad()
+    def postprocess(self, sem, instance_cells):
+        cells = instance_cells.reshape(sem.shape[0], sem.shape[-2], sem.shape[-1]).to(torch.int32)
+        max_ids = int(cells.max().item())
+        return self.panoptic_merge_int(sem, cells, max_ids)
+
+    def __call__(self, image, size, upsampling=1):
+        assert math.log(upsampling, 2).is_integer(), 'Upsampling factor not log base 2!'
+        assert image.ndim == 4 and image.size(0) == 1
+        h, w = size
+        image = factor_pad(image, self.padding_factor)
+        image = self.to_model_device(image)
+        model_out = self.infer(image, int(2 + math.log(upsampling, 2)))
+        cells, _, _, kmax = self.instance_cells_int(model_out['ctr_hmp'], model_out['offsets'], upsampling)
+        pan_seg = self.panoptic_merge_int(model_out['sem'], cells, kmax)
+        return pan_seg[..., :h, :w]
+
+    # ---- batched extension (config 2: "equal to N sequential reference calls") ----
+    @torch.no_grad()
+    def infer_batch(self, images, sizes=None, upsampling=1, sub=0.0, mul=1.0):
+        """images (N,1,H,W) already padded to ``padding_factor``; returns pan (N,H,W) int64."""
+        rs = int(2 + math.log(upsampling, 2))
+        out = self.model(images, rs, interpolate_ins=not self.coarse_boundaries, sub=sub, mul=mul)
+        sem = logits_to_prob(out['sem_logits'])
+        cells, _, _, kmax = self.instance_cells_int(out['ctr_hmp'], out['offsets'], upsampling)
+        return self.panoptic_merge_int(sem, cells, kmax)
+
+
+class PanopticDeepLabRenderEngine3d(_MedianQueue, PanopticDeepLabRenderEngine):
+    """engines.py:327-394."""
+
+    def __init__(self, model, thing_list, label_divisor=1000, stuff_area=64, void_label=0, nms_threshold=0.1,
+                 nms_kernel=7, confidence_thr=0.5, median_kernel_size=3, padding_factor=16, coarse_boundaries=True,
+                 **kwargs):
+        super().__init__(model=model, thing_list=thing_list, label_divisor=label_divisor, stuff_area=stuff_area,
+                         void_label=void_label, nms_threshold=nms_threshold, nms_kernel=nms_kernel,
+                         confidence_thr=confidence_thr, median_kernel_size=median_kernel_size,
+                         padding_factor=padding_factor, coarse_boundaries=coarse_boundaries)
+
+    def _segment(self, model_out, upsampling):
+        cells, _, _, kmax = self.instance_cells_int(model_out['ctr_hmp'], model_out['offsets'], upsampling)
+        return self.panoptic_merge_int(model_out['sem'], cells, kmax)
+
+    def end(self, upsampling=1):
+        final_segs = []
+        for model_out in list(self.median_queue)[self.mid_idx + 1:]:
+            h, w = model_out['size']
+            final_segs.append(self._segment(model_out, upsampling)[..., :h, :w])
+        return final_segs
+
+    def __call__(self, image, size, upsampling=1):
+        assert math.log(upsampling, 2).is_integer(), 'Upsampling factor not log base 2!'
+        assert image.ndim == 4 and image.size(0) == 1
+        h, w = size
+        image = factor_pad(image, self.padding_factor)
+        image = self.to_model_device(image)
+        model_out = self.infer(image, int(2 + math.log(upsampling, 2)))
+        model_out['size'] = size
+        self.enqueue(model_out)
+        median_out = self.get_next(keys=['sem'])
+        if median_out is None:
+            return None
+        return self._segment(median_out, upsampling)[..., :h, :w]

@@ -1,0 +1,191 @@
+/*
+ * empanada_hip.h -- C ABI of libempanada_hip.so, the MI355X (gfx950) engine
+ * behind the empanada panoptic-inference hot path.
+ *
+ * The reference (volume-em/empanada-napari) has no FFI: its boundary for this
+ * path is the Python API of empanada/inference/engines.py and
+ * empanada_napari/inference.py.  Each entry point below replaces the work one
+ * of those Python functions hands to torch / torch.jit / numba, and cites it.
+ * The Python mirror of the reference classes (empanada-napari_amd/engines.py,
+ * inference.py) binds these symbols with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer owned by the caller;
+ *     h_* is a HOST pointer; `stream` is a hipStream_t passed as void*.
+ *   - return value: 0 on success, a negative emp_status otherwise; no C++
+ *     exception crosses the ABI; emp_last_error() returns a static message.
+ *   - nothing here synchronises the device except where stated (functions that
+ *     return a host count).
+ *   - dense float outputs use the reference's NCHW fp32 layout; label maps are
+ *     int32 or int64 as stated per function.
+ */
+#ifndef EMPANADA_HIP_H
+#define EMPANADA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define EMP_API __attribute__((visibility("default")))
+#else
+#define EMP_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  EMP_OK = 0,
+  EMP_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+  EMP_ERR_HIP = -2,       /* a HIP runtime call failed */
+  EMP_ERR_STATE = -3,     /* call order (missing parameter, not finalized) */
+  EMP_ERR_NOMEM = -4
+} emp_status;
+
+EMP_API const char* emp_last_error(void);
+EMP_API int emp_abi_version(void);
+/* number of visible HIP devices, or a negative emp_status */
+EMP_API int emp_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * 1. Network forward (hot loop 1)
+ *    replaces: model(image, render_steps, interpolate_ins) as called from
+ *    PanopticDeepLabRenderEngine.infer, empanada/inference/engines.py:248-255,
+ *    i.e. QuantizablePanopticDeepLabPR.forward,
+ *    empanada/models/quantization/panoptic_deeplab.py:238-250.
+ * ---------------------------------------------------------------------- */
+typedef struct emp_pdl emp_pdl_t;
+
+typedef struct {
+  int32_t num_classes;            /* semantic channels C (1 = binary/sigmoid)          */
+  int32_t stage4_stride;          /* 16 (layer4 dilated) or 32                         */
+  int32_t decoder_channels;       /* 256                                               */
+  int32_t aspp_channels;          /* 0 -> decoder_channels                             */
+  int32_t n_stages;               /* number of low-level decoder stages (<=3)          */
+  int32_t low_level_stages[3];    /* pyramid index per stage (1..3)                    */
+  int32_t low_level_proj_sem[3];  /* projected channels, semantic decoder              */
+  int32_t low_level_proj_ins[3];  /* projected channels, instance decoder              */
+  int32_t atrous_rates[3];
+  int32_t ins_decoder;            /* 1: separate instance decoder                      */
+  int32_t num_fc;                 /* PointRend MLP depth (3)                           */
+  int32_t subdivision_num_points; /* 8192                                              */
+} emp_pdl_config;
+
+EMP_API int emp_pdl_create(const emp_pdl_config* cfg, emp_pdl_t** out);
+EMP_API void emp_pdl_destroy(emp_pdl_t* net);
+
+/* Folded fp32 parameter of one convolution, by the reference's module path
+ * (e.g. "encoder.layer1.0.conv1"); h_w is OIHW (or (O,I,1) for the PointRend
+ * Conv1d layers), h_b has shape[0] entries or is NULL (zero bias).  BatchNorm
+ * is already folded by the host (weights.fold_state_dict). */
+EMP_API int emp_pdl_set_param(emp_pdl_t* net, const char* name, const float* h_w,
+                      const int64_t* shape, int ndim, const float* h_b);
+/* Packs fp16 weights on the device; fails if a parameter is missing. */
+EMP_API int emp_pdl_finalize(emp_pdl_t* net);
+/* Number of parameters the network expects, and the name of the i-th one. */
+EMP_API int emp_pdl_num_params(const emp_pdl_t* net);
+EMP_API const char* emp_pdl_param_name(const emp_pdl_t* net, int i);
+
+/* (Re)allocates the activation arena for batches up to N x H x W.  Called
+ * implicitly by emp_pdl_forward when the shape grows; call it explicitly
+ * before capturing the forward into a hipGraph. */
+EMP_API int emp_pdl_reserve(emp_pdl_t* net, int N, int H, int W);
+EMP_API size_t emp_pdl_arena_bytes(const emp_pdl_t* net);
+
+typedef enum { EMP_IMG_F32 = 0, EMP_IMG_U8 = 1, EMP_IMG_U16 = 2 } emp_image_dtype;
+
+/* d_image: (N,H,W) single channel, H % 16 == 0 and W % 16 == 0
+ *   EMP_IMG_F32: already normalised (Preprocessor + factor_pad output);
+ *   EMP_IMG_U8/U16: raw tile, normalised in the stem as (x - sub) * mul
+ *   (empanada_napari/utils.py:153-165).
+ * Outputs (fp32, NCHW):
+ *   d_sem_logits (N, C, H*2^(rs-2), W*2^(rs-2))
+ *   d_ctr_hmp    (N, 1, h, w), d_offsets (N, 2, h, w) with h,w = H/4,W/4, or
+ *   H,W when interpolate_ins != 0 (bilinear x4, align_corners=True).  */
+EMP_API int emp_pdl_forward(emp_pdl_t* net, const void* d_image, int image_dtype,
+                    float sub, float mul, int N, int H, int W,
+                    int render_steps, int interpolate_ins,
+                    float* d_sem_logits, float* d_ctr_hmp, float* d_offsets,
+                    void* stream);
+
+/* Algorithmic FLOPs (2*MAC) of one forward at this shape: conv/GEMM work only. */
+EMP_API double emp_pdl_flops(const emp_pdl_t* net, int N, int H, int W, int render_steps);
+
+/* Parity/debug taps: keep every intermediate activation addressable by name
+ * after a forward ("stem", "encoder.layer1.0", ..., "semantic_x").  Returns
+ * the device pointer (fp16 NHWC) and shape {N,H,W,C,ld}. */
+EMP_API int emp_pdl_tap(emp_pdl_t* net, const char* name, void** d_ptr, int64_t shape5[5]);
+EMP_API int emp_pdl_num_taps(const emp_pdl_t* net);
+/* device-to-device copy on `stream` (lets a host language without a HIP binding read a tap) */
+EMP_API int emp_copy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
+EMP_API const char* emp_pdl_tap_name(const emp_pdl_t* net, int i);
+
+/* ------------------------------------------------------------------------
+ * 2. Building-block operators (used by the network, exported for parity
+ *    tests and for callers that run their own graph)
+ * ---------------------------------------------------------------------- */
+
+/* NHWC fp16 implicit-GEMM convolution on MFMA, fp32 accumulate, fused
+ * bias + per-image bias + residual + ReLU.  replaces: nn.Conv2d(+folded
+ * BatchNorm)(+ReLU)(+skip add), e.g. encoders/resnet.py:109-129.
+ *   d_in  : (N,H,W,in_ld) fp16, the conv reads channels [0,Cin); Cin % 64 == 0
+ *   d_w   : (Cout, KH*KW, Cin) fp16
+ *   d_bias: (Cout) fp32 or NULL;  d_bias_n: (N,Cout) fp32 or NULL
+ *   d_res : (N,Ho,Wo,res_ld) fp16 or NULL
+ *   d_out : (N,Ho,Wo,out_ld) fp16; writes channels [0,Cout); Cout % 8 == 0 */
+EMP_API int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_ld,
+                        const void* d_w, const float* d_bias, const float* d_bias_n,
+                        const void* d_res, int res_ld,
+                        void* d_out, int out_ld, int Cout,
+                        int KH, int KW, int stride, int pad, int dil, int relu,
+                        int variant, void* stream);
+
+/* ------------------------------------------------------------------------
+ * 3. Instance post-processing (hot loop 2), one launch group per batch
+ * ---------------------------------------------------------------------- */
+
+/* logits -> probabilities: sigmoid (C==1) or channel softmax (C>1).
+ * replaces logits_to_prob, engines.py:22-30.  (N,C,H,W) fp32 in/out. */
+EMP_API int emp_logits_to_prob(const float* d_logits, float* d_prob, int N, int C, int H, int W, void* stream);
+
+/* Recursive per-pixel median over a ks-deep queue of probability maps.
+ * replaces _MedianQueue.get_median, engines.py:59-66 (torch.cat + torch.median).
+ * d_slices: array of ks device pointers (host array), each (C,H,W) fp32;
+ * d_out may alias d_slices[mid] (that is what the reference does, :76-84). */
+EMP_API int emp_median_slices(const float* const* h_slice_ptrs, int ks, float* d_out,
+                      size_t count, void* stream);
+
+/* Centre NMS + voting + nearest upsampling: get_instance_cells,
+ * engines.py:257-275 (find_instance_center postprocess.py:38-76 and
+ * group_pixels :78-169).  Batched over N images.
+ *   d_ctr_hmp (N,1,h,w) fp32, d_offsets (N,2,h,w) fp32
+ *   step: 4 (coarse boundaries) or 1;  up = upsampling*step (nearest factor)
+ *   d_cells (N, h*up, w*up) int32: 0 where the image has no centre
+ *   d_centers (N, max_centers, 2) int32 (y,x) in row-major order,
+ *   d_num_centers (N) int32 (clamped to max_centers; overflow is reported by
+ *   a negative return of emp_instance_cells_check).
+ *   d_work: scratch of emp_instance_cells_work_bytes(N,h,w) bytes. */
+EMP_API size_t emp_instance_cells_work_bytes(int N, int h, int w);
+EMP_API int emp_instance_cells(const float* d_ctr_hmp, const float* d_offsets, int N, int h, int w,
+                       float nms_threshold, int nms_kernel, int step, int up,
+                       int32_t* d_cells, int32_t* d_centers, int32_t* d_num_centers,
+                       int max_centers, void* d_work, void* stream);
+
+/* harden + thing-mask + majority vote + per-class renumbering + stuff filter:
+ * PanopticDeepLabRenderEngine.postprocess, engines.py:277-298 with
+ * merge_semantic_and_instance, postprocess.py:223-296.  Batched over N.
+ *   d_sem (N,C,H,W) fp32 probabilities; d_cells (N,H,W) int32
+ *   thing_list: host array of n_things class ids
+ *   d_pan (N,H,W) int64 (reference dtype) ; max_ids: upper bound on cell ids
+ *   d_work: scratch of emp_panoptic_merge_work_bytes(N, C, max_ids) bytes */
+EMP_API size_t emp_panoptic_merge_work_bytes(int N, int C, int max_ids);
+EMP_API int emp_panoptic_merge(const float* d_sem, const int32_t* d_cells, int N, int C, int H, int W,
+                       float confidence_thr, const int32_t* h_thing_list, int n_things,
+                       int64_t label_divisor, int64_t stuff_area, int64_t void_label,
+                       int max_ids, int64_t* d_pan, void* d_work, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMPANADA_HIP_H */

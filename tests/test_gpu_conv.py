@@ -1,0 +1,68 @@
+"""Implicit-GEMM MFMA conv (csrc/conv_igemm.hip) vs a torch fp32 reference of
+the same op on the same fp16-rounded operands.  Tolerance: the kernel
+accumulates in fp32 and rounds the result to fp16 once -> |err| <= 2^-10 |y| +
+small accumulation-order noise; asserted as atol 2e-3*scale, rtol 2e-3."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, relu, res, bias_n
+    (2, 16, 16, 64, 64, 1, 1, 0, 1, True, False, False),
+    (1, 16, 24, 64, 256, 1, 1, 0, 1, True, True, False),
+    (2, 16, 16, 128, 128, 3, 1, 1, 1, True, False, False),
+    (1, 20, 12, 128, 128, 3, 2, 1, 1, True, False, False),     # stride 2, M tail
+    (1, 16, 16, 256, 512, 1, 2, 0, 1, False, False, False),    # downsample
+    (1, 12, 12, 512, 256, 3, 1, 6, 6, True, False, False),     # ASPP rate 6 (mostly padding)
+    (2, 8, 8, 2048, 256, 3, 1, 2, 2, True, False, False),      # ASPP rate 2, K = 18432
+    (2, 8, 8, 1024, 256, 1, 1, 0, 1, True, False, True),       # projection with per-image bias
+    (1, 24, 24, 256, 32, 1, 1, 0, 1, True, False, False),      # low-level project (Cout 32)
+    (1, 24, 24, 256, 16, 1, 1, 0, 1, True, False, False),      # Cout 16
+    (1, 16, 16, 288, 256, 1, 1, 0, 1, True, False, False),     # Cin padded 288 -> 320
+    (1, 1, 300, 257, 256, 1, 1, 0, 1, True, False, False),     # PointRend MLP shape (Cin 257)
+    (3, 9, 7, 64, 64, 3, 1, 1, 1, False, True, False),         # odd sizes + residual, no relu
+]
+
+
+@pytest.mark.parametrize('variant', [1, 2])
+@pytest.mark.parametrize('case', CASES)
+def test_conv_matches_fp32_reference(case, variant):
+    from gpu_common import conv_hip, conv_ref, dev
+    N, H, W, Cin, Cout, k, stride, pad, dil, relu, use_res, use_bn = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = (torch.randn((N, H, W, Cin), generator=g)).to(torch.float16).to(dev())
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (1.0 / np.sqrt(Cin * k * k))
+    b = torch.randn((Cout,), generator=g) * 0.1
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = torch.randn((N, Ho, Wo, Cout), generator=g).to(torch.float16).to(dev()) if use_res else None
+    bn = torch.randn((N, Cout), generator=g) * 0.2 if use_bn else None
+    y = conv_hip(x, w, b, bn, res, stride, pad, dil, relu, variant).float().cpu()
+    ref = conv_ref(x, w, b, bn, res, stride, pad, dil, relu)
+    err = (y - ref).abs()
+    tol = 2e-3 + 2e-3 * ref.abs()
+    assert torch.all(err <= tol), f'max err {err.max():.4e} at ref {ref.flatten()[err.argmax()]:.4f}'
+
+
+def test_conv_writes_only_its_channel_slice():
+    """torch.cat elimination: the conv writes channels [coff, coff+Cout) of a wider buffer."""
+    from gpu_common import conv_hip, conv_ref, dev
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((1, 8, 8, 64), generator=g).to(torch.float16).to(dev())
+    w = torch.randn((32, 64, 1, 1), generator=g) * 0.1
+    out = conv_hip(x, w, None, None, None, 1, 0, 1, True, 0, out_ld=320, out_coff=256).float().cpu()
+    ref = conv_ref(x, w, None, None, None, 1, 0, 1, True)
+    assert torch.all(out[..., :256] == 7.0) and torch.all(out[..., 288:] == 7.0)
+    assert torch.allclose(out[..., 256:288], ref, atol=2e-3, rtol=2e-3)
+
+
+def test_conv_rejects_bad_arguments():
+    from empanada_napari_amd import _abi
+    from gpu_common import dev
+    lib = _abi.load()
+    x = torch.zeros((1, 4, 4, 48), dtype=torch.float16, device=dev())
+    rc = lib.emp_conv2d_nhwc_f16(_abi.ptr(x), 1, 4, 4, 48, 48, _abi.ptr(x), None, None, None, 0, _abi.ptr(x), 8, 8,
+                                 1, 1, 1, 0, 1, 0, 0, None)
+    assert rc == -1 and b'multiple of 64' in lib.emp_last_error()

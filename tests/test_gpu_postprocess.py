@@ -1,0 +1,146 @@
+"""HIP instance post-processing vs the numpy oracle and the reference golden
+vectors: label maps must be bit-exact given identical fp32 head tensors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NSPEC = 9
+
+
+class _Fake:
+    """model stand-in returning canned head tensors (like the golden generator)."""
+
+    def __init__(self, outs):
+        self.outs = outs if isinstance(outs, list) else [outs]
+        self.i = 0
+        self._p = torch.zeros(1, device='cuda')
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        yield self._p
+
+    def __call__(self, x, render_steps=2, interpolate_ins=True):
+        o = self.outs[min(self.i, len(self.outs) - 1)]
+        self.i += 1
+        return {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in o.items()}
+
+
+def _case(g, i):
+    from empanada_napari_amd import synth
+    H, W, n, coarse, ncls, k = [int(v) for v in g[f'{i}_spec']]
+    thr = float(g[f'{i}_thr'])
+    sem, ctr, off = synth.head_outputs(H, W, n, seed=100 + i, coarse=bool(coarse), num_classes=ncls,
+                                       plateau=i in (3, 4, 6))
+    return H, W, bool(coarse), ncls, k, thr, sem, ctr, off
+
+
+@pytest.mark.parametrize('i', range(NSPEC))
+def test_cells_and_centers_match_reference(golden_dir, i):
+    from empanada_napari_amd.engines import PanopticDeepLabRenderEngine
+    g = np.load(os.path.join(golden_dir, 'postprocess.npz'))
+    H, W, coarse, ncls, k, thr, sem, ctr, off = _case(g, i)
+    eng = PanopticDeepLabRenderEngine(_Fake({}), [1], nms_threshold=thr, nms_kernel=k, coarse_boundaries=coarse)
+    cells, centers, num, kmax = eng.instance_cells_int(torch.from_numpy(ctr).cuda(), torch.from_numpy(off).cuda(), 1)
+    K = g[f'{i}_centers'].shape[0]
+    assert int(num[0]) == K == kmax
+    np.testing.assert_array_equal(centers[0, :K].cpu().numpy(), g[f'{i}_centers'])
+    np.testing.assert_array_equal(cells.cpu().numpy()[:, None], g[f'{i}_cells'])
+    f = eng.get_instance_cells(torch.from_numpy(ctr).cuda(), torch.from_numpy(off).cuda(), 1)
+    assert f.dtype == torch.float32 and tuple(f.shape) == g[f'{i}_cells'].shape
+
+
+@pytest.mark.parametrize('i', range(NSPEC))
+@pytest.mark.parametrize('divisor,conf', [(1000, 0.5), (10000, 0.3)])
+def test_render_engine_matches_reference(golden_dir, i, divisor, conf):
+    from empanada_napari_amd.engines import PanopticDeepLabRenderEngine
+    g = np.load(os.path.join(golden_dir, 'postprocess.npz'))
+    H, W, coarse, ncls, k, thr, sem, ctr, off = _case(g, i)
+    eng = PanopticDeepLabRenderEngine(_Fake({'sem_logits': sem, 'ctr_hmp': ctr, 'offsets': off}),
+                                      [1] if ncls == 1 else [1, 2], label_divisor=divisor, nms_threshold=thr,
+                                      nms_kernel=k, confidence_thr=conf, coarse_boundaries=coarse)
+    pan = eng(torch.zeros(1, 1, H, W), (H - 3, W - 5), 1)
+    ref = g[f'{i}_pan_{divisor}']
+    assert pan.dtype == torch.int64 and tuple(pan.shape) == ref.shape
+    got = pan.cpu().numpy()
+    if not np.array_equal(got, ref):
+        # the only legitimate source of a flip is sigmoid/softmax rounding exactly at the threshold
+        from oracle import postprocess as opp
+        p = opp.logits_to_prob(sem)[..., :H - 3, :W - 5]
+        near = np.abs(p - conf).min(axis=1) < 1e-6 if ncls == 1 else np.zeros(got.shape, bool)
+        assert np.all((got == ref) | near), f'{np.sum(got != ref)} label flips away from the threshold'
+
+
+def test_batched_postprocess_equals_per_image():
+    """N images per launch group == N single-image calls (oracle on each image)."""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.engines import PanopticDeepLabRenderEngine
+    from oracle import postprocess as opp
+    H = W = 256
+    outs = [synth.head_outputs(H, W, n, seed=500 + n, coarse=True) for n in (0, 7, 33, 150)]
+    sem = np.concatenate([o[0] for o in outs])
+    ctr = np.concatenate([o[1] for o in outs])
+    off = np.concatenate([o[2] for o in outs])
+    eng = PanopticDeepLabRenderEngine(_Fake({}), [1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3,
+                                      confidence_thr=0.5, coarse_boundaries=True)
+    prob = opp.logits_to_prob(sem)
+    cells, centers, num, kmax = eng.instance_cells_int(torch.from_numpy(ctr).cuda(), torch.from_numpy(off).cuda(), 1)
+    pan = eng.panoptic_merge_int(torch.from_numpy(prob).cuda(), cells, kmax).cpu().numpy()
+    for n in range(4):
+        c = opp.get_instance_cells(ctr[n:n + 1], off[n:n + 1], 0.1, 3, True, 1)
+        np.testing.assert_array_equal(cells[n].cpu().numpy(), c[0, 0].astype(np.int32))
+        hard = opp.harden_seg(prob[n:n + 1], 0.5)[0]
+        ref = opp.get_panoptic_seg(hard, c, [1], 10000, 64, 0)
+        np.testing.assert_array_equal(pan[n], ref[0])
+
+
+def test_logits_to_prob():
+    from empanada_napari_amd.engines import logits_to_prob
+    from oracle import postprocess as opp
+    rng = np.random.default_rng(0)
+    for C in (1, 4):
+        x = (rng.standard_normal((2, C, 33, 47)) * 4).astype(np.float32)
+        got = logits_to_prob(torch.from_numpy(x).cuda()).cpu().numpy()
+        np.testing.assert_allclose(got, opp.logits_to_prob(x), atol=2e-7, rtol=2e-6)  # float domain: ~1 ulp
+
+
+@pytest.mark.parametrize('ks', [1, 3, 5, 7])
+def test_engine3d_trace_matches_reference(golden_dir, ks):
+    from empanada_napari_amd.engines import PanopticDeepLabRenderEngine3d
+    g = np.load(os.path.join(golden_dir, 'median3d.npz'))
+    n = g['sem_logits'].shape[0]
+    outs = [{'sem_logits': g['sem_logits'][z], 'ctr_hmp': g['ctr_hmp'][z], 'offsets': g['offsets'][z]} for z in range(n)]
+    eng = PanopticDeepLabRenderEngine3d(_Fake(outs), [1], label_divisor=1000, nms_threshold=0.1, nms_kernel=3,
+                                        confidence_thr=0.5, median_kernel_size=ks, coarse_boundaries=True)
+    segs = []
+    for z in range(n):
+        r = eng(torch.zeros(1, 1, 64, 64), (64, 64), 1)
+        if r is not None:
+            segs.append(r.cpu().numpy())
+    segs += [s.cpu().numpy() for s in eng.end(1)]
+    got = np.stack(segs).astype(np.int32)
+    ref = g[f'pan_ks{ks}']
+    if not np.array_equal(got, ref):
+        from oracle import postprocess as opp
+        frac = np.mean(got != ref)
+        assert frac < 1e-5, f'{frac} of labels differ'  # sigmoid rounding at the threshold only
+
+
+def test_median_is_exact_selection():
+    from empanada_napari_amd import _abi
+    import ctypes as C
+    lib = _abi.load()
+    rng = np.random.default_rng(5)
+    for ks in (1, 3, 5, 7, 9):
+        x = rng.standard_normal((ks, 3, 50, 70)).astype(np.float32)
+        x[:, 0, :5] = x[0, 0, :5]  # ties
+        t = [torch.from_numpy(x[k]).cuda() for k in range(ks)]
+        out = torch.empty_like(t[0])
+        ptrs = (C.c_void_p * ks)(*[a.data_ptr() for a in t])
+        _abi.check(lib.emp_median_slices(ptrs, ks, _abi.ptr(out), out.numel(), _abi.stream_ptr()), 'median')
+        np.testing.assert_array_equal(out.cpu().numpy(), np.sort(x, axis=0)[(ks - 1) // 2])

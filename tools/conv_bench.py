@@ -1,0 +1,70 @@
+"""A/B timing of the implicit-GEMM conv variants on the network's main shapes
+(interleaved rounds in ONE process, HIP events).  Usage: python tools/conv_bench.py [batch]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+graft.load_package()
+from empanada_napari_amd import _abi  # noqa: E402
+
+SHAPES = [  # name, H, W, Cin, Cout, k, stride, pad, dil  (spatial sizes for a 1024^2 tile)
+    ('l1.conv1 256->64 1x1', 256, 256, 256, 64, 1, 1, 0, 1),
+    ('l1.conv2 64->64 3x3', 256, 256, 64, 64, 3, 1, 1, 1),
+    ('l1.conv3 64->256 1x1', 256, 256, 64, 256, 1, 1, 0, 1),
+    ('l2.conv2 128 3x3', 128, 128, 128, 128, 3, 1, 1, 1),
+    ('l2.conv3 128->512', 128, 128, 128, 512, 1, 1, 0, 1),
+    ('l3.conv2 256 3x3', 64, 64, 256, 256, 3, 1, 1, 1),
+    ('l3.conv3 256->1024', 64, 64, 256, 1024, 1, 1, 0, 1),
+    ('l3.conv1 1024->256', 64, 64, 1024, 256, 1, 1, 0, 1),
+    ('l4.conv2 512 3x3 d2', 64, 64, 512, 512, 3, 1, 2, 2),
+    ('l4.conv3 512->2048', 64, 64, 512, 2048, 1, 1, 0, 1),
+    ('l4.conv1 2048->512', 64, 64, 2048, 512, 1, 1, 0, 1),
+    ('aspp 3x3 d4 2048->256', 64, 64, 2048, 256, 3, 1, 4, 4),
+    ('aspp 1x1 2048->256', 64, 64, 2048, 256, 1, 1, 0, 1),
+    ('fuse pw 320->256', 256, 256, 320, 256, 1, 1, 0, 1),
+    ('head pw 256->256', 256, 256, 256, 256, 1, 1, 0, 1),
+]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    lib = _abi.load()
+    dev = torch.device('cuda:0')
+    rows = []
+    for name, H, W, Cin, Cout, k, s, p, d in SHAPES:
+        x = (torch.randn((B, H, W, Cin), device=dev) * 1.0).to(torch.float16)
+        w = (torch.randn((Cout, k * k, Cin), device=dev) / np.sqrt(Cin * k * k)).to(torch.float16)
+        b = torch.randn((Cout,), device=dev)
+        Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1
+        Wo = (W + 2 * p - d * (k - 1) - 1) // s + 1
+        out = torch.empty((B, Ho, Wo, Cout), device=dev, dtype=torch.float16)
+        flops = 2.0 * B * Ho * Wo * Cout * Cin * k * k
+        times = {1: [], 2: []}
+        for rnd in range(5):
+            for v in (1, 2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                reps = 3
+                e0.record()
+                for _ in range(reps):
+                    _abi.check(lib.emp_conv2d_nhwc_f16(_abi.ptr(x), B, H, W, Cin, Cin, _abi.ptr(w), _abi.ptr(b), None,
+                                                       None, 0, _abi.ptr(out), Cout, Cout, k, k, s, p, d, 1, v,
+                                                       _abi.stream_ptr(dev)), 'conv')
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd > 0:
+                    times[v].append(e0.elapsed_time(e1) / reps)
+        t1, t2 = np.median(times[1]), np.median(times[2])
+        gb = (x.numel() + out.numel() + w.numel()) * 2 / 1e9
+        rows.append((name, flops / 1e9, t1, flops / t1 / 1e9, t2, flops / t2 / 1e9, gb / min(t1, t2) * 1e3))
+        print(f'{name:26s} {flops/1e9:9.1f} GF | reg {t1:8.3f} ms {flops/t1/1e9:7.1f} TF/s | glds {t2:8.3f} ms '
+              f'{flops/t2/1e9:7.1f} TF/s | min-traffic {gb/min(t1,t2)*1e3:7.1f} GB/s', flush=True)
+
+
+if __name__ == '__main__':
+    main()
