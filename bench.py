@@ -33,7 +33,7 @@ def cpu_baseline(cfg, P, tile_size, n_tiles, seed):
     from empanada_napari_amd import synth
     from empanada_napari_amd.preprocess import normalize
     from oracle import pdl_model, postprocess as opp
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))  # oneDNN convs stop scaling beyond ~32 threads
     tiles = synth.em_tiles(n_tiles, tile_size, seed=seed)
 
     def model(x, rs, interp):
@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--micro-batch', type=int, default=0, help='forward in chunks of this many tiles (0 = whole batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-tiles', type=int, default=2)
+    ap.add_argument('--cpu-tiles', type=int, default=1)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))

@@ -71,8 +71,8 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream);
 int launch_stem7x7(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
                    const float* w /*49x64*/, const float* b /*64*/, half_t* out, hipStream_t s);
 int launch_maxpool3x3s2(const half_t* in, int N, int H, int W, int C, half_t* out, hipStream_t s);
-int launch_dwconv5x5(const half_t* in, int N, int H, int W, int C, int in_ld, const float* w /*25 x C*/,
-                     half_t* out, int out_ld, hipStream_t s);
+int launch_dwconv5x5(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* w /*25 x C fp16*/,
+                     half_t* out, int out_ld, const half_t* zero, hipStream_t s);
 int launch_bilinear_ac(const half_t* in, int N, int h, int w, int C, int in_ld, half_t* out, int H, int W,
                        int out_ld, hipStream_t s);
 int launch_avgpool(const half_t* in, int N, int HW, int C, int in_ld, float* out /*N x C*/, float* part,

@@ -38,7 +38,7 @@ __device__ __forceinline__ int perm32(int x) {
   return ((i >> 2) << 3) + (t << 2) + (i & 3);
 }
 
-template <int BM, int BN, int WPM, int WPN, bool GLDS>
+template <int BM, int BN, int WPM, int WPN, bool GLDS, bool EPI_LDS>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) {
   constexpr int TM = BM / WPM, TN = BN / WPN;
   constexpr int PT = TM / 16, CT = TN / 16;
@@ -205,6 +205,69 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) 
     __syncthreads();
   }
 
+  if constexpr (EPI_LDS) {
+    // ---- epilogue through LDS: each wave transposes its TM x TN fp32 tile so that one wave
+    //      store instruction writes whole TN*2-byte pixel rows (full 128-byte lines for TN = 64)
+    //      and the residual is read the same way.  fp32 staging keeps the single fp16 rounding. ----
+    constexpr int RB = TN * 4;        // bytes per staged pixel row (fp32)
+    constexpr int C4 = TN / 4;        // 16-byte (4 x fp32) chunks per row
+    constexpr int CPR = TN / 8;       // 8-cout output chunks per row
+    constexpr int RPI = 64 / CPR;     // pixel rows per wave store instruction
+    static_assert(4 * TM * RB <= 2 * (A_BYTES + B_BYTES), "staging tile must fit the main-loop LDS");
+    char* stg = lds + w * (TM * RB);  // wave-private (main-loop buffers are dead: last barrier passed)
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+      const int row = t * 16 + fr;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int ch = (c >> 1) * 8 + fq * 2 + (c & 1);  // fp32 chunk of couts (c>>1)*32 + fq*8 + (c&1)*4 ..+3
+        *reinterpret_cast<f32x4*>(stg + row * RB + ((ch ^ (row & (C4 - 1))) << 4)) = acc[c][t];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave reads back only its own writes
+    const int c8 = l % CPR;
+    const int co = n0 + wn * TN + c8 * 8;
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool co_ok = co < p.Cout;
+    if (p.bias && co_ok) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+      bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < TM / RPI; ++i) {
+      const int row = i * RPI + l / CPR;
+      const int m = m0 + wm * TM + row;
+      if (m >= p.M || !co_ok) continue;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(stg + row * RB + (((2 * c8) ^ (row & (C4 - 1))) << 4));
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(stg + row * RB + (((2 * c8 + 1) ^ (row & (C4 - 1))) << 4));
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = a0[r] + bv[r]; v[4 + r] = a1[r] + bv[4 + r]; }
+      if (p.bias_n) {
+        const float* bn = p.bias_n + (size_t)(m / HoWo) * p.Cout + co;
+        const float4 b0 = *reinterpret_cast<const float4*>(bn);
+        const float4 b1 = *reinterpret_cast<const float4*>(bn + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (p.res) {
+        const f16x8 rv = *reinterpret_cast<const f16x8*>(p.res + (size_t)m * p.res_ld + co);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+      }
+      f16x8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float x = v[r];
+        if (p.relu) x = x > 0.f ? x : 0.f;
+        o[r] = (half_t)x;
+      }
+      *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + co) = o;
+    }
+    return;
+  }
   // ---- epilogue: lane (fq, fr) owns couts P*32 + fq*8 + [0,8) of pixel fr of each pixel tile ----
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
@@ -251,13 +314,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(const ConvParams p) 
   }
 }
 
-template <int BM, int BN, int WPM, int WPN, bool GLDS>
+template <int BM, int BN, int WPM, int WPN, bool GLDS, bool EPI_LDS>
 int launch_tpl(ConvParams p, hipStream_t stream) {
   p.mt = cdiv(p.M, BM);
   p.nt = cdiv(p.Cout, BN);
   p.mt_per_xcd = cdiv(p.mt, 8);
   const int grid = 8 * p.mt_per_xcd * p.nt;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WPM, WPN, GLDS>), dim3(grid), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WPM, WPN, GLDS, EPI_LDS>), dim3(grid), dim3(256), 0, stream, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
@@ -274,11 +337,16 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
                   ((uintptr_t)p.res % 16) == 0,
               "conv: pointers must be 16-byte aligned");
   EMP_REQUIRE((int64_t)p.N * p.Ho * p.Wo < (1ll << 31), "conv: too many output pixels");
-  const bool glds = (variant == 2) || (variant == 0);
+  // variant: 0 auto | 1 register staging | 2 LDS-DMA staging | 3 LDS-DMA staging + LDS-transposed epilogue
+  const int v = variant == 0 ? 2 : variant;
   if (p.Cout > 64) {
-    return glds ? launch_tpl<128, 128, 2, 2, true>(p, stream) : launch_tpl<128, 128, 2, 2, false>(p, stream);
+    if (v == 1) return launch_tpl<128, 128, 2, 2, false, false>(p, stream);
+    if (v == 2) return launch_tpl<128, 128, 2, 2, true, false>(p, stream);
+    return launch_tpl<128, 128, 2, 2, true, true>(p, stream);
   }
-  return glds ? launch_tpl<128, 64, 2, 2, true>(p, stream) : launch_tpl<128, 64, 2, 2, false>(p, stream);
+  if (v == 1) return launch_tpl<128, 64, 2, 2, false, false>(p, stream);
+  if (v == 2) return launch_tpl<128, 64, 2, 2, true, false>(p, stream);
+  return launch_tpl<128, 64, 2, 2, true, true>(p, stream);
 }
 
 }  // namespace emp

@@ -136,63 +136,99 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const half_t* __restr
 
 // ---------------------------------------------------------------------------
 // 5x5 depthwise conv, stride 1, pad 2, no bias (blocks.py:24-29, first conv of
-// SeparableConv2d).  thread = 8 channels x 4 consecutive output columns.
-// weights fp32 [25][C].
+// SeparableConv2d).  HBM-bound byte mover: one block = 8x32 output pixels x 64
+// channels; the 12x36x64 input halo tile is brought into LDS by LDS-DMA
+// (pixel-major, 128 B per pixel; out-of-image pixels read the zero page), each
+// thread then slides a 5-wide window down one column for its 8 channels with
+// the 25x8 taps held in registers as packed fp16 (fp32 accumulate).
+// weights fp16 [25][C].
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) dwconv5x5_kernel(const half_t* __restrict__ in, int N, int H, int W, int C,
-                                                        int in_ld, const float* __restrict__ wgt,
-                                                        half_t* __restrict__ out, int out_ld, int64_t total) {
-  const int CG = C >> 3;
-  const int WQ = (W + 3) >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    int cg = (int)(i % CG);
-    int64_t p = i / CG;
-    int xq = (int)(p % WQ); p /= WQ;
-    int oy = (int)(p % H);
-    int n = (int)(p / H);
-    const int ox0 = xq * 4;
-    float acc[4][8];
+constexpr int DW_TH = 8, DW_TW = 32, DW_IH = DW_TH + 4, DW_IW = DW_TW + 4;
+__global__ void __launch_bounds__(256, 2) dwconv5x5_kernel(const half_t* __restrict__ in, int N, int H, int W, int C,
+                                                           int in_ld, const half_t* __restrict__ wgt,
+                                                           half_t* __restrict__ out, int out_ld,
+                                                           const half_t* __restrict__ zero, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(1024))) char lds[DW_IH * DW_IW * 128];
+  int b = blockIdx.x;
+  const int cb = b % (C >> 6); b /= (C >> 6);
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y; b /= tiles_y;
+  const int n = b;
+  const int y0 = ty * DW_TH, x0 = tx * DW_TW;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const half_t* src = in + (size_t)n * H * W * in_ld + cb * 64 + (l & 7) * 8;
+  constexpr int NPIX = DW_IH * DW_IW;        // 432
+  constexpr int NINSTR = (NPIX + 7) / 8;     // 54 wave-instructions of 8 pixels
+  for (int i = w; i < NINSTR; i += 4) {
+    const int p = i * 8 + (l >> 3);
+    const int py = p / DW_IW, px = p - py * DW_IW;
+    const int iy = y0 + py - 2, ix = x0 + px - 2;
+    const bool ok = p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const half_t* g = ok ? src + ((size_t)iy * W + ix) * in_ld : zero;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(lds + i * 1024), 16, 0, 0);
+  }
+  // thread = 4 channels (cq) x columns {colb, colb+16}; fp32 taps in registers
+  const int cq = tid & 15, colb = tid >> 4;
+  float wv[25][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+  for (int t = 0; t < 25; ++t) {
+    const f16x4 h = *reinterpret_cast<const f16x4*>(wgt + (size_t)t * C + cb * 64 + cq * 4);
 #pragma unroll
-      for (int c = 0; c < 8; ++c) acc[k][c] = 0.f;
+    for (int c = 0; c < 4; ++c) wv[t][c] = (float)h[c];
+  }
+  __syncthreads();
+  const bool odd = cq & 1;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    const int col = colb + 16 * pass;
+    float acc[DW_TH][4];
 #pragma unroll
-    for (int ky = 0; ky < 5; ++ky) {
-      int iy = oy + ky - 2;
-      if (iy < 0 || iy >= H) continue;
-      const half_t* rowp = in + ((size_t)n * H + iy) * W * in_ld + cg * 8;
-      float xv[8][8];
+    for (int y = 0; y < DW_TH; ++y)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int ix = ox0 + j - 2;
-        if (ix >= 0 && ix < W) {
-          f16x8 v = *reinterpret_cast<const f16x8*>(rowp + (size_t)ix * in_ld);
+      for (int c = 0; c < 4; ++c) acc[y][c] = 0.f;
+    f16x4 nxt[5];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) xv[j][c] = (float)v[c];
-        } else {
+    for (int kx = 0; kx < 5; ++kx)
+      nxt[kx] = *reinterpret_cast<const f16x4*>(lds + (0 * DW_IW + col + kx) * 128 + cq * 8);
 #pragma unroll
-          for (int c = 0; c < 8; ++c) xv[j][c] = 0.f;
-        }
+    for (int r = 0; r < DW_IH; ++r) {
+      float xv[5][4];
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xv[kx][c] = (float)nxt[kx][c];
+      if (r + 1 < DW_IH) {
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx)
+          nxt[kx] = *reinterpret_cast<const f16x4*>(lds + ((r + 1) * DW_IW + col + kx) * 128 + cq * 8);
       }
 #pragma unroll
-      for (int kx = 0; kx < 5; ++kx) {
-        const float4* wp = reinterpret_cast<const float4*>(wgt + (size_t)(ky * 5 + kx) * C + cg * 8);
-        float4 w0 = wp[0], w1 = wp[1];
-        float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      for (int ky = 0; ky < 5; ++ky) {
+        const int y = r - ky;
+        if (y < 0 || y >= DW_TH) continue;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
-          for (int c = 0; c < 8; ++c) acc[k][c] = fmaf(xv[k + kx][c], wv[c], acc[k][c]);
+          for (int c = 0; c < 4; ++c) acc[y][c] = fmaf(xv[kx][c], wv[ky * 5 + kx][c], acc[y][c]);
       }
+      __builtin_amdgcn_sched_barrier(0);  // keep the live range of a row's taps inside its iteration
     }
+    // pair lanes (cq, cq^1) so that each lane stores 16 B: even lane -> row y, odd lane -> row y+1
+    const int ox = x0 + col;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      int ox = ox0 + k;
-      if (ox >= W) continue;
-      f16x8 o;
+    for (int y = 0; y < DW_TH; y += 2) {
+      f16x4 ra, rb;  // my rows y and y+1
 #pragma unroll
-      for (int c = 0; c < 8; ++c) o[c] = (half_t)acc[k][c];
-      *reinterpret_cast<f16x8*>(out + (((size_t)n * H + oy) * W + ox) * out_ld + cg * 8) = o;
+      for (int c = 0; c < 4; ++c) { ra[c] = (half_t)acc[y][c]; rb[c] = (half_t)acc[y + 1][c]; }
+      const uint2 ua = *reinterpret_cast<uint2*>(&ra), ub = *reinterpret_cast<uint2*>(&rb);
+      uint2 snd = odd ? ua : ub, rcv;
+      rcv.x = __shfl_xor(snd.x, 1);
+      rcv.y = __shfl_xor(snd.y, 1);
+      uint4 o = odd ? uint4{rcv.x, rcv.y, ub.x, ub.y} : uint4{ua.x, ua.y, rcv.x, rcv.y};
+      const int oy = y0 + y + (odd ? 1 : 0);
+      if (ox < W && oy < H)
+        *reinterpret_cast<uint4*>(out + (((size_t)n * H + oy) * W + ox) * out_ld + cb * 64 + (cq & ~1) * 4) = o;
     }
   }
 }
@@ -418,12 +454,14 @@ int launch_maxpool3x3s2(const half_t* in, int N, int H, int W, int C, half_t* ou
   return EMP_OK;
 }
 
-int launch_dwconv5x5(const half_t* in, int N, int H, int W, int C, int in_ld, const float* w, half_t* out, int out_ld,
-                     hipStream_t s) {
-  EMP_REQUIRE(C % 8 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0, "dwconv: channels must be multiples of 8");
-  int64_t total = (int64_t)N * H * ((W + 3) / 4) * (C / 8);
-  hipLaunchKernelGGL(dwconv5x5_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, N, H, W, C, in_ld, w,
-                     out, out_ld, total);
+int launch_dwconv5x5(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* w, half_t* out,
+                     int out_ld, const half_t* zero, hipStream_t s) {
+  EMP_REQUIRE(C % 64 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0, "dwconv: C=%d must be a multiple of 64", C);
+  const int tiles_x = cdiv(W, DW_TW), tiles_y = cdiv(H, DW_TH);
+  const int64_t grid = (int64_t)N * tiles_x * tiles_y * (C / 64);
+  EMP_REQUIRE(grid < (1ll << 31), "dwconv: grid too large");
+  hipLaunchKernelGGL(dwconv5x5_kernel, dim3((unsigned)grid), dim3(256), 0, s, in, N, H, W, C, in_ld, w, out, out_ld,
+                     zero, tiles_x, tiles_y);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }

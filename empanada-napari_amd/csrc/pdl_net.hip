@@ -59,7 +59,8 @@ struct emp_pdl {
 
   // device parameters
   std::map<std::string, DevConv> convs;
-  std::map<std::string, float*> f32w;  // fp32 device blobs (stem, dw, gemv, heads)
+  std::map<std::string, float*> f32w;  // fp32 device blobs (stem, gemv, heads)
+  std::map<std::string, half_t*> f16w;  // fp16 device blobs (depthwise taps)
   std::vector<void*> owned;
 
   // arena
@@ -167,16 +168,21 @@ int upload_f32(emp_pdl* n, const std::string& key, const std::vector<float>& v) 
   return EMP_OK;
 }
 
-// depthwise (C,1,5,5) -> [25][Cpad] fp32
+// depthwise (C,1,5,5) -> [25][Cpad] fp16
 int pack_dw(emp_pdl* n, const std::string& name, int cpad) {
   const HostParam& hp = n->params.at(name);
   const int C = (int)hp.shape[0];
   EMP_REQUIRE(hp.shape.size() == 4 && hp.shape[1] == 1 && hp.shape[2] == 5 && hp.shape[3] == 5 && cpad >= C,
               "%s: expected a (C,1,5,5) depthwise weight", name.c_str());
-  std::vector<float> pk((size_t)25 * cpad, 0.f);
+  EMP_REQUIRE(cpad % 64 == 0, "%s: padded channel count must be a multiple of 64", name.c_str());
+  std::vector<half_t> pk((size_t)25 * cpad, (half_t)0.f);
   for (int c = 0; c < C; ++c)
-    for (int t = 0; t < 25; ++t) pk[(size_t)t * cpad + c] = hp.w[(size_t)c * 25 + t];
-  return upload_f32(n, name, pk);
+    for (int t = 0; t < 25; ++t) pk[(size_t)t * cpad + c] = (half_t)hp.w[(size_t)c * 25 + t];
+  void* d;
+  int rc = dev_upload(n, pk.data(), pk.size() * sizeof(half_t), &d);
+  if (rc) return rc;
+  n->f16w[name] = (half_t*)d;
+  return EMP_OK;
 }
 
 // ---- arena planning ------------------------------------------------------
@@ -405,7 +411,8 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       RC(launch_bilinear_ac(xa.p, N, xa.H, xa.W, xch, xa.ld, cb.p, cb.H, cb.W, cb.ld, s));
       RC(conv(n, p + ".project." + std::to_string(i) + ".0", A(pyr[st]), 0, cb, xch, 1, 0, 1, true, nullptr, nullptr, s));
       const std::string fz = p + ".fuse." + std::to_string(i) + ".0.sepconv.";
-      RC(launch_dwconv5x5(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f32w.at(fz + "0"), A(q + ".dw").p, cb.ld, s));
+      RC(launch_dwconv5x5(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), A(q + ".dw").p, cb.ld,
+                          rawp<half_t>(n, "zero"), s));
       n->flops += 2.0 * 25.0 * (double)N * cb.H * cb.W * (xch + n->convs.at(p + ".project." + std::to_string(i) + ".0").cout);
       RC(conv(n, fz + "1", A(q + ".dw"), 0, A(q + ".out"), 0, 1, 0, 1, true, nullptr, nullptr, s));
       x = q + ".out";
@@ -425,8 +432,8 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
   for (int k = 0; k < 3; ++k) {
     std::string p = heads[k];
     const Act& xin = k == 0 ? semx : insx;
-    RC(launch_dwconv5x5(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f32w.at(p + ".head.0.0.sepconv.0"), A(p + ".dw").p,
-                        n->dec_ch, s));
+    RC(launch_dwconv5x5(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f16w.at(p + ".head.0.0.sepconv.0"), A(p + ".dw").p,
+                        n->dec_ch, rawp<half_t>(n, "zero"), s));
     n->flops += 2.0 * 25.0 * (double)N * hq * wq * n->dec_ch;
     RC(conv(n, p + ".head.0.0.sepconv.1", A(p + ".dw"), 0, A(p + ".pw"), 0, 1, 0, 1, true, nullptr, nullptr, s));
     float* dst = rawp<float>(n, p + ".out");

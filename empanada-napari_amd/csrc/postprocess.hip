@@ -240,22 +240,40 @@ __device__ __forceinline__ bool is_thing(const ThingList& tl, int cls) {
   return r;
 }
 
+// counts[(id*CLS + cls)] (things) and counts[(max_ids+1)*CLS + cls] (pixels outside every
+// instance) per image.  Each thread run-length-compresses 8 consecutive pixels, the block
+// aggregates its runs in a 256-entry LDS hash table and only distinct keys reach global atomics
+// (one block sees a handful of instances; the background key would otherwise serialise).
 __global__ void __launch_bounds__(256) merge_count_kernel(const float* __restrict__ sem, const int32_t* __restrict__ cells,
                                                           int C, int CLS, int64_t plane, float thr, ThingList tl,
                                                           int max_ids, int32_t* __restrict__ counts_all,
-                                                          int32_t* __restrict__ stuff_all, size_t img_stride_i32) {
+                                                          size_t img_stride_i32) {
+  __shared__ int tkey[256];
+  __shared__ int tval[256];
   const int n = blockIdx.y;
   const float* s = sem + (size_t)n * C * plane;
   const int32_t* ce = cells + (size_t)n * plane;
   int32_t* counts = counts_all + (size_t)n * img_stride_i32;
-  int32_t* stuff = stuff_all + (size_t)n * img_stride_i32;
-  // each thread walks 8 consecutive pixels and flushes run-length partial counts
+  tkey[threadIdx.x] = -1;
+  tval[threadIdx.x] = 0;
+  __syncthreads();
+  const int stuff_base = (max_ids + 1) * CLS;
   const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-  int run_key = -1, run_cnt = 0;  // key = id*CLS + cls for things, -(cls+2) for stuff
+  int run_key = -1, run_cnt = 0;
   auto flush = [&]() {
     if (run_cnt == 0) return;
-    if (run_key >= 0) atomicAdd(&counts[run_key], run_cnt);
-    else atomicAdd(&stuff[-(run_key + 2)], run_cnt);
+    unsigned h = ((unsigned)run_key * 2654435761u) >> 24;
+    bool done = false;
+    for (int probe = 0; probe < 256 && !done; ++probe) {
+      int old = atomicCAS(&tkey[h], -1, run_key);
+      if (old == -1 || old == run_key) {
+        atomicAdd(&tval[h], run_cnt);
+        done = true;
+      } else {
+        h = (h + 1) & 255u;
+      }
+    }
+    if (!done) atomicAdd(&counts[run_key], run_cnt);  // table full (never seen in practice)
     run_cnt = 0;
   };
   for (int j = 0; j < 8; ++j) {
@@ -263,12 +281,15 @@ __global__ void __launch_bounds__(256) merge_count_kernel(const float* __restric
     if (p >= plane) break;
     int cls = harden(s, C, plane, p, thr);
     int id = is_thing(tl, cls) ? ce[p] : 0;
-    if (id > max_ids) id = 0;  // cannot happen when max_ids bounds the centre count
-    int key = id > 0 ? id * CLS + cls : -(cls + 2);
+    if (id > max_ids || id < 0) id = 0;  // cannot happen when max_ids bounds the centre count
+    int key = id > 0 ? id * CLS + cls : stuff_base + cls;
     if (key != run_key) { flush(); run_key = key; }
     ++run_cnt;
   }
   flush();
+  __syncthreads();
+  const int k = tkey[threadIdx.x];
+  if (k >= 0) atomicAdd(&counts[k], tval[threadIdx.x]);
 }
 
 // one block per image: ids in ascending order get per-class consecutive numbers
@@ -426,7 +447,7 @@ int emp_panoptic_merge(const float* d_sem, const int32_t* d_cells, int N, int C,
   const int64_t plane = (int64_t)H * W;
   const int nb = (int)cdiv64(plane, 256 * 8);
   hipLaunchKernelGGL(merge_count_kernel, dim3(nb, N), dim3(256), 0, s, d_sem, d_cells, C, CLS, plane, confidence_thr,
-                     tl, max_ids, counts, stuff, stride);
+                     tl, max_ids, counts, stride);
   EMP_LAUNCH_CHECK();
   hipLaunchKernelGGL(merge_assign_kernel, dim3(N), dim3(256), 0, s, CLS, max_ids, label_divisor, counts, map, stride,
                      map_stride);

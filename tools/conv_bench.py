@@ -45,9 +45,9 @@ def main():
         Wo = (W + 2 * p - d * (k - 1) - 1) // s + 1
         out = torch.empty((B, Ho, Wo, Cout), device=dev, dtype=torch.float16)
         flops = 2.0 * B * Ho * Wo * Cout * Cin * k * k
-        times = {1: [], 2: []}
+        times = {1: [], 2: [], 3: []}
         for rnd in range(5):
-            for v in (1, 2):
+            for v in (1, 2, 3):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 reps = 3
                 e0.record()
@@ -59,11 +59,11 @@ def main():
                 torch.cuda.synchronize()
                 if rnd > 0:
                     times[v].append(e0.elapsed_time(e1) / reps)
-        t1, t2 = np.median(times[1]), np.median(times[2])
+        t1, t2, t3 = np.median(times[1]), np.median(times[2]), np.median(times[3])
         gb = (x.numel() + out.numel() + w.numel()) * 2 / 1e9
-        rows.append((name, flops / 1e9, t1, flops / t1 / 1e9, t2, flops / t2 / 1e9, gb / min(t1, t2) * 1e3))
-        print(f'{name:26s} {flops/1e9:9.1f} GF | reg {t1:8.3f} ms {flops/t1/1e9:7.1f} TF/s | glds {t2:8.3f} ms '
-              f'{flops/t2/1e9:7.1f} TF/s | min-traffic {gb/min(t1,t2)*1e3:7.1f} GB/s', flush=True)
+        print(f'{name:26s} {flops/1e9:9.1f} GF | reg {t1:7.3f} ms {flops/t1/1e9:7.1f} TF/s | glds {t2:7.3f} ms '
+              f'{flops/t2/1e9:7.1f} TF/s | glds+ldsepi {t3:7.3f} ms {flops/t3/1e9:7.1f} TF/s | '
+              f'min-traffic {gb/min(t1,t2,t3)*1e3:7.1f} GB/s', flush=True)
 
 
 if __name__ == '__main__':
