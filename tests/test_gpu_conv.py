@@ -26,7 +26,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 16 + 3, 32 + 1, 32 + 2, 32 + 3, 48 + 1, 48 + 2, 48 + 3])
 @pytest.mark.parametrize('case', CASES)
 def test_conv_matches_fp32_reference(case, variant):
     from gpu_common import conv_hip, conv_ref, dev

@@ -13,7 +13,12 @@ import __graft_entry__ as graft  # noqa: E402
 graft.load_package()
 from empanada_napari_amd import _abi  # noqa: E402
 
-SHAPES = [  # name, H, W, Cin, Cout, k, stride, pad, dil  (spatial sizes for a 1024^2 tile)
+SHAPES = [
+    ('exp 64->64 1x1', 256, 256, 64, 64, 1, 1, 0, 1),
+    ('exp 64->128 1x1', 256, 256, 64, 128, 1, 1, 0, 1),
+    ('exp 64->512 1x1', 256, 256, 64, 512, 1, 1, 0, 1),
+    ('exp 128->128 1x1', 256, 256, 128, 128, 1, 1, 0, 1),
+  # name, H, W, Cin, Cout, k, stride, pad, dil  (spatial sizes for a 1024^2 tile)
     ('l1.conv1 256->64 1x1', 256, 256, 256, 64, 1, 1, 0, 1),
     ('l1.conv2 64->64 3x3', 256, 256, 64, 64, 3, 1, 1, 1),
     ('l1.conv3 64->256 1x1', 256, 256, 64, 256, 1, 1, 0, 1),
@@ -37,33 +42,36 @@ def main():
     lib = _abi.load()
     dev = torch.device('cuda:0')
     rows = []
-    for name, H, W, Cin, Cout, k, s, p, d in SHAPES:
+    for name, H, W, Cin, Cout, k_, s, p, d in SHAPES:
         x = (torch.randn((B, H, W, Cin), device=dev) * 1.0).to(torch.float16)
-        w = (torch.randn((Cout, k * k, Cin), device=dev) / np.sqrt(Cin * k * k)).to(torch.float16)
+        w = (torch.randn((Cout, k_ * k_, Cin), device=dev) / np.sqrt(Cin * k_ * k_)).to(torch.float16)
         b = torch.randn((Cout,), device=dev)
-        Ho = (H + 2 * p - d * (k - 1) - 1) // s + 1
-        Wo = (W + 2 * p - d * (k - 1) - 1) // s + 1
+        Ho = (H + 2 * p - d * (k_ - 1) - 1) // s + 1
+        Wo = (W + 2 * p - d * (k_ - 1) - 1) // s + 1
         out = torch.empty((B, Ho, Wo, Cout), device=dev, dtype=torch.float16)
-        flops = 2.0 * B * Ho * Wo * Cout * Cin * k * k
-        times = {1: [], 2: [], 3: []}
+        flops = 2.0 * B * Ho * Wo * Cout * Cin * k_ * k_
+        VARS = [('128x128', 16 + 3), ('128x64', 32 + 3), ('64x64', 48 + 3), ('64x64d', 48 + 2), ('auto', 0)]
+        times = {k: [] for k, _ in VARS}
         for rnd in range(5):
-            for v in (1, 2, 3):
+            for k, v in VARS:
+                if v == 16 + 3 and Cout <= 32:
+                    pass
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 reps = 3
                 e0.record()
                 for _ in range(reps):
                     _abi.check(lib.emp_conv2d_nhwc_f16(_abi.ptr(x), B, H, W, Cin, Cin, _abi.ptr(w), _abi.ptr(b), None,
-                                                       None, 0, _abi.ptr(out), Cout, Cout, k, k, s, p, d, 1, v,
+                                                       None, 0, _abi.ptr(out), Cout, Cout, k_, k_, s, p, d, 1, v,
                                                        _abi.stream_ptr(dev)), 'conv')
                 e1.record()
                 torch.cuda.synchronize()
                 if rnd > 0:
-                    times[v].append(e0.elapsed_time(e1) / reps)
-        t1, t2, t3 = np.median(times[1]), np.median(times[2]), np.median(times[3])
+                    times[k].append(e0.elapsed_time(e1) / reps)
         gb = (x.numel() + out.numel() + w.numel()) * 2 / 1e9
-        print(f'{name:26s} {flops/1e9:9.1f} GF | reg {t1:7.3f} ms {flops/t1/1e9:7.1f} TF/s | glds {t2:7.3f} ms '
-              f'{flops/t2/1e9:7.1f} TF/s | glds+ldsepi {t3:7.3f} ms {flops/t3/1e9:7.1f} TF/s | '
-              f'min-traffic {gb/min(t1,t2,t3)*1e3:7.1f} GB/s', flush=True)
+        med = {k: np.median(v) for k, v in times.items()}
+        best = min(med.values())
+        print(f'{name:24s} {flops/1e9:8.1f} GF | ' + ' | '.join(f'{k} {t:6.3f} ms {flops/t/1e9:6.1f}' for k, t in med.items())
+              + f' | traffic {gb/best*1e3:6.0f} GB/s', flush=True)
 
 
 if __name__ == '__main__':
