@@ -139,6 +139,12 @@ def main():
 
     if rank == 0:
         fwd_ms_per_step = fwd_total_ms / args.steps
+        traffic = None
+        try:  # HBM bytes per step from the committed PMC passes (only valid for the default workload)
+            if B == 32 and S == 1024 and mb == 32:
+                traffic = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['hbm_bytes_per_step']
+        except Exception:
+            traffic = None
         achieved = flops_fwd / (fwd_ms_per_step * 1e-3) / 1e12
         res = {
             'metric': 'EM tiles/sec (1024^2 fp16)', 'value': round(value, 2), 'unit': 'tiles/s', 'n_gpus': world,
@@ -150,7 +156,9 @@ def main():
                        'tile': S, 'batch_per_gpu': B, 'micro_batch': mb, 'weights': 'seeded random init (seed 0)',
                        'parallelism': f'tile-sharded x{world}, no collective'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_F16_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
+                         'traffic_note': 'HBM bytes per step (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes, '
+                                         'profiles/r01_hbm_traffic.json)',
                          'kernel': 'network forward (all kernels; implicit-GEMM conv dominates)',
                          'flops_per_tile': round(flops_fwd / B / 1e9, 2), 'forward_ms_per_step': round(fwd_ms_per_step, 3)},
             'arena_gib': round(model.arena_bytes() / 2 ** 30, 2),
