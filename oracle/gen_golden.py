@@ -208,3 +208,152 @@ if __name__ == '__main__':
         gen_postprocess()
     if 'median' in which:
         gen_median()
+
+
+# ----------------------------------------------------------------------------
+# D. sparse label algebra: matcher / tracker / voting / consensus
+# ----------------------------------------------------------------------------
+def _stub_numba_skimage():
+    """array_utils / consensus / tracker / matcher import numba (and matcher imports skimage.measure
+    without using it in rle_matcher): stub both so the plain-Python bodies run."""
+    import types
+    if 'numba' not in sys.modules:
+        nb = types.ModuleType('numba')
+        nb.jit = lambda *a, **k: (lambda f: f)
+        nb.int64 = int
+        nb.types = types.ModuleType('numba.types')
+        nb.typed = types.ModuleType('numba.typed')
+        nb.typed.List = list
+        sys.modules['numba'] = nb
+        sys.modules['numba.types'] = nb.types
+        sys.modules['numba.typed'] = nb.typed
+    if 'skimage' not in sys.modules:
+        sk = types.ModuleType('skimage')
+        sk.measure = types.ModuleType('skimage.measure')
+        sys.modules['skimage'] = sk
+        sys.modules['skimage.measure'] = sk.measure
+
+
+def synth_label_volume(shape, n_obj, seed):
+    """Ground-truth-like 3-D instance labels: random ellipsoids, later ids overwrite earlier ones."""
+    rng = np.random.default_rng(seed)
+    d, h, w = shape
+    zz, yy, xx = np.mgrid[0:d, 0:h, 0:w].astype(np.float32)
+    vol = np.zeros(shape, dtype=np.int64)
+    for i in range(1, n_obj + 1):
+        c = rng.uniform(0.15, 0.85, 3) * np.array(shape)
+        r = rng.uniform(0.08, 0.22, 3) * np.array(shape)
+        m = ((zz - c[0]) / r[0]) ** 2 + ((yy - c[1]) / r[1]) ** 2 + ((xx - c[2]) / r[2]) ** 2 < 1
+        vol[m] = i
+    return vol
+
+
+def axis_pan_slices(vol, axis, divisor, seed):
+    """Per-slice 'panoptic predictions' along an axis: class-1 instances with slice-local ids and a
+    little per-axis boundary jitter, the way an independent 2-D model would produce them."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(vol.shape[axis]):
+        sl = np.take(vol, i, axis=axis).copy()
+        drop = rng.random(sl.shape) < 0.03
+        sl[drop] = 0
+        ids = np.unique(sl)
+        ids = ids[ids > 0]
+        perm = rng.permutation(len(ids)) + 1
+        pan = np.zeros_like(sl)
+        for k, v in zip(perm, ids):
+            pan[sl == v] = divisor + k
+        out.append(pan)
+    return out
+
+
+def flatten_instances(inst):
+    keys = np.array([int(k) for k in inst.keys()], dtype=np.int64)
+    boxes = np.array([list(inst[k]['box']) for k in inst.keys()], dtype=np.int64).reshape(len(keys), -1)
+    starts = [np.asarray(inst[k]['starts'], dtype=np.int64) for k in inst.keys()]
+    runs = [np.asarray(inst[k]['runs'], dtype=np.int64) for k in inst.keys()]
+    off = np.cumsum([0] + [len(s) for s in starts]).astype(np.int64)
+    cat = lambda l: np.concatenate(l) if l else np.zeros(0, np.int64)
+    return {'keys': keys, 'boxes': boxes, 'off': off, 'starts': cat(starts), 'runs': cat(runs)}
+
+
+def gen_sparse():
+    _stub_numba_skimage()
+    from empanada import array_utils as au
+    from empanada.consensus import merge_objects_from_trackers, merge_semantic_from_trackers
+    from empanada.inference.matcher import RLEMatcher
+    from empanada.inference.tracker import InstanceTracker
+    from oracle import sparse as osp
+    out = {}
+    rng = np.random.default_rng(11)
+
+    # --- range primitives on random inputs ---
+    for t in range(6):
+        n = int(rng.integers(2, 40))
+        lists = []
+        for _ in range(int(rng.integers(2, 4))):
+            s = np.sort(rng.choice(400, size=n, replace=False))
+            r = rng.integers(1, 6, size=n)
+            e = np.minimum(s + r, np.append(s[1:], 10 ** 6))   # non-overlapping within one source
+            lists.append(np.stack([s, e], axis=1).astype(np.int64))
+        out[f'rng{t}_n'] = np.int64(len(lists))
+        for j, l in enumerate(lists):
+            out[f'rng{t}_in{j}'] = l
+        for thr in (1, 2, 3):
+            out[f'rng{t}_vote{thr}'] = np.asarray(au.vote_by_ranges([l.copy() for l in lists], thr)).reshape(-1, 2)
+        a, b = lists[0], lists[1]
+        out[f'rng{t}_inter'] = np.int64(au.rle_intersection(a[:, 0], a[:, 1] - a[:, 0], b[:, 0], b[:, 1] - b[:, 0]))
+        out[f'rng{t}_iou'] = np.float64(au.rle_iou(a[:, 0], a[:, 1] - a[:, 0], b[:, 0], b[:, 1] - b[:, 0]))
+        ms, mr = au.merge_rles(a[:, 0].copy(), (a[:, 1] - a[:, 0]).copy(), b[:, 0].copy(), (b[:, 1] - b[:, 0]).copy())
+        out[f'rng{t}_merge'] = np.stack([ms, mr], axis=1)
+        out[f'rng{t}_invert'] = np.asarray(au.invert_ranges(au.join_ranges([a.copy(), b.copy()]), 500)).reshape(-1, 2)
+
+    # --- matcher -> tracker -> consensus on a synthetic volume ---
+    shape = (24, 28, 32)
+    divisor = 1000
+    vol = synth_label_volume(shape, 7, seed=5)
+    trackers = []
+    for axis, name in enumerate(('xy', 'xz', 'yz')):
+        slices = axis_pan_slices(vol, axis, divisor, seed=100 + axis)
+        rle_stack = []
+        matcher = RLEMatcher(1, divisor, 0.25, 0.25)
+        for pan in slices:                                      # forward_matching, patterns.py:68-100
+            seg = osp.pan_seg_to_rle_seg(pan, [1], divisor, [1], force_connected=True)
+            if matcher.target_rle is None:
+                matcher.initialize_target(seg[1])
+            else:
+                seg[1] = matcher(seg[1])
+            rle_stack.append(seg)
+        matcher.target_rle = None                               # backward_matching, patterns.py:102-121
+        matcher.assign_new = False
+        tr = InstanceTracker(1, divisor, shape, name)
+        for idx in range(len(slices) - 1, -1, -1):
+            seg = rle_stack[idx]
+            if matcher.target_rle is None:
+                matcher.initialize_target(seg[1])
+            else:
+                seg[1] = matcher(seg[1])
+            tr.update(seg[1], idx)
+        tr.finish()
+        trackers.append(tr)
+        for k, v in flatten_instances(tr.instances).items():
+            out[f'trk_{name}_{k}'] = v
+    for thr, ciou, bypass in ((2, 0.75, False), (1, 0.75, True), (3, 0.5, False)):
+        inst = merge_objects_from_trackers(trackers, thr, ciou, bypass)
+        for k, v in flatten_instances(inst).items():
+            out[f'cons_{thr}_{int(bypass)}_{k}'] = v
+    # semantic consensus: one instance per tracker
+    sem_tr = []
+    for tr in trackers:
+        t2 = InstanceTracker(2, divisor, shape, tr.axis)
+        allr = au.join_ranges([np.stack([a['starts'], a['starts'] + a['runs']], axis=1) for a in tr.instances.values()])
+        t2.instances = {2000: {'box': (0, 0, 0) + shape, 'starts': allr[:, 0], 'runs': allr[:, 1] - allr[:, 0]}}
+        sem_tr.append(t2)
+    for k, v in flatten_instances(merge_semantic_from_trackers(sem_tr, 2)).items():
+        out[f'semcons_{k}'] = v
+    out['volume_shape'] = np.array(shape, dtype=np.int64)
+    save('sparse', **out)
+
+
+if __name__ == '__main__' and 'sparse' in (sys.argv[1:] or ['sparse']):
+    gen_sparse()
