@@ -1,0 +1,430 @@
+// Label-map <-> run-length kernels and the host-side range algebra of the 3-D
+// stitching path.
+//
+// Device (gfx950):
+//   emp_ccl8            8-connected components of EQUAL non-zero label, numbered 1..K per image in
+//                       raster order of each component's first pixel
+//                       (skimage.measure.label / cc3d as used by empanada/inference/rle.py:18-24,
+//                       Engine2d.force_connected empanada_napari/inference.py:263-279)
+//   emp_rle_extract     runs of equal non-zero label over the raveled image, in raster order
+//                       (regionprops(...).coords -> rle_encode, rle.py:73-81, array_utils.py:213-239)
+//   emp_rle_fill        run list -> dense volume (numpy_fill_instances, array_utils.py:754-766)
+// Host (C++, sorted-sweep restatements of the numba kernels):
+//   emp_rle_pair_intersections   array_utils.py:344-407 (two-pointer merge)
+//   emp_ranges_vote              array_utils.py:461-639 (k-of-n vote; thr 1 = join_ranges :658-699)
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace emp {
+namespace {
+
+inline int grid_for(int64_t total, int per_block = 256, int cap = 256 * 16) {
+  int64_t g = (total + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* sh, uint32_t* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = wave_incl_scan(v, lane);
+  __syncthreads();
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < w) base += sh[i];
+  *total = sh[0] + sh[1] + sh[2] + sh[3];
+  return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------
+// connected components: lock-free union-find on linear pixel indices; a root is the smallest
+// index of its component, so ranking the roots in index order IS raster order of first pixels.
+// ---------------------------------------------------------------------------
+// parent words are read past the per-CU L1 (agent-scope relaxed loads): other workgroups update them
+// with atomicMin while this one walks the tree
+__device__ __forceinline__ int uf_load(int* parent, int a) {
+  return __hip_atomic_load(&parent[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int uf_find(int* parent, int a) {
+  int p = uf_load(parent, a);
+  while (p != a) {
+    a = p;
+    p = uf_load(parent, a);
+  }
+  return a;
+}
+__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
+  while (true) {
+    a = uf_find(parent, a);
+    b = uf_find(parent, b);
+    if (a == b) return;
+    if (a < b) { int t = a; a = b; b = t; }   // a > b: hang the larger root under the smaller
+    int old = atomicMin(&parent[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+__global__ void __launch_bounds__(256) ccl_init_kernel(const int32_t* __restrict__ in, int* __restrict__ parent,
+                                                       int64_t total, int hw) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    parent[i] = in[i] != 0 ? (int)(i % hw) : -1;
+}
+
+__global__ void __launch_bounds__(256) ccl_merge_kernel(const int32_t* __restrict__ in, int* __restrict__ parent_all,
+                                                        int h, int w) {
+  const int n = blockIdx.y;
+  const int hw = h * w;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  const int32_t* im = in + (size_t)n * hw;
+  int* parent = parent_all + (size_t)n * hw;
+  const int32_t v = im[p];
+  if (v == 0) return;
+  const int y = p / w, x = p - y * w;
+  if (x > 0 && im[p - 1] == v) uf_union(parent, p, p - 1);
+  if (y > 0) {
+    if (im[p - w] == v) uf_union(parent, p, p - w);
+    if (x > 0 && im[p - w - 1] == v) uf_union(parent, p, p - w - 1);
+    if (x + 1 < w && im[p - w + 1] == v) uf_union(parent, p, p - w + 1);
+  }
+}
+
+__global__ void __launch_bounds__(256) ccl_flatten_kernel(int* __restrict__ parent_all, int hw) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw) return;
+  int* parent = parent_all + (size_t)n * hw;
+  if (parent[p] >= 0) parent[p] = uf_find(parent, p);
+}
+
+constexpr int CHUNK = 2048;
+// per block: number of roots (parent[p] == p) in its chunk
+__global__ void __launch_bounds__(256) ccl_count_kernel(const int* __restrict__ parent_all, int hw,
+                                                        uint32_t* __restrict__ blockcnt, int nb) {
+  __shared__ uint32_t sh[8];
+  const int n = blockIdx.y;
+  const int* parent = parent_all + (size_t)n * hw;
+  const int e0 = blockIdx.x * CHUNK + threadIdx.x * 8;
+  uint32_t c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int p = e0 + j;
+    if (p < hw && parent[p] == p) ++c;
+  }
+  uint32_t total;
+  block_excl_scan(c, sh, &total);
+  if (threadIdx.x == 0) blockcnt[(size_t)n * nb + blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(256) scan_blocks_kernel(const uint32_t* __restrict__ blockcnt,
+                                                          uint32_t* __restrict__ blockoff, int nb,
+                                                          int32_t* __restrict__ totals) {
+  __shared__ uint32_t sh[8];
+  const int n = blockIdx.x;
+  uint32_t carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += 256) {
+    int b = b0 + threadIdx.x;
+    uint32_t c = b < nb ? blockcnt[(size_t)n * nb + b] : 0;
+    uint32_t t;
+    uint32_t e = block_excl_scan(c, sh, &t);
+    if (b < nb) blockoff[(size_t)n * nb + b] = carry + e;
+    carry += t;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && totals) totals[n] = (int32_t)carry;
+}
+// rank[root] = 1-based raster rank, stored in a side array indexed by root pixel
+__global__ void __launch_bounds__(256) ccl_rank_kernel(const int* __restrict__ parent_all, int hw,
+                                                       const uint32_t* __restrict__ blockoff, int nb,
+                                                       int32_t* __restrict__ rank_all) {
+  __shared__ uint32_t sh[8];
+  const int n = blockIdx.y;
+  const int* parent = parent_all + (size_t)n * hw;
+  int32_t* rank = rank_all + (size_t)n * hw;
+  const int e0 = blockIdx.x * CHUNK + threadIdx.x * 8;
+  uint32_t c = 0, flags = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int p = e0 + j;
+    if (p < hw && parent[p] == p) { ++c; flags |= 1u << j; }
+  }
+  uint32_t total;
+  uint32_t pos = block_excl_scan(c, sh, &total) + blockoff[(size_t)n * nb + blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (flags & (1u << j)) rank[e0 + j] = (int32_t)(++pos);
+}
+__global__ void __launch_bounds__(256) ccl_relabel_kernel(const int* __restrict__ parent_all,
+                                                          const int32_t* __restrict__ rank_all,
+                                                          int32_t* __restrict__ out, int64_t total, int hw) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = parent_all[i];
+    out[i] = r < 0 ? 0 : rank_all[(i / hw) * hw + r];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// run extraction over the raveled image
+// flags: bit0 = run start (label != 0 and differs from the previous element),
+//        bit1 = run end   (label != 0 and differs from the next element)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t run_flags(const int32_t* im, int hw, int e0, uint32_t* fs, uint32_t* fe) {
+  uint32_t s = 0, e = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int p = e0 + j;
+    if (p < hw) {
+      const int32_t v = im[p];
+      if (v != 0) {
+        const int32_t pv = p > 0 ? im[p - 1] : 0;
+        const int32_t nv = p + 1 < hw ? im[p + 1] : 0;
+        s |= (uint32_t)(pv != v) << j;
+        e |= (uint32_t)(nv != v) << j;
+      }
+    }
+  }
+  *fs = s;
+  *fe = e;
+  return (uint32_t)__popc(s) | ((uint32_t)__popc(e) << 16);
+}
+__global__ void __launch_bounds__(256) rle_count_kernel(const int32_t* __restrict__ in, int hw,
+                                                        uint32_t* __restrict__ blockcnt, int nb) {
+  __shared__ uint32_t sh[8];
+  const int n = blockIdx.y;
+  uint32_t fs, fe;
+  uint32_t c = run_flags(in + (size_t)n * hw, hw, blockIdx.x * CHUNK + threadIdx.x * 8, &fs, &fe);
+  uint32_t total;
+  block_excl_scan(c & 0xffffu, sh, &total);  // starts and ends are equinumerous per image, not per block
+  if (threadIdx.x == 0) blockcnt[((size_t)n * nb + blockIdx.x) * 2] = total;
+  uint32_t t2;
+  block_excl_scan(c >> 16, sh, &t2);
+  if (threadIdx.x == 0) blockcnt[((size_t)n * nb + blockIdx.x) * 2 + 1] = t2;
+}
+__global__ void __launch_bounds__(256) rle_scan_kernel(const uint32_t* __restrict__ blockcnt,
+                                                       uint32_t* __restrict__ blockoff, int nb,
+                                                       int32_t* __restrict__ totals) {
+  __shared__ uint32_t sh[8];
+  const int n = blockIdx.x;
+  uint32_t cs = 0, ce = 0;
+  for (int b0 = 0; b0 < nb; b0 += 256) {
+    int b = b0 + threadIdx.x;
+    uint32_t a = b < nb ? blockcnt[((size_t)n * nb + b) * 2] : 0;
+    uint32_t c = b < nb ? blockcnt[((size_t)n * nb + b) * 2 + 1] : 0;
+    uint32_t ta, tc;
+    uint32_t ea = block_excl_scan(a, sh, &ta);
+    uint32_t ec = block_excl_scan(c, sh, &tc);
+    if (b < nb) {
+      blockoff[((size_t)n * nb + b) * 2] = cs + ea;
+      blockoff[((size_t)n * nb + b) * 2 + 1] = ce + ec;
+    }
+    cs += ta;
+    ce += tc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[n] = (int32_t)cs;
+}
+// runs (max_runs, 3) per image: {start, length, label}; ends are written as start + length later
+__global__ void __launch_bounds__(256) rle_write_kernel(const int32_t* __restrict__ in, int hw,
+                                                        const uint32_t* __restrict__ blockoff, int nb,
+                                                        int32_t* __restrict__ runs_all, int max_runs) {
+  __shared__ uint32_t sh[8];
+  const int n = blockIdx.y;
+  const int32_t* im = in + (size_t)n * hw;
+  int32_t* runs = runs_all + (size_t)n * max_runs * 3;
+  const int e0 = blockIdx.x * CHUNK + threadIdx.x * 8;
+  uint32_t fs, fe;
+  uint32_t c = run_flags(im, hw, e0, &fs, &fe);
+  uint32_t t;
+  uint32_t ps = block_excl_scan(c & 0xffffu, sh, &t) + blockoff[((size_t)n * nb + blockIdx.x) * 2];
+  uint32_t pe = block_excl_scan(c >> 16, sh, &t) + blockoff[((size_t)n * nb + blockIdx.x) * 2 + 1];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (fs & (1u << j)) {
+      if (ps < (uint32_t)max_runs) { runs[ps * 3] = e0 + j; runs[ps * 3 + 2] = im[e0 + j]; }
+      ++ps;
+    }
+    if (fe & (1u << j)) {
+      if (pe < (uint32_t)max_runs) runs[pe * 3 + 1] = e0 + j + 1;  // exclusive end, fixed up below
+      ++pe;
+    }
+  }
+}
+__global__ void rle_fixup_kernel(int32_t* __restrict__ runs_all, const int32_t* __restrict__ totals, int max_runs) {
+  const int n = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int cnt = totals[n];
+  cnt = cnt < max_runs ? cnt : max_runs;
+  if (i >= cnt) return;
+  int32_t* r = runs_all + ((size_t)n * max_runs + i) * 3;
+  r[1] -= r[0];
+}
+
+// one wave per run
+template <typename T>
+__global__ void __launch_bounds__(256) rle_fill_kernel(const int64_t* __restrict__ starts,
+                                                       const int64_t* __restrict__ lens,
+                                                       const int64_t* __restrict__ vals, int64_t nruns,
+                                                       T* __restrict__ vol, int64_t size) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t r = wave0; r < nruns; r += nw) {
+    const int64_t s = starts[r], e = min(size, s + lens[r]);
+    const T v = (T)vals[r];
+    for (int64_t p = s + lane; p < e; p += 64) vol[p] = v;
+  }
+}
+
+}  // namespace
+}  // namespace emp
+
+using namespace emp;
+
+extern "C" {
+
+size_t emp_ccl8_work_bytes(int N, int H, int W) {
+  const size_t hw = (size_t)H * W;
+  const size_t nb = (hw + CHUNK - 1) / CHUNK;
+  return (size_t)N * (hw * 8 + nb * 8) + 512;
+}
+
+int emp_ccl8(const int32_t* d_in, int N, int H, int W, int32_t* d_out, int32_t* d_num, void* d_work, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  EMP_REQUIRE(d_in && d_out && d_work && N > 0 && H > 0 && W > 0, "ccl8: bad arguments");
+  EMP_REQUIRE((int64_t)H * W < (1ll << 30), "ccl8: image too large");
+  const int hw = H * W;
+  const int nb = cdiv(hw, CHUNK);
+  int* parent = (int*)d_work;
+  int32_t* rank = (int32_t*)(parent + (size_t)N * hw);
+  uint32_t* blockcnt = (uint32_t*)(rank + (size_t)N * hw);
+  uint32_t* blockoff = blockcnt + (size_t)N * nb;
+  const int64_t total = (int64_t)N * hw;
+  hipLaunchKernelGGL(ccl_init_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_in, parent, total, hw);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3(cdiv(hw, 256), N), dim3(256), 0, s, d_in, parent, H, W);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(hw, 256), N), dim3(256), 0, s, parent, hw);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ccl_count_kernel, dim3(nb, N), dim3(256), 0, s, parent, hw, blockcnt, nb);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(N), dim3(256), 0, s, blockcnt, blockoff, nb, d_num);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ccl_rank_kernel, dim3(nb, N), dim3(256), 0, s, parent, hw, blockoff, nb, rank);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ccl_relabel_kernel, dim3(grid_for(total)), dim3(256), 0, s, parent, rank, d_out, total, hw);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+size_t emp_rle_extract_work_bytes(int N, int H, int W) {
+  const size_t nb = ((size_t)H * W + CHUNK - 1) / CHUNK;
+  return (size_t)N * nb * 16 + 512;
+}
+
+int emp_rle_extract(const int32_t* d_labels, int N, int H, int W, int32_t* d_runs, int32_t* d_num_runs, int max_runs,
+                    void* d_work, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  EMP_REQUIRE(d_labels && d_runs && d_num_runs && d_work && N > 0 && H > 0 && W > 0 && max_runs > 0,
+              "rle_extract: bad arguments");
+  EMP_REQUIRE((int64_t)H * W < (1ll << 30), "rle_extract: image too large");
+  const int hw = H * W;
+  const int nb = cdiv(hw, CHUNK);
+  uint32_t* blockcnt = (uint32_t*)d_work;
+  uint32_t* blockoff = blockcnt + (size_t)N * nb * 2;
+  hipLaunchKernelGGL(rle_count_kernel, dim3(nb, N), dim3(256), 0, s, d_labels, hw, blockcnt, nb);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rle_scan_kernel, dim3(N), dim3(256), 0, s, blockcnt, blockoff, nb, d_num_runs);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rle_write_kernel, dim3(nb, N), dim3(256), 0, s, d_labels, hw, blockoff, nb, d_runs, max_runs);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rle_fixup_kernel, dim3(cdiv(max_runs, 256), N), dim3(256), 0, s, d_runs, d_num_runs, max_runs);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int emp_rle_fill(const int64_t* d_starts, const int64_t* d_lens, const int64_t* d_vals, int64_t nruns, void* d_volume,
+                 int64_t size, int elem_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  EMP_REQUIRE(d_volume && nruns >= 0 && size > 0, "rle_fill: bad arguments");
+  if (nruns == 0) return EMP_OK;
+  const int grid = grid_for(nruns * 64, 256, 256 * 32);
+  switch (elem_bytes) {
+    case 1: hipLaunchKernelGGL(rle_fill_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_vals, nruns, (uint8_t*)d_volume, size); break;
+    case 2: hipLaunchKernelGGL(rle_fill_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_vals, nruns, (uint16_t*)d_volume, size); break;
+    case 4: hipLaunchKernelGGL(rle_fill_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_vals, nruns, (uint32_t*)d_volume, size); break;
+    case 8: hipLaunchKernelGGL(rle_fill_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_vals, nruns, (uint64_t*)d_volume, size); break;
+    default: EMP_REQUIRE(false, "rle_fill: element size %d unsupported", elem_bytes);
+  }
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host range algebra
+// ---------------------------------------------------------------------------
+int emp_rle_pair_intersections(const int64_t* h_starts, const int64_t* h_runs, const int64_t* h_off,
+                               const int64_t* h_pairs, int64_t n_pairs, int64_t* h_out) {
+  EMP_REQUIRE(h_starts && h_runs && h_off && h_pairs && h_out && n_pairs >= 0, "rle_pair_intersections: null argument");
+  for (int64_t k = 0; k < n_pairs; ++k) {
+    const int64_t a = h_pairs[2 * k], b = h_pairs[2 * k + 1];
+    int64_t i = h_off[a], ie = h_off[a + 1], j = h_off[b], je = h_off[b + 1];
+    int64_t tot = 0;
+    while (i < ie && j < je) {
+      const int64_t s1 = h_starts[i], e1 = s1 + h_runs[i], s2 = h_starts[j], e2 = s2 + h_runs[j];
+      const int64_t lo = s1 > s2 ? s1 : s2, hi = e1 < e2 ? e1 : e2;
+      if (hi > lo) tot += hi - lo;
+      if (e1 < e2) ++i; else ++j;
+    }
+    h_out[k] = tot;
+  }
+  return EMP_OK;
+}
+
+// ranges: (n,2) [start,end) in any order; out: maximal ranges whose every index is covered by >= thr
+// input ranges (touching ranges chain, like the reference's running range).  Returns the number of
+// output ranges through *n_out; h_out must hold n ranges.
+int emp_ranges_vote(const int64_t* h_ranges, int64_t n, int thr, int64_t* h_out, int64_t* n_out) {
+  EMP_REQUIRE(h_ranges && h_out && n_out && n >= 0 && thr >= 1, "ranges_vote: bad arguments");
+  std::vector<std::pair<int64_t, int>> ev;
+  ev.reserve((size_t)n * 2);
+  for (int64_t i = 0; i < n; ++i) {
+    if (h_ranges[2 * i + 1] <= h_ranges[2 * i]) continue;
+    ev.emplace_back(h_ranges[2 * i], +1);
+    ev.emplace_back(h_ranges[2 * i + 1], -1);
+  }
+  // at equal coordinates starts (+1) sort before ends (-1): touching ranges stay chained
+  std::sort(ev.begin(), ev.end(), [](const std::pair<int64_t, int>& x, const std::pair<int64_t, int>& y) {
+    return x.first != y.first ? x.first < y.first : x.second > y.second;
+  });
+  int64_t cnt = 0, m = 0, open_at = 0;
+  bool open = false;
+  for (size_t k = 0; k < ev.size();) {
+    const int64_t pos = ev[k].first;
+    while (k < ev.size() && ev[k].first == pos) cnt += ev[k++].second;  // net coverage just right of pos
+    const bool ok = cnt >= thr;
+    if (ok && !open) { open = true; open_at = pos; }
+    else if (!ok && open) {
+      open = false;
+      h_out[2 * m] = open_at;
+      h_out[2 * m + 1] = pos;
+      ++m;
+    }
+  }
+  *n_out = m;
+  return EMP_OK;
+}
+
+}  // extern "C"

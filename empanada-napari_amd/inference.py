@@ -1,0 +1,336 @@
+"""MI355X mirror of ``empanada_napari.inference`` (upper drop-in boundary).
+
+``Engine2d``, ``Engine3d``, ``tracker_consensus`` and ``stack_postprocessing`` keep
+the reference's constructor arguments, attributes, ``update_params`` and return
+types (empanada_napari/inference.py:56-578) so the napari widgets can swap the
+import.  Differences, all behind the same results:
+  * the network forward runs batched on the GPU (slices are independent; the
+    recursive median queue is then fed strictly in slice order);
+  * dense -> RLE (connected components + run extraction) runs on the GPU for a
+    whole chunk of slices; no worker process, no pickled dense maps;
+  * ``model_config['model']`` may be a TorchScript file (the reference's export),
+    a state dict, or an already built ``HipPanopticDeepLab``.
+Not built yet (raise ``NotImplementedError``): ``tile_size > 0`` (cztile tiler),
+``inference_scale > 1`` input down-scaling (cv2), label erosion / dilation / hole
+filling, zarr stores when zarr is not installed.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import sparse, weights
+from .engines import (HipPanopticDeepLab, PanopticDeepLabRenderEngine, PanopticDeepLabRenderEngine3d,
+                      factor_pad, logits_to_prob)
+from .preprocess import Preprocessor
+
+try:  # the widgets run these generators in a Qt worker thread
+    from napari.qt.threading import thread_worker
+except Exception:  # napari is not part of the hot path
+    def thread_worker(fn):
+        return fn
+
+__all__ = ['Engine2d', 'Engine3d', 'tracker_consensus', 'stack_postprocessing', 'instance_relabel', 'take']
+
+instance_relabel = sparse.instance_relabel
+
+
+def take(array, indices, axis=0):
+    """array_utils.py:10-27."""
+    idx = tuple(slice(None) if n != axis else indices for n in range(array.ndim))
+    return array[idx]
+
+
+def load_model(model_config, device):
+    """utils.load_model_to_device (empanada_napari/utils.py:80-106) for the HIP engine."""
+    m = model_config['model']
+    if isinstance(m, HipPanopticDeepLab):
+        return m
+    cfg = dict(weights.MITONET_PDL_CFG, **model_config.get('arch', {}))
+    if isinstance(m, dict):
+        return HipPanopticDeepLab(m, cfg, device=device)
+    if isinstance(m, str) and os.path.isfile(m):
+        ts = torch.jit.load(m, map_location='cpu')
+        return HipPanopticDeepLab(ts.state_dict(), cfg, device=device)
+    raise FileNotFoundError(f'model {m!r} is not a local TorchScript file (no network access from the engine)')
+
+
+def _require_scale_one(scale):
+    if scale != 1:
+        raise NotImplementedError('inference_scale > 1 needs the cv2.resize down-scaling (next tier, SURVEY section 8f)')
+
+
+def _open_zarr(store_url, mode=None):
+    try:
+        import zarr
+    except ImportError as e:
+        raise NotImplementedError('zarr output stores need the zarr package') from e
+    return zarr.open(store_url, mode=mode) if mode else zarr.open(store_url)
+
+
+def _class_volume(zarr_store, name, shape, dtype, chunks):
+    if zarr_store is not None:
+        return zarr_store.create_array(name, shape=shape, dtype=dtype, overwrite=True, chunks=chunks)
+    return np.zeros(shape, dtype=dtype)
+
+
+def _fill(volume, instances):
+    if isinstance(volume, np.ndarray):
+        sparse.fill_volume(volume, instances)
+    else:  # zarr array: fill a host copy chunk-free, then assign
+        tmp = np.zeros(volume.shape, dtype=volume.dtype)
+        sparse.fill_volume(tmp, instances)
+        volume[...] = tmp
+
+
+@thread_worker
+def stack_postprocessing(trackers, store_url, model_config, label_divisor=1000, min_size=200, min_extent=4,
+                         dtype=np.uint32, chunk_size=(256, 256, 256)):
+    """empanada_napari/inference.py:56-109."""
+    thing_list = model_config['thing_list']
+    zarr_store = _open_zarr(store_url) if store_url is not None else None
+    for class_id, class_name in model_config['class_names'].items():
+        class_tracker = sparse.get_axis_trackers_by_class(trackers, class_id)[0]
+        shape3d = class_tracker.shape3d
+        stack_tracker = sparse.InstanceTracker(class_id, label_divisor, shape3d, 'xy')
+        stack_tracker.instances = instance_relabel(class_tracker)
+        if class_id in thing_list:
+            sparse.remove_small_objects(stack_tracker, min_size=min_size)
+            sparse.remove_pancakes(stack_tracker, min_span=min_extent)
+            class_dtype = dtype
+        else:
+            class_dtype = np.uint8
+        vol = _class_volume(zarr_store, f'{class_name}', shape3d, class_dtype if zarr_store is not None else dtype,
+                            chunk_size)
+        _fill(vol, stack_tracker.instances)
+        yield vol, class_name, stack_tracker.instances
+
+
+@thread_worker
+def tracker_consensus(trackers, store_url, model_config, label_divisor=1000, pixel_vote_thr=2, cluster_iou_thr=0.75,
+                      allow_one_view=False, min_size=200, min_extent=4, dtype=np.uint32, chunk_size=(256, 256, 256)):
+    """empanada_napari/inference.py:111-169."""
+    thing_list = model_config['thing_list']
+    zarr_store = _open_zarr(store_url) if store_url is not None else None
+    for class_id, class_name in model_config['class_names'].items():
+        class_trackers = sparse.get_axis_trackers_by_class(trackers, class_id)
+        shape3d = class_trackers[0].shape3d
+        if class_id in thing_list:
+            consensus = sparse.create_instance_consensus(class_trackers, pixel_vote_thr, cluster_iou_thr, allow_one_view)
+            sparse.remove_small_objects(consensus, min_size=min_size)
+            sparse.remove_pancakes(consensus, min_span=min_extent)
+            class_dtype = dtype
+        else:
+            consensus = sparse.create_semantic_consensus(class_trackers, pixel_vote_thr)
+            class_dtype = np.uint8
+        vol = _class_volume(zarr_store, f'{class_name}', shape3d, class_dtype if zarr_store is not None else dtype,
+                            chunk_size)
+        _fill(vol, consensus.instances)
+        yield vol, class_name, consensus.instances
+
+
+class Engine2d:
+    """empanada_napari/inference.py:171-325."""
+
+    def __init__(self, model_config, inference_scale=1, label_divisor=1000, nms_threshold=0.1, nms_kernel=3,
+                 confidence_thr=0.3, semantic_only=False, fine_boundaries=False, tile_size=0, use_gpu=True,
+                 use_quantized=False):
+        if not (torch.cuda.is_available() and use_gpu):
+            raise RuntimeError('Engine2d: the MI355X engine has no CPU path (use_gpu=True and a HIP device required)')
+        device = torch.device('cuda:0')
+        model = load_model(model_config, device)
+        self.thing_list = model_config['thing_list']
+        self.labels = model_config['labels']
+        self.class_names = model_config['class_names']
+        self.label_divisor = label_divisor
+        self.padding_factor = model_config['padding_factor']
+        self.inference_scale = inference_scale
+        self.fine_boundaries = fine_boundaries
+        self.tile_size = tile_size
+        self.engine = PanopticDeepLabRenderEngine(
+            model, thing_list=[] if semantic_only else self.thing_list, label_divisor=label_divisor,
+            nms_threshold=nms_threshold, nms_kernel=nms_kernel, confidence_thr=confidence_thr,
+            padding_factor=self.padding_factor, coarse_boundaries=not fine_boundaries)
+        self.preprocessor = Preprocessor(**model_config['norms'])
+
+    def update_params(self, inference_scale, label_divisor, nms_threshold, nms_kernel, confidence_thr,
+                      fine_boundaries, semantic_only=False, tile_size=0):
+        self.inference_scale = inference_scale
+        self.engine.input_scale = inference_scale
+        self.label_divisor = label_divisor
+        self.engine.label_divisor = label_divisor
+        self.nms_threshold = nms_threshold
+        self.engine.nms_threshold = nms_threshold
+        self.nms_kernel = nms_kernel
+        self.engine.nms_kernel = nms_kernel
+        self.confidence_thr = confidence_thr
+        self.engine.confidence_thr = confidence_thr
+        self.fine_boundaries = fine_boundaries
+        self.engine.coarse_boundaries = not fine_boundaries
+        self.engine.thing_list = [] if semantic_only else self.thing_list
+        self.tile_size = tile_size
+
+    @torch.no_grad()
+    def force_connected(self, pan_seg):
+        """:263-279 on the GPU; accepts the device label map and returns an int32 numpy array."""
+        pan = pan_seg if isinstance(pan_seg, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pan_seg)).cuda()
+        pan = pan.to(torch.int32)
+        for label in self.engine.thing_list:
+            lo = label * self.label_divisor
+            hi = lo + self.label_divisor
+            inst = torch.where((pan >= lo) & (pan < hi), pan, torch.zeros_like(pan))
+            cc, _ = sparse.ccl8(inst[None])
+            cc = cc[0]
+            pan = torch.where(cc > 0, cc + lo, pan)
+        return pan.cpu().numpy().astype(np.int32)
+
+    def infer(self, image):
+        if self.tile_size > 0 and any(s > self.tile_size for s in image.shape):
+            raise NotImplementedError('tiled 2-D inference (cztile Tiler + tile consensus) is a next-tier row')
+        _require_scale_one(self.inference_scale)
+        size = image.shape
+        x = self.preprocessor(image)['image'].unsqueeze(0)
+        pan_seg = self.engine(x, size, upsampling=self.inference_scale)
+        return self.force_connected(pan_seg.squeeze(0))
+
+
+class Engine3d:
+    """empanada_napari/inference.py:327-578."""
+
+    def __init__(self, model_config, inference_scale=1, label_divisor=1000, median_kernel_size=5, stuff_area=64,
+                 void_label=0, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.3, force_connected=True,
+                 min_size=500, min_extent=4, fine_boundaries=False, semantic_only=False, use_gpu=True,
+                 use_quantized=False, store_url=None, chunk_size=(256, 256, 256), save_panoptic=False,
+                 label_erosion=0, label_dilation=0, fill_holes_in_segmentation=False, batch_size=8):
+        if not (torch.cuda.is_available() and use_gpu):
+            raise RuntimeError('Engine3d: the MI355X engine has no CPU path (use_gpu=True and a HIP device required)')
+        device = torch.device('cuda:0')
+        model = load_model(model_config, device)
+        self.model_config = model_config
+        self.labels = model_config['labels']
+        self.class_names = model_config['class_names']
+        self.label_divisor = label_divisor
+        self.padding_factor = model_config['padding_factor']
+        self.inference_scale = inference_scale
+        self.label_erosion = label_erosion
+        self.label_dilation = label_dilation
+        self.fill_holes_in_segmentation = fill_holes_in_segmentation
+        self.thing_list = [] if semantic_only else model_config['thing_list']
+        self.engine = PanopticDeepLabRenderEngine3d(
+            model, thing_list=self.thing_list, median_kernel_size=median_kernel_size, label_divisor=label_divisor,
+            stuff_area=stuff_area, void_label=void_label, nms_threshold=nms_threshold, nms_kernel=nms_kernel,
+            confidence_thr=confidence_thr, padding_factor=self.padding_factor, coarse_boundaries=not fine_boundaries)
+        self.preprocessor = Preprocessor(**model_config['norms'])
+        self.axes = {'xy': 0, 'xz': 1, 'yz': 2}
+        self.merge_iou_thr = 0.25
+        self.merge_ioa_thr = 0.25
+        self.force_connected = force_connected
+        self.min_size = min_size
+        self.min_extent = min_extent
+        self.fine_boundaries = fine_boundaries
+        self.save_panoptic = save_panoptic
+        self.chunk_size = chunk_size
+        self.zarr_store = _open_zarr(store_url, mode='w') if store_url is not None else None
+        self.dtype = np.int32
+        self.batch_size = batch_size
+
+    def update_params(self, inference_scale, label_divisor, median_kernel_size, nms_threshold, nms_kernel,
+                      confidence_thr, min_size, min_extent, fine_boundaries, semantic_only, store_url, chunk_size,
+                      save_panoptic, label_erosion, label_dilation, fill_holes_in_segmentation):
+        self.label_divisor = label_divisor
+        self.inference_scale = inference_scale
+        self.min_size = min_size
+        self.min_extent = min_extent
+        self.fine_boundaries = fine_boundaries
+        e = self.engine
+        e.label_divisor = label_divisor
+        e.ks = median_kernel_size
+        e.mid_idx = (median_kernel_size - 1) // 2
+        e.nms_threshold = nms_threshold
+        e.nms_kernel = nms_kernel
+        e.confidence_thr = confidence_thr
+        e.coarse_boundaries = not fine_boundaries
+        self.label_erosion = label_erosion
+        self.label_dilation = label_dilation
+        self.fill_holes_in_segmentation = fill_holes_in_segmentation
+        self.thing_list = [] if semantic_only else self.model_config['thing_list']
+        e.thing_list = self.thing_list
+        e.reset()
+        self.save_panoptic = save_panoptic
+        self.chunk_size = chunk_size
+        self.zarr_store = _open_zarr(store_url, mode='w') if store_url is not None else None
+
+    def create_trackers(self, shape3d, axis_name):
+        return [sparse.InstanceTracker(label, self.label_divisor, shape3d, axis_name) for label in self.labels]
+
+    def create_panoptic_stack(self, axis_name, shape3d):
+        if self.zarr_store is not None and self.save_panoptic:
+            return self.zarr_store.create_array(f'panoptic_{axis_name}', shape=shape3d, dtype=self.dtype,
+                                                chunks=self.chunk_size, overwrite=True)
+        if self.save_panoptic:
+            return np.zeros(shape3d, dtype=self.dtype)
+        return None
+
+    @torch.no_grad()
+    def predict_slices(self, volume, axis):
+        """Per-slice panoptic maps (device, int64 (h,w)) in slice order: batched forward, then the
+        engine's queue / median / voting exactly as PanopticDeepLabRenderEngine3d.__call__ (engines.py:363-394)."""
+        eng = self.engine
+        n = volume.shape[axis]
+        ups = self.inference_scale
+        rs = int(2 + math.log(ups, 2))
+        out = []
+        for i0 in range(0, n, self.batch_size):
+            imgs = [self.preprocessor(np.asarray(take(volume, i, axis)))['image'] for i in range(i0, min(n, i0 + self.batch_size))]
+            size = tuple(imgs[0].shape[-2:])
+            x = factor_pad(torch.stack(imgs), eng.padding_factor)
+            mo = eng.model(eng.to_model_device(x), rs, interpolate_ins=not eng.coarse_boundaries)
+            sem = logits_to_prob(mo['sem_logits'])
+            for j in range(x.shape[0]):
+                item = {'sem_logits': mo['sem_logits'][j:j + 1], 'ctr_hmp': mo['ctr_hmp'][j:j + 1],
+                        'offsets': mo['offsets'][j:j + 1], 'sem': sem[j:j + 1].clone(), 'size': size}
+                eng.enqueue(item)
+                med = eng.get_next(keys=['sem'])
+                if med is not None:
+                    h, w = size
+                    out.append(eng._segment(med, ups)[0, :h, :w])
+        for seg in eng.end(ups):
+            out.append(seg[0])
+        eng.reset()
+        return out
+
+    def infer_on_axis(self, volume, axis_name):
+        """:491-578 -> (stack, trackers)."""
+        _require_scale_one(self.inference_scale)
+        if self.label_erosion or self.label_dilation or self.fill_holes_in_segmentation:
+            raise NotImplementedError('label erosion / dilation / hole filling are next-tier rows (filters.py:154-210)')
+        axis = self.axes[axis_name]
+        trackers = self.create_trackers(volume.shape, axis_name)
+        matchers = sparse.create_matchers(self.thing_list, self.label_divisor, self.merge_iou_thr, self.merge_ioa_thr)
+        stack = self.create_panoptic_stack(axis_name, volume.shape)
+        pan_segs = self.predict_slices(volume, axis)
+        assert len(pan_segs) == volume.shape[axis]
+        # forward matching (patterns.py:68-100): dense -> RLE on the GPU in chunks, matching in slice order
+        rle_stack = []
+        for i0 in range(0, len(pan_segs), 64):
+            chunk = torch.stack(pan_segs[i0:i0 + 64])
+            for seg in sparse.pan_stack_to_rle_segs(chunk, self.labels, self.label_divisor, self.thing_list,
+                                                    force_connected=True):
+                rle_stack.append(sparse.apply_matchers(seg, matchers))
+        axis_len = volume.shape[axis]
+        for index, rle_seg in sparse.backward_matching(rle_stack, matchers, axis_len):
+            sparse.update_trackers(rle_seg, index, trackers)
+        sparse.finish_tracking(trackers)
+        for tr in trackers:
+            sparse.remove_small_objects(tr, min_size=self.min_size)
+            sparse.remove_pancakes(tr, min_span=self.min_extent)
+        if stack is not None:
+            if isinstance(stack, np.ndarray):
+                sparse.fill_panoptic_volume(stack, trackers)
+            else:
+                tmp = np.zeros(stack.shape, dtype=stack.dtype)
+                sparse.fill_panoptic_volume(tmp, trackers)
+                stack[...] = tmp
+        self.engine.reset()
+        return stack, trackers

@@ -1,0 +1,642 @@
+"""Sparse label algebra of the 3-D stitching path on the MI355X engine.
+
+Mirrors the names of ``empanada.inference.rle`` / ``matcher`` / ``tracker`` /
+``filters`` / ``empanada.array_utils`` / ``empanada.consensus`` that the
+orchestration layer (``inference.py``) calls.  The dense -> sparse step
+(connected components + run extraction) runs on the GPU; the range arithmetic
+(pairwise run intersections, k-of-n voting, unions) runs in the C++ host half of
+``libempanada_hip.so``; assignment uses scipy's Hungarian solver and the
+consensus graph uses networkx, the same third-party packages the reference
+calls (matcher.py:213, consensus.py:2).  Dict schema is the reference's:
+``{label: {'box', 'starts', 'runs'}}`` over row-major raveled indices.
+"""
+import ctypes as C
+import math
+from itertools import combinations
+
+import numpy as np
+import torch
+
+from . import _abi
+
+i64 = np.int64
+MIN_OVERLAP = 100     # consensus.py:7
+MIN_IOU = 1e-2        # consensus.py:8
+
+
+def _lib():
+    return _abi.load()
+
+
+def _dev(device=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError('empanada_napari_amd needs a HIP device (MI355X); there is no CPU fallback')
+    return torch.device(device or 'cuda:0')
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ----------------------------------------------------------------------------
+# device: connected components and run extraction
+# ----------------------------------------------------------------------------
+@torch.no_grad()
+def ccl8(labels):
+    """labels (N,H,W) int32 cuda -> (components (N,H,W) int32, count (N,) int32)."""
+    lib = _lib()
+    labels = labels.contiguous()
+    N, H, W = labels.shape
+    out = torch.empty_like(labels)
+    num = torch.empty((N,), dtype=torch.int32, device=labels.device)
+    work = torch.empty((int(lib.emp_ccl8_work_bytes(N, H, W)),), dtype=torch.uint8, device=labels.device)
+    _abi.check(lib.emp_ccl8(_abi.ptr(labels), N, H, W, _abi.ptr(out), _abi.ptr(num), _abi.ptr(work),
+                            _abi.stream_ptr(labels.device)), 'emp_ccl8')
+    return out, num
+
+
+@torch.no_grad()
+def extract_runs(labels, max_runs=1 << 16):
+    """labels (N,H,W) int32 cuda -> list of (n_i,3) int64 numpy arrays {start, length, label} in raster order."""
+    lib = _lib()
+    labels = labels.contiguous()
+    N, H, W = labels.shape
+    work = torch.empty((int(lib.emp_rle_extract_work_bytes(N, H, W)),), dtype=torch.uint8, device=labels.device)
+    while True:
+        runs = torch.empty((N, max_runs, 3), dtype=torch.int32, device=labels.device)
+        num = torch.empty((N,), dtype=torch.int32, device=labels.device)
+        _abi.check(lib.emp_rle_extract(_abi.ptr(labels), N, H, W, _abi.ptr(runs), _abi.ptr(num), max_runs,
+                                       _abi.ptr(work), _abi.stream_ptr(labels.device)), 'emp_rle_extract')
+        counts = num.cpu().numpy()
+        if counts.max(initial=0) <= max_runs:
+            break
+        max_runs = 1 << int(counts.max() - 1).bit_length()
+    top = int(counts.max(initial=0))
+    host = runs[:, :max(top, 1)].cpu().numpy().astype(i64)
+    return [host[n, :counts[n]] for n in range(N)]
+
+
+def _runs_to_attrs(runs, W, id_offset=0):
+    """(n,3) {start,len,label} in raster order -> {label: {'box','starts','runs'}} with labels ascending
+    (regionprops order) and bbox half-open (min_row, min_col, max_row+1, max_col+1)."""
+    if len(runs) == 0:
+        return {}
+    order = np.argsort(runs[:, 2], kind='stable')
+    r = runs[order]
+    s, ln, lab = r[:, 0], r[:, 1], r[:, 2]
+    e = s + ln - 1
+    y0, y1 = s // W, e // W
+    x0 = np.where(y0 == y1, s % W, 0)
+    x1 = np.where(y0 == y1, e % W, W - 1)
+    cut = np.flatnonzero(np.diff(lab)) + 1
+    bounds = np.concatenate([[0], cut, [len(lab)]])
+    idx = bounds[:-1]
+    ymin = np.minimum.reduceat(y0, idx)
+    ymax = np.maximum.reduceat(y1, idx)
+    xmin = np.minimum.reduceat(x0, idx)
+    xmax = np.maximum.reduceat(x1, idx)
+    out = {}
+    for k, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+        out[int(lab[a]) + id_offset] = {
+            'box': (int(ymin[k]), int(xmin[k]), int(ymax[k]) + 1, int(xmax[k]) + 1),
+            'starts': s[a:b].copy(), 'runs': ln[a:b].copy()}
+    return out
+
+
+def _as_device_i32(pan, device=None):
+    if isinstance(pan, np.ndarray):
+        pan = torch.from_numpy(np.ascontiguousarray(pan))
+    return pan.to(_dev(device), non_blocking=True).to(torch.int32)
+
+
+@torch.no_grad()
+def pan_stack_to_rle_segs(pan, labels, label_divisor, thing_list, force_connected=True):
+    """Batched rle.pan_seg_to_rle_seg (rle.py:26-86): pan (N,H,W) integer labels (numpy or cuda tensor)
+    -> list of N rle_seg dicts {class: {instance_id: attrs}}."""
+    pan = _as_device_i32(pan)
+    N, H, W = pan.shape
+    segs = [dict() for _ in range(N)]
+    for label in labels:
+        lo = label * label_divisor
+        hi = lo + label_divisor
+        inst = torch.where((pan >= lo) & (pan < hi), pan, torch.zeros_like(pan))
+        off = 0
+        if force_connected and label in thing_list:
+            inst, _ = ccl8(inst)
+            off = lo   # rle.py:68-69: component index + min_id
+        for n, runs in enumerate(extract_runs(inst)):
+            segs[n][label] = _runs_to_attrs(runs, W, off)
+    return segs
+
+
+def pan_seg_to_rle_seg(pan_seg, labels, label_divisor, thing_list, force_connected=True):
+    """rle.py:26-86 for one (H,W) panoptic map."""
+    p = pan_seg if isinstance(pan_seg, torch.Tensor) else np.asarray(pan_seg)
+    return pan_stack_to_rle_segs(p[None], labels, label_divisor, thing_list, force_connected)[0]
+
+
+def connected_components(seg):
+    """rle.py:18-24 on the GPU; numpy in -> numpy out (same dtype family as skimage: int)."""
+    if isinstance(seg, torch.Tensor):
+        return ccl8(seg.to(torch.int32)[None])[0][0]
+    out, _ = ccl8(_as_device_i32(np.asarray(seg))[None])
+    return out[0].cpu().numpy().astype(np.int64)
+
+
+def rle_seg_to_pan_seg(rle_seg, shape):
+    """rle.py:88-118 (uint32 output)."""
+    pan = np.zeros(int(np.prod(shape)), dtype=np.uint32)
+    for inst in rle_seg.values():
+        for oid, a in inst.items():
+            if len(a['starts']):
+                idx = np.concatenate([np.arange(s, s + r) for s, r in zip(a['starts'], a['runs'])])
+                pan[idx] = oid
+    return pan.reshape(shape)
+
+
+# ----------------------------------------------------------------------------
+# host range algebra (C++ half of the library)
+# ----------------------------------------------------------------------------
+def _sorted_runs(s, r):
+    """Tracker instances built by the backward pass hold their slices in descending order
+    (patterns.py:102-121 + tracker.py:89-100): the two-pointer sweep needs runs sorted by start
+    (the reference sorts inside rle_intersection, array_utils.py:393-402)."""
+    s, r = np.asarray(s, dtype=i64), np.asarray(r, dtype=i64)
+    if len(s) > 1 and np.any(s[1:] < s[:-1]):
+        order = np.argsort(s, kind='stable')
+        return s[order], r[order]
+    return s, r
+
+
+def _csr(objs):
+    """list of (starts, runs) -> concatenated int64 arrays + offsets."""
+    objs = [_sorted_runs(s, r) for s, r in objs]
+    off = np.zeros(len(objs) + 1, dtype=i64)
+    for k, (s, _) in enumerate(objs):
+        off[k + 1] = off[k] + len(s)
+    starts = np.ascontiguousarray(np.concatenate([np.asarray(s, dtype=i64) for s, _ in objs]) if objs else np.zeros(0, i64))
+    runs = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=i64) for _, r in objs]) if objs else np.zeros(0, i64))
+    return starts, runs, off
+
+
+def rle_pair_intersections(objs, pairs):
+    """Intersections |A_i ∩ B_j| for index pairs into ``objs`` (array_utils.py:375-407)."""
+    pairs = np.ascontiguousarray(np.asarray(pairs, dtype=i64).reshape(-1, 2))
+    out = np.zeros(len(pairs), dtype=i64)
+    if len(pairs) == 0:
+        return out
+    starts, runs, off = _csr(objs)
+    _abi.check(_lib().emp_rle_pair_intersections(_hp(starts), _hp(runs), _hp(off), _hp(pairs), len(pairs), _hp(out)),
+               'emp_rle_pair_intersections')
+    return out
+
+
+def rle_intersection(sa, ra, sb, rb):
+    return int(rle_pair_intersections([(sa, ra), (sb, rb)], [[0, 1]])[0])
+
+
+def rle_iou(sa, ra, sb, rb, return_intersection=False):
+    inter = rle_intersection(sa, ra, sb, rb)
+    iou = inter / (np.sum(ra) + np.sum(rb) - inter)
+    return (iou, inter) if return_intersection else iou
+
+
+def rle_ioa(sa, ra, sb, rb, return_intersection=False):
+    inter = rle_intersection(sa, ra, sb, rb)
+    ioa = inter / np.sum(rb)
+    return (ioa, inter) if return_intersection else ioa
+
+
+def vote_by_ranges(list_of_ranges, vote_thr=2):
+    """array_utils.py:627-639: (n_i,2) [start,end) range lists -> ranges with >= vote_thr votes."""
+    lst = [np.asarray(r, dtype=i64) for r in list_of_ranges if len(r) > 0]
+    if vote_thr > 1 and len(lst) < vote_thr:
+        return np.array([])
+    if not lst:
+        return np.array([])
+    ranges = np.ascontiguousarray(np.concatenate(lst, axis=0))
+    out = np.empty_like(ranges)
+    n_out = C.c_int64(0)
+    _abi.check(_lib().emp_ranges_vote(_hp(ranges), len(ranges), int(vote_thr), _hp(out), C.byref(n_out)),
+               'emp_ranges_vote')
+    return out[:n_out.value].copy()
+
+
+def join_ranges(list_of_ranges):
+    return vote_by_ranges(list_of_ranges, 1)
+
+
+def merge_rles(sa, ra, sb=None, rb=None):
+    """array_utils.py:719-752."""
+    lst = [np.stack([sa, sa + ra], axis=1)]
+    if sb is not None and rb is not None:
+        lst.append(np.stack([sb, sb + rb], axis=1))
+    j = join_ranges(lst)
+    return j[:, 0], j[:, 1] - j[:, 0]
+
+
+def merge_boxes(b1, b2):
+    h = len(b1) // 2
+    return tuple(min(a, b) if i < h else max(a, b) for i, (a, b) in enumerate(zip(b1, b2)))
+
+
+def box_overlap_pairs(boxes1, boxes2):
+    """Index pairs with a non-empty box intersection, row-major (array_utils.py:148-211)."""
+    b1, b2 = np.asarray(boxes1), np.asarray(boxes2)
+    if len(b1) == 0 or len(b2) == 0:
+        return np.zeros((0, 2), dtype=i64)
+    nd = b1.shape[1] // 2
+    lo = np.maximum(b1[:, None, :nd], b2[None, :, :nd])
+    hi = np.minimum(b1[:, None, nd:], b2[None, :, nd:])
+    return np.argwhere(np.all(hi > lo, axis=2)).astype(i64)
+
+
+# ----------------------------------------------------------------------------
+# slice-to-slice matching (matcher.py)
+# ----------------------------------------------------------------------------
+def _unpack(rles):
+    labels = np.array([int(k) for k in rles], dtype=i64)
+    boxes = np.array([a['box'] for a in rles.values()])
+    objs = [(a['starts'], a['runs']) for a in rles.values()]
+    return labels, boxes, objs
+
+
+def rle_matcher(target_rles, match_rles, iou_thr=0.5):
+    """matcher.py:136-232 (return_ioa=True form) -> (matched, [target_labels, match_labels], ious, ioa_matrix)."""
+    from scipy.optimize import linear_sum_assignment
+    tl, tb, tobj = _unpack(target_rles)
+    ml, mb, mobj = _unpack(match_rles)
+    if len(tl) == 0 or len(ml) == 0:
+        e = np.array([])
+        return (e, e), (tl, ml), e, e
+    pairs = box_overlap_pairs(tb, mb)
+    nt = len(tobj)
+    inter = rle_pair_intersections(tobj + mobj, pairs + np.array([0, nt])) if len(pairs) else np.zeros(0, i64)
+    ta = np.array([np.sum(r) for _, r in tobj], dtype=i64)
+    ma = np.array([np.sum(r) for _, r in mobj], dtype=i64)
+    iou = np.zeros((len(tl), len(ml)), dtype='float')
+    ioa = np.zeros((len(tl), len(ml)), dtype=np.float32)
+    if len(pairs):
+        r, c = pairs[:, 0], pairs[:, 1]
+        iou[r, c] = inter / (ta[r] + ma[c] - inter)
+        ioa[r, c] = inter / ma[c]
+    rows, cols = linear_sum_assignment(iou, maximize=True)
+    keep = iou[rows, cols] >= iou_thr
+    rows, cols = rows[keep], cols[keep]
+    return (tl[rows], ml[cols]), [tl, ml], iou[rows, cols], ioa
+
+
+def merge_attrs(a1, a2):
+    s, r = merge_rles(a1['starts'], a1['runs'], a2['starts'], a2['runs'])
+    return {'box': merge_boxes(a1['box'], a2['box']), 'starts': s, 'runs': r}
+
+
+class RLEMatcher:
+    """matcher.py:234-326: propagates labels from the previous slice (IoU match, IoA merge, else new)."""
+
+    def __init__(self, class_id, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25, assign_new=True, **kwargs):
+        self.class_id = class_id
+        self.label_divisor = label_divisor
+        self.merge_iou_thr = merge_iou_thr
+        self.merge_ioa_thr = merge_ioa_thr
+        self.assign_new = assign_new
+        self.next_label = (class_id * label_divisor) + 1
+        self.target_rle = None
+
+    def initialize_target(self, target_instance_rles):
+        self.target_rle = target_instance_rles
+        if len(target_instance_rles) > 0:
+            self.next_label = max(target_instance_rles.keys()) + 1
+
+    def update_target(self, instance_rles):
+        self.target_rle = instance_rles
+
+    def __call__(self, match_instance_rle, update_target=True):
+        assert self.target_rle is not None, 'Initialize target rle before running!'
+        matched, (tl, ml), _, ioa = rle_matcher(self.target_rle, match_instance_rle, self.merge_iou_thr)
+        by_match = {m: t for t, m in zip(matched[0], matched[1])}
+        out = {}
+        for col, (m, attrs) in enumerate(match_instance_rle.items()):
+            if m in by_match:
+                new = by_match[m]
+            else:
+                best = ioa[:, col].max() if len(ioa) > 0 else 0
+                if best >= self.merge_ioa_thr:
+                    new = tl[ioa[:, col].argmax()]
+                elif self.assign_new:
+                    new = self.next_label
+                    self.next_label += 1
+                else:
+                    new = m
+            out[new] = attrs if new not in out else merge_attrs(out[new], attrs)
+        if update_target:
+            self.update_target(out)
+        return out
+
+
+def create_matchers(thing_list, label_divisor, merge_iou_thr, merge_ioa_thr):
+    return [RLEMatcher(c, label_divisor, merge_iou_thr, merge_ioa_thr) for c in thing_list]
+
+
+def apply_matchers(rle_seg, matchers):
+    """patterns.py:55-66."""
+    for m in matchers:
+        if m.target_rle is None:
+            m.initialize_target(rle_seg[m.class_id])
+        else:
+            rle_seg[m.class_id] = m(rle_seg[m.class_id])
+    return rle_seg
+
+
+def backward_matching(rle_stack, matchers, axis_len):
+    """patterns.py:102-121."""
+    for m in matchers:
+        m.target_rle = None
+        m.assign_new = False
+    for idx in range(axis_len - 1, -1, -1):
+        yield idx, apply_matchers(rle_stack[idx], matchers)
+
+
+# ----------------------------------------------------------------------------
+# 3-D trackers (tracker.py) and filters (filters.py:22-56)
+# ----------------------------------------------------------------------------
+class InstanceTracker:
+    AXES = {'xy': 0, 'xz': 1, 'yz': 2}
+
+    def __init__(self, class_id=None, label_divisor=None, shape3d=None, axis='xy'):
+        assert axis in self.AXES
+        self.class_id = class_id
+        self.label_divisor = label_divisor
+        self.shape3d = shape3d
+        self.axis = axis
+        self.finished = False
+        self.axis_nums = dict(self.AXES)
+        self.reset()
+
+    def reset(self):
+        self.instances = {}
+
+    def update(self, instance_rles, index2d):
+        """tracker.py:61-100: lift a slice's 2-D runs into raveled 3-D indices."""
+        assert self.class_id is not None and self.label_divisor is not None and self.shape3d is not None
+        assert not self.finished, 'Cannot update tracker after calling finish!'
+        D, H, W = self.shape3d
+        for label, a in instance_rles.items():
+            y1, x1, y2, x2 = a['box']
+            st, rn = np.asarray(a['starts'], dtype=i64), np.asarray(a['runs'], dtype=i64)
+            if self.axis == 'xy':       # slice plane (H,W) at depth index2d
+                box = (index2d, y1, x1, index2d + 1, y2, x2)
+                starts, runs = st + index2d * (H * W), rn
+            elif self.axis == 'xz':     # slice plane (D,W) at row index2d: runs along x stay runs
+                box = (y1, index2d, x1, y2, index2d + 1, x2)
+                starts, runs = (st // W) * (H * W) + index2d * W + (st % W), rn
+            else:                       # slice plane (D,H) at column index2d: every voxel is its own run
+                box = (y1, x1, index2d, y2, x2, index2d + 1)
+                flat = np.repeat(st - np.cumsum(rn) + rn, rn) + np.arange(rn.sum()) if len(rn) else np.zeros(0, i64)
+                starts = (flat // H) * (H * W) + (flat % H) * W + index2d
+                runs = np.ones_like(starts)
+            if label not in self.instances:
+                self.instances[label] = {'box': box, 'starts': [starts], 'runs': [runs]}
+            else:
+                d = self.instances[label]
+                d['box'] = merge_boxes(box, d['box'])
+                d['starts'].append(starts)
+                d['runs'].append(runs)
+
+    def finish(self):
+        """tracker.py:102-123."""
+        for d in self.instances.values():
+            if not isinstance(d['starts'], list):
+                continue
+            starts = np.concatenate(d['starts'])
+            if self.axis == 'yz':
+                srt = np.sort(starts, kind='stable')
+                brk = np.flatnonzero(srt[1:] != srt[:-1] + 1) + 1
+                edges = np.concatenate([[0], brk, [len(srt)]])
+                starts, runs = srt[edges[:-1]], np.diff(edges)
+            else:
+                runs = np.concatenate(d['runs'])
+            d['starts'], d['runs'] = starts, runs
+        self.finished = True
+
+
+def update_trackers(rle_seg, index, trackers):
+    for tr in trackers:
+        tr.update(rle_seg[tr.class_id], index)
+
+
+def finish_tracking(trackers):
+    for tr in trackers:
+        tr.finish()
+
+
+def remove_small_objects(object_tracker, min_size=64):
+    for k in list(object_tracker.instances):
+        if object_tracker.instances[k]['runs'].sum() < min_size:
+            del object_tracker.instances[k]
+
+
+def remove_pancakes(object_tracker, min_span=4):
+    for k in list(object_tracker.instances):
+        b = object_tracker.instances[k]['box']
+        if min(b[3] - b[0], b[4] - b[1], b[5] - b[2]) < min_span:
+            del object_tracker.instances[k]
+
+
+def instance_relabel(tracker):
+    """empanada_napari/inference.py:31-54: ids 1..n, runs stably sorted by start."""
+    out = {}
+    for new_id, a in enumerate(tracker.instances.values(), start=1):
+        order = np.argsort(a['starts'], kind='stable')
+        out[new_id] = {'box': a['box'], 'starts': a['starts'][order], 'runs': a['runs'][order]}
+    return out
+
+
+def get_axis_trackers_by_class(trackers, class_id):
+    return [t for axis_trackers in trackers.values() for t in axis_trackers if t.class_id == class_id]
+
+
+# ----------------------------------------------------------------------------
+# ortho-plane consensus (consensus.py:199-469)
+# ----------------------------------------------------------------------------
+def _avg_weight(G, c1, c2, key):
+    w = [G[a][b][key] if G.has_edge(a, b) else 0 for a in c1 for b in c2]
+    return sum(w) / len(w)
+
+
+def _cluster_graph(G, thr):
+    import networkx as nx
+    H = G.copy()
+    H.remove_edges_from([(u, v) for u, v, d in G.edges(data=True) if d['iou'] <= thr])
+    CG = nx.Graph()
+    for i, comp in enumerate(nx.connected_components(H)):
+        CG.add_node(i, cluster=comp)
+    for a, b in combinations(CG.nodes, 2):
+        ca, cb = CG.nodes[a]['cluster'], CG.nodes[b]['cluster']
+        wi, wo = _avg_weight(G, ca, cb, 'iou'), _avg_weight(G, ca, cb, 'overlap')
+        if wi > MIN_IOU or wo > MIN_OVERLAP:
+            CG.add_edge(a, b, iou=wi, overlap=wo)
+    return CG
+
+
+def _absorb(H, src, dst):
+    H.nodes[dst]['cluster'] = H.nodes[dst]['cluster'].union(H.nodes[src]['cluster'])
+    H.remove_edge(src, dst)
+
+
+def _merge_clusters(G):
+    """consensus.py:86-142, including the re-added (hub, neighbour) edge."""
+    H = G.copy()
+    while H.number_of_edges() > 0:
+        hub = sorted(H.nodes, key=lambda n: len(list(H.neighbors(n))), reverse=True)[0]
+        nbrs = sorted(H.neighbors(hub), key=lambda n: len(H.nodes[n]['cluster']), reverse=True)
+        if len(H.nodes[nbrs[0]]['cluster']) > len(H.nodes[hub]['cluster']):
+            for nb in nbrs:
+                _absorb(H, hub, nb)
+            H.remove_node(hub)
+        else:
+            for nb in nbrs:
+                _absorb(H, nb, hub)
+                for sn in list(H.neighbors(nb)):
+                    if not H.has_edge(hub, sn):
+                        H.add_edge(hub, nb, iou=H[nb][sn]['iou'])
+                H.remove_node(nb)
+    return H
+
+
+def _merge_overlapping(cluster_instances):
+    """consensus.py:166-197."""
+    import networkx as nx
+    if len(cluster_instances) < 2:
+        return list(cluster_instances.values())
+    ids = list(cluster_instances)
+    objs = [(cluster_instances[k]['starts'], cluster_instances[k]['runs']) for k in ids]
+    pairs = np.array(list(combinations(range(len(ids)), 2)), dtype=i64)
+    inter = rle_pair_intersections(objs, pairs)
+    area = np.array([np.sum(r) for _, r in objs], dtype=i64)
+    g = nx.Graph()
+    g.add_nodes_from(ids)
+    for (a, b), it in zip(pairs, inter):
+        if it / (area[a] + area[b] - it) > MIN_IOU or it > MIN_OVERLAP:
+            g.add_edge(ids[a], ids[b])
+    merged = []
+    for comp in nx.connected_components(g):
+        members = [v for k, v in cluster_instances.items() if k in comp]
+        cur = members[0]
+        for m in members[1:]:
+            cur = merge_attrs(cur, m)
+        merged.append(cur if len(members) > 1 else members[0])
+    return merged
+
+
+def merge_objects_from_trackers(object_trackers, pixel_vote_thr=2, cluster_iou_thr=0.75, bypass=False):
+    """consensus.py:348-469."""
+    import networkx as nx
+    n_votes = len(object_trackers)
+    min_cluster = 1 if bypass else n_votes // 2 + 1
+    if pixel_vote_thr < min_cluster:
+        cluster_iou_thr = 0
+    src, boxes, objs = [], [], []
+    for ti, tr in enumerate(object_trackers):
+        for a in tr.instances.values():
+            src.append(ti)
+            boxes.append(a['box'])
+            objs.append((a['starts'], a['runs']))
+    if not boxes:
+        return {}
+    src, boxes = np.array(src), np.array(boxes)
+    # bounding-box screen: unique unordered pairs from different trackers (consensus.py:199-236)
+    p = box_overlap_pairs(boxes, boxes)
+    p = p[src[p[:, 0]] != src[p[:, 1]]]
+    p = np.unique(np.sort(p, axis=1), axis=0)
+    inter = rle_pair_intersections(objs, p)
+    area = np.array([np.sum(r) for _, r in objs], dtype=i64)
+    G = nx.Graph()
+    for n in range(len(objs)):
+        G.add_node(n)
+    for (a, b), it in zip(p, inter):
+        if it > 0:
+            G.add_edge(int(a), int(b), iou=it / (area[a] + area[b] - it), overlap=it)
+    instances, next_id = {}, 1
+    for comp in nx.connected_components(G):
+        if len(comp) < min_cluster:
+            continue
+        CG = _merge_clusters(_cluster_graph(G.subgraph(comp), cluster_iou_thr))
+        cluster_instances, cid = {}, 1
+        for node in CG.nodes:
+            cluster = list(CG.nodes[node]['cluster'])
+            if len(cluster) < min_cluster:
+                continue
+            box = tuple(int(v) for v in boxes[cluster[0]])
+            for n in cluster[1:]:
+                box = merge_boxes(box, tuple(int(v) for v in boxes[n]))
+            voted = vote_by_ranges([np.stack([objs[n][0], objs[n][0] + objs[n][1]], axis=1) for n in cluster],
+                                   pixel_vote_thr)
+            if len(voted) > 0:
+                cluster_instances[cid] = {'box': box, 'starts': voted[:, 0], 'runs': voted[:, 1] - voted[:, 0]}
+                cid += 1
+        for a in _merge_overlapping(cluster_instances):
+            instances[next_id] = a
+            next_id += 1
+    return instances
+
+
+def merge_semantic_from_trackers(semantic_trackers, pixel_vote_thr=2):
+    """consensus.py:289-346."""
+    boxes, ranges = [], []
+    for tr in semantic_trackers:
+        assert len(tr.instances) <= 1, 'Semantic classes only have 1 label!'
+        for a in tr.instances.values():
+            boxes.append(a['box'])
+            ranges.append(np.stack([a['starts'], a['starts'] + a['runs']], axis=1))
+    if not boxes:
+        return {}
+    box = boxes[0]
+    for b in boxes[1:]:
+        box = merge_boxes(box, b)
+    v = vote_by_ranges(ranges, pixel_vote_thr)
+    return {1: {'box': box, 'starts': v[:, 0], 'runs': v[:, 1] - v[:, 0]}}
+
+
+def create_instance_consensus(class_trackers, pixel_vote_thr=2, cluster_iou_thr=0.75, bypass=False):
+    t0 = class_trackers[0]
+    out = InstanceTracker(t0.class_id, t0.label_divisor, t0.shape3d, 'xy')
+    out.instances = merge_objects_from_trackers(class_trackers, pixel_vote_thr, cluster_iou_thr, bypass)
+    return out
+
+
+def create_semantic_consensus(class_trackers, pixel_vote_thr=2):
+    t0 = class_trackers[0]
+    out = InstanceTracker(t0.class_id, t0.label_divisor, t0.shape3d, 'xy')
+    out.instances = merge_semantic_from_trackers(class_trackers, pixel_vote_thr)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# RLE -> dense (patterns.py:204-220, array_utils.py:754-766)
+# ----------------------------------------------------------------------------
+@torch.no_grad()
+def fill_volume(volume, instances, device=None):
+    """Fills ``volume`` (numpy array or cuda tensor) in place with the instances' ids."""
+    lib = _lib()
+    ids = list(instances)
+    if not ids:
+        return volume
+    starts = np.concatenate([np.asarray(instances[k]['starts'], dtype=i64) for k in ids])
+    lens = np.concatenate([np.asarray(instances[k]['runs'], dtype=i64) for k in ids])
+    vals = np.concatenate([np.full(len(instances[k]['starts']), int(k), dtype=i64) for k in ids])
+    is_np = isinstance(volume, np.ndarray)
+    dev = _dev(device) if is_np else volume.device
+    dvol = torch.from_numpy(volume).to(dev) if is_np else volume
+    assert dvol.is_contiguous()
+    ds, dl, dv = (torch.from_numpy(a).to(dev) for a in (starts, lens, vals))
+    _abi.check(lib.emp_rle_fill(_abi.ptr(ds), _abi.ptr(dl), _abi.ptr(dv), len(starts), _abi.ptr(dvol), dvol.numel(),
+                                dvol.element_size(), _abi.stream_ptr(dev)), 'emp_rle_fill')
+    if is_np:
+        volume[...] = dvol.cpu().numpy()
+    return volume
+
+
+def fill_panoptic_volume(volume, trackers):
+    for tr in trackers:
+        fill_volume(volume, tr.instances)

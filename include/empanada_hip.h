@@ -185,6 +185,39 @@ EMP_API int emp_panoptic_merge(const float* d_sem, const int32_t* d_cells, int N
                        int64_t label_divisor, int64_t stuff_area, int64_t void_label,
                        int max_ids, int64_t* d_pan, void* d_work, void* stream);
 
+/* ------------------------------------------------------------------------
+ * 4. Label map <-> run-length encoding (3-D stitching path)
+ * ---------------------------------------------------------------------- */
+
+/* 8-connected components of EQUAL non-zero label, numbered 1..K per image in raster order of each
+ * component's first pixel.  replaces rle.connected_components (skimage.measure.label / cc3d),
+ * empanada/inference/rle.py:18-24, used by pan_seg_to_rle_seg (:66-69) and
+ * Engine2d.force_connected (empanada_napari/inference.py:263-279).
+ *   d_in, d_out (N,H,W) int32; d_num (N) int32 components per image (may be NULL). */
+EMP_API size_t emp_ccl8_work_bytes(int N, int H, int W);
+EMP_API int emp_ccl8(const int32_t* d_in, int N, int H, int W, int32_t* d_out, int32_t* d_num,
+             void* d_work, void* stream);
+
+/* Runs of equal non-zero label over the raveled image, in raster order.  replaces
+ * regionprops(...).coords -> rle_encode, rle.py:73-81 + array_utils.py:213-239.
+ *   d_runs (N, max_runs, 3) int32 {start, length, label}; d_num_runs (N) int32 (un-clamped). */
+EMP_API size_t emp_rle_extract_work_bytes(int N, int H, int W);
+EMP_API int emp_rle_extract(const int32_t* d_labels, int N, int H, int W, int32_t* d_runs,
+                    int32_t* d_num_runs, int max_runs, void* d_work, void* stream);
+
+/* Run list -> dense volume of elem_bytes-wide integers.  replaces numpy_fill_instances,
+ * array_utils.py:754-766 (runs must not overlap: later-overwrites-earlier is not defined here). */
+EMP_API int emp_rle_fill(const int64_t* d_starts, const int64_t* d_lens, const int64_t* d_vals,
+                 int64_t nruns, void* d_volume, int64_t size, int elem_bytes, void* stream);
+
+/* HOST: intersections of pairs of run-length objects stored CSR-style (object k owns runs
+ * [h_off[k], h_off[k+1])).  replaces rle_intersection, array_utils.py:344-407. */
+EMP_API int emp_rle_pair_intersections(const int64_t* h_starts, const int64_t* h_runs, const int64_t* h_off,
+                               const int64_t* h_pairs, int64_t n_pairs, int64_t* h_out);
+/* HOST: k-of-n vote over (n,2) ranges -> maximal ranges covered >= thr times (thr 1 = union).
+ * replaces vote_by_ranges / rle_voting / join_ranges, array_utils.py:461-699. */
+EMP_API int emp_ranges_vote(const int64_t* h_ranges, int64_t n, int thr, int64_t* h_out, int64_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

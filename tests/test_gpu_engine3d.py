@@ -1,0 +1,117 @@
+"""Upper boundary (Engine2d / Engine3d / tracker_consensus) on the MI355X vs the oracle's sparse
+pipeline fed with the SAME per-slice panoptic maps: trackers, consensus instances and the filled
+volumes must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DIV = 1000
+
+
+@pytest.fixture(scope='module')
+def model_config():
+    from empanada_napari_amd import weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    return {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+            'norms': {'mean': 0.57571, 'std': 0.12765}}
+
+
+def _oracle_axis(pan_segs, shape, axis_name, min_size, min_extent):
+    from oracle import sparse as osp
+    m = osp.RLEMatcher(1, DIV, 0.25, 0.25)
+    stack = []
+    for pan in pan_segs:
+        seg = osp.pan_seg_to_rle_seg(pan, [1], DIV, [1], force_connected=True)
+        stack.append(osp.apply_matchers(seg, [m]))
+    m.target_rle = None
+    m.assign_new = False
+    tr = osp.InstanceTracker(1, DIV, shape, axis_name)
+    for idx in range(len(pan_segs) - 1, -1, -1):
+        seg = osp.apply_matchers(stack[idx], [m])
+        tr.update(seg[1], idx)
+    tr.finish()
+    osp.remove_small_objects(tr, min_size)
+    osp.remove_pancakes(tr, min_extent)
+    return tr
+
+
+def _same_instances(a, b):
+    assert [int(k) for k in a] == [int(k) for k in b]
+    for ka, kb in zip(a, b):
+        assert tuple(int(v) for v in a[ka]['box']) == tuple(int(v) for v in b[kb]['box'])
+        np.testing.assert_array_equal(np.asarray(a[ka]['starts']), np.asarray(b[kb]['starts']))
+        np.testing.assert_array_equal(np.asarray(a[ka]['runs']), np.asarray(b[kb]['runs']))
+
+
+def test_engine3d_orthoplane_consensus(model_config):
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine3d, tracker_consensus
+    from oracle import sparse as osp
+    vol = synth.blob_volume(20, 48, 40, seed=3, n_blobs=5)
+    eng = Engine3d(model_config, label_divisor=DIV, median_kernel_size=3, nms_kernel=3, confidence_thr=0.5,
+                   min_size=30, min_extent=2, save_panoptic=True, batch_size=7)
+    trackers, otrackers = {}, {}
+    for axis_name, axis in (('xy', 0), ('xz', 1), ('yz', 2)):
+        pans = [p.cpu().numpy() for p in eng.predict_slices(vol, axis)]
+        assert len(pans) == vol.shape[axis] and pans[0].shape == tuple(s for i, s in enumerate(vol.shape) if i != axis)
+        stack, trs = eng.infer_on_axis(vol, axis_name)
+        otr = _oracle_axis(pans, vol.shape, axis_name, 30, 2)
+        _same_instances(trs[0].instances, otr.instances)
+        want = osp.numpy_fill_instances(np.zeros(vol.shape, np.int32), otr.instances)
+        np.testing.assert_array_equal(stack, want)
+        assert stack.dtype == np.int32
+        trackers[axis_name], otrackers[axis_name] = trs, otr
+    assert sum(len(t[0].instances) for t in trackers.values()) > 0
+    out = list(tracker_consensus(trackers, None, model_config, label_divisor=DIV, pixel_vote_thr=2,
+                                 cluster_iou_thr=0.75, allow_one_view=False, min_size=30, min_extent=2,
+                                 dtype=np.uint32))
+    assert len(out) == 1
+    cvol, name, inst = out[0]
+    ocons = osp.InstanceTracker(1, DIV, vol.shape, 'xy')
+    ocons.instances = osp.merge_objects_from_trackers(list(otrackers.values()), 2, 0.75, False)
+    osp.remove_small_objects(ocons, 30)
+    osp.remove_pancakes(ocons, 2)
+    _same_instances(inst, ocons.instances)
+    np.testing.assert_array_equal(cvol, osp.numpy_fill_instances(np.zeros(vol.shape, np.uint32), ocons.instances))
+    assert name == 'mito' and cvol.dtype == np.uint32
+
+
+def test_engine2d_force_connected(model_config):
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine2d
+    from oracle import sparse as osp
+    img = synth.em_tiles(1, 200, seed=9)[0][:150, :170]      # needs factor padding (150x170 -> 160x176)
+    eng = Engine2d(model_config, label_divisor=DIV, nms_kernel=3, confidence_thr=0.5)
+    x = eng.preprocessor(img)['image'].unsqueeze(0)
+    raw = eng.engine(x, img.shape, 1).squeeze(0).cpu().numpy().astype(np.int32)
+    got = eng.infer(img)
+    assert got.shape == img.shape and got.dtype == np.int32
+    np.testing.assert_array_equal(got, osp.force_connected_pan(raw.copy(), [1], DIV))
+    with pytest.raises(Exception, match='float'):
+        eng.infer(img.astype(np.float32))                     # Preprocessor contract, utils.py:196-197
+
+
+def test_batched_slices_equal_single_slice_calls(model_config):
+    """predict_slices (batched forward) == calling the 3d engine slice by slice like the reference loop"""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine3d
+    vol = synth.blob_volume(9, 32, 48, seed=4)
+    eng = Engine3d(model_config, label_divisor=DIV, median_kernel_size=3, confidence_thr=0.5, batch_size=4)
+    a = [p.cpu().numpy() for p in eng.predict_slices(vol, 0)]
+    e = eng.engine
+    b = []
+    for i in range(vol.shape[0]):
+        x = eng.preprocessor(vol[i])['image'].unsqueeze(0)
+        r = e(x, vol[i].shape, 1)
+        if r is not None:
+            b.append(r[0].cpu().numpy())
+    b += [s[0].cpu().numpy() for s in e.end(1)]
+    e.reset()
+    assert len(a) == len(b) == 9
+    for p, q in zip(a, b):
+        np.testing.assert_array_equal(p, q)

@@ -1,0 +1,101 @@
+"""Device half of the 3-D stitching path: connected components, run extraction, RLE fill."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _label_image(rng, h, w, n):
+    img = np.zeros((h, w), np.int64)
+    for i in range(n):
+        y, x = rng.integers(0, h), rng.integers(0, w)
+        hh, ww = rng.integers(1, h // 3 + 2), rng.integers(1, w // 3 + 2)
+        img[y:y + hh, x:x + ww] = 1000 + rng.integers(1, 6)   # few distinct ids -> same-id pieces touch / split
+    img[rng.random((h, w)) < 0.15] = 0
+    return img
+
+
+@pytest.mark.parametrize('shape', [(17, 23), (64, 64), (96, 130)])
+def test_ccl8_matches_oracle(shape):
+    from empanada_napari_amd import sparse as ps
+    from oracle import sparse as osp
+    rng = np.random.default_rng(shape[0])
+    imgs = np.stack([_label_image(rng, *shape, 12) for _ in range(3)])
+    imgs[0, :, :] = np.where(np.add.outer(np.arange(shape[0]), np.arange(shape[1])) % 2 == 0, 7, 0)  # diagonal-only links
+    out, num = ps.ccl8(torch.from_numpy(imgs.astype(np.int32)).cuda())
+    for n in range(3):
+        want = osp.connected_components(imgs[n])
+        np.testing.assert_array_equal(out[n].cpu().numpy(), want)
+        assert int(num[n]) == want.max()
+
+
+def test_pan_seg_to_rle_seg_matches_oracle():
+    from empanada_napari_amd import sparse as ps
+    from oracle import sparse as osp
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        pan = _label_image(rng, 48, 70, 10)
+        pan[40:, :20] = 2000        # a stuff class region
+        for fc in (True, False):
+            got = ps.pan_seg_to_rle_seg(pan, [1, 2], 1000, [1], force_connected=fc)
+            want = osp.pan_seg_to_rle_seg(pan, [1, 2], 1000, [1], force_connected=fc)
+            assert list(got) == list(want)
+            for c in want:
+                assert list(got[c]) == list(want[c]), (trial, fc, c)
+                for k in want[c]:
+                    assert tuple(got[c][k]['box']) == tuple(want[c][k]['box'])
+                    np.testing.assert_array_equal(got[c][k]['starts'], want[c][k]['starts'])
+                    np.testing.assert_array_equal(got[c][k]['runs'], want[c][k]['runs'])
+        back = ps.rle_seg_to_pan_seg(ps.pan_seg_to_rle_seg(pan, [1, 2], 1000, [1], False), pan.shape)
+        np.testing.assert_array_equal(back, pan.astype(np.uint32))
+
+
+def test_runs_span_rows_and_empty_images():
+    from empanada_napari_amd import sparse as ps
+    img = np.zeros((3, 4, 5), np.int32)
+    img[1, 0, 3:] = 9
+    img[1, 1, :2] = 9      # contiguous with the previous row in raveled order -> one run of 4
+    img[2] = 3             # whole image one run
+    runs = ps.extract_runs(torch.from_numpy(img).cuda())
+    assert runs[0].shape == (0, 3)
+    assert runs[1].tolist() == [[3, 4, 9]]
+    assert runs[2].tolist() == [[0, 20, 3]]
+    a = ps._runs_to_attrs(runs[1], 5)
+    assert a[9]['box'] == (0, 0, 2, 5)
+
+
+def test_pipeline_with_gpu_rle_matches_reference(golden_dir):
+    """full matcher -> tracker chain with the dense->RLE step on the GPU, vs the reference goldens"""
+    import os
+    import sparse_case
+    from empanada_napari_amd import sparse as ps
+    g = np.load(os.path.join(golden_dir, 'sparse.npz'))
+    trackers = sparse_case.run_axis_pipeline(ps)
+    for tr in trackers:
+        keys = np.array([int(k) for k in tr.instances])
+        np.testing.assert_array_equal(keys, g[f'trk_{tr.axis}_keys'])
+        starts = np.concatenate([tr.instances[k]['starts'] for k in tr.instances])
+        np.testing.assert_array_equal(starts, g[f'trk_{tr.axis}_starts'])
+
+
+def test_fill_volume_matches_oracle():
+    from empanada_napari_amd import sparse as ps
+    from oracle import sparse as osp
+    rng = np.random.default_rng(1)
+    shape = (12, 20, 24)
+    inst = {}
+    taken = np.zeros(int(np.prod(shape)), bool)
+    for k in range(1, 9):
+        s = np.sort(rng.choice(taken.size - 10, size=30, replace=False))
+        r = rng.integers(1, 9, size=30)
+        keep = []
+        for a, b in zip(s, r):
+            if not taken[a:a + b].any():
+                taken[a:a + b] = True
+                keep.append((a, b))
+        inst[k * 3] = {'box': (0, 0, 0) + shape, 'starts': np.array([a for a, _ in keep]), 'runs': np.array([b for _, b in keep])}
+    for dt in (np.uint8, np.int32, np.int64):
+        got = ps.fill_volume(np.zeros(shape, dt), inst)
+        want = osp.numpy_fill_instances(np.zeros(shape, dt), inst)
+        np.testing.assert_array_equal(got, want)
