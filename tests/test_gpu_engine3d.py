@@ -16,6 +16,14 @@ def model_config():
     from empanada_napari_amd.engines import HipPanopticDeepLab
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    # tiny test volumes: lift the centre head's bias so that every slice has centres (the seeded head gives
+    # ~90 centres per 1024^2 tile, i.e. none on a 48x40 slice) and make the semantic head mostly foreground
+    w, b = P['ins_center.head.1']
+    P['ins_center.head.1'] = (w, b + np.float32(0.75))
+    w, b = P['semantic_head.head.1']
+    P['semantic_head.head.1'] = (w, b + np.float32(2.5))
+    w, b = P['semantic_pr.point_head.predictor']
+    P['semantic_pr.point_head.predictor'] = (w, b + np.float32(2.5))
     model = HipPanopticDeepLab(P, cfg, folded=True)
     return {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
             'norms': {'mean': 0.57571, 'std': 0.12765}}

@@ -1,0 +1,86 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo groups run the z-slab driver of
+empanada-napari_amd/multigpu.py with the oracle's arithmetic plugged in, and must reproduce the
+single-process reference trace (tests/golden/median3d.npz: PanopticDeepLabRenderEngine3d)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ks, out_path):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    graft.load_package()
+    from empanada_napari_amd import multigpu
+    from oracle import postprocess as opp
+    from oracle import sparse as osp
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'median3d.npz'))
+    n = g['sem_logits'].shape[0]
+    eng = opp.RenderEngine(None, [1], label_divisor=1000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                           coarse_boundaries=True)
+
+    def forward_fn(lo, hi):
+        return [{'sem': torch.from_numpy(opp.logits_to_prob(g['sem_logits'][z])), 'ctr_hmp': g['ctr_hmp'][z],
+                 'offsets': g['offsets'][z]} for z in range(lo, hi)]
+
+    def median_fn(maps):
+        st = np.stack([m.numpy() for m in maps])
+        return torch.from_numpy(np.sort(st, axis=0)[(len(maps) - 1) // 2])
+
+    def segment_fn(item):
+        cells = eng.cells(item['ctr_hmp'], item['offsets'], 1)
+        return eng.postprocess(item['sem'].numpy(), cells)[0]
+
+    def to_rle_fn(pans):
+        return [osp.pan_seg_to_rle_seg(p, [1], 1000, [1], force_connected=True) for p in pans]
+
+    segs = multigpu.distributed_stack_inference(n, forward_fn, median_fn, segment_fn, to_rle_fn, ks)
+    if rank == 0:
+        pans = np.stack([osp.rle_seg_to_pan_seg(s, (64, 64)) for s in segs]).astype(np.int64)
+        np.save(out_path, pans)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,ks', [(2, 3), (2, 5), (3, 3), (2, 1)])
+def test_zslab_driver_reproduces_reference_trace(tmp_path, golden_dir, world, ks):
+    from oracle import sparse as osp
+    out = str(tmp_path / 'pans.npy')
+    mp.spawn(_worker, args=(world, _free_port(), ks, out), nprocs=world, join=True)
+    got = np.load(out)
+    g = np.load(os.path.join(golden_dir, 'median3d.npz'))
+    ref = g[f'pan_ks{ks}'][:, 0].astype(np.int64)     # reference engine trace, (n,1,64,64)
+    # compare through the same dense -> RLE -> dense round trip (connected components renumber instances)
+    want = np.stack([osp.rle_seg_to_pan_seg(osp.pan_seg_to_rle_seg(p, [1], 1000, [1], True), (64, 64)) for p in ref])
+    np.testing.assert_array_equal(got, want.astype(np.int64))
+
+
+def test_slab_bounds_and_single_process_filter():
+    from empanada_napari_amd import multigpu
+    assert multigpu.slab_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert multigpu.slab_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    vals = [5, 1, 9, 0, 7, 2]
+    med = lambda xs: sorted(xs)[(len(xs) - 1) // 2]
+    assert multigpu.filtered_stack(vals, 3, med) == [5, 5, 5, 5, 5, 2]
+    # split after slice 3: second slab needs the filtered carry [f3] and the first the raw look-ahead [7]
+    a = multigpu.filtered_stack(vals[:4], 3, med, None, vals[4:5], first=True, last=False)
+    b = multigpu.filtered_stack(vals[4:], 3, med, a[-1:], None, first=False, last=True)
+    assert a + b == [5, 5, 5, 5, 5, 2]
