@@ -47,6 +47,7 @@ PROTOTYPES = {
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'emp_logits_to_prob': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'emp_median_slices': (c_int, [C.POINTER(vp), c_int, vp, sz, vp]),
+    'emp_median_recursive': (c_int, [vp, vp, c_int, c_int, c_int, vp, sz, vp]),
     'emp_instance_cells_work_bytes': (sz, [c_int, c_int, c_int]),
     'emp_instance_cells': (c_int, [vp, vp, c_int, c_int, c_int, c_f32, c_int, c_int, c_int, vp, vp, vp, c_int, vp, vp]),
     'emp_panoptic_merge_work_bytes': (sz, [c_int, c_int, c_int]),

@@ -93,6 +93,49 @@ __global__ void __launch_bounds__(256) median_kernel(MedianPtrs ptrs, int ks, fl
   }
 }
 
+// recursive median over a run of consecutive slices in ONE launch (the z recursion is per pixel, so
+// a thread walks its pixel through the slices, carrying the filtered history in registers):
+//   hist: (mid, count) filtered maps preceding the run (only if n_hist == mid), raw: (n_raw, count) raw maps
+//   out[j] = median(hist/out[j-mid..j-1], raw[j..j+mid]) for j in [0, n_out); needs n_raw >= n_out + mid
+template <int KS>
+__global__ void __launch_bounds__(256) median_recursive_kernel(const float* __restrict__ hist,
+                                                               const float* __restrict__ raw, int n_out,
+                                                               float* __restrict__ out, size_t count) {
+  constexpr int MID = (KS - 1) / 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    float h[MID > 0 ? MID : 1];
+#pragma unroll
+    for (int k = 0; k < MID; ++k) h[k] = hist[(size_t)k * count + i];
+    float ahead[MID + 1];  // raw[j .. j+mid]
+#pragma unroll
+    for (int k = 0; k <= MID; ++k) ahead[k] = raw[(size_t)k * count + i];
+    for (int j = 0; j < n_out; ++j) {
+      float v[KS];
+#pragma unroll
+      for (int k = 0; k < MID; ++k) v[k] = h[k];
+#pragma unroll
+      for (int k = 0; k <= MID; ++k) v[MID + k] = ahead[k];
+#pragma unroll
+      for (int a = 1; a < KS; ++a) {
+#pragma unroll
+        for (int b = a; b > 0; --b) {
+          float lo = fminf(v[b - 1], v[b]), hi = fmaxf(v[b - 1], v[b]);
+          v[b - 1] = lo;
+          v[b] = hi;
+        }
+      }
+      const float m = v[MID];
+      out[(size_t)j * count + i] = m;
+#pragma unroll
+      for (int k = 0; k + 1 < MID; ++k) h[k] = h[k + 1];
+      if (MID > 0) h[MID - 1] = m;
+#pragma unroll
+      for (int k = 0; k < MID; ++k) ahead[k] = ahead[k + 1];
+      if (j + 1 < n_out) ahead[MID] = raw[(size_t)(j + 1 + MID) * count + i];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // centre NMS -> bitmask (one bit per heat-map pixel, row-major)
 // ---------------------------------------------------------------------------
@@ -389,6 +432,23 @@ int emp_median_slices(const float* const* h_slice_ptrs, int ks, float* d_out, si
   for (int k = 0; k < MAX_KS; ++k) ptrs.p[k] = k < ks ? h_slice_ptrs[k] : h_slice_ptrs[0];
   hipLaunchKernelGGL(median_kernel, dim3(grid_for((int64_t)count)), dim3(256), 0, (hipStream_t)stream, ptrs, ks, d_out,
                      count);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int emp_median_recursive(const float* d_hist, const float* d_raw, int n_raw, int ks, int n_out, float* d_out,
+                         size_t count, void* stream) {
+  EMP_REQUIRE(d_hist && d_raw && d_out && count > 0, "median_recursive: null argument");
+  EMP_REQUIRE((ks & 1) && ks >= 3 && ks <= 9, "median_recursive: kernel size %d must be odd, 3..9", ks);
+  EMP_REQUIRE(n_out >= 1 && n_raw >= n_out + (ks - 1) / 2, "median_recursive: need n_out + mid raw maps");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = grid_for((int64_t)count);
+  switch (ks) {
+    case 3: hipLaunchKernelGGL(median_recursive_kernel<3>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
+    case 5: hipLaunchKernelGGL(median_recursive_kernel<5>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
+    case 7: hipLaunchKernelGGL(median_recursive_kernel<7>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
+    default: hipLaunchKernelGGL(median_recursive_kernel<9>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
+  }
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }

@@ -274,29 +274,76 @@ class Engine3d:
 
     @torch.no_grad()
     def predict_slices(self, volume, axis):
-        """Per-slice panoptic maps (device, int64 (h,w)) in slice order: batched forward, then the
-        engine's queue / median / voting exactly as PanopticDeepLabRenderEngine3d.__call__ (engines.py:363-394)."""
+        """Per-slice panoptic maps (device, int64 (h,w)) in slice order.
+
+        Same arithmetic as feeding PanopticDeepLabRenderEngine3d.__call__ slice by slice
+        (engines.py:363-394): f[z] = raw[z] for the first / last ``mid`` slices, otherwise
+        median(f[z-mid..z-1], raw[z..z+mid]).  Here the forward runs in batches and every run of
+        consecutive slices goes through ONE recursive-median launch and ONE batched voting / merge
+        launch group instead of a per-slice Python loop with a host sync each."""
         eng = self.engine
+        lib = eng.lib
+        from . import _abi
         n = volume.shape[axis]
+        ks, mid = eng.ks, eng.mid_idx
         ups = self.inference_scale
         rs = int(2 + math.log(ups, 2))
         out = []
+        fhist = []            # last `mid` filtered maps, each (1,C,H,W)
+        pend = []             # raw (sem, ctr, off) of slices not yet emitted, each with batch dim 1..B
+        zp = 0                # global index of the first pending slice
+        avail = 0
+        size = None
+
+        def emit(sem_f, ctr, off):
+            cells, _, _, kmax = eng.instance_cells_int(ctr, off, ups)
+            pan = eng.panoptic_merge_int(sem_f, cells, kmax)
+            h, w = size
+            out.extend(pan[:, :h, :w].unbind(0))
+
+        def process(upto):
+            """emit slices zp .. upto-1 (their look-ahead is available or they are tail slices)"""
+            nonlocal zp, pend, fhist
+            if upto <= zp:
+                return
+            sem = torch.cat([p[0] for p in pend])
+            ctr = torch.cat([p[1] for p in pend])
+            off = torch.cat([p[2] for p in pend])
+            cnt = upto - zp
+            filt = []
+            z = zp
+            while z < upto:
+                loc = z - zp
+                if z < mid or z >= n - mid or mid == 0:     # head / tail slices stay unfiltered (engines.py:70-72,89-90)
+                    f = sem[loc:loc + 1]
+                    filt.append(f)
+                    fhist = (fhist + [f])[-max(mid, 1):]
+                    z += 1
+                    continue
+                run = min(upto, n - mid) - z                # consecutive filtered slices
+                hist = torch.cat(fhist[-mid:]).contiguous()
+                raw = sem[loc:loc + run + mid].contiguous()
+                res = torch.empty((run,) + tuple(sem.shape[1:]), dtype=sem.dtype, device=sem.device)
+                cntpx = sem[0].numel()
+                _abi.check(lib.emp_median_recursive(_abi.ptr(hist), _abi.ptr(raw), raw.shape[0], ks, run, _abi.ptr(res),
+                                                    cntpx, _abi.stream_ptr(sem.device)), 'emp_median_recursive')
+                filt.append(res)
+                fhist = (fhist + list(res[-mid:].split(1)))[-mid:]
+                z += run
+            emit(torch.cat(filt), ctr[:cnt], off[:cnt])
+            rest = sem.shape[0] - cnt
+            pend = [(sem[cnt:], ctr[cnt:], off[cnt:])] if rest > 0 else []
+            zp = upto
+
         for i0 in range(0, n, self.batch_size):
             imgs = [self.preprocessor(np.asarray(take(volume, i, axis)))['image'] for i in range(i0, min(n, i0 + self.batch_size))]
             size = tuple(imgs[0].shape[-2:])
             x = factor_pad(torch.stack(imgs), eng.padding_factor)
             mo = eng.model(eng.to_model_device(x), rs, interpolate_ins=not eng.coarse_boundaries)
-            sem = logits_to_prob(mo['sem_logits'])
-            for j in range(x.shape[0]):
-                item = {'sem_logits': mo['sem_logits'][j:j + 1], 'ctr_hmp': mo['ctr_hmp'][j:j + 1],
-                        'offsets': mo['offsets'][j:j + 1], 'sem': sem[j:j + 1].clone(), 'size': size}
-                eng.enqueue(item)
-                med = eng.get_next(keys=['sem'])
-                if med is not None:
-                    h, w = size
-                    out.append(eng._segment(med, ups)[0, :h, :w])
-        for seg in eng.end(ups):
-            out.append(seg[0])
+            pend.append((logits_to_prob(mo['sem_logits']), mo['ctr_hmp'].clone(), mo['offsets'].clone()))
+            avail += x.shape[0]
+            process(min(avail - mid, n - mid) if avail < n else n)
+        process(n)
         eng.reset()
         return out
 

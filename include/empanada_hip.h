@@ -156,6 +156,13 @@ EMP_API int emp_logits_to_prob(const float* d_logits, float* d_prob, int N, int 
 EMP_API int emp_median_slices(const float* const* h_slice_ptrs, int ks, float* d_out,
                       size_t count, void* stream);
 
+/* The same filter over a run of consecutive slices in one launch (batched 3-D path): the recursion of
+ * _MedianQueue.get_next (engines.py:76-84) is per pixel, so one thread carries the filtered history.
+ *   d_hist (mid,count) filtered maps preceding the run; d_raw (n_raw,count) raw maps of the run plus
+ *   mid look-ahead maps; d_out (n_out,count): out[j] = median(filtered[j-mid..j-1], raw[j..j+mid]). */
+EMP_API int emp_median_recursive(const float* d_hist, const float* d_raw, int n_raw, int ks, int n_out,
+                         float* d_out, size_t count, void* stream);
+
 /* Centre NMS + voting + nearest upsampling: get_instance_cells,
  * engines.py:257-275 (find_instance_center postprocess.py:38-76 and
  * group_pixels :78-169).  Batched over N images.

@@ -1,0 +1,74 @@
+"""BASELINE configs[2]: ortho-plane 3-D inference + consensus on a synthetic cube, one MI355X.
+    python tools/bench_stack3d.py [size=256] [batch=16]
+Prints one JSON line: voxels/s over the whole job (3 axes + consensus + fill) and a time breakdown."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+graft.load_package()
+from empanada_napari_amd import synth, weights  # noqa: E402
+from empanada_napari_amd.engines import HipPanopticDeepLab  # noqa: E402
+from empanada_napari_amd.inference import Engine3d, tracker_consensus  # noqa: E402
+
+
+def main():
+    size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.57571, 'std': 0.12765}}
+    vol = synth.blob_volume(size, size, size, seed=0, n_blobs=max(8, (size // 32) ** 2))
+    eng = Engine3d(mc, label_divisor=10000, median_kernel_size=3, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5,
+                   min_size=500, min_extent=5, batch_size=batch)
+    eng.predict_slices(vol[:batch], 0)  # warm-up (arena allocation, first-touch)
+    torch.cuda.synchronize()
+    t = {}
+    t0 = time.perf_counter()
+    trackers = {}
+    for name, axis in (('xy', 0), ('xz', 1), ('yz', 2)):
+        ta = time.perf_counter()
+        pans = eng.predict_slices(vol, axis)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        # same as infer_on_axis from here (re-using the predicted slices keeps the breakdown honest)
+        from empanada_napari_amd import sparse
+        trs = eng.create_trackers(vol.shape, name)
+        matchers = sparse.create_matchers(eng.thing_list, eng.label_divisor, eng.merge_iou_thr, eng.merge_ioa_thr)
+        rle_stack = []
+        for i0 in range(0, len(pans), 64):
+            for seg in sparse.pan_stack_to_rle_segs(torch.stack(pans[i0:i0 + 64]), eng.labels, eng.label_divisor,
+                                                    eng.thing_list, True):
+                rle_stack.append(sparse.apply_matchers(seg, matchers))
+        tc = time.perf_counter()
+        for index, seg in sparse.backward_matching(rle_stack, matchers, vol.shape[axis]):
+            sparse.update_trackers(seg, index, trs)
+        sparse.finish_tracking(trs)
+        for tr in trs:
+            sparse.remove_small_objects(tr, eng.min_size)
+            sparse.remove_pancakes(tr, eng.min_extent)
+        td = time.perf_counter()
+        trackers[name] = trs
+        t[name] = {'forward_post_s': round(tb - ta, 3), 'rle_forward_match_s': round(tc - tb, 3),
+                   'backward_track_s': round(td - tc, 3), 'objects': len(trs[0].instances)}
+    te = time.perf_counter()
+    out = list(tracker_consensus(trackers, None, mc, label_divisor=10000, pixel_vote_thr=2, cluster_iou_thr=0.75,
+                                 allow_one_view=False, min_size=500, min_extent=5, dtype=np.uint32))
+    tf = time.perf_counter()
+    total = tf - t0
+    print(json.dumps({'metric': 'voxels/sec, 3-D ortho-plane stack + consensus', 'value': round(vol.size / total, 1),
+                      'unit': 'voxels/s', 'volume': list(vol.shape), 'seconds': round(total, 3), 'axes': t,
+                      'consensus_fill_s': round(tf - te, 3), 'consensus_objects': len(out[0][2]), 'batch': batch}))
+
+
+if __name__ == '__main__':
+    main()
