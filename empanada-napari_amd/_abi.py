@@ -20,7 +20,7 @@ class PdlConfig(C.Structure):
         ('aspp_channels', c_i32), ('n_stages', c_i32), ('low_level_stages', c_i32 * 3),
         ('low_level_proj_sem', c_i32 * 3), ('low_level_proj_ins', c_i32 * 3),
         ('atrous_rates', c_i32 * 3), ('ins_decoder', c_i32), ('num_fc', c_i32),
-        ('subdivision_num_points', c_i32),
+        ('subdivision_num_points', c_i32), ('arch', c_i32), ('fpn_dim', c_i32), ('fpn_layers', c_i32),
     ]
 
 

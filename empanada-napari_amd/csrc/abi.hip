@@ -75,7 +75,8 @@ int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_l
   p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   EMP_REQUIRE(p.Ho > 0 && p.Wo > 0, "conv2d: empty output");
   p.out_ld = out_ld;
-  p.relu = relu;
+  p.act = relu;
+  p.ps_cout = 0;
   p.M = N * p.Ho * p.Wo;
   return launch_conv_igemm(p, variant, (hipStream_t)stream);
 }

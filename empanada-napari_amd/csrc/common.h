@@ -55,7 +55,9 @@ struct ConvParams {
   const half_t* zero; // zero page
   int N, H, W, Cin, in_ld;
   int Cout, KH, KW, stride, pad, dil;
-  int Ho, Wo, out_ld, res_ld, relu;
+  int Ho, Wo, out_ld, res_ld;
+  int act;         // 0 none, 1 ReLU, 2 SiLU
+  int ps_cout;     // > 0: k2s2 transposed-conv pixel-shuffle store, Cout == 4*ps_cout
   int M;           // N*Ho*Wo
   int mt, nt;      // tiles along pixels / couts
   int mt_per_xcd;  // ceil(mt/8)
@@ -71,8 +73,13 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream);
 int launch_stem7x7(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
                    const float* w /*49x64*/, const float* b /*64*/, half_t* out, hipStream_t s);
 int launch_maxpool3x3s2(const half_t* in, int N, int H, int W, int C, half_t* out, hipStream_t s);
-int launch_dwconv5x5(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* w /*25 x C fp16*/,
-                     half_t* out, int out_ld, const half_t* zero, hipStream_t s);
+// depthwise KxK (K = 3 or 5), stride 1, pad K/2; weights fp16 [K*K][C]
+int launch_dwconv(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* w, int K,
+                  half_t* out, int out_ld, const half_t* zero, hipStream_t s);
+// BiFPN fast-normalised fusion (bifpn.py:52-69,106-134): out = ca*resize(a) + cb*b (+ cc*c)
+//   mode 0: a is at half resolution, nearest x2 up-sampling; mode 1: a is at double resolution, 3x3/2 max-pool
+int launch_fuse_combine(const half_t* a, const half_t* b, const half_t* c, float ca, float cb, float cc, int mode,
+                        int N, int H, int W, int C, half_t* out, hipStream_t s);
 int launch_bilinear_ac(const half_t* in, int N, int h, int w, int C, int in_ld, half_t* out, int H, int W,
                        int out_ld, hipStream_t s);
 int launch_avgpool(const half_t* in, int N, int HW, int C, int in_ld, float* out /*N x C*/, float* part,

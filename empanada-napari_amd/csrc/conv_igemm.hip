@@ -46,6 +46,24 @@ __device__ __forceinline__ int perm32(int x) {
   return ((i >> 2) << 3) + (t << 2) + (i & 3);
 }
 
+// epilogue activation: 0 none | 1 ReLU | 2 SiLU (x * sigmoid(x), bifpn.py:35,91)
+__device__ __forceinline__ float apply_act(float x, int act) {
+  if (act == 1) return fmaxf(x, 0.f);
+  if (act == 2) return x / (1.f + __expf(-x));
+  return x;
+}
+// output element offset of pixel m / cout co.  ps_cout > 0: the GEMM computes a k=2,s=2 transposed
+// convolution as 4 sub-pixel 1x1 convs (cout blocks q = dy*2+dx of ps_cout channels each) and the
+// store does the pixel shuffle: (n,y,x,q*C+c) -> (n, 2y+dy, 2x+dx, c)   (blocks.py:154-171)
+__device__ __forceinline__ size_t out_offset(const ConvParams& p, int m, int co, int HoWo) {
+  if (p.ps_cout == 0) return (size_t)m * p.out_ld + co;
+  const int q = co / p.ps_cout, c = co - q * p.ps_cout;
+  const int n = m / HoWo, r = m - n * HoWo;
+  const int y = r / p.Wo, x = r - y * p.Wo;
+  const size_t opix = ((size_t)n * (2 * p.Ho) + 2 * y + (q >> 1)) * (2 * p.Wo) + 2 * x + (q & 1);
+  return opix * p.out_ld + c;
+}
+
 template <int BM, int BN, int WPM, int WPN, bool GLDS, bool EPI_LDS, int OCC>
 __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p) {
   constexpr int TM = BM / WPM, TN = BN / WPN;
@@ -270,7 +288,6 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave reads back only its own writes
-    const float lo = p.relu ? 0.f : -INFINITY;
 #pragma unroll
     for (int i = 0; i < TM / RPI; ++i) {
       const int row = i * RPI + l / CPR;
@@ -294,14 +311,13 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
       }
       f16x8 o;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = (half_t)fmaxf(v[r], lo);
-      *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + co_l) = o;
+      for (int r = 0; r < 8; ++r) o[r] = (half_t)apply_act(v[r], p.act);
+      *reinterpret_cast<f16x8*>(p.out + out_offset(p, m, co_l, HoWo)) = o;
     }
     return;
   } else {
     compute((S - 1) & 1);
     // ---- direct epilogue: lane (fq, fr) owns couts P*32 + fq*8 + [0,8) of pixel fr of each pixel tile ----
-    const float lo = p.relu ? 0.f : -INFINITY;
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       const int m = m0 + wm * TM + t * 16 + fr;
@@ -337,8 +353,8 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
         }
         f16x8 o;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] = (half_t)fmaxf(v[r], lo);
-        *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + co) = o;
+        for (int r = 0; r < 8; ++r) o[r] = (half_t)apply_act(v[r], p.act);
+        *reinterpret_cast<f16x8*>(p.out + out_offset(p, m, co, HoWo)) = o;
       }
     }
   }
@@ -361,7 +377,10 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   EMP_REQUIRE(p.Cin % BK == 0 && p.Cin > 0, "conv: Cin=%d must be a positive multiple of 64", p.Cin);
   EMP_REQUIRE(p.in_ld % 8 == 0 && p.in_ld >= p.Cin, "conv: in_ld=%d must be >= Cin and a multiple of 8", p.in_ld);
   EMP_REQUIRE(p.Cout % 8 == 0 && p.Cout > 0, "conv: Cout=%d must be a positive multiple of 8", p.Cout);
-  EMP_REQUIRE(p.out_ld % 8 == 0 && p.out_ld >= p.Cout, "conv: out_ld=%d invalid", p.out_ld);
+  EMP_REQUIRE(p.out_ld % 8 == 0 && p.out_ld >= (p.ps_cout ? p.ps_cout : p.Cout), "conv: out_ld=%d invalid", p.out_ld);
+  EMP_REQUIRE(p.ps_cout == 0 || (p.ps_cout % 8 == 0 && p.Cout == 4 * p.ps_cout && p.res == nullptr),
+              "conv: pixel-shuffle store needs Cout == 4*ps_cout, ps_cout %% 8 == 0, no residual");
+  EMP_REQUIRE(p.act >= 0 && p.act <= 2, "conv: act must be 0 (none), 1 (ReLU) or 2 (SiLU)");
   EMP_REQUIRE(p.res == nullptr || p.res_ld % 8 == 0, "conv: res_ld=%d must be a multiple of 8", p.res_ld);
   EMP_REQUIRE(((uintptr_t)p.in % 16) == 0 && ((uintptr_t)p.out % 16) == 0 && ((uintptr_t)p.wgt % 16) == 0 &&
                   ((uintptr_t)p.res % 16) == 0 && ((uintptr_t)p.zero % 256) == 0 && p.zero != nullptr,

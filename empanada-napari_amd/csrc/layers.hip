@@ -135,20 +135,23 @@ __global__ void __launch_bounds__(256) maxpool3x3s2_kernel(const half_t* __restr
 }
 
 // ---------------------------------------------------------------------------
-// 5x5 depthwise conv, stride 1, pad 2, no bias (blocks.py:24-29, first conv of
-// SeparableConv2d).  HBM-bound byte mover: one block = 8x32 output pixels x 64
-// channels; the 12x36x64 input halo tile is brought into LDS by LDS-DMA
-// (pixel-major, 128 B per pixel; out-of-image pixels read the zero page), each
-// thread then slides a 5-wide window down one column for its 8 channels with
-// the 25x8 taps held in registers as packed fp16 (fp32 accumulate).
-// weights fp16 [25][C].
+// KxK depthwise conv (K = 3 | 5), stride 1, pad K/2, no bias (blocks.py:24-29, first conv of
+// SeparableConv2d).  HBM-bound byte mover: one block = 8x32 output pixels x 64 channels; the
+// (8+K-1)x(32+K-1)x64 input halo tile is brought into LDS by LDS-DMA (pixel-major, 128 B per
+// pixel; out-of-image pixels read the zero page), each thread then slides a K-wide window down
+// two columns for its 4 channels with the KxKx4 taps held in registers (fp32 accumulate).
+// weights fp16 [K*K][C].
 // ---------------------------------------------------------------------------
-constexpr int DW_TH = 8, DW_TW = 32, DW_IH = DW_TH + 4, DW_IW = DW_TW + 4;
-__global__ void __launch_bounds__(256, 2) dwconv5x5_kernel(const half_t* __restrict__ in, int N, int H, int W, int C,
-                                                           int in_ld, const half_t* __restrict__ wgt,
-                                                           half_t* __restrict__ out, int out_ld,
-                                                           const half_t* __restrict__ zero, int tiles_x, int tiles_y) {
-  __shared__ __attribute__((aligned(1024))) char lds[DW_IH * DW_IW * 128];
+constexpr int DW_TH = 8, DW_TW = 32;
+template <int K>
+__global__ void __launch_bounds__(256, 2) dwconv_kernel(const half_t* __restrict__ in, int N, int H, int W, int C,
+                                                        int in_ld, const half_t* __restrict__ wgt,
+                                                        half_t* __restrict__ out, int out_ld,
+                                                        const half_t* __restrict__ zero, int tiles_x, int tiles_y) {
+  constexpr int P = K / 2, DW_IH = DW_TH + K - 1, DW_IW = DW_TW + K - 1;
+  constexpr int NPIX = DW_IH * DW_IW;
+  constexpr int NINSTR = (NPIX + 7) / 8;     // wave-instructions of 8 pixels
+  __shared__ __attribute__((aligned(1024))) char lds[NINSTR * 1024];
   int b = blockIdx.x;
   const int cb = b % (C >> 6); b /= (C >> 6);
   const int tx = b % tiles_x; b /= tiles_x;
@@ -157,12 +160,10 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_kernel(const half_t* __restr
   const int y0 = ty * DW_TH, x0 = tx * DW_TW;
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   const half_t* src = in + (size_t)n * H * W * in_ld + cb * 64 + (l & 7) * 8;
-  constexpr int NPIX = DW_IH * DW_IW;        // 432
-  constexpr int NINSTR = (NPIX + 7) / 8;     // 54 wave-instructions of 8 pixels
   for (int i = w; i < NINSTR; i += 4) {
     const int p = i * 8 + (l >> 3);
     const int py = p / DW_IW, px = p - py * DW_IW;
-    const int iy = y0 + py - 2, ix = x0 + px - 2;
+    const int iy = y0 + py - P, ix = x0 + px - P;
     const bool ok = p < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     const half_t* g = ok ? src + ((size_t)iy * W + ix) * in_ld : zero;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -170,9 +171,9 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_kernel(const half_t* __restr
   }
   // thread = 4 channels (cq) x columns {colb, colb+16}; fp32 taps in registers
   const int cq = tid & 15, colb = tid >> 4;
-  float wv[25][4];
+  float wv[K * K][4];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) {
+  for (int t = 0; t < K * K; ++t) {
     const f16x4 h = *reinterpret_cast<const f16x4*>(wgt + (size_t)t * C + cb * 64 + cq * 4);
 #pragma unroll
     for (int c = 0; c < 4; ++c) wv[t][c] = (float)h[c];
@@ -187,30 +188,30 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_kernel(const half_t* __restr
     for (int y = 0; y < DW_TH; ++y)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[y][c] = 0.f;
-    f16x4 nxt[5];
+    f16x4 nxt[K];
 #pragma unroll
-    for (int kx = 0; kx < 5; ++kx)
+    for (int kx = 0; kx < K; ++kx)
       nxt[kx] = *reinterpret_cast<const f16x4*>(lds + (0 * DW_IW + col + kx) * 128 + cq * 8);
 #pragma unroll
     for (int r = 0; r < DW_IH; ++r) {
-      float xv[5][4];
+      float xv[K][4];
 #pragma unroll
-      for (int kx = 0; kx < 5; ++kx)
+      for (int kx = 0; kx < K; ++kx)
 #pragma unroll
         for (int c = 0; c < 4; ++c) xv[kx][c] = (float)nxt[kx][c];
       if (r + 1 < DW_IH) {
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx)
+        for (int kx = 0; kx < K; ++kx)
           nxt[kx] = *reinterpret_cast<const f16x4*>(lds + ((r + 1) * DW_IW + col + kx) * 128 + cq * 8);
       }
 #pragma unroll
-      for (int ky = 0; ky < 5; ++ky) {
+      for (int ky = 0; ky < K; ++ky) {
         const int y = r - ky;
         if (y < 0 || y >= DW_TH) continue;
 #pragma unroll
-        for (int kx = 0; kx < 5; ++kx)
+        for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[y][c] = fmaf(xv[kx][c], wv[ky * 5 + kx][c], acc[y][c]);
+          for (int c = 0; c < 4; ++c) acc[y][c] = fmaf(xv[kx][c], wv[ky * K + kx][c], acc[y][c]);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the live range of a row's taps inside its iteration
     }
@@ -230,6 +231,61 @@ __global__ void __launch_bounds__(256, 2) dwconv5x5_kernel(const half_t* __restr
       if (ox < W && oy < H)
         *reinterpret_cast<uint4*>(out + (((size_t)n * H + oy) * W + ox) * out_ld + cb * 64 + (cq & ~1) * 4) = o;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// BiFPN fast-normalised fusion: out = ca*resize(a) + cb*b (+ cc*c), NHWC fp16, same C for all.
+//   mode 0 (top-down, bifpn.py:60-67): a is (N,H/2,W/2,C), nearest x2 up-sampling (Resize2d 'up')
+//   mode 1 (bottom-up, bifpn.py:119-131): a is (N,2H,2W,C), 3x3 stride-2 pad-1 max-pool (Resize2d 'down')
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fuse_combine_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
+                                                           const half_t* __restrict__ c, float ca, float cb, float cc,
+                                                           int mode, int N, int H, int W, int C,
+                                                           half_t* __restrict__ out, int64_t total) {
+  const int CG = C >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % CG);
+    int64_t p = i / CG;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int n = (int)(p / H);
+    float ra[8];
+    if (mode == 0) {
+      const int ah = H >> 1, aw = W >> 1;
+      const f16x8 v = *reinterpret_cast<const f16x8*>(a + (((size_t)n * ah + (y >> 1)) * aw + (x >> 1)) * C + cg * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ra[k] = (float)v[k];
+    } else {
+      const int ah = H * 2, aw = W * 2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ra[k] = -INFINITY;
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = 2 * y + dy;
+        if (iy < 0 || iy >= ah) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int ix = 2 * x + dx;
+          if (ix < 0 || ix >= aw) continue;
+          const f16x8 v = *reinterpret_cast<const f16x8*>(a + (((size_t)n * ah + iy) * aw + ix) * C + cg * 8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) ra[k] = fmaxf(ra[k], (float)v[k]);
+        }
+      }
+    }
+    const size_t o = (((size_t)n * H + y) * W + x) * C + cg * 8;
+    const f16x8 vb = *reinterpret_cast<const f16x8*>(b + o);
+    f16x8 r;
+    if (c) {
+      const f16x8 vc = *reinterpret_cast<const f16x8*>(c + o);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] = (half_t)(ca * ra[k] + cb * (float)vb[k] + cc * (float)vc[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] = (half_t)(ca * ra[k] + cb * (float)vb[k]);
+    }
+    *reinterpret_cast<f16x8*>(out + o) = r;
   }
 }
 
@@ -454,14 +510,30 @@ int launch_maxpool3x3s2(const half_t* in, int N, int H, int W, int C, half_t* ou
   return EMP_OK;
 }
 
-int launch_dwconv5x5(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* w, half_t* out,
-                     int out_ld, const half_t* zero, hipStream_t s) {
+int launch_dwconv(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* w, int K, half_t* out,
+                  int out_ld, const half_t* zero, hipStream_t s) {
   EMP_REQUIRE(C % 64 == 0 && in_ld % 8 == 0 && out_ld % 8 == 0, "dwconv: C=%d must be a multiple of 64", C);
+  EMP_REQUIRE(K == 3 || K == 5, "dwconv: kernel size %d unsupported (3 or 5)", K);
   const int tiles_x = cdiv(W, DW_TW), tiles_y = cdiv(H, DW_TH);
   const int64_t grid = (int64_t)N * tiles_x * tiles_y * (C / 64);
   EMP_REQUIRE(grid < (1ll << 31), "dwconv: grid too large");
-  hipLaunchKernelGGL(dwconv5x5_kernel, dim3((unsigned)grid), dim3(256), 0, s, in, N, H, W, C, in_ld, w, out, out_ld,
-                     zero, tiles_x, tiles_y);
+  if (K == 5)
+    hipLaunchKernelGGL(dwconv_kernel<5>, dim3((unsigned)grid), dim3(256), 0, s, in, N, H, W, C, in_ld, w, out, out_ld,
+                       zero, tiles_x, tiles_y);
+  else
+    hipLaunchKernelGGL(dwconv_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, in, N, H, W, C, in_ld, w, out, out_ld,
+                       zero, tiles_x, tiles_y);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_fuse_combine(const half_t* a, const half_t* b, const half_t* c, float ca, float cb, float cc, int mode, int N,
+                        int H, int W, int C, half_t* out, hipStream_t s) {
+  EMP_REQUIRE(C % 8 == 0 && (mode == 0 || mode == 1), "fuse_combine: bad arguments");
+  EMP_REQUIRE(mode == 1 || (H % 2 == 0 && W % 2 == 0), "fuse_combine: up-sampled operand needs even H, W");
+  const int64_t total = (int64_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(fuse_combine_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, a, b, c, ca, cb, cc,
+                     mode, N, H, W, C, out, total);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }

@@ -61,6 +61,7 @@ struct emp_pdl {
   std::map<std::string, DevConv> convs;
   std::map<std::string, float*> f32w;  // fp32 device blobs (stem, gemv, heads)
   std::map<std::string, half_t*> f16w;  // fp16 device blobs (depthwise taps)
+  std::map<std::string, std::vector<float>> fusew;  // BiFPN fast-fusion weights after relu / (sum + eps)
   std::vector<void*> owned;
 
   // arena
@@ -99,8 +100,36 @@ void build_param_list(emp_pdl* n) {
       expect(n, p + ".conv3");
       if (b == 0) expect(n, p + ".downsample.0");
     }
+  if (c.arch == 1) {
+    expect(n, "p2_resample.conv.0");
+    const int F = c.fpn_dim;
+    const int w0[5] = {512, 1024, 2048, F, F};
+    const char* dn[2] = {"semantic", "instance"};
+    for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
+      std::string fp = std::string(dn[d]) + "_fpn";
+      expect(n, fp + ".p6_resample.conv.0");
+      for (int li = 0; li < c.fpn_layers; ++li) {
+        int nins[5];
+        for (int i = 0; i < 5; ++i) nins[i] = li == 0 ? w0[i] : F;
+        const int td[4] = {nins[3], nins[2], nins[1], nins[0]};
+        const int bu[4] = {nins[1], nins[2], nins[3], nins[4]};
+        for (int dir = 0; dir < 2; ++dir) {
+          std::string pre = fp + ".bifpns." + std::to_string(li) + (dir == 0 ? ".top_down_fpn" : ".bottom_up_fpn");
+          for (int i = 0; i < 4; ++i)
+            if ((dir == 0 ? td[i] : bu[i]) != F) expect(n, pre + ".resamplings." + std::to_string(i) + ".conv.0");
+          expect(n, pre + ".after_combines.0.0.sepconv.0");
+          expect(n, pre + ".after_combines.0.0.sepconv.1");
+          expect(n, pre + ".weights");
+        }
+      }
+      std::string dp = std::string(dn[d]) + "_decoder";
+      for (int i = 0; i < 5; ++i) expect(n, dp + ".upsamplings." + std::to_string(i) + ".0");
+      expect(n, dp + ".fusion.0.sepconv.0");
+      expect(n, dp + ".fusion.0.sepconv.1");
+    }
+  }
   const char* decs[2] = {"semantic_decoder", "instance_decoder"};
-  for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
+  for (int d = 0; d < ((c.arch == 0 && c.ins_decoder) ? 2 : (c.arch == 0 ? 1 : 0)); ++d) {
     std::string p = decs[d];
     expect(n, p + ".aspp.convs.0.0");
     for (int i = 1; i <= 3; ++i) expect(n, p + ".aspp.convs." + std::to_string(i) + ".0");
@@ -172,16 +201,47 @@ int upload_f32(emp_pdl* n, const std::string& key, const std::vector<float>& v) 
 int pack_dw(emp_pdl* n, const std::string& name, int cpad) {
   const HostParam& hp = n->params.at(name);
   const int C = (int)hp.shape[0];
-  EMP_REQUIRE(hp.shape.size() == 4 && hp.shape[1] == 1 && hp.shape[2] == 5 && hp.shape[3] == 5 && cpad >= C,
-              "%s: expected a (C,1,5,5) depthwise weight", name.c_str());
+  EMP_REQUIRE(hp.shape.size() == 4 && hp.shape[1] == 1 && hp.shape[2] == hp.shape[3] &&
+                  (hp.shape[2] == 5 || hp.shape[2] == 3) && cpad >= C,
+              "%s: expected a (C,1,k,k) depthwise weight with k in {3,5}", name.c_str());
   EMP_REQUIRE(cpad % 64 == 0, "%s: padded channel count must be a multiple of 64", name.c_str());
-  std::vector<half_t> pk((size_t)25 * cpad, (half_t)0.f);
+  const int KK = (int)(hp.shape[2] * hp.shape[3]);
+  std::vector<half_t> pk((size_t)KK * cpad, (half_t)0.f);
   for (int c = 0; c < C; ++c)
-    for (int t = 0; t < 25; ++t) pk[(size_t)t * cpad + c] = (half_t)hp.w[(size_t)c * 25 + t];
+    for (int t = 0; t < KK; ++t) pk[(size_t)t * cpad + c] = (half_t)hp.w[(size_t)c * KK + t];
   void* d;
   int rc = dev_upload(n, pk.data(), pk.size() * sizeof(half_t), &d);
   if (rc) return rc;
   n->f16w[name] = (half_t*)d;
+  return EMP_OK;
+}
+
+// ConvTranspose2d(k=2,s=2) weight (Cin,Cout,2,2) -> 1x1 conv with 4*Cout outputs [(dy*2+dx)*Cout + co][Cin]
+int pack_convT(emp_pdl* n, const std::string& name) {
+  const HostParam& hp = n->params.at(name);
+  EMP_REQUIRE(hp.shape.size() == 4 && hp.shape[2] == 2 && hp.shape[3] == 2, "%s: expected (Cin,Cout,2,2)", name.c_str());
+  DevConv dc;
+  dc.cin = (int)hp.shape[0];
+  const int co = (int)hp.shape[1];
+  dc.cout = 4 * co;
+  dc.cin_pad = round_up(dc.cin, 64);
+  dc.kh = dc.kw = 1;
+  std::vector<half_t> pk((size_t)dc.cout * dc.cin_pad, (half_t)0.f);
+  std::vector<float> b((size_t)dc.cout, 0.f);
+  for (int q = 0; q < 4; ++q)
+    for (int o = 0; o < co; ++o) {
+      b[(size_t)q * co + o] = hp.b[o];
+      for (int i = 0; i < dc.cin; ++i)
+        pk[((size_t)q * co + o) * dc.cin_pad + i] = (half_t)hp.w[(((size_t)i * co + o) * 2 + (q >> 1)) * 2 + (q & 1)];
+    }
+  void* d;
+  int rc = dev_upload(n, pk.data(), pk.size() * sizeof(half_t), &d);
+  if (rc) return rc;
+  dc.w = (half_t*)d;
+  rc = dev_upload(n, b.data(), b.size() * sizeof(float), &d);
+  if (rc) return rc;
+  dc.b = (float*)d;
+  n->convs[name] = dc;
   return EMP_OK;
 }
 
@@ -240,31 +300,70 @@ int plan(emp_pdl* n, int N, int H, int W, int RS) {
     ph[li] = h; pw[li] = w;
   }
   (void)inpl;
-  const int h5 = ph[4], w5 = pw[4];
-  add_raw(n, pl, "pooled", (size_t)N * 2048 * 4);
-  add_raw(n, pl, "pool_part", (size_t)avgpool_scratch_floats(N, 2048) * 4);
-  const char* decs[2] = {"semantic_decoder", "instance_decoder"};
-  for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
-    std::string p = decs[d];
-    add_raw(n, pl, p + ".poolfeat", (size_t)N * n->aspp_ch * 4);
-    add_raw(n, pl, p + ".bias_n", (size_t)N * n->aspp_ch * 4);
-    add_act(n, pl, p + ".aspp.cat", N, h5, w5, 4 * n->aspp_ch);
-    add_act(n, pl, p + ".aspp", N, h5, w5, n->aspp_ch);
-    int xch = n->aspp_ch;
-    for (int i = 0; i < c.n_stages; ++i) {
-      const int st = c.low_level_stages[i];
-      const int lp = d == 0 ? c.low_level_proj_sem[i] : c.low_level_proj_ins[i];
-      const int cpad = round_up(xch + lp, 64);
-      std::string q = p + ".stage" + std::to_string(i);
-      add_act(n, pl, q + ".cat", N, ph[st], pw[st], cpad);
-      add_act(n, pl, q + ".dw", N, ph[st], pw[st], cpad);
-      add_act(n, pl, q + ".out", N, ph[st], pw[st], n->dec_ch);
-      xch = n->dec_ch;
+  int hq = 0, wq = 0;
+  if (c.arch == 0) {
+    const int h5 = ph[4], w5 = pw[4];
+    add_raw(n, pl, "pooled", (size_t)N * 2048 * 4);
+    add_raw(n, pl, "pool_part", (size_t)avgpool_scratch_floats(N, 2048) * 4);
+    const char* decs[2] = {"semantic_decoder", "instance_decoder"};
+    for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
+      std::string p = decs[d];
+      add_raw(n, pl, p + ".poolfeat", (size_t)N * n->aspp_ch * 4);
+      add_raw(n, pl, p + ".bias_n", (size_t)N * n->aspp_ch * 4);
+      add_act(n, pl, p + ".aspp.cat", N, h5, w5, 4 * n->aspp_ch);
+      add_act(n, pl, p + ".aspp", N, h5, w5, n->aspp_ch);
+      int xch = n->aspp_ch;
+      for (int i = 0; i < c.n_stages; ++i) {
+        const int st = c.low_level_stages[i];
+        const int lp = d == 0 ? c.low_level_proj_sem[i] : c.low_level_proj_ins[i];
+        const int cpad = round_up(xch + lp, 64);
+        std::string q = p + ".stage" + std::to_string(i);
+        add_act(n, pl, q + ".cat", N, ph[st], pw[st], cpad);
+        add_act(n, pl, q + ".dw", N, ph[st], pw[st], cpad);
+        add_act(n, pl, q + ".out", N, ph[st], pw[st], n->dec_ch);
+        xch = n->dec_ch;
+      }
+    }
+    const int st_last = c.low_level_stages[c.n_stages - 1];
+    hq = ph[st_last]; wq = pw[st_last];  // resolution of semantic_x (1/4 for MitoNet)
+    EMP_REQUIRE(hq * 4 == H && wq * 4 == W, "the last decoder stage must be at 1/4 resolution (got %dx%d)", hq, wq);
+
+  } else {
+    EMP_REQUIRE(H % 128 == 0 && W % 128 == 0, "BiFPN forward: H=%d W=%d must be multiples of 128", H, W);
+    const int F = c.fpn_dim;
+    hq = ph[1]; wq = pw[1];
+    add_act(n, pl, "p2f", N, ph[1], pw[1], F);
+    // level sizes P3..P7
+    int lh[5], lw[5];
+    for (int i = 0; i < 3; ++i) { lh[i] = ph[2 + i]; lw[i] = pw[2 + i]; }
+    lh[3] = lh[2] / 2; lw[3] = lw[2] / 2; lh[4] = lh[3] / 2; lw[4] = lw[3] / 2;
+    const char* dn[2] = {"semantic", "instance"};
+    for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
+      std::string fp = std::string(dn[d]) + "_fpn";
+      add_act(n, pl, fp + ".p6pre", N, lh[2], lw[2], F);
+      add_act(n, pl, fp + ".in.P6", N, lh[3], lw[3], F);
+      add_act(n, pl, fp + ".in.P7", N, lh[4], lw[4], F);
+      for (int li = 0; li < c.fpn_layers; ++li) {
+        std::string L = fp + ".l" + std::to_string(li);
+        for (int lv = 0; lv < 5; ++lv) {
+          std::string q = L + ".P" + std::to_string(3 + lv);
+          if (li == 0 && lv < 3) { add_act(n, pl, q + ".rtd", N, lh[lv], lw[lv], F); add_act(n, pl, q + ".rbu", N, lh[lv], lw[lv], F); }
+          add_act(n, pl, q + ".fuse", N, lh[lv], lw[lv], F);
+          add_act(n, pl, q + ".dw", N, lh[lv], lw[lv], F);
+          add_act(n, pl, q + ".td", N, lh[lv], lw[lv], F);
+          add_act(n, pl, q + ".bu", N, lh[lv], lw[lv], F);
+        }
+      }
+      std::string dp = std::string(dn[d]) + "_decoder";
+      int hh = lh[4], ww = lw[4];
+      for (int i = 0; i < 5; ++i) {
+        hh *= 2; ww *= 2;
+        add_act(n, pl, dp + ".cat" + std::to_string(i), N, hh, ww, 2 * F);
+      }
+      add_act(n, pl, dp + ".dw", N, hq, wq, 2 * F);
+      add_act(n, pl, dp + ".out", N, hq, wq, F);
     }
   }
-  const int st_last = c.low_level_stages[c.n_stages - 1];
-  const int hq = ph[st_last], wq = pw[st_last];  // resolution of semantic_x (1/4 for MitoNet)
-  EMP_REQUIRE(hq * 4 == H && wq * 4 == W, "the last decoder stage must be at 1/4 resolution (got %dx%d)", hq, wq);
   const char* heads[3] = {"semantic_head", "ins_center", "ins_xy"};
   const int hc[3] = {n->ncls, 1, 2};
   for (int k = 0; k < 3; ++k) {
@@ -318,7 +417,7 @@ T* rawp(emp_pdl* n, const std::string& name) {
 
 // conv helper: in (channels [0,Cin_pad) of `in`), out channels [coff, coff+Cout) of `out`
 int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const Act& out, int out_coff, int stride,
-         int pad, int dil, bool relu, const Act* res, const float* bias_n, hipStream_t s) {
+         int pad, int dil, int act, const Act* res, const float* bias_n, hipStream_t s, int ps_cout = 0) {
   const DevConv& dc = n->convs.at(wname);
   ConvParams p{};
   p.in = in.p + in_coff;
@@ -333,12 +432,14 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
   p.Cout = dc.cout; p.KH = dc.kh; p.KW = dc.kw; p.stride = stride; p.pad = pad; p.dil = dil;
   p.Ho = (in.H + 2 * pad - dil * (dc.kh - 1) - 1) / stride + 1;
   p.Wo = (in.W + 2 * pad - dil * (dc.kw - 1) - 1) / stride + 1;
-  EMP_REQUIRE(p.Ho == out.H && p.Wo == out.W && in.N == out.N, "%s: output shape mismatch (%dx%d vs %dx%d)",
-              wname.c_str(), p.Ho, p.Wo, out.H, out.W);
-  EMP_REQUIRE(in_coff + dc.cin_pad <= in.ld && out_coff + dc.cout <= out.ld, "%s: channel slice out of range",
-              wname.c_str());
+  const int up = ps_cout ? 2 : 1;
+  EMP_REQUIRE(p.Ho * up == out.H && p.Wo * up == out.W && in.N == out.N, "%s: output shape mismatch (%dx%d vs %dx%d)",
+              wname.c_str(), p.Ho * up, p.Wo * up, out.H, out.W);
+  EMP_REQUIRE(in_coff + dc.cin_pad <= in.ld && out_coff + (ps_cout ? ps_cout : dc.cout) <= out.ld,
+              "%s: channel slice out of range", wname.c_str());
   p.out_ld = out.ld;
-  p.relu = relu ? 1 : 0;
+  p.act = act;
+  p.ps_cout = ps_cout;
   p.M = p.N * p.Ho * p.Wo;
   n->flops += 2.0 * (double)p.M * dc.cout * (double)(dc.cin * dc.kh * dc.kw);
   return launch_conv_igemm(p, 0, s);
@@ -381,12 +482,110 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
     }
     pyr[li] = xname;
   }
+  std::string dec_out[2];
+  if (c.arch == 1) {
+    // ---- BiFPN decoders (bifpn.py:185-236, panoptic_bifpn.py:70-82) ----
+    const int F = c.fpn_dim;
+    const half_t* zero = rawp<half_t>(n, "zero");
+    RC(conv(n, "p2_resample.conv.0", A(pyr[1]), 0, A("p2f"), 0, 1, 0, 1, 0, nullptr, nullptr, s));
+    const char* dn[2] = {"semantic", "instance"};
+    for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
+      const std::string fp = std::string(dn[d]) + "_fpn";
+      // P6 / P7 (bifpn.py:187-188)
+      RC(conv(n, fp + ".p6_resample.conv.0", A(pyr[4]), 0, A(fp + ".p6pre"), 0, 1, 0, 1, 0, nullptr, nullptr, s));
+      {
+        const Act& a6 = A(fp + ".p6pre");
+        RC(launch_maxpool3x3s2(a6.p, N, a6.H, a6.W, F, A(fp + ".in.P6").p, s));
+        const Act& b6 = A(fp + ".in.P6");
+        RC(launch_maxpool3x3s2(b6.p, N, b6.H, b6.W, F, A(fp + ".in.P7").p, s));
+      }
+      std::string feat[5] = {pyr[2], pyr[3], pyr[4], fp + ".in.P6", fp + ".in.P7"};   // P3..P7
+      for (int li = 0; li < c.fpn_layers; ++li) {
+        const std::string L = fp + ".l" + std::to_string(li);
+        const std::string pre = fp + ".bifpns." + std::to_string(li);
+        auto node = [&](const std::string& dirpre, const std::string& q, const half_t* a, const half_t* b2,
+                        const half_t* c3, float ca, float cb, float cc, int mode, const std::string& outname) -> int {
+          const Act& fz = A(q + ".fuse");
+          RC(launch_fuse_combine(a, b2, c3, ca, cb, cc, mode, N, fz.H, fz.W, F, fz.p, s));
+          RC(launch_dwconv(fz.p, N, fz.H, fz.W, F, F, n->f16w.at(dirpre + ".after_combines.0.0.sepconv.0"), 3,
+                           A(q + ".dw").p, F, zero, s));
+          n->flops += 2.0 * 9.0 * (double)N * fz.H * fz.W * F;
+          return conv(n, dirpre + ".after_combines.0.0.sepconv.1", A(q + ".dw"), 0, A(outname), 0, 1, 0, 1, 2, nullptr,
+                      nullptr, s);
+        };
+        // top-down: P7 -> P3 (bifpn.py:47-69); level index lv: 0=P3 .. 4=P7
+        {
+          const std::string dp = pre + ".top_down_fpn";
+          const float* w = n->fusew.at(dp + ".weights").data();
+          std::string td_prev = feat[4];
+          for (int i = 0; i < 4; ++i) {
+            const int lv = 3 - i;
+            const std::string q = L + ".P" + std::to_string(3 + lv);
+            std::string hi = feat[lv];
+            const std::string rk = dp + ".resamplings." + std::to_string(i) + ".conv.0";
+            if (n->convs.count(rk)) {
+              RC(conv(n, rk, A(feat[lv]), 0, A(q + ".rtd"), 0, 1, 0, 1, 0, nullptr, nullptr, s));
+              hi = q + ".rtd";
+            }
+            const float den = w[i] + w[i + 1] + 1e-4f;
+            RC(node(dp, q, A(td_prev).p, A(hi).p, nullptr, w[i] / den, w[i + 1] / den, 0.f, 0, q + ".td"));
+            td_prev = q + ".td";
+          }
+        }
+        // bottom-up: P3' -> P7 (bifpn.py:103-137)
+        {
+          const std::string dp = pre + ".bottom_up_fpn";
+          const float* w = n->fusew.at(dp + ".weights").data();
+          std::string bu_prev = L + ".P3.td";
+          std::string newfeat[5];
+          newfeat[0] = bu_prev;
+          for (int i = 0; i < 4; ++i) {
+            const int lv = i + 1;
+            const std::string q = L + ".P" + std::to_string(3 + lv);
+            std::string lo = feat[lv];
+            const std::string rk = dp + ".resamplings." + std::to_string(i) + ".conv.0";
+            if (n->convs.count(rk)) {
+              RC(conv(n, rk, A(feat[lv]), 0, A(q + ".rbu"), 0, 1, 0, 1, 0, nullptr, nullptr, s));
+              lo = q + ".rbu";
+            }
+            if (i < 3) {
+              const float den = w[i] + w[i + 1] + w[i + 2] + 1e-4f;
+              RC(node(dp, q, A(bu_prev).p, A(lo).p, A(q + ".td").p, w[i] / den, w[i + 1] / den, w[i + 2] / den, 1,
+                      q + ".bu"));
+            } else {
+              const float den = w[i] + w[i + 1] + 1e-4f;
+              RC(node(dp, q, A(bu_prev).p, A(lo).p, nullptr, w[i] / den, w[i + 1] / den, 0.f, 1, q + ".bu"));
+            }
+            bu_prev = q + ".bu";
+            newfeat[lv] = bu_prev;
+          }
+          for (int lv = 0; lv < 5; ++lv) feat[lv] = newfeat[lv];
+        }
+      }
+      // decoder: 5 x (ConvTranspose k2 s2 + BN + ReLU, concat skip), 5x5 separable fusion (bifpn.py:226-236)
+      const std::string dp = std::string(dn[d]) + "_decoder";
+      const std::string skips[5] = {feat[3], feat[2], feat[1], feat[0], "p2f"};
+      std::string x = feat[4];
+      for (int i = 0; i < 5; ++i) {
+        const Act& cat = A(dp + ".cat" + std::to_string(i));
+        RC(conv(n, dp + ".upsamplings." + std::to_string(i) + ".0", A(x), 0, cat, 0, 1, 0, 1, 1, nullptr, nullptr, s, F));
+        const Act& sk = A(skips[i]);
+        RC(launch_bilinear_ac(sk.p, N, sk.H, sk.W, F, sk.ld, cat.p + F, cat.H, cat.W, cat.ld, s));  // same size: strided copy
+        x = dp + ".cat" + std::to_string(i);
+      }
+      const Act& cat = A(x);
+      RC(launch_dwconv(cat.p, N, cat.H, cat.W, 2 * F, cat.ld, n->f16w.at(dp + ".fusion.0.sepconv.0"), 5, A(dp + ".dw").p,
+                       2 * F, zero, s));
+      n->flops += 2.0 * 25.0 * (double)N * cat.H * cat.W * 2 * F;
+      RC(conv(n, dp + ".fusion.0.sepconv.1", A(dp + ".dw"), 0, A(dp + ".out"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+      dec_out[d] = dp + ".out";
+    }
+  } else {
   const Act& p5 = A(pyr[4]);
 
   // ---- decoders ----
   RC(launch_avgpool(p5.p, N, p5.H * p5.W, p5.C, p5.ld, rawp<float>(n, "pooled"), rawp<float>(n, "pool_part"), s));
   const char* decs[2] = {"semantic_decoder", "instance_decoder"};
-  std::string dec_out[2];
   for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
     std::string p = decs[d];
     float* poolfeat = rawp<float>(n, p + ".poolfeat");
@@ -411,14 +610,15 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       RC(launch_bilinear_ac(xa.p, N, xa.H, xa.W, xch, xa.ld, cb.p, cb.H, cb.W, cb.ld, s));
       RC(conv(n, p + ".project." + std::to_string(i) + ".0", A(pyr[st]), 0, cb, xch, 1, 0, 1, true, nullptr, nullptr, s));
       const std::string fz = p + ".fuse." + std::to_string(i) + ".0.sepconv.";
-      RC(launch_dwconv5x5(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), A(q + ".dw").p, cb.ld,
-                          rawp<half_t>(n, "zero"), s));
+      RC(launch_dwconv(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), 5, A(q + ".dw").p, cb.ld,
+                       rawp<half_t>(n, "zero"), s));
       n->flops += 2.0 * 25.0 * (double)N * cb.H * cb.W * (xch + n->convs.at(p + ".project." + std::to_string(i) + ".0").cout);
       RC(conv(n, fz + "1", A(q + ".dw"), 0, A(q + ".out"), 0, 1, 0, 1, true, nullptr, nullptr, s));
       x = q + ".out";
       xch = n->dec_ch;
     }
     dec_out[d] = x;
+  }
   }
   if (!c.ins_decoder) dec_out[1] = dec_out[0];
   const Act& semx = A(dec_out[0]);
@@ -432,8 +632,8 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
   for (int k = 0; k < 3; ++k) {
     std::string p = heads[k];
     const Act& xin = k == 0 ? semx : insx;
-    RC(launch_dwconv5x5(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f16w.at(p + ".head.0.0.sepconv.0"), A(p + ".dw").p,
-                        n->dec_ch, rawp<half_t>(n, "zero"), s));
+    RC(launch_dwconv(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f16w.at(p + ".head.0.0.sepconv.0"), 5, A(p + ".dw").p,
+                     n->dec_ch, rawp<half_t>(n, "zero"), s));
     n->flops += 2.0 * 25.0 * (double)N * hq * wq * n->dec_ch;
     RC(conv(n, p + ".head.0.0.sepconv.1", A(p + ".dw"), 0, A(p + ".pw"), 0, 1, 0, 1, true, nullptr, nullptr, s));
     float* dst = rawp<float>(n, p + ".out");
@@ -492,10 +692,16 @@ int emp_pdl_create(const emp_pdl_config* cfg, emp_pdl_t** out) {
   EMP_REQUIRE(cfg && out, "pdl_create: null argument");
   EMP_REQUIRE(cfg->num_classes >= 1 && cfg->num_classes <= 8, "num_classes=%d unsupported", cfg->num_classes);
   EMP_REQUIRE(cfg->stage4_stride == 16 || cfg->stage4_stride == 32, "stage4_stride must be 16 or 32");
+  EMP_REQUIRE(cfg->arch == 0 || cfg->arch == 1, "arch must be 0 (PanopticDeepLabPR) or 1 (PanopticBiFPNPR)");
+  if (cfg->arch == 1) {
+    EMP_REQUIRE(cfg->fpn_dim > 0 && cfg->fpn_dim % 64 == 0 && cfg->fpn_layers >= 1 && cfg->stage4_stride == 32,
+                "BiFPN: fpn_dim must be a multiple of 64, fpn_layers >= 1, stage4_stride 32");
+  } else {
   EMP_REQUIRE(cfg->n_stages >= 1 && cfg->n_stages <= 3, "n_stages=%d unsupported", cfg->n_stages);
   EMP_REQUIRE(cfg->decoder_channels % 64 == 0 && cfg->decoder_channels > 0, "decoder_channels must be a multiple of 64");
+  }
   EMP_REQUIRE(cfg->num_fc >= 1 && cfg->subdivision_num_points > 0, "bad PointRend configuration");
-  for (int i = 0; i < cfg->n_stages; ++i) {
+  for (int i = 0; i < (cfg->arch == 0 ? cfg->n_stages : 0); ++i) {
     EMP_REQUIRE(cfg->low_level_stages[i] >= 1 && cfg->low_level_stages[i] <= 3, "low_level_stages[%d] out of range", i);
     EMP_REQUIRE(cfg->low_level_proj_sem[i] % 8 == 0 && (!cfg->ins_decoder || cfg->low_level_proj_ins[i] % 8 == 0),
                 "projected low-level channels must be multiples of 8");
@@ -503,7 +709,7 @@ int emp_pdl_create(const emp_pdl_config* cfg, emp_pdl_t** out) {
   emp_pdl* n = new (std::nothrow) emp_pdl();
   if (!n) return EMP_ERR_NOMEM;
   n->cfg = *cfg;
-  n->dec_ch = cfg->decoder_channels;
+  n->dec_ch = cfg->arch == 1 ? cfg->fpn_dim : cfg->decoder_channels;
   n->aspp_ch = cfg->aspp_channels > 0 ? cfg->aspp_channels : cfg->decoder_channels;
   n->ncls = cfg->num_classes;
   build_param_list(n);
@@ -524,7 +730,7 @@ int emp_pdl_set_param(emp_pdl_t* net, const char* name, const float* h_w, const 
   EMP_REQUIRE(net && name && h_w && shape, "set_param: null argument");
   auto it = net->params.find(name);
   EMP_REQUIRE(it != net->params.end(), "set_param: unknown parameter '%s'", name);
-  EMP_REQUIRE(ndim == 3 || ndim == 4, "set_param(%s): ndim must be 3 or 4", name);
+  EMP_REQUIRE(ndim == 1 || ndim == 3 || ndim == 4, "set_param(%s): ndim must be 1, 3 or 4", name);
   HostParam& hp = it->second;
   hp.shape.assign(shape, shape + ndim);
   size_t cnt = 1;
@@ -567,6 +773,31 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       RC(pack_conv(n, p + ".conv3"));
       if (b == 0) RC(pack_conv(n, p + ".downsample.0"));
     }
+  if (c.arch == 1) {
+    const int F = c.fpn_dim;
+    RC(pack_conv(n, "p2_resample.conv.0"));
+    for (const auto& nm : n->param_names) {
+      const bool fpn = nm.find("_fpn.") != std::string::npos, dec = nm.find("_decoder.") != std::string::npos;
+      if (!fpn && !dec) continue;
+      if (nm.size() > 8 && nm.compare(nm.size() - 8, 8, ".weights") == 0) {
+        const HostParam& hp = n->params[nm];
+        EMP_REQUIRE(hp.w.size() == 5, "%s: expected 5 fusion weights", nm.c_str());
+        std::vector<float> w(5);
+        float sum = 0.f;
+        for (int i = 0; i < 5; ++i) { w[i] = hp.w[i] > 0.f ? hp.w[i] : 0.f; sum += w[i]; }
+        for (int i = 0; i < 5; ++i) w[i] = w[i] / (sum + 1e-4f);   // bifpn.py:52-55
+        n->fusew[nm] = w;
+      } else if (nm.find(".sepconv.0") != std::string::npos) {
+        const HostParam& hp = n->params[nm];
+        RC(pack_dw(n, nm, round_up((int)hp.shape[0], 64)));
+      } else if (nm.find(".upsamplings.") != std::string::npos) {
+        RC(pack_convT(n, nm));
+        EMP_REQUIRE(n->convs[nm].cout == 4 * F, "%s: transposed conv must produce fpn_dim channels", nm.c_str());
+      } else {
+        RC(pack_conv(n, nm));
+      }
+    }
+  } else {
   const char* decs[2] = {"semantic_decoder", "instance_decoder"};
   for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
     std::string p = decs[d];
@@ -604,6 +835,7 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       RC(pack_conv(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1", cpad));
       xch = n->dec_ch;
     }
+  }
   }
   const char* heads[3] = {"semantic_head", "ins_center", "ins_xy"};
   for (int k = 0; k < 3; ++k) {

@@ -52,22 +52,27 @@ class HipPanopticDeepLab:
 
     def __init__(self, state_dict, cfg=None, device='cuda:0', folded=False):
         self.device = _require_gpu(device)
-        self.cfg = dict(weights.MITONET_PDL_CFG, **(cfg or {}))
+        bifpn = 'BiFPN' in (cfg or {}).get('arch', '')
+        self.cfg = dict(weights.MITONET_MINI_CFG if bifpn else weights.MITONET_PDL_CFG, **(cfg or {}))
         self.lib = _abi.load()
         c = _abi.PdlConfig()
         cfgd = self.cfg
         c.num_classes = cfgd['num_classes']
-        c.stage4_stride = cfgd['stage4_stride']
-        c.decoder_channels = cfgd['decoder_channels']
-        c.aspp_channels = cfgd['aspp_channels'] or 0
-        stages = cfgd['low_level_stages']
-        c.n_stages = len(stages)
-        for i, s in enumerate(stages):
-            c.low_level_stages[i] = s
-            c.low_level_proj_sem[i] = cfgd['low_level_channels_project'][i]
-            c.low_level_proj_ins[i] = int(cfgd['low_level_channels_project'][i] * cfgd['ins_ratio'])
-        for i, r in enumerate(cfgd['atrous_rates']):
-            c.atrous_rates[i] = r
+        if bifpn:
+            c.arch, c.fpn_dim, c.fpn_layers, c.stage4_stride = 1, cfgd['fpn_dim'], cfgd['fpn_layers'], 32
+            c.decoder_channels = cfgd['fpn_dim']
+        else:
+            c.stage4_stride = cfgd['stage4_stride']
+            c.decoder_channels = cfgd['decoder_channels']
+            c.aspp_channels = cfgd['aspp_channels'] or 0
+            stages = cfgd['low_level_stages']
+            c.n_stages = len(stages)
+            for i, s in enumerate(stages):
+                c.low_level_stages[i] = s
+                c.low_level_proj_sem[i] = cfgd['low_level_channels_project'][i]
+                c.low_level_proj_ins[i] = int(cfgd['low_level_channels_project'][i] * cfgd['ins_ratio'])
+            for i, r in enumerate(cfgd['atrous_rates']):
+                c.atrous_rates[i] = r
         c.ins_decoder = int(bool(cfgd['ins_decoder']))
         c.num_fc = cfgd['num_fc']
         c.subdivision_num_points = cfgd['subdivision_num_points']

@@ -34,6 +34,12 @@ MITONET_PDL_CFG = dict(
     subdivision_num_points=8192,
 )
 
+# MitoNet_v1_mini-class configuration (empanada_napari/training/bifpn_model.yaml:1-15)
+MITONET_MINI_CFG = dict(
+    arch='PanopticBiFPNPR', encoder='resnet50', num_classes=1, fpn_dim=128, fpn_layers=3,
+    ins_decoder=True, depthwise=True, num_fc=3, subdivision_num_points=8192,
+)
+
 RESNET50_LAYERS = (3, 4, 6, 3)
 RESNET_PLANES = (64, 128, 256, 512)
 
@@ -90,6 +96,58 @@ def pdl_head_spec(prefix, nin, ncls, out_std=1.0, bias_mean=0.0):
     ]
 
 
+def bifpn_spec(cfg=None):
+    """Ordered layer list of QuantizablePanopticBiFPNPR (models/panoptic_bifpn.py:22-67,
+    decoders/bifpn.py:17-236, quantization/panoptic_bifpn.py:83-105).  ``alias`` lists the extra
+    state-dict prefixes under which a SHARED module appears (one conv block instance serves every
+    level of a direction, bifpn.py:41-42,97-98)."""
+    cfg = dict(MITONET_MINI_CFG, **(cfg or {}))
+    assert cfg['encoder'] == 'resnet50' and cfg['depthwise']
+    F, ncls = cfg['fpn_dim'], cfg['num_classes']
+    L = resnet50_spec()
+    L.append(_L('p2_resample.conv.0', (F, 256, 1, 1), bn='p2_resample.conv.1'))
+    widths = [512, 1024, 2048, F, F]                      # P3..P7 inputs of the first BiFPN layer
+    for dec in (['semantic'] + (['instance'] if cfg['ins_decoder'] else [])):
+        fp = f'{dec}_fpn'
+        L.append(_L(f'{fp}.p6_resample.conv.0', (F, 2048, 1, 1), bn=f'{fp}.p6_resample.conv.1'))
+        for li in range(cfg['fpn_layers']):
+            nins = widths if li == 0 else [F] * 5
+            td_nins = nins[::-1][1:]                        # P6, P5, P4, P3
+            bu_nins = nins[1:]                              # P4, P5, P6, P7
+            for dname, dn in (('top_down_fpn', td_nins), ('bottom_up_fpn', bu_nins)):
+                pre = f'{fp}.bifpns.{li}.{dname}'
+                for i, nin in enumerate(dn):
+                    if nin != F:
+                        L.append(_L(f'{pre}.resamplings.{i}.conv.0', (F, nin, 1, 1), bn=f'{pre}.resamplings.{i}.conv.1'))
+                al = [f'{pre}.after_combines.{i}' for i in range(1, 4)]
+                d = _L(f'{pre}.after_combines.0.0.sepconv.0', (F, 1, 3, 3), kind='dw')
+                d['alias'] = [a + '.0.sepconv.0' for a in al]
+                L.append(d)
+                d = _L(f'{pre}.after_combines.0.0.sepconv.1', (F, F, 1, 1), bn=f'{pre}.after_combines.0.1')
+                d['alias'] = [a + '.0.sepconv.1' for a in al]
+                d['bn_alias'] = [a + '.1' for a in al]
+                L.append(d)
+                L.append(_L(f'{pre}.weights', (5,), kind='fw'))
+        dp = f'{dec}_decoder'
+        for i in range(5):
+            L.append(_L(f'{dp}.upsamplings.{i}.0', (F if i == 0 else 2 * F, F, 2, 2), bn=f'{dp}.upsamplings.{i}.1', kind='convT'))
+        L.append(_L(f'{dp}.fusion.0.sepconv.0', (2 * F, 1, 5, 5), kind='dw'))
+        L.append(_L(f'{dp}.fusion.0.sepconv.1', (F, 2 * F, 1, 1), bn=f'{dp}.fusion.1'))
+    L += pdl_head_spec('semantic_head', F, ncls, out_std=0.8)
+    L += pdl_head_spec('ins_center', F, 1, out_std=0.25, bias_mean=-0.5)
+    L += pdl_head_spec('ins_xy', F, 2, out_std=3.0)
+    fin = F + ncls
+    for k in range(cfg['num_fc']):
+        L.append(_L(f'semantic_pr.point_head.fc_layers.{k}.0', (F, fin, 1), bias=True, kind='fc'))
+    L.append(_L('semantic_pr.point_head.predictor', (ncls, fin, 1), bias=True, kind='fc', gain=0.8, zero_mean=True))
+    return L
+
+
+def model_spec(cfg=None):
+    arch = (cfg or {}).get('arch', 'PanopticDeepLabPR')
+    return bifpn_spec(cfg) if 'BiFPN' in arch else pdl_spec(cfg)
+
+
 def pdl_spec(cfg=None):
     """Ordered layer list of QuantizablePanopticDeepLabPR for ``cfg``."""
     cfg = dict(MITONET_PDL_CFG, **(cfg or {}))
@@ -126,9 +184,14 @@ def seeded_state_dict(cfg=None, seed=0):
     """
     rng = np.random.default_rng(seed)
     sd = OrderedDict()
-    for L in pdl_spec(cfg):
+    for L in model_spec(cfg):
         shp = L['shape']
-        fan_in = int(np.prod(shp[1:]))
+        if L['kind'] == 'fw':   # fast-normalised fusion weights; one negative entry exercises the ReLU clip
+            w = rng.uniform(0.4, 1.6, shp)
+            w[rng.integers(0, shp[0])] = -0.2
+            sd[L['name']] = w.astype(np.float32)
+            continue
+        fan_in = int(np.prod(shp[1:])) if L['kind'] != 'convT' else int(shp[0])
         std = L['gain'] * (np.sqrt(2.0 / fan_in) if L['bn'] or L['kind'] == 'fc' or L['kind'] == 'dw'
                            else np.sqrt(1.0 / fan_in))
         if L['kind'] == 'dw':
@@ -137,16 +200,21 @@ def seeded_state_dict(cfg=None, seed=0):
         if L['zero_mean']:  # keeps the output of a post-ReLU input centred
             w = w - w.mean(axis=1, keepdims=True)
         sd[L['name'] + '.weight'] = w.astype(np.float32)
+        for a in L.get('alias', []):
+            sd[a + '.weight'] = sd[L['name'] + '.weight']
         if L['bias']:
             sd[L['name'] + '.bias'] = (L['bias_mean'] + rng.standard_normal(shp[0]) * 0.1).astype(np.float32)
         if L['bn']:
-            c = shp[0]
+            c = shp[1] if L['kind'] == 'convT' else shp[0]
             g = L['bn_gamma']
             sd[L['bn'] + '.weight'] = (g * rng.uniform(0.8, 1.2, c)).astype(np.float32)
             sd[L['bn'] + '.bias'] = (rng.standard_normal(c) * 0.05).astype(np.float32)
             sd[L['bn'] + '.running_mean'] = (rng.standard_normal(c) * 0.05).astype(np.float32)
             sd[L['bn'] + '.running_var'] = rng.uniform(0.8, 1.2, c).astype(np.float32)
             sd[L['bn'] + '.num_batches_tracked'] = np.array(0, dtype=np.int64)
+            for a in L.get('bn_alias', []):
+                for suf in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'):
+                    sd[a + '.' + suf] = sd[L['bn'] + '.' + suf]
     return sd
 
 
@@ -164,8 +232,12 @@ def fold_state_dict(sd, cfg=None):
     Conv+BN become ``<name>.weight/bias``, BatchNorm keys disappear).
     """
     out = OrderedDict()
-    for L in pdl_spec(cfg):
+    for L in model_spec(cfg):
         n = L['name']
+        if L['kind'] == 'fw':
+            v = _np(sd[n]).astype(np.float32)
+            out[n] = (np.ascontiguousarray(v), np.zeros(v.shape[0], dtype=np.float32))
+            continue
         if n + '.weight' in sd:
             w = _np(sd[n + '.weight']).astype(np.float32)
             b = _np(sd[n + '.bias']).astype(np.float32) if n + '.bias' in sd else None
@@ -176,8 +248,9 @@ def fold_state_dict(sd, cfg=None):
             raise KeyError(f'parameter for layer {n!r} not found in state dict')
         if tuple(w.shape) != L['shape']:
             raise ValueError(f'{n}: expected shape {L["shape"]}, got {tuple(w.shape)}')
+        cdim = 1 if L['kind'] == 'convT' else 0      # ConvTranspose2d weight is (Cin, Cout, kh, kw)
         if b is None:
-            b = np.zeros(w.shape[0], dtype=np.float32)
+            b = np.zeros(w.shape[cdim], dtype=np.float32)
         bn = L['bn']
         if bn and bn + '.running_mean' in sd:
             gamma = _np(sd[bn + '.weight']).astype(np.float32)
@@ -187,7 +260,9 @@ def fold_state_dict(sd, cfg=None):
             # same arithmetic as torch.nn.utils.fusion.fuse_conv_bn_weights (fp32)
             rstd = (1.0 / np.sqrt(var + np.float32(BN_EPS))).astype(np.float32)
             scale = (gamma * rstd).astype(np.float32)
-            w = (w * scale.reshape((-1,) + (1,) * (w.ndim - 1))).astype(np.float32)
+            bshape = [1] * w.ndim
+            bshape[cdim] = -1
+            w = (w * scale.reshape(bshape)).astype(np.float32)
             b = ((b - mean) * rstd * gamma + beta).astype(np.float32)
         out[n] = (np.ascontiguousarray(w), np.ascontiguousarray(b))
     return out

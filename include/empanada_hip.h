@@ -53,7 +53,9 @@ EMP_API int emp_device_count(void);
  *    replaces: model(image, render_steps, interpolate_ins) as called from
  *    PanopticDeepLabRenderEngine.infer, empanada/inference/engines.py:248-255,
  *    i.e. QuantizablePanopticDeepLabPR.forward,
- *    empanada/models/quantization/panoptic_deeplab.py:238-250.
+ *    empanada/models/quantization/panoptic_deeplab.py:238-250, or (arch 1)
+ *    QuantizablePanopticBiFPNPR.forward, quantization/panoptic_bifpn.py:147-161
+ *    (H and W must then be multiples of 128).
  * ---------------------------------------------------------------------- */
 typedef struct emp_pdl emp_pdl_t;
 
@@ -70,6 +72,9 @@ typedef struct {
   int32_t ins_decoder;            /* 1: separate instance decoder                      */
   int32_t num_fc;                 /* PointRend MLP depth (3)                           */
   int32_t subdivision_num_points; /* 8192                                              */
+  int32_t arch;                   /* 0 PanopticDeepLabPR (MitoNet_v1), 1 PanopticBiFPNPR (MitoNet_v1_mini)  */
+  int32_t fpn_dim;                /* BiFPN width (128)                                 */
+  int32_t fpn_layers;             /* BiFPN depth (3)                                   */
 } emp_pdl_config;
 
 EMP_API int emp_pdl_create(const emp_pdl_config* cfg, emp_pdl_t** out);

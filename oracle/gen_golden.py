@@ -86,6 +86,39 @@ def gen_model():
     save('pdl_forward', **out)
 
 
+def gen_bifpn():
+    """MitoNet_v1_mini-class (PanopticBiFPNPR) goldens, incl. a 4-class model (BASELINE configs[4])."""
+    from empanada.models.quantization.panoptic_bifpn import QuantizablePanopticBiFPNPR
+    out = {}
+    for tag, ncls in (('m1', 1), ('m4', 4)):
+        cfg = dict(weights.MITONET_MINI_CFG, num_classes=ncls)
+        sd = weights.seeded_state_dict(cfg, seed=3)
+        m = QuantizablePanopticBiFPNPR(quantize=False, **{k: v for k, v in cfg.items() if k != 'arch'})
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        m.eval()
+        cases = {'a': (np.stack([synth.blob_image(128, 128, seed=1), synth.em_tiles(1, 128, seed=2)[0]]), 2, False),
+                 'b': (np.stack([synth.blob_image(128, 256, seed=3)]), 2, True)}
+        with torch.no_grad():
+            for k, (img, rs, interp) in cases.items():
+                o = m(torch.from_numpy(norm_image(img))[:, None], rs, interp)
+                out[f'{tag}{k}_image'] = img
+                out[f'{tag}{k}_render_steps'] = np.int64(rs)
+                out[f'{tag}{k}_interpolate_ins'] = np.int64(interp)
+                for name in ('sem_logits', 'ctr_hmp', 'offsets'):
+                    out[f'{tag}{k}_{name}'] = o[name].numpy().astype(np.float32)
+            # the exported model only fuses the encoder (quantization/panoptic_bifpn.py:163-164)
+            x = torch.from_numpy(norm_image(cases['a'][0]))[:, None]
+            ref = m(x, 2, False)
+            m.fuse_model()
+            fo = m(x, 2, False)
+            assert all(torch.allclose(ref[n], fo[n], atol=5e-4, rtol=1e-4) for n in ref)
+            A = weights.fold_state_dict(sd, cfg)
+            B = weights.fold_state_dict({k: v.numpy() for k, v in m.state_dict().items()}, cfg)
+            for n in A:
+                assert np.allclose(A[n][0], B[n][0], atol=1e-6, rtol=1e-5) and np.allclose(A[n][1], B[n][1], atol=1e-5, rtol=1e-4), n
+    save('bifpn_forward', **out)
+
+
 # ----------------------------------------------------------------------------
 # B. post-processing on synthetic head tensors
 # ----------------------------------------------------------------------------
@@ -200,7 +233,9 @@ def gen_median():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['model', 'postprocess', 'median']
+    which = sys.argv[1:] or ['model', 'bifpn', 'postprocess', 'median']
+    if 'bifpn' in which:
+        gen_bifpn()
     torch.manual_seed(0)
     if 'model' in which:
         gen_model()

@@ -163,3 +163,99 @@ def pdl_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None):
         ctr = F.interpolate(ctr, scale_factor=4.0, mode='bilinear', align_corners=True)
         off = F.interpolate(off, scale_factor=4.0, mode='bilinear', align_corners=True)
     return {'sem_logits': sem_logits, 'ctr_hmp': ctr, 'offsets': off}
+
+
+# ----------------------------------------------------------------------------
+# PanopticBiFPN(PR)  (models/panoptic_bifpn.py, decoders/bifpn.py)
+# ----------------------------------------------------------------------------
+def _silu(x):
+    return x * torch.sigmoid(x)
+
+
+def _fusion_weights(P, name, eps=1e-4):
+    """bifpn.py:52-55 / 106-109: relu, then divide by (sum + eps)."""
+    w = F.relu(_t(P[name][0]))
+    return w / (w.sum() + eps)
+
+
+def _sep3(P, pre, x):
+    """shared after_combine block: depthwise 3x3 + pointwise (+folded BN) + SiLU (bifpn.py:35,91)."""
+    x = _conv(x, (P[f'{pre}.after_combines.0.0.sepconv.0'][0], None), padding=1, groups=x.shape[1])
+    return _silu(_conv(x, P[f'{pre}.after_combines.0.0.sepconv.1']))
+
+
+def _resample(P, pre, i, x):
+    k = f'{pre}.resamplings.{i}.conv.0'
+    return _conv(x, P[k]) if k in P else x          # Resample2d is the identity when nin == fpn_dim (blocks.py:62-67)
+
+
+def bifpn_layer(P, pre, feats, eps=1e-4):
+    """BiFPNLayer.forward (bifpn.py:147-156): feats = [P3..P7] -> [P3'..P7']."""
+    # top-down over [P7, P6, P5, P4, P3]
+    rev = feats[::-1]
+    w = _fusion_weights(P, f'{pre}.top_down_fpn.weights')
+    td = [rev[0]]
+    for i in range(4):
+        hi = _resample(P, f'{pre}.top_down_fpn', i, rev[i + 1])
+        up = F.interpolate(td[-1], scale_factor=2.0, mode='nearest')
+        fused = (w[i] * up + w[i + 1] * hi) / (w[i] + w[i + 1] + eps)
+        td.append(_sep3(P, f'{pre}.top_down_fpn', fused))
+    tdr = td[::-1]                                   # [P3', P4', P5', P6', P7]
+    w = _fusion_weights(P, f'{pre}.bottom_up_fpn.weights')
+    pyr = feats[1:]                                  # [P4, P5, P6, P7]
+    bu = [tdr[0]]
+    for i in range(4):
+        down = F.max_pool2d(bu[-1], 3, stride=2, padding=1)
+        lo = _resample(P, f'{pre}.bottom_up_fpn', i, pyr[i])
+        if i < 3:
+            fused = (w[i] * down + w[i + 1] * lo + w[i + 2] * tdr[i + 1]) / (w[i] + w[i + 1] + w[i + 2] + eps)
+        else:
+            fused = (w[i] * down + w[i + 1] * lo) / (w[i] + w[i + 1] + eps)
+        bu.append(_sep3(P, f'{pre}.bottom_up_fpn', fused))
+    return bu
+
+
+def bifpn_forward_decoder(P, dec, pyr345, p2f, n_layers, taps=None):
+    """BiFPN.forward (bifpn.py:185-196) + BiFPNDecoder.forward (:226-236)."""
+    fp = f'{dec}_fpn'
+    p6 = F.max_pool2d(_conv(pyr345[-1], P[f'{fp}.p6_resample.conv.0']), 3, stride=2, padding=1)
+    p7 = F.max_pool2d(p6, 3, stride=2, padding=1)
+    feats = list(pyr345) + [p6, p7]
+    for li in range(n_layers):
+        feats = bifpn_layer(P, f'{fp}.bifpns.{li}', feats)
+        if taps is not None:
+            taps[f'{fp}.layer{li}.P3'] = feats[0]
+    seq = ([p2f] + feats)[::-1]                      # [P7, P6, P5, P4, P3, P2]
+    x = seq[0]
+    for i in range(5):
+        w, b = P[f'{dec}_decoder.upsamplings.{i}.0']
+        x = F.relu(F.conv_transpose2d(x, _t(w), _t(b), stride=2))
+        x = torch.cat([x, seq[i + 1]], dim=1)
+    x = _conv(x, (P[f'{dec}_decoder.fusion.0.sepconv.0'][0], None), padding=2, groups=x.shape[1])
+    return _conv(x, P[f'{dec}_decoder.fusion.0.sepconv.1'], relu=True)
+
+
+@torch.no_grad()
+def bifpn_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None):
+    """QuantizablePanopticBiFPNPR.forward, eval (quantization/panoptic_bifpn.py:147-161)."""
+    pyr = resnet50_forward(P, x, 32, taps)          # quantizable resnet50() default output_stride = 32
+    p2f = _conv(pyr[1], P['p2_resample.conv.0'])
+    nl = cfg['fpn_layers']
+    semantic_x = bifpn_forward_decoder(P, 'semantic', pyr[2:], p2f, nl, taps)
+    instance_x = bifpn_forward_decoder(P, 'instance', pyr[2:], p2f, nl, taps) if cfg['ins_decoder'] else semantic_x
+    sem = head_forward(P, 'semantic_head', semantic_x)
+    ctr = head_forward(P, 'ins_center', instance_x)
+    off = head_forward(P, 'ins_xy', instance_x)
+    if taps is not None:
+        taps.update(semantic_x=semantic_x, instance_x=instance_x, sem_coarse=sem)
+    sem_logits = point_rend_forward(P, sem, semantic_x, render_steps, cfg['subdivision_num_points'], cfg['num_fc'], taps)
+    if interpolate_ins:
+        ctr = F.interpolate(ctr, scale_factor=4.0, mode='bilinear', align_corners=True)
+        off = F.interpolate(off, scale_factor=4.0, mode='bilinear', align_corners=True)
+    return {'sem_logits': sem_logits, 'ctr_hmp': ctr, 'offsets': off}
+
+
+def model_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None):
+    if 'BiFPN' in cfg.get('arch', ''):
+        return bifpn_forward(P, x, cfg, render_steps, interpolate_ins, taps)
+    return pdl_forward(P, x, cfg, render_steps, interpolate_ins, taps)

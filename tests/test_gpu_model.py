@@ -132,3 +132,29 @@ def test_forward_errors(setup):
     from empanada_napari_amd._abi import EmpError
     with pytest.raises(EmpError):
         model(torch.zeros((1, 1, 40, 64), device='cuda'), 2, False)  # not a multiple of 16
+
+
+@pytest.mark.parametrize('tag,ncls', [('m1', 1), ('m4', 4)])
+@pytest.mark.parametrize('case', ['a', 'b'])
+def test_bifpn_heads_match_reference_golden(golden_dir, tag, ncls, case):
+    """PanopticBiFPNPR (MitoNet_v1_mini-class; 4-class = BASELINE configs[4]) on the HIP engine."""
+    from empanada_napari_amd import weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    g = np.load(os.path.join(golden_dir, 'bifpn_forward.npz'))
+    cfg = dict(weights.MITONET_MINI_CFG, num_classes=ncls)
+    model = HipPanopticDeepLab(weights.seeded_state_dict(cfg, seed=3), cfg)
+    x = _norm(g[f'{tag}{case}_image']).cuda()
+    out = model(x, int(g[f'{tag}{case}_render_steps']), bool(g[f'{tag}{case}_interpolate_ins']))
+    torch.cuda.synchronize()
+    for name in ('ctr_hmp', 'offsets', 'sem_logits'):
+        got, ref = out[name].cpu().numpy(), g[f'{tag}{case}_{name}']
+        assert got.shape == ref.shape
+        scale = float(np.abs(ref).mean()) + 1e-6
+        err = np.abs(got - ref)
+        print(f'[{tag}{case}] {name}: max abs {err.max():.3e} (mean |ref| {scale:.3f}), rms rel {np.sqrt((err**2).mean())/scale:.3e}, '
+              f'frac>1%*scale {np.mean(err > 0.05 * scale):.4f}')
+        if name != 'sem_logits':
+            assert np.sqrt((err ** 2).mean()) / scale < 1e-2
+        else:
+            # PointRend cell selection can differ on near-ties; the bulk must agree
+            assert np.mean(err > 0.05 * scale) < 2e-2

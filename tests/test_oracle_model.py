@@ -66,3 +66,22 @@ def test_fold_accepts_fused_layout(golden_dir, folded):
     Q = weights.fold_state_dict(fsd, cfg)
     for n in P:
         np.testing.assert_allclose(Q[n][0], P[n][0], atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize('tag,ncls', [('m1', 1), ('m4', 4)])
+@pytest.mark.parametrize('case', ['a', 'b'])
+def test_bifpn_forward_matches_reference(golden_dir, tag, ncls, case):
+    """PanopticBiFPNPR (MitoNet_v1_mini-class, and the 4-class variant of BASELINE configs[4])."""
+    g = np.load(os.path.join(golden_dir, 'bifpn_forward.npz'))
+    cfg = dict(weights.MITONET_MINI_CFG, num_classes=ncls)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
+    x = torch.from_numpy(normalize(g[f'{tag}{case}_image'], 0.57571, 0.12765))[:, None]
+    out = pdl_model.model_forward(P, x, cfg, int(g[f'{tag}{case}_render_steps']), bool(g[f'{tag}{case}_interpolate_ins']))
+    for name in ('sem_logits', 'ctr_hmp', 'offsets'):
+        ref = g[f'{tag}{case}_{name}']
+        got = out[name].numpy()
+        assert got.shape == ref.shape
+        tol = 5e-4 * max(1.0, float(np.abs(ref).max()))
+        bad = np.abs(got - ref) > tol
+        # multi-class PointRend: a top-2 tie in the uncertainty ranking may pick a different cell
+        assert bad.mean() < (2e-3 if name == 'sem_logits' else 1e-12), (name, bad.mean(), np.abs(got - ref).max())
