@@ -389,6 +389,8 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   // variant = staging + 16 * tile
   //   staging: 0 auto | 1 register staging | 2 LDS-DMA | 3 LDS-DMA + LDS-transposed epilogue
   //   tile   : 0 auto | 1 128x128 | 2 128x64 | 3 64x64
+  // (tried and removed, slower on MI355X: a persistent cross-tile pipeline, and a 256x128 8-wave tile with
+  //  three LDS stages + counted vmcnt / raw barriers: 865 vs 990 TF/s on the ASPP shape -- DESIGN.md section 4)
   int v = variant & 15, tile = variant >> 4;
   EMP_REQUIRE(v <= 3 && tile <= 3, "conv: bad variant %d", variant);
   if (tile == 0) tile = (p.Cout <= 64) ? 2 : 1;

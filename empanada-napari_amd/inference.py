@@ -11,7 +11,7 @@ import.  Differences, all behind the same results:
   * ``model_config['model']`` may be a TorchScript file (the reference's export),
     a state dict, or an already built ``HipPanopticDeepLab``.
 Not built yet (raise ``NotImplementedError``): ``tile_size > 0`` (cztile tiler),
-``inference_scale > 1`` input down-scaling (cv2), label erosion / dilation / hole
+label erosion / dilation / hole
 filling, zarr stores when zarr is not installed.
 """
 import math
@@ -23,7 +23,7 @@ import torch
 from . import sparse, weights
 from .engines import (HipPanopticDeepLab, PanopticDeepLabRenderEngine, PanopticDeepLabRenderEngine3d,
                       factor_pad, logits_to_prob)
-from .preprocess import Preprocessor
+from .preprocess import Preprocessor, resize_by_factor
 
 try:  # the widgets run these generators in a Qt worker thread
     from napari.qt.threading import thread_worker
@@ -57,8 +57,9 @@ def load_model(model_config, device):
 
 
 def _require_scale_one(scale):
-    if scale != 1:
-        raise NotImplementedError('inference_scale > 1 needs the cv2.resize down-scaling (next tier, SURVEY section 8f)')
+    """inference_scale is a power of two (volume_dataset.py:26-27)."""
+    if not math.log(scale, 2).is_integer():
+        raise Exception(f'Image rescaling must be log base 2, got {scale}')
 
 
 def _open_zarr(store_url, mode=None):
@@ -190,7 +191,7 @@ class Engine2d:
             raise NotImplementedError('tiled 2-D inference (cztile Tiler + tile consensus) is a next-tier row')
         _require_scale_one(self.inference_scale)
         size = image.shape
-        x = self.preprocessor(image)['image'].unsqueeze(0)
+        x = self.preprocessor(resize_by_factor(image, self.inference_scale))['image'].unsqueeze(0)
         pan_seg = self.engine(x, size, upsampling=self.inference_scale)
         return self.force_connected(pan_seg.squeeze(0))
 
@@ -336,8 +337,9 @@ class Engine3d:
             zp = upto
 
         for i0 in range(0, n, self.batch_size):
-            imgs = [self.preprocessor(np.asarray(take(volume, i, axis)))['image'] for i in range(i0, min(n, i0 + self.batch_size))]
-            size = tuple(imgs[0].shape[-2:])
+            raws = [np.asarray(take(volume, i, axis)) for i in range(i0, min(n, i0 + self.batch_size))]
+            size = tuple(raws[0].shape[-2:])          # label maps come back at the ORIGINAL slice size
+            imgs = [self.preprocessor(resize_by_factor(r, ups))['image'] for r in raws]
             x = factor_pad(torch.stack(imgs), eng.padding_factor)
             mo = eng.model(eng.to_model_device(x), rs, interpolate_ins=not eng.coarse_boundaries)
             pend.append((logits_to_prob(mo['sem_logits']), mo['ctr_hmp'].clone(), mo['offsets'].clone()))

@@ -37,3 +37,24 @@ class Preprocessor:
         max_value = np.iinfo(image.dtype).max
         image = normalize(image, self.mean, self.std, max_pixel_value=max_value)
         return {'image': torch.from_numpy(image[None])}
+
+
+def resize_by_factor(image, scale_factor=1):
+    """data/utils/transforms.py:9-21: cv2.resize(image, (ceil(w/s), ceil(h/s))) with cv2's default
+    INTER_LINEAR (half-pixel centres, edge replicate, no anti-aliasing) == bilinear, align_corners=False.
+    Pinned by the reference's three float cases (tests/test_transforms.py:6-28, restated in
+    tests/test_host_misc.py); for integer images cv2 rounds in fixed point -- parity unpinned there
+    (cv2 is absent from this image), the float result is rounded half away from zero and clipped."""
+    if scale_factor == 1:
+        return image
+    import math
+    import torch
+    import torch.nn.functional as F
+    h, w = image.shape
+    dh, dw = math.ceil(h / scale_factor), math.ceil(w / scale_factor)
+    x = torch.from_numpy(np.ascontiguousarray(image).astype(np.float64))[None, None]
+    y = F.interpolate(x, size=(dh, dw), mode='bilinear', align_corners=False)[0, 0].numpy()
+    if np.issubdtype(image.dtype, np.integer):
+        info = np.iinfo(image.dtype)
+        y = np.clip(np.floor(y + 0.5), info.min, info.max)
+    return y.astype(image.dtype)

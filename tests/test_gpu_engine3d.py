@@ -123,3 +123,20 @@ def test_batched_slices_equal_single_slice_calls(model_config):
     assert len(a) == len(b) == 9
     for p, q in zip(a, b):
         np.testing.assert_array_equal(p, q)
+
+
+def test_engine2d_inference_scale_2(model_config):
+    """inference_scale = 2: input down-scaled by resize_by_factor, PointRend renders one extra step
+    (render_steps = 3) and cells are up-sampled x8, so the label map comes back at the original size."""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine2d
+    from empanada_napari_amd.preprocess import resize_by_factor
+    from oracle import sparse as osp
+    img = synth.em_tiles(1, 256, seed=12)[0][:250, :230]
+    eng = Engine2d(model_config, inference_scale=2, label_divisor=DIV, nms_kernel=3, confidence_thr=0.5)
+    got = eng.infer(img)
+    assert got.shape == img.shape and got.dtype == np.int32
+    small = resize_by_factor(img, 2)
+    x = eng.preprocessor(small)['image'].unsqueeze(0)
+    raw = eng.engine(x, img.shape, 2).squeeze(0).cpu().numpy().astype(np.int32)
+    np.testing.assert_array_equal(got, osp.force_connected_pan(raw.copy(), [1], DIV))
