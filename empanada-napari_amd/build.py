@@ -21,7 +21,8 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-fvisibility=
 PER_FILE = {
     'postprocess.hip': ['-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt'],
 }
-SOURCES = ['abi.hip', 'conv_igemm.hip', 'layers.hip', 'pointrend.hip', 'postprocess.hip', 'pdl_net.hip', 'sparse.hip']
+SOURCES = ['abi.hip', 'conv_igemm.hip', 'layers.hip', 'pointrend.hip', 'postprocess.hip', 'pdl_net.hip', 'sparse.hip',
+           'sepconv.hip']
 
 
 def _hipcc():

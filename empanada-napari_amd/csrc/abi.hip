@@ -21,8 +21,8 @@ const void* zero_page() {
   static void* page = nullptr;
   static std::once_flag once;
   std::call_once(once, [] {
-    if (hipMalloc(&page, 256) != hipSuccess) { page = nullptr; return; }
-    if (hipMemset(page, 0, 256) != hipSuccess) { (void)hipFree(page); page = nullptr; }
+    if (hipMalloc(&page, 2048) != hipSuccess) { page = nullptr; return; }
+    if (hipMemset(page, 0, 2048) != hipSuccess) { (void)hipFree(page); page = nullptr; }
   });
   return page;
 }
@@ -79,6 +79,29 @@ int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_l
   p.ps_cout = 0;
   p.M = N * p.Ho * p.Wo;
   return launch_conv_igemm(p, variant, (hipStream_t)stream);
+}
+
+int emp_dwconv_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld, const void* d_w, int K, void* d_out,
+                        int out_ld, void* stream) {
+  EMP_REQUIRE(d_in && d_w && d_out, "dwconv: null pointer");
+  const half_t* zero = (const half_t*)zero_page();
+  EMP_REQUIRE(zero != nullptr, "dwconv: could not allocate the zero page");
+  return launch_dwconv((const half_t*)d_in, N, H, W, C, in_ld, (const half_t*)d_w, K, (half_t*)d_out, out_ld, zero,
+                       (hipStream_t)stream);
+}
+
+int emp_sepconv5x5_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld, const void* d_dw_w,
+                            const void* d_pw_w, int pw_ld, const float* d_bias, int Cout, int act, void* d_out,
+                            int out_ld, const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
+                            void* stream) {
+  EMP_REQUIRE(d_in && d_dw_w && d_pw_w, "sepconv5x5: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0, "sepconv5x5: bad geometry");
+  EMP_REQUIRE(head_c == 0 || (d_head_w && d_head_out), "sepconv5x5: head pointers missing");
+  const half_t* zero = (const half_t*)zero_page();
+  EMP_REQUIRE(zero != nullptr, "sepconv5x5: could not allocate the zero page");
+  return launch_sepconv5((const half_t*)d_in, N, H, W, C, in_ld, (const half_t*)d_dw_w, (const half_t*)d_pw_w, pw_ld,
+                         d_bias, Cout, act, head_c ? nullptr : (half_t*)d_out, out_ld, d_head_w, d_head_b, head_c,
+                         d_head_out, (int64_t)H * W, zero, (hipStream_t)stream);
 }
 
 }  // extern "C"

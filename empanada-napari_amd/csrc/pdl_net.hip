@@ -277,7 +277,7 @@ int plan(emp_pdl* n, int N, int H, int W, int RS) {
   n->act_order.clear();
   n->raw.clear();
   Planner pl;
-  add_raw(n, pl, "zero", 256);
+  add_raw(n, pl, "zero", 2048);
   add_act(n, pl, "stem", N, H / 2, W / 2, 64);
   add_act(n, pl, "p1", N, H / 4, W / 4, 64);
   int h = H / 4, w = W / 4, inpl = 64;

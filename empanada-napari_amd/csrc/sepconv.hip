@@ -1,0 +1,457 @@
+// Fused depthwise-separable convolution for gfx950 (MI355X):
+//   y = act( pw( dw5x5(x) ) + bias )            [+ optional 1x1 head on y]
+// replaces nn.Conv2d(C,C,5,groups=C,pad=2,bias=False) -> nn.Conv2d(C,Cout,1) -> folded BN -> ReLU
+// (the 'depthwise_separable_conv' of the Panoptic-DeepLab decoder / heads, models/blocks.py, called from
+// models/decoders/panoptic_deeplab.py and models/heads) -- and, for the heads, the final 1x1 conv
+// (Cout -> hc <= 4) so that the Cout-channel map never leaves the chip.
+//
+// There is no non-linearity between the depthwise and the pointwise conv, so the depthwise output is
+// only ever the B operand of the pointwise GEMM: it is produced straight into LDS.
+//
+// One persistent workgroup per CU, 512 threads = 8 waves with two roles (one wave of each per SIMD, so
+// the vector ALU and the matrix pipe of every SIMD are both fed):
+//   waves 0-3  "dw":  fp32 depthwise 5x5 on the VALU (v_pk_fma_f32 over channel pairs) from a
+//                     12x20-pixel x 64-channel halo tile in LDS into a 128-pixel x 64-channel fp16
+//                     B tile in LDS (XOR-swizzled rows of 128 B).
+//   waves 4-7  "mma": LDS-DMA (global_load_lds) of the NEXT halo tile, then the pointwise GEMM of the
+//                     PREVIOUS B tile: 16x16x32 f16 MFMA, A fragments (pointwise weights) straight
+//                     from L2, accumulators (Cout x 128 pixels) resident across the C/64 channel
+//                     chunks; epilogue bias + act + 16-byte NHWC stores (or the head reduction).
+// The pipeline is flattened over (tile, chunk) steps with ONE barrier per step, so fill and drain are
+// paid once per workgroup, not per tile.  Halo tiles are DMA'd TWO steps ahead into a ring of three
+// (HBM latency under load is about one step); the barrier fences LDS only (lgkmcnt), and the mma waves
+// wait with a counted vmcnt so that the youngest DMA batch stays in flight across it.  [measured: with
+// one-step prefetch and a full __syncthreads the mma role alone took 1.07 ms of a 1.15 ms launch.]
+//
+// Summation order of the depthwise taps (ky-major, kx-minor, fp32 fma chain from 0) and of the GEMM
+// (ascending 32-channel K-steps) equals the unfused dwconv_kernel + conv_igemm_kernel pair.
+#include "common.h"
+
+namespace emp {
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SC_TH = 8, SC_TW = 16;                  // output tile (rows x cols) = 128 pixels
+constexpr int SC_IH = SC_TH + 4, SC_IW = SC_TW + 4;   // halo tile 12 x 20
+constexpr int SC_NPIX = SC_IH * SC_IW;                // 240 pixels = 30 LDS-DMA instructions of 8 pixels
+constexpr int SC_NST = SC_NPIX / 8;
+constexpr int SC_HALO_BYTES = SC_NPIX * 128;          // 30720
+constexpr int SC_BT_BYTES = 128 * 128;                // 16384
+constexpr int SC_RED_BYTES = 4 * 128 * 4 * 4;         // head partials [4 waves][128 px][4]
+
+struct SepParams {
+  const half_t* in;
+  int N, H, W, C, in_ld;
+  const half_t* dww;     // [25][C] fp16
+  const half_t* pww;     // [Cout][pw_ld] fp16
+  int pw_ld;
+  const float* bias;     // [Cout]
+  half_t* out;           // (N,H,W,out_ld) or nullptr (head mode)
+  int out_ld, act;
+  const half_t* zero;    // >= 2 KiB of zeros
+  int tiles_x, tiles_y;
+  int tiles;
+  const float* hw;       // head mode: [hc][Cout] fp32
+  const float* hb;       // [hc]
+  int hc;
+  float* hout;           // (N,hc) planes of `plane` floats
+  int64_t plane;
+  int dbg;
+};
+
+template <int ACT>
+__device__ __forceinline__ float sc_act(float x) {
+  if (ACT == 1) return fmaxf(x, 0.f);
+  if (ACT == 2) return x / (1.f + __expf(-x));
+  return x;
+}
+
+__device__ __forceinline__ void tile_coords(const SepParams& p, int tile, int& n, int& y0, int& x0) {
+  const int tx = tile % p.tiles_x;
+  const int r = tile / p.tiles_x;
+  const int ty = r % p.tiles_y;
+  n = r / p.tiles_y;
+  y0 = ty * SC_TH;
+  x0 = tx * SC_TW;
+}
+
+// workgroup barrier that orders LDS traffic only: global loads / LDS-DMA stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int MT, bool HEAD, int ACT>
+__global__ void __launch_bounds__(512, 1) sepconv5_kernel(const SepParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  char* const halo = lds;                                   // 3 x SC_HALO_BYTES (ring)
+  char* const bt = lds + 3 * SC_HALO_BYTES;                 // 2 x SC_BT_BYTES
+  float* const dwl = reinterpret_cast<float*>(bt + 2 * SC_BT_BYTES);   // [C/64][25][64] fp32
+  float* const biasl = dwl + p.C * 25;                      // [Cout] epilogue bias
+  float* const hwl = biasl + 64 * MT;                       // HEAD: [4][Cout] head weights,
+  float* const red = hwl + 4 * 64 * MT;                     //       [4 waves][128 px][4] partial sums
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int NC = p.C >> 6;
+  // XCD-aware tile order: at iteration `it` XCD x owns tiles [(it*8+x)*nx, +nx)
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, nx = gridDim.x >> 3;
+  auto tile_of = [&](int it) { return (it * 8 + xcd) * nx + jx; };
+  int my_tiles = 0;
+  while (tile_of(my_tiles) < p.tiles) ++my_tiles;
+  const int S = my_tiles * NC;
+
+  // depthwise taps -> LDS, fp32, chunk-major
+  for (int i = tid; i < p.C * 25; i += 512) {
+    const int t = i / p.C, c = i - t * p.C;
+    dwl[((c >> 6) * 25 + t) * 64 + (c & 63)] = (float)p.dww[i];
+  }
+  for (int i = tid; i < 64 * MT; i += 512) biasl[i] = p.bias ? p.bias[i] : 0.f;
+  if (HEAD) {
+    for (int i = tid; i < p.hc * 64 * MT; i += 512) hwl[i] = p.hw[i];
+  }
+
+  if (wave < 4) {
+    // ------------------------------------------------------------------ dw role
+    const int cp = lane & 31, combo = wave * 2 + (lane >> 5), cg = combo & 3, rg = combo >> 2;
+    const int hoff = ((4 * rg) * SC_IW + 4 * cg) * 128 + cp * 4;
+    const int sw = (cp >> 2), sub = (cp & 3) * 4;
+    if (p.dbg & 128) __builtin_amdgcn_s_setprio(3);
+    __syncthreads();
+    f32x2 w[25];            // taps of the chunk of the coming step: read before the barrier, off the critical path
+#pragma unroll
+    for (int t = 0; t < 25; ++t) w[t] = reinterpret_cast<const f32x2*>(dwl)[t * 32 + cp];
+    long long busy = 0, t0 = __builtin_readcyclecounter();
+    for (int g = 0; g <= S + (HEAD ? 1 : 0); ++g) {
+      if (g < S && !(p.dbg & 1)) {
+        const int buf = g & 1;
+        const char* hb = halo + (g % 3) * SC_HALO_BYTES + hoff;
+        f32x2 acc[4][4];
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[y][j] = f32x2{0.f, 0.f};
+        f16x2 nxt[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) nxt[c] = *reinterpret_cast<const f16x2*>(hb + c * 128);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          f32x2 x[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) x[c] = f32x2{(float)nxt[c][0], (float)nxt[c][1]};
+          if (r + 1 < 8) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+              nxt[c] = *reinterpret_cast<const f16x2*>(hb + ((r + 1) * SC_IW + c) * 128);
+          }
+#pragma unroll
+          for (int ky = 0; ky < 5; ++ky) {
+            const int y = r - ky;
+            if (y < 0 || y >= 4) continue;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[y][j] = __builtin_elementwise_fma(x[j + kx], w[ky * 5 + kx], acc[y][j]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        char* bb = bt + buf * SC_BT_BYTES;
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int px = (4 * rg + y) * SC_TW + 4 * cg + j;
+            f16x2 h;
+            h[0] = (half_t)acc[y][j][0];
+            h[1] = (half_t)acc[y][j][1];
+            *reinterpret_cast<f16x2*>(bb + px * 128 + ((sw ^ (px & 7)) << 4) + sub) = h;
+          }
+        const f32x2* wl = reinterpret_cast<const f32x2*>(dwl + ((g + 1) % NC) * 25 * 64) + cp;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) w[t] = wl[t * 32];
+      }
+      if (p.dbg & 256) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); busy += __builtin_readcyclecounter() - t0; }
+      lds_barrier();
+      if (p.dbg & 256) t0 = __builtin_readcyclecounter();
+    }
+    if ((p.dbg & 256) && lane == 0) p.hout[blockIdx.x * 8 + wave] = (float)busy;
+  } else {
+    // ------------------------------------------------------------------ mma role
+    const int wm = wave - 4, g16 = lane >> 4, n16 = lane & 15;
+    const int Cout = 64 * MT;
+    if (p.dbg & 64) __builtin_amdgcn_s_setprio(3);
+    if (p.dbg & 128) __builtin_amdgcn_s_setprio(0);
+    const half_t* aptr[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+      const int i = n16, tp = t & 1;
+      const int co = wm * 16 * MT + (t >> 1) * 32 + ((i >> 2) << 3) + (tp << 2) + (i & 3);
+      aptr[t] = p.pww + (size_t)co * p.pw_ld + g16 * 8;
+    }
+    const half_t* sptr[8];
+    auto set_stage_ptrs = [&](int tile) {
+      int n, y0, x0;
+      tile_coords(p, tile, n, y0, x0);
+      const half_t* src = p.in + (size_t)n * p.H * p.W * p.in_ld + (lane & 7) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = min(wm + 4 * k, SC_NST - 1);
+        const int q = i * 8 + (lane >> 3);
+        const int py = q / SC_IW, px = q - py * SC_IW;
+        const int iy = y0 + py - 2, ix = x0 + px - 2;
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        sptr[k] = ok ? src + ((size_t)iy * p.W + ix) * p.in_ld : p.zero;
+      }
+    };
+    auto stage = [&](int g, bool valid) {
+      // Always exactly 8 DMA instructions per wave (waves 2,3 write slot 29 twice with the same data; a step
+      // without a halo to fetch copies the zero page into the free ring slot), so that every step has the
+      // same VM issue sequence and the counted waits below are compile-time constants.
+      const int ch = g % NC;
+      if (valid && ch == 0) set_stage_ptrs(tile_of(g / NC));
+      char* hb = halo + (g % 3) * SC_HALO_BYTES;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = min(wm + 4 * k, SC_NST - 1);
+        const half_t* src = valid ? sptr[k] + ch * 64 : p.zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(hb + i * 1024), 16, 0, 0);
+      }
+    };
+    f32x4 acc[MT][8];
+    f16x8 a[MT][2];
+    auto load_a = [&](int ch) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const half_t* ap = aptr[t] + ch * 64;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
+                     : "=&v"(a[t][0]), "=&v"(a[t][1]) : "v"(ap) : "memory");
+      }
+    };
+    float hb_lo = 0.f, hb_hi = 0.f;   // head bias of classes h = lane>>5 and h + 2
+    if (HEAD) {
+      if ((lane >> 5) < p.hc) hb_lo = p.hb[lane >> 5];
+      if ((lane >> 5) + 2 < p.hc) hb_hi = p.hb[(lane >> 5) + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sptr[k] = p.zero;
+    load_a(0);
+    stage(0, S > 0);
+    stage(1, S > 1);
+    __syncthreads();                                      // full wait; dwl / epilogue constants visible
+    long long busy = 0, t0 = __builtin_readcyclecounter(), twait = 0;
+    long long tsec[6] = {0, 0, 0, 0, 0, 0};
+    auto probe = [&](int i, long long& tp) { if (p.dbg & 256) { const long long t = __builtin_readcyclecounter(); tsec[i] += t - tp; tp = t; } };
+    for (int g = 0; g <= S + (HEAD ? 1 : 0); ++g) {
+      if (HEAD && g >= 2 && g - 2 < S && (g - 2) % NC == NC - 1) {
+        // finish the head of the tile whose last chunk was multiplied in the previous step
+        int n, y0, x0;
+        tile_coords(p, tile_of((g - 2) / NC), n, y0, x0);
+        const int px = wm * 32 + (lane & 31);
+        const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
+        for (int h = lane >> 5; h < p.hc; h += 2) {
+          const float v = red[(0 * 128 + px) * 4 + h] + red[(1 * 128 + px) * 4 + h] + red[(2 * 128 + px) * 4 + h] +
+                          red[(3 * 128 + px) * 4 + h] + (h < 2 ? hb_lo : hb_hi);
+          if (oy < p.H && ox < p.W) p.hout[((size_t)n * p.hc + h) * p.plane + (size_t)oy * p.W + ox] = v;
+        }
+      }
+      const bool do_mma = g >= 1 && g - 1 < S && !(p.dbg & 2);
+      const bool staged = g + 2 < S && !(p.dbg & 4);
+      // VM issue order: [weights of the next step, issued at the end of the previous step] [stores] [8 DMA loads
+      // of stage(g+2)].  Loads retire in order, so vmcnt(8) == "the weights AND the halo of step g+1 (DMA'd one
+      // step ago) have landed, only the youngest DMA batch may still be in flight"; stores only make the wait
+      // stricter.  The weight loads come from inline asm so that the compiler's own wait-count insertion does
+      // not see them (it answers a pending load behind LDS-DMA traffic with vmcnt(0), draining the DMA batch
+      // that is meant to stay in flight); the counted wait names the registers as operands, which orders it
+      // before their first use.
+      long long tp = t0;
+      probe(0, tp);
+      stage(g + 2, staged);
+      probe(1, tp);
+      long long tw0 = 0;
+      if (p.dbg & 256) tw0 = __builtin_readcyclecounter();
+      if (MT == 4)
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]),
+                     "+v"(a[MT - 2][0]), "+v"(a[MT - 2][1]), "+v"(a[MT - 1][0]), "+v"(a[MT - 1][1]) :: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]) :: "memory");
+      if (p.dbg & 256) twait += __builtin_readcyclecounter() - tw0;
+      probe(2, tp);
+      if (do_mma) {
+        const int ch = (g - 1) % NC, buf = (g - 1) & 1;
+        if (ch == 0) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const char* bb = bt + buf * SC_BT_BYTES + n16 * 128;
+        auto bfrag = [&](int i) {   // i = nt*2 + ks
+          return *reinterpret_cast<const f16x8*>(bb + (i >> 1) * 16 * 128 + ((((i & 1) * 4 + g16) ^ (n16 & 7)) << 4));
+        };
+        f16x8 b0 = bfrag(0), b1 = bfrag(1);
+        if (!(p.dbg & 16))
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const int nt = i >> 1;
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][0], b0, acc[t][nt], 0, 0, 0);
+          if (i + 2 < 16) b0 = bfrag(i + 2);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][1], b1, acc[t][nt], 0, 0, 0);
+          if (i + 3 < 16) b1 = bfrag(i + 3);
+        }
+      }
+      probe(3, tp);
+      if (!(p.dbg & 8)) load_a(g % NC);
+      probe(4, tp);
+           // weights of chunk g, multiplied in step g+1; `a` is dead from here to the next wait
+      if (do_mma) {
+        const int ch = (g - 1) % NC;
+        if (ch == NC - 1 && !(p.dbg & 32)) {
+          int n, y0, x0;
+          tile_coords(p, tile_of((g - 1) / NC), n, y0, x0);
+          const int ox = x0 + n16;
+          if (!HEAD) {
+#pragma unroll
+            for (int blk = 0; blk < MT / 2; ++blk) {
+              const int cb = wm * 16 * MT + blk * 32 + g16 * 8;
+              float bv[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) bv[e] = biasl[cb + e];
+#pragma unroll
+              for (int nt = 0; nt < 8; ++nt) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  o[e] = (half_t)sc_act<ACT>(acc[2 * blk][nt][e] + bv[e]);
+                  o[4 + e] = (half_t)sc_act<ACT>(acc[2 * blk + 1][nt][e] + bv[4 + e]);
+                }
+                const int oy = y0 + nt;
+                if (oy < p.H && ox < p.W)
+                  *reinterpret_cast<f16x8*>(p.out + (((size_t)n * p.H + oy) * p.W + ox) * p.out_ld + cb) = o;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int blk = 0; blk < MT / 2; ++blk) {
+              const int cb = wm * 16 * MT + blk * 32 + g16 * 8;
+              float bv[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) bv[e] = biasl[cb + e];
+#pragma unroll
+              for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  acc[2 * blk][nt][e] = sc_act<ACT>(acc[2 * blk][nt][e] + bv[e]);
+                  acc[2 * blk + 1][nt][e] = sc_act<ACT>(acc[2 * blk + 1][nt][e] + bv[4 + e]);
+                }
+            }
+#pragma unroll 1
+            for (int h = 0; h < p.hc; ++h) {
+              float sum[8];
+#pragma unroll
+              for (int nt = 0; nt < 8; ++nt) sum[nt] = 0.f;
+#pragma unroll
+              for (int blk = 0; blk < MT / 2; ++blk) {
+                const float* hp = hwl + h * Cout + wm * 16 * MT + blk * 32 + g16 * 8;
+                float hv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = hp[e];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    sum[nt] = fmaf(acc[2 * blk][nt][e], hv[e], sum[nt]);
+                    sum[nt] = fmaf(acc[2 * blk + 1][nt][e], hv[4 + e], sum[nt]);
+                  }
+              }
+#pragma unroll
+              for (int nt = 0; nt < 8; ++nt) {
+                float v = sum[nt];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (g16 == 0) red[(wm * 128 + nt * 16 + n16) * 4 + h] = v;
+              }
+            }
+          }
+        }
+      }
+      probe(5, tp);
+      if (p.dbg & 256) busy += __builtin_readcyclecounter() - t0;
+      lds_barrier();
+      if (p.dbg & 256) t0 = __builtin_readcyclecounter();
+    }
+    if ((p.dbg & 256) && lane == 0) { p.hout[blockIdx.x * 8 + wave] = (float)busy; p.hout[gridDim.x * 8 + blockIdx.x * 8 + wave] = (float)twait;
+      for (int i = 0; i < 6; ++i) p.hout[(2 + i) * gridDim.x * 8 + blockIdx.x * 8 + wave] = (float)tsec[i]; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the last (dummy) DMA batch
+  }
+}
+
+template <int MT, bool HEAD, int ACT>
+int launch_act(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv5_kernel<MT, HEAD, ACT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((sepconv5_kernel<MT, HEAD, ACT>), dim3(grid), dim3(512), lds_bytes, s, p);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+template <int MT, bool HEAD>
+int launch_one(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
+  if (p.act == 1) return launch_act<MT, HEAD, 1>(p, lds_bytes, grid, s);
+  if (p.act == 2) return launch_act<MT, HEAD, 2>(p, lds_bytes, grid, s);
+  return launch_act<MT, HEAD, 0>(p, lds_bytes, grid, s);
+}
+
+}  // namespace
+
+static size_t sepconv5_lds_bytes(int C, int Cout, int head_c) {
+  return 3 * SC_HALO_BYTES + 2 * SC_BT_BYTES + (size_t)C * 25 * 4 + (size_t)Cout * 4 +
+         (head_c ? (size_t)4 * Cout * 4 + SC_RED_BYTES : 0);
+}
+
+bool sepconv5_supported(int C, int Cout, int head_c) {
+  return C % 64 == 0 && C >= 128 && (Cout == 128 || Cout == 256) && head_c >= 0 && head_c <= 4 &&
+         sepconv5_lds_bytes(C, Cout, head_c) <= 160 * 1024;   // C <= 320 (features) / C <= 192 (heads)
+}
+
+// out != nullptr: y = act(pw(dw(x)) + bias) -> (N,H,W,out_ld) fp16.
+// head_c > 0   : hout[n][h] = head_w[h] . y + head_b[h] as fp32 planes of `plane` floats; y is not stored.
+int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* dww, const half_t* pww,
+                    int pw_ld, const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
+                    const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s) {
+  EMP_REQUIRE(sepconv5_supported(C, Cout, head_c), "sepconv5: unsupported shape C=%d Cout=%d head=%d", C, Cout, head_c);
+  EMP_REQUIRE(act >= 0 && act <= 2, "sepconv5: bad activation %d", act);
+  EMP_REQUIRE((head_c > 0) != (out != nullptr), "sepconv5: exactly one of the feature / head outputs");
+  EMP_REQUIRE(in_ld % 8 == 0 && pw_ld % 8 == 0 && (out == nullptr || out_ld % 8 == 0), "sepconv5: 16-byte row alignment");
+  SepParams p{};
+  p.in = in; p.N = N; p.H = H; p.W = W; p.C = C; p.in_ld = in_ld;
+  p.dww = dww; p.pww = pww; p.pw_ld = pw_ld; p.bias = bias;
+  p.out = out; p.out_ld = out_ld; p.act = act; p.zero = zero;
+  p.tiles_x = cdiv(W, SC_TW); p.tiles_y = cdiv(H, SC_TH);
+  const int64_t tiles = (int64_t)N * p.tiles_x * p.tiles_y;
+  EMP_REQUIRE(tiles < (1ll << 30), "sepconv5: too many tiles");
+  p.tiles = (int)tiles;
+  { const char* e = getenv("EMP_SEPCONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+  p.hw = head_w; p.hb = head_b; p.hc = head_c; p.hout = hout; p.plane = plane;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    EMP_CHECK_HIP(hipGetDevice(&dev));
+    EMP_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = n_cu >= 8 ? (n_cu / 8) * 8 : 8;
+  }
+  const int grid = n_cu;
+  const size_t lds_bytes = sepconv5_lds_bytes(C, Cout, head_c);
+  if (Cout == 256) return head_c ? launch_one<4, true>(p, lds_bytes, grid, s) : launch_one<4, false>(p, lds_bytes, grid, s);
+  return head_c ? launch_one<2, true>(p, lds_bytes, grid, s) : launch_one<2, false>(p, lds_bytes, grid, s);
+}
+
+}  // namespace emp

@@ -146,6 +146,28 @@ EMP_API int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, 
                         int KH, int KW, int stride, int pad, int dil, int relu,
                         int variant, void* stream);
 
+/* NHWC fp16 depthwise KxK convolution (K in {3,5}, stride 1, pad K/2, no bias), fp32 accumulate.
+ * replaces nn.Conv2d(C, C, K, groups=C, bias=False): the first half of the decoder's separable convs
+ * (models/blocks.py separable conv, models/decoders/bifpn.py SeparableConv2d).
+ *   d_w: (K*K, C) fp16;  C % 64 == 0 */
+EMP_API int emp_dwconv_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld,
+                        const void* d_w, int K, void* d_out, int out_ld, void* stream);
+
+/* Fused separable convolution: y = act(pointwise(depthwise5x5(x)) + bias), and optionally the
+ * 1x1 head on top of it (head_c in 1..4) so that y never reaches HBM.
+ * replaces the 'depthwise_separable_conv' blocks of the Panoptic-DeepLab decoder / heads
+ * (models/decoders/panoptic_deeplab.py fuse convs, models/heads/panoptic_deeplab.py head.0 -> head.1).
+ *   d_in    : (N,H,W,in_ld) fp16, channels [0,C), C % 64 == 0, 128 <= C <= 512
+ *   d_dw_w  : (25, C) fp16;  d_pw_w: (Cout, pw_ld) fp16, Cout in {128,256};  d_bias: (Cout) fp32 or NULL
+ *   act     : 0 none | 1 ReLU | 2 SiLU
+ *   head_c == 0: d_out (N,H,W,out_ld) fp16 receives y
+ *   head_c  > 0: d_head_out (N,head_c,H,W) fp32 receives d_head_w (head_c,Cout) . y + d_head_b; d_out unused */
+EMP_API int emp_sepconv5x5_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld,
+                        const void* d_dw_w, const void* d_pw_w, int pw_ld, const float* d_bias,
+                        int Cout, int act, void* d_out, int out_ld,
+                        const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
+                        void* stream);
+
 /* ------------------------------------------------------------------------
  * 3. Instance post-processing (hot loop 2), one launch group per batch
  * ---------------------------------------------------------------------- */
