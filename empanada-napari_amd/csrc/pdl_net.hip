@@ -56,6 +56,8 @@ struct emp_pdl {
   std::vector<std::string> param_names;
   std::map<std::string, HostParam> params;
   bool finalized = false;
+  // fused separable convs (sepconv.hip); EMP_FUSE_SEPCONV=0 keeps the dwconv + 1x1 conv + head1x1 launches (A/B runs)
+  bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
 
   // device parameters
   std::map<std::string, DevConv> convs;
@@ -610,10 +612,21 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       RC(launch_bilinear_ac(xa.p, N, xa.H, xa.W, xch, xa.ld, cb.p, cb.H, cb.W, cb.ld, s));
       RC(conv(n, p + ".project." + std::to_string(i) + ".0", A(pyr[st]), 0, cb, xch, 1, 0, 1, true, nullptr, nullptr, s));
       const std::string fz = p + ".fuse." + std::to_string(i) + ".0.sepconv.";
-      RC(launch_dwconv(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), 5, A(q + ".dw").p, cb.ld,
-                       rawp<half_t>(n, "zero"), s));
       n->flops += 2.0 * 25.0 * (double)N * cb.H * cb.W * (xch + n->convs.at(p + ".project." + std::to_string(i) + ".0").cout);
-      RC(conv(n, fz + "1", A(q + ".dw"), 0, A(q + ".out"), 0, 1, 0, 1, true, nullptr, nullptr, s));
+      {
+        const DevConv& pwc = n->convs.at(fz + "1");
+        const Act& so = A(q + ".out");
+        if (n->fuse_sepconv && pwc.cin_pad == cb.ld && so.ld == pwc.cout && sepconv5_supported(cb.ld, pwc.cout, 0)) {
+          // depthwise 5x5 -> pointwise -> bias -> ReLU in one launch (sepconv.hip); the depthwise map stays in LDS
+          RC(launch_sepconv5(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), pwc.w, pwc.cin_pad, pwc.b,
+                             pwc.cout, 1, so.p, so.ld, nullptr, nullptr, 0, nullptr, 0, rawp<half_t>(n, "zero"), s));
+          n->flops += 2.0 * (double)N * cb.H * cb.W * pwc.cout * (double)pwc.cin;
+        } else {
+          RC(launch_dwconv(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), 5, A(q + ".dw").p, cb.ld,
+                           rawp<half_t>(n, "zero"), s));
+          RC(conv(n, fz + "1", A(q + ".dw"), 0, so, 0, 1, 0, 1, true, nullptr, nullptr, s));
+        }
+      }
       x = q + ".out";
       xch = n->dec_ch;
     }
@@ -632,16 +645,27 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
   for (int k = 0; k < 3; ++k) {
     std::string p = heads[k];
     const Act& xin = k == 0 ? semx : insx;
-    RC(launch_dwconv(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f16w.at(p + ".head.0.0.sepconv.0"), 5, A(p + ".dw").p,
-                     n->dec_ch, rawp<half_t>(n, "zero"), s));
     n->flops += 2.0 * 25.0 * (double)N * hq * wq * n->dec_ch;
-    RC(conv(n, p + ".head.0.0.sepconv.1", A(p + ".dw"), 0, A(p + ".pw"), 0, 1, 0, 1, true, nullptr, nullptr, s));
     float* dst = rawp<float>(n, p + ".out");
     if (k == 1 && !interp) dst = o_ctr;
     if (k == 2 && !interp) dst = o_off;
     head_out[k] = dst;
-    RC(launch_head1x1(A(p + ".pw").p, N, hq * wq, n->dec_ch, n->dec_ch, n->f32w.at(p + ".head.1.w"),
-                      n->f32w.at(p + ".head.1.b"), hc[k], dst, (int64_t)hq * wq, nullptr, s));
+    const DevConv& pwc = n->convs.at(p + ".head.0.0.sepconv.1");
+    if (n->fuse_sepconv && xin.C == n->dec_ch && pwc.cin_pad == n->dec_ch && pwc.cout == n->dec_ch && hc[k] <= 2 &&
+        sepconv5_supported(n->dec_ch, pwc.cout, hc[k])) {
+      // head.0 (depthwise 5x5 -> pointwise -> ReLU) and head.1 (1x1 -> hc planes) in one launch: neither the
+      // depthwise nor the dec_ch-channel map reaches HBM (sepconv.hip)
+      RC(launch_sepconv5(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f16w.at(p + ".head.0.0.sepconv.0"), pwc.w, pwc.cin_pad,
+                         pwc.b, pwc.cout, 1, nullptr, 0, n->f32w.at(p + ".head.1.w"), n->f32w.at(p + ".head.1.b"), hc[k],
+                         dst, (int64_t)hq * wq, rawp<half_t>(n, "zero"), s));
+      n->flops += 2.0 * (double)N * hq * wq * pwc.cout * (double)pwc.cin;
+    } else {
+      RC(launch_dwconv(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f16w.at(p + ".head.0.0.sepconv.0"), 5, A(p + ".dw").p,
+                       n->dec_ch, rawp<half_t>(n, "zero"), s));
+      RC(conv(n, p + ".head.0.0.sepconv.1", A(p + ".dw"), 0, A(p + ".pw"), 0, 1, 0, 1, true, nullptr, nullptr, s));
+      RC(launch_head1x1(A(p + ".pw").p, N, hq * wq, n->dec_ch, n->dec_ch, n->f32w.at(p + ".head.1.w"),
+                        n->f32w.at(p + ".head.1.b"), hc[k], dst, (int64_t)hq * wq, nullptr, s));
+    }
     n->flops += 2.0 * (double)N * hq * wq * n->dec_ch * hc[k];
   }
   if (interp) {

@@ -39,7 +39,6 @@ constexpr int SC_NPIX = SC_IH * SC_IW;                // 240 pixels = 30 LDS-DMA
 constexpr int SC_NST = SC_NPIX / 8;
 constexpr int SC_HALO_BYTES = SC_NPIX * 128;          // 30720
 constexpr int SC_BT_BYTES = 128 * 128;                // 16384
-constexpr int SC_RED_BYTES = 4 * 128 * 4 * 4;         // head partials [4 waves][128 px][4]
 
 struct SepParams {
   const half_t* in;
@@ -58,7 +57,6 @@ struct SepParams {
   int hc;
   float* hout;           // (N,hc) planes of `plane` floats
   int64_t plane;
-  int dbg;
 };
 
 template <int ACT>
@@ -84,15 +82,19 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int MT, bool HEAD, int ACT>
-__global__ void __launch_bounds__(512, 1) sepconv5_kernel(const SepParams p) {
+// NMW = number of mma waves (4 or 8), MT = 16-cout MFMA row tiles per mma wave: Cout = NMW * 16 * MT.
+template <int NMW, int MT, bool HEAD, int ACT>
+__global__ void __launch_bounds__(64 * (4 + NMW), 1) sepconv5_kernel(const SepParams p) {
+  constexpr int NT = 64 * (4 + NMW);        // threads
+  constexpr int COUT = NMW * 16 * MT;
+  constexpr int NDMA = 32 / NMW;            // LDS-DMA instructions per mma wave and step (8 or 4)
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   char* const halo = lds;                                   // 3 x SC_HALO_BYTES (ring)
   char* const bt = lds + 3 * SC_HALO_BYTES;                 // 2 x SC_BT_BYTES
   float* const dwl = reinterpret_cast<float*>(bt + 2 * SC_BT_BYTES);   // [C/64][25][64] fp32
   float* const biasl = dwl + p.C * 25;                      // [Cout] epilogue bias
-  float* const hwl = biasl + 64 * MT;                       // HEAD: [4][Cout] head weights,
-  float* const red = hwl + 4 * 64 * MT;                     //       [4 waves][128 px][4] partial sums
+  float* const hwl = biasl + COUT;                          // HEAD: [2][Cout] head weights,
+  float* const red = hwl + 2 * COUT;                        //       [NMW waves][128 px][2] partial sums
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int NC = p.C >> 6;
@@ -102,32 +104,33 @@ __global__ void __launch_bounds__(512, 1) sepconv5_kernel(const SepParams p) {
   int my_tiles = 0;
   while (tile_of(my_tiles) < p.tiles) ++my_tiles;
   const int S = my_tiles * NC;
+  const int LAST = S + (HEAD ? 1 : 0);      // last step index (HEAD: one more to finish the last tile's head)
 
-  // depthwise taps -> LDS, fp32, chunk-major
-  for (int i = tid; i < p.C * 25; i += 512) {
+  // depthwise taps -> LDS, fp32, chunk-major; epilogue constants
+  for (int i = tid; i < p.C * 25; i += NT) {
     const int t = i / p.C, c = i - t * p.C;
     dwl[((c >> 6) * 25 + t) * 64 + (c & 63)] = (float)p.dww[i];
   }
-  for (int i = tid; i < 64 * MT; i += 512) biasl[i] = p.bias ? p.bias[i] : 0.f;
+  for (int i = tid; i < COUT; i += NT) biasl[i] = p.bias ? p.bias[i] : 0.f;
   if (HEAD) {
-    for (int i = tid; i < p.hc * 64 * MT; i += 512) hwl[i] = p.hw[i];
+    for (int i = tid; i < p.hc * COUT; i += NT) hwl[i] = p.hw[i];
   }
 
   if (wave < 4) {
     // ------------------------------------------------------------------ dw role
+    // thread = channel pair cp x columns 4cg..4cg+3 x rows 4rg..4rg+3 of the 8x16 tile
     const int cp = lane & 31, combo = wave * 2 + (lane >> 5), cg = combo & 3, rg = combo >> 2;
     const int hoff = ((4 * rg) * SC_IW + 4 * cg) * 128 + cp * 4;
     const int sw = (cp >> 2), sub = (cp & 3) * 4;
-    if (p.dbg & 128) __builtin_amdgcn_s_setprio(3);
     __syncthreads();
     f32x2 w[25];            // taps of the chunk of the coming step: read before the barrier, off the critical path
 #pragma unroll
     for (int t = 0; t < 25; ++t) w[t] = reinterpret_cast<const f32x2*>(dwl)[t * 32 + cp];
-    long long busy = 0, t0 = __builtin_readcyclecounter();
-    for (int g = 0; g <= S + (HEAD ? 1 : 0); ++g) {
-      if (g < S && !(p.dbg & 1)) {
-        const int buf = g & 1;
-        const char* hb = halo + (g % 3) * SC_HALO_BYTES + hoff;
+    int ring = 0, chn = 0;   // g % 3, (g + 1) % NC
+    for (int g = 0; g <= LAST; ++g) {
+      chn = chn + 1 == NC ? 0 : chn + 1;
+      if (g < S) {
+        const char* hb = halo + ring * SC_HALO_BYTES + hoff;
         f32x2 acc[4][4];
 #pragma unroll
         for (int y = 0; y < 4; ++y)
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(512, 1) sepconv5_kernel(const SepParams p) {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        char* bb = bt + buf * SC_BT_BYTES;
+        char* bb = bt + (g & 1) * SC_BT_BYTES;
 #pragma unroll
         for (int y = 0; y < 4; ++y)
 #pragma unroll
@@ -168,21 +171,17 @@ __global__ void __launch_bounds__(512, 1) sepconv5_kernel(const SepParams p) {
             h[1] = (half_t)acc[y][j][1];
             *reinterpret_cast<f16x2*>(bb + px * 128 + ((sw ^ (px & 7)) << 4) + sub) = h;
           }
-        const f32x2* wl = reinterpret_cast<const f32x2*>(dwl + ((g + 1) % NC) * 25 * 64) + cp;
+        const f32x2* wl = reinterpret_cast<const f32x2*>(dwl + chn * 25 * 64) + cp;
 #pragma unroll
         for (int t = 0; t < 25; ++t) w[t] = wl[t * 32];
       }
-      if (p.dbg & 256) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); busy += __builtin_readcyclecounter() - t0; }
+      ring = ring == 2 ? 0 : ring + 1;
       lds_barrier();
-      if (p.dbg & 256) t0 = __builtin_readcyclecounter();
     }
-    if ((p.dbg & 256) && lane == 0) p.hout[blockIdx.x * 8 + wave] = (float)busy;
   } else {
     // ------------------------------------------------------------------ mma role
     const int wm = wave - 4, g16 = lane >> 4, n16 = lane & 15;
-    const int Cout = 64 * MT;
-    if (p.dbg & 64) __builtin_amdgcn_s_setprio(3);
-    if (p.dbg & 128) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(3);      // few instructions, long latencies: issue ahead of the VALU-bound dw wave
     const half_t* aptr[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -190,34 +189,37 @@ __global__ void __launch_bounds__(512, 1) sepconv5_kernel(const SepParams p) {
       const int co = wm * 16 * MT + (t >> 1) * 32 + ((i >> 2) << 3) + (tp << 2) + (i & 3);
       aptr[t] = p.pww + (size_t)co * p.pw_ld + g16 * 8;
     }
-    const half_t* sptr[8];
-    auto set_stage_ptrs = [&](int tile) {
-      int n, y0, x0;
-      tile_coords(p, tile, n, y0, x0);
-      const half_t* src = p.in + (size_t)n * p.H * p.W * p.in_ld + (lane & 7) * 8;
+    // Halo DMA: wave wm issues slots i = wm + NMW*k.  Always exactly NDMA instructions per step (the two spare
+    // slots repeat slot 29 with the same data; a step without a halo to fetch copies the zero page into the free
+    // ring slot), so that every step has the same VM issue sequence and the counted wait is a constant.
+    const half_t* sptr[NDMA];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = min(wm + 4 * k, SC_NST - 1);
-        const int q = i * 8 + (lane >> 3);
-        const int py = q / SC_IW, px = q - py * SC_IW;
-        const int iy = y0 + py - 2, ix = x0 + px - 2;
-        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        sptr[k] = ok ? src + ((size_t)iy * p.W + ix) * p.in_ld : p.zero;
+    for (int k = 0; k < NDMA; ++k) sptr[k] = p.zero;
+    auto stage = [&](int tile_it, int ch, int ringslot, bool valid) {
+      if (!valid) {
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) sptr[k] = p.zero;
+      } else if (ch == 0) {
+        int n, y0, x0;
+        tile_coords(p, tile_of(tile_it), n, y0, x0);
+        const half_t* src = p.in + (size_t)n * p.H * p.W * p.in_ld + (lane & 7) * 8;
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) {
+          const int i = min(wm + NMW * k, SC_NST - 1);
+          const int q = i * 8 + (lane >> 3);
+          const int py = q / SC_IW, px = q - py * SC_IW;
+          const int iy = y0 + py - 2, ix = x0 + px - 2;
+          const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          sptr[k] = ok ? src + ((size_t)iy * p.W + ix) * p.in_ld : p.zero;
+        }
       }
-    };
-    auto stage = [&](int g, bool valid) {
-      // Always exactly 8 DMA instructions per wave (waves 2,3 write slot 29 twice with the same data; a step
-      // without a halo to fetch copies the zero page into the free ring slot), so that every step has the
-      // same VM issue sequence and the counted waits below are compile-time constants.
-      const int ch = g % NC;
-      if (valid && ch == 0) set_stage_ptrs(tile_of(g / NC));
-      char* hb = halo + (g % 3) * SC_HALO_BYTES;
+      char* hb = halo + ringslot * SC_HALO_BYTES;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = min(wm + 4 * k, SC_NST - 1);
-        const half_t* src = valid ? sptr[k] + ch * 64 : p.zero;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+      for (int k = 0; k < NDMA; ++k) {
+        const int i = min(wm + NMW * k, SC_NST - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sptr[k],
                                          (__attribute__((address_space(3))) void*)(hb + i * 1024), 16, 0, 0);
+        sptr[k] += 64;      // next chunk (zero-page pointers stay inside the 2 KiB page: <= NC + 2 increments)
       }
     };
     f32x4 acc[MT][8];
@@ -230,69 +232,61 @@ __global__ void __launch_bounds__(512, 1) sepconv5_kernel(const SepParams p) {
                      : "=&v"(a[t][0]), "=&v"(a[t][1]) : "v"(ap) : "memory");
       }
     };
-    float hb_lo = 0.f, hb_hi = 0.f;   // head bias of classes h = lane>>5 and h + 2
-    if (HEAD) {
-      if ((lane >> 5) < p.hc) hb_lo = p.hb[lane >> 5];
-      if ((lane >> 5) + 2 < p.hc) hb_hi = p.hb[(lane >> 5) + 2];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) sptr[k] = p.zero;
+    // head finishing lanes: output idx = wm*64 + lane -> (class h = idx >> 7, pixel idx & 127)
+    const int fidx = wm * 64 + lane, fh = fidx >> 7, fpx = fidx & 127;
+    float fhb = 0.f;
+    if (HEAD && fh < p.hc) fhb = p.hb[fh];
     load_a(0);
-    stage(0, S > 0);
-    stage(1, S > 1);
-    __syncthreads();                                      // full wait; dwl / epilogue constants visible
-    long long busy = 0, t0 = __builtin_readcyclecounter(), twait = 0;
-    long long tsec[6] = {0, 0, 0, 0, 0, 0};
-    auto probe = [&](int i, long long& tp) { if (p.dbg & 256) { const long long t = __builtin_readcyclecounter(); tsec[i] += t - tp; tp = t; } };
-    for (int g = 0; g <= S + (HEAD ? 1 : 0); ++g) {
-      if (HEAD && g >= 2 && g - 2 < S && (g - 2) % NC == NC - 1) {
-        // finish the head of the tile whose last chunk was multiplied in the previous step
+    stage(0, 0, 0, S > 0);
+    stage(0, NC > 1 ? 1 : 0, 1, S > 1);      // S > 1 implies NC >= 2 (launcher) or a second tile; see launcher
+    __syncthreads();                          // full wait; dwl / epilogue constants visible
+    // step counters: c1 = (g-1) % NC with tile t1, c2 = (g+2) % NC with tile t2, ring2 = (g+2) % 3
+    int c1 = NC - 1, t1 = -1, c2 = 2 % NC, t2 = 2 / NC, ring2 = 2;
+    for (int g = 0; g <= LAST; ++g) {
+      if (HEAD && g >= 2 && c1 == 0 && fh < p.hc) {
+        // finish the head of tile t1 - 1 (its last chunk was multiplied in the previous step)
         int n, y0, x0;
-        tile_coords(p, tile_of((g - 2) / NC), n, y0, x0);
-        const int px = wm * 32 + (lane & 31);
-        const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
-        for (int h = lane >> 5; h < p.hc; h += 2) {
-          const float v = red[(0 * 128 + px) * 4 + h] + red[(1 * 128 + px) * 4 + h] + red[(2 * 128 + px) * 4 + h] +
-                          red[(3 * 128 + px) * 4 + h] + (h < 2 ? hb_lo : hb_hi);
-          if (oy < p.H && ox < p.W) p.hout[((size_t)n * p.hc + h) * p.plane + (size_t)oy * p.W + ox] = v;
-        }
+        tile_coords(p, tile_of(t1 - 1), n, y0, x0);
+        const int oy = y0 + (fpx >> 4), ox = x0 + (fpx & 15);
+        float v = fhb;
+#pragma unroll
+        for (int wv = 0; wv < NMW; ++wv) v += red[(wv * 128 + fpx) * 2 + fh];
+        if (oy < p.H && ox < p.W) p.hout[((size_t)n * p.hc + fh) * p.plane + (size_t)oy * p.W + ox] = v;
       }
-      const bool do_mma = g >= 1 && g - 1 < S && !(p.dbg & 2);
-      const bool staged = g + 2 < S && !(p.dbg & 4);
-      // VM issue order: [weights of the next step, issued at the end of the previous step] [stores] [8 DMA loads
-      // of stage(g+2)].  Loads retire in order, so vmcnt(8) == "the weights AND the halo of step g+1 (DMA'd one
+      const bool do_mma = g >= 1 && g - 1 < S;
+      // VM issue order: [weights of this step, issued at the end of the previous step] [stores] [NDMA DMA loads of
+      // stage(g+2)].  Loads retire in order, so vmcnt(NDMA) == "the weights AND the halo of step g+1 (DMA'd one
       // step ago) have landed, only the youngest DMA batch may still be in flight"; stores only make the wait
       // stricter.  The weight loads come from inline asm so that the compiler's own wait-count insertion does
       // not see them (it answers a pending load behind LDS-DMA traffic with vmcnt(0), draining the DMA batch
       // that is meant to stay in flight); the counted wait names the registers as operands, which orders it
       // before their first use.
-      long long tp = t0;
-      probe(0, tp);
-      stage(g + 2, staged);
-      probe(1, tp);
-      long long tw0 = 0;
-      if (p.dbg & 256) tw0 = __builtin_readcyclecounter();
-      if (MT == 4)
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]),
-                     "+v"(a[MT - 2][0]), "+v"(a[MT - 2][1]), "+v"(a[MT - 1][0]), "+v"(a[MT - 1][1]) :: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]) :: "memory");
-      if (p.dbg & 256) twait += __builtin_readcyclecounter() - tw0;
-      probe(2, tp);
+      stage(t2, c2, ring2, g + 2 < S);
+      if (MT == 4) {
+        if (NDMA == 8)
+          asm volatile("s_waitcnt vmcnt(8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]),
+                       "+v"(a[MT - 2][0]), "+v"(a[MT - 2][1]), "+v"(a[MT - 1][0]), "+v"(a[MT - 1][1]) :: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(4)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]),
+                       "+v"(a[MT - 2][0]), "+v"(a[MT - 2][1]), "+v"(a[MT - 1][0]), "+v"(a[MT - 1][1]) :: "memory");
+      } else {
+        if (NDMA == 8)
+          asm volatile("s_waitcnt vmcnt(8)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]) :: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(4)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]) :: "memory");
+      }
       if (do_mma) {
-        const int ch = (g - 1) % NC, buf = (g - 1) & 1;
-        if (ch == 0) {
+        if (c1 == 0) {
 #pragma unroll
           for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const char* bb = bt + buf * SC_BT_BYTES + n16 * 128;
+        const char* bb = bt + ((g - 1) & 1) * SC_BT_BYTES + n16 * 128;
         auto bfrag = [&](int i) {   // i = nt*2 + ks
           return *reinterpret_cast<const f16x8*>(bb + (i >> 1) * 16 * 128 + ((((i & 1) * 4 + g16) ^ (n16 & 7)) << 4));
         };
         f16x8 b0 = bfrag(0), b1 = bfrag(1);
-        if (!(p.dbg & 16))
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
           const int nt = i >> 1;
@@ -304,121 +298,116 @@ __global__ void __launch_bounds__(512, 1) sepconv5_kernel(const SepParams p) {
           if (i + 3 < 16) b1 = bfrag(i + 3);
         }
       }
-      probe(3, tp);
-      if (!(p.dbg & 8)) load_a(g % NC);
-      probe(4, tp);
-           // weights of chunk g, multiplied in step g+1; `a` is dead from here to the next wait
-      if (do_mma) {
-        const int ch = (g - 1) % NC;
-        if (ch == NC - 1 && !(p.dbg & 32)) {
-          int n, y0, x0;
-          tile_coords(p, tile_of((g - 1) / NC), n, y0, x0);
-          const int ox = x0 + n16;
-          if (!HEAD) {
+      load_a(c1 + 1 == NC ? 0 : c1 + 1);   // weights of chunk g % NC, multiplied in step g+1; `a` is dead until the next wait
+      if (do_mma && c1 == NC - 1) {
+        int n, y0, x0;
+        tile_coords(p, tile_of(t1), n, y0, x0);
+        const int ox = x0 + n16;
+        if (!HEAD) {
 #pragma unroll
-            for (int blk = 0; blk < MT / 2; ++blk) {
-              const int cb = wm * 16 * MT + blk * 32 + g16 * 8;
-              float bv[8];
+          for (int blk = 0; blk < MT / 2; ++blk) {
+            const int cb = wm * 16 * MT + blk * 32 + g16 * 8;
+            float bv[8];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) bv[e] = biasl[cb + e];
+            for (int e = 0; e < 8; ++e) bv[e] = biasl[cb + e];
 #pragma unroll
-              for (int nt = 0; nt < 8; ++nt) {
-                f16x8 o;
+            for (int nt = 0; nt < 8; ++nt) {
+              f16x8 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  o[e] = (half_t)sc_act<ACT>(acc[2 * blk][nt][e] + bv[e]);
-                  o[4 + e] = (half_t)sc_act<ACT>(acc[2 * blk + 1][nt][e] + bv[4 + e]);
-                }
-                const int oy = y0 + nt;
-                if (oy < p.H && ox < p.W)
-                  *reinterpret_cast<f16x8*>(p.out + (((size_t)n * p.H + oy) * p.W + ox) * p.out_ld + cb) = o;
+              for (int e = 0; e < 4; ++e) {
+                o[e] = (half_t)sc_act<ACT>(acc[2 * blk][nt][e] + bv[e]);
+                o[4 + e] = (half_t)sc_act<ACT>(acc[2 * blk + 1][nt][e] + bv[4 + e]);
               }
+              const int oy = y0 + nt;
+              if (oy < p.H && ox < p.W)
+                *reinterpret_cast<f16x8*>(p.out + (((size_t)n * p.H + oy) * p.W + ox) * p.out_ld + cb) = o;
             }
-          } else {
+          }
+        } else {
+#pragma unroll
+          for (int blk = 0; blk < MT / 2; ++blk) {
+            const int cb = wm * 16 * MT + blk * 32 + g16 * 8;
+            float bv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = biasl[cb + e];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                acc[2 * blk][nt][e] = sc_act<ACT>(acc[2 * blk][nt][e] + bv[e]);
+                acc[2 * blk + 1][nt][e] = sc_act<ACT>(acc[2 * blk + 1][nt][e] + bv[4 + e]);
+              }
+          }
+#pragma unroll 1
+          for (int h = 0; h < p.hc; ++h) {
+            float sum[8];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) sum[nt] = 0.f;
 #pragma unroll
             for (int blk = 0; blk < MT / 2; ++blk) {
-              const int cb = wm * 16 * MT + blk * 32 + g16 * 8;
-              float bv[8];
+              const float* hp = hwl + h * COUT + wm * 16 * MT + blk * 32 + g16 * 8;
+              float hv[8];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) bv[e] = biasl[cb + e];
+              for (int e = 0; e < 8; ++e) hv[e] = hp[e];
 #pragma unroll
               for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  acc[2 * blk][nt][e] = sc_act<ACT>(acc[2 * blk][nt][e] + bv[e]);
-                  acc[2 * blk + 1][nt][e] = sc_act<ACT>(acc[2 * blk + 1][nt][e] + bv[4 + e]);
+                  sum[nt] = fmaf(acc[2 * blk][nt][e], hv[e], sum[nt]);
+                  sum[nt] = fmaf(acc[2 * blk + 1][nt][e], hv[4 + e], sum[nt]);
                 }
             }
-#pragma unroll 1
-            for (int h = 0; h < p.hc; ++h) {
-              float sum[8];
 #pragma unroll
-              for (int nt = 0; nt < 8; ++nt) sum[nt] = 0.f;
-#pragma unroll
-              for (int blk = 0; blk < MT / 2; ++blk) {
-                const float* hp = hwl + h * Cout + wm * 16 * MT + blk * 32 + g16 * 8;
-                float hv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) hv[e] = hp[e];
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) {
-                    sum[nt] = fmaf(acc[2 * blk][nt][e], hv[e], sum[nt]);
-                    sum[nt] = fmaf(acc[2 * blk + 1][nt][e], hv[4 + e], sum[nt]);
-                  }
-              }
-#pragma unroll
-              for (int nt = 0; nt < 8; ++nt) {
-                float v = sum[nt];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                if (g16 == 0) red[(wm * 128 + nt * 16 + n16) * 4 + h] = v;
-              }
+            for (int nt = 0; nt < 8; ++nt) {
+              float v = sum[nt];
+              v += __shfl_xor(v, 16);
+              v += __shfl_xor(v, 32);
+              if (g16 == 0) red[(wm * 128 + nt * 16 + n16) * 2 + h] = v;
             }
           }
         }
       }
-      probe(5, tp);
-      if (p.dbg & 256) busy += __builtin_readcyclecounter() - t0;
+      // advance the step counters
+      if (++c1 == NC) { c1 = 0; }
+      if (c1 == 0) ++t1;
+      if (++c2 == NC) { c2 = 0; ++t2; }
+      ring2 = ring2 == 2 ? 0 : ring2 + 1;
       lds_barrier();
-      if (p.dbg & 256) t0 = __builtin_readcyclecounter();
     }
-    if ((p.dbg & 256) && lane == 0) { p.hout[blockIdx.x * 8 + wave] = (float)busy; p.hout[gridDim.x * 8 + blockIdx.x * 8 + wave] = (float)twait;
-      for (int i = 0; i < 6; ++i) p.hout[(2 + i) * gridDim.x * 8 + blockIdx.x * 8 + wave] = (float)tsec[i]; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the last (dummy) DMA batch
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the last (dummy) DMA batch and weight loads
   }
 }
 
-template <int MT, bool HEAD, int ACT>
+template <int NMW, int MT, bool HEAD, int ACT>
 int launch_act(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv5_kernel<MT, HEAD, ACT>),
+    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv5_kernel<NMW, MT, HEAD, ACT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((sepconv5_kernel<MT, HEAD, ACT>), dim3(grid), dim3(512), lds_bytes, s, p);
+  hipLaunchKernelGGL((sepconv5_kernel<NMW, MT, HEAD, ACT>), dim3(grid), dim3(64 * (4 + NMW)), lds_bytes, s, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
 
-template <int MT, bool HEAD>
+template <int NMW, int MT, bool HEAD>
 int launch_one(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
-  if (p.act == 1) return launch_act<MT, HEAD, 1>(p, lds_bytes, grid, s);
-  if (p.act == 2) return launch_act<MT, HEAD, 2>(p, lds_bytes, grid, s);
-  return launch_act<MT, HEAD, 0>(p, lds_bytes, grid, s);
+  if (p.act == 1) return launch_act<NMW, MT, HEAD, 1>(p, lds_bytes, grid, s);
+  if (p.act == 2) return launch_act<NMW, MT, HEAD, 2>(p, lds_bytes, grid, s);
+  return launch_act<NMW, MT, HEAD, 0>(p, lds_bytes, grid, s);
 }
 
 }  // namespace
 
 static size_t sepconv5_lds_bytes(int C, int Cout, int head_c) {
+  const int nmw = Cout == 256 ? 8 : 4;
   return 3 * SC_HALO_BYTES + 2 * SC_BT_BYTES + (size_t)C * 25 * 4 + (size_t)Cout * 4 +
-         (head_c ? (size_t)4 * Cout * 4 + SC_RED_BYTES : 0);
+         (head_c ? (size_t)2 * Cout * 4 + (size_t)nmw * 128 * 2 * 4 : 0);
 }
 
 bool sepconv5_supported(int C, int Cout, int head_c) {
-  return C % 64 == 0 && C >= 128 && (Cout == 128 || Cout == 256) && head_c >= 0 && head_c <= 4 &&
+  return C % 64 == 0 && C >= 128 && (Cout == 128 || Cout == 256) && head_c >= 0 && head_c <= 2 &&
          sepconv5_lds_bytes(C, Cout, head_c) <= 160 * 1024;   // C <= 320 (features) / C <= 192 (heads)
 }
 
@@ -439,7 +428,6 @@ int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, con
   const int64_t tiles = (int64_t)N * p.tiles_x * p.tiles_y;
   EMP_REQUIRE(tiles < (1ll << 30), "sepconv5: too many tiles");
   p.tiles = (int)tiles;
-  { const char* e = getenv("EMP_SEPCONV_DBG"); p.dbg = e ? atoi(e) : 0; }
   p.hw = head_w; p.hb = head_b; p.hc = head_c; p.hout = hout; p.plane = plane;
   static int n_cu = 0;
   if (!n_cu) {
@@ -450,8 +438,8 @@ int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, con
   }
   const int grid = n_cu;
   const size_t lds_bytes = sepconv5_lds_bytes(C, Cout, head_c);
-  if (Cout == 256) return head_c ? launch_one<4, true>(p, lds_bytes, grid, s) : launch_one<4, false>(p, lds_bytes, grid, s);
-  return head_c ? launch_one<2, true>(p, lds_bytes, grid, s) : launch_one<2, false>(p, lds_bytes, grid, s);
+  if (Cout == 256) return head_c ? launch_one<8, 2, true>(p, lds_bytes, grid, s) : launch_one<8, 2, false>(p, lds_bytes, grid, s);
+  return head_c ? launch_one<4, 2, true>(p, lds_bytes, grid, s) : launch_one<4, 2, false>(p, lds_bytes, grid, s);
 }
 
 }  // namespace emp

@@ -127,7 +127,7 @@ def test_dwconv_matches_fp32_reference():
     assert torch.all(err <= 1e-3 + 1e-3 * ref.abs()), err.max()
 
 
-@pytest.mark.parametrize('hc', [1, 2, 4])
+@pytest.mark.parametrize('hc', [1, 2])
 @pytest.mark.parametrize('case', [CASES[4], CASES[2], CASES[0], CASES[5]])   # heads: C <= 256 (LDS budget)
 def test_fused_head(case, hc):
     x, dw, pw, b = _operands(case, seed=3)
