@@ -61,10 +61,14 @@ struct ConvParams {
   int M;           // N*Ho*Wo
   int mt, nt;      // tiles along pixels / couts
   int mt_per_xcd;  // ceil(mt/8)
+  int kgroup;      // channel slabs (64 ch) per K-walk group, set by launch_conv_igemm
 };
 
 // variant: 0 = auto, 1 = register-staged, 2 = LDS-DMA staged
 int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream);
+// 256x256 tile for the MFMA-bound layers (conv_igemm256.hip)
+bool conv_igemm256_supported(const ConvParams& p);
+int launch_conv_igemm256(ConvParams p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------
 // element-wise / stencil kernels (layers.hip)

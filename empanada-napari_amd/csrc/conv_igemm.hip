@@ -3,7 +3,9 @@
 //
 // GEMM view:  out[m][co] = sum_{tap,ci} in[pix(m)+tap][ci] * w[co][tap][ci]
 //   m  = (n, oy, ox) flattened output pixel, M = N*Ho*Wo
-//   K  = KH*KW*Cin, walked tap-major in slabs of BK = 64 input channels
+//   K  = KH*KW*Cin in slabs of BK = 64 input channels; walked group-major: for each group of `kgroup`
+//        channel slabs all KH*KW taps, so that the rows a tap re-reads are still in the XCD's L2
+//        [measured on ASPP 3x3 d4, 2048 ch: tap-major fetched 13.5x the input (7.4 GB, 6 TB/s = HBM-bound)]
 // One workgroup = 256 threads = 4 waves owns a BM x BN (pixels x couts) tile.
 // Both operands are K-contiguous in memory (NHWC pixels, [Cout][tap][Cin]
 // weights), so every LDS row is one 128-byte K-slab and a fragment is one
@@ -126,15 +128,17 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
     }
   }
   const half_t* b_cur[B_ITERS];
+  const half_t* b_base[B_ITERS];
   int b_inc[B_ITERS];
 #pragma unroll
   for (int i = 0; i < B_ITERS; ++i) {
     const int row = 8 * (w + 4 * i) + srow;                  // LDS row in the B tile
     const int co = n0 + (row & ~31) + perm32(row & 31);      // cout staged into that row
     const bool ok = co < p.Cout;
-    b_cur[i] = ok ? p.wgt + (size_t)co * KT * p.Cin + schunk * 8 : p.zero;
+    b_base[i] = b_cur[i] = ok ? p.wgt + (size_t)co * KT * p.Cin + schunk * 8 : p.zero;
     b_inc[i] = ok ? BK : 0;
   }
+  const int KG = p.kgroup;          // channel slabs per group (divides CB); KG == CB: plain tap-major walk
 
   // ---- epilogue operands that do not depend on the accumulators: fetch them now ----
   constexpr int CPR = TN / 8;       // 8-cout output chunks per staged row
@@ -152,19 +156,25 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
   }
 
   f16x8 ra[A_ITERS], rb[B_ITERS];
-  int st_ky = 0, st_kx = 0, st_cb = 0;  // tap / channel block of the step being staged
+  int st_ky = 0, st_kx = 0, st_cb = 0, st_grp = 0;  // tap / slab within the group / group of the step being staged
 
   auto stage_issue = [&](int buf) {
     char* a_s = lds + buf * (A_BYTES + B_BYTES);
     char* b_s = a_s + A_BYTES;
-    if (!pointwise && st_cb == 0) {  // uniform: new tap -> re-derive the row sources once
+    if (!pointwise && st_cb == 0) {  // uniform: new tap (or group) -> re-derive the row sources once
       const int dy = st_ky * p.dil, dx = st_kx * p.dil;
+      const int c0 = st_grp * KG * BK;
 #pragma unroll
       for (int i = 0; i < A_ITERS; ++i) {
         const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
         const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        a_cur[i] = ok ? a_img[i] + ((size_t)iy * p.W + ix) * p.in_ld : p.zero;
+        a_cur[i] = ok ? a_img[i] + ((size_t)iy * p.W + ix) * p.in_ld + c0 : p.zero;
         a_inc[i] = ok ? BK : 0;
+      }
+      if (KG != CB) {
+        const int koff = (st_ky * p.KW + st_kx) * p.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) b_cur[i] = b_base[i] + (b_inc[i] ? koff : 0);
       }
     }
 #pragma unroll
@@ -189,9 +199,12 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
       }
       b_cur[i] += b_inc[i];
     }
-    if (++st_cb == CB) {
+    if (++st_cb == KG) {
       st_cb = 0;
-      if (++st_kx == p.KW) { st_kx = 0; ++st_ky; }
+      if (++st_kx == p.KW) {
+        st_kx = 0;
+        if (++st_ky == p.KH) { st_ky = 0; ++st_grp; }
+      }
     }
   };
   auto stage_commit = [&](int buf) {
@@ -388,26 +401,47 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   EMP_REQUIRE((int64_t)p.N * p.Ho * p.Wo < (1ll << 31), "conv: too many output pixels");
   // variant = staging + 16 * tile
   //   staging: 0 auto | 1 register staging | 2 LDS-DMA | 3 LDS-DMA + LDS-transposed epilogue
-  //   tile   : 0 auto | 1 128x128 | 2 128x64 | 3 64x64
+  //   tile   : 0 auto | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x256 (conv_igemm256.hip; Cout % 256 == 0)
   // (tried and removed, slower on MI355X: a persistent cross-tile pipeline, and a 256x128 8-wave tile with
   //  three LDS stages + counted vmcnt / raw barriers: 865 vs 990 TF/s on the ASPP shape -- DESIGN.md section 4)
-  int v = variant & 15, tile = variant >> 4;
-  EMP_REQUIRE(v <= 3 && tile <= 3, "conv: bad variant %d", variant);
-  if (tile == 0) tile = (p.Cout <= 64) ? 2 : 1;
+  int v = variant & 15, tile = (variant >> 4) & 15, kg = variant >> 8;
+  EMP_REQUIRE(v <= 3 && tile <= 4, "conv: bad variant %d", variant);
+  if (tile == 4) return launch_conv_igemm256(p, stream);
+  // K walk (variant bits 8+: 0 auto | g = channel slabs per group): with many input channels and several taps a
+  // tap-major walk streams the whole input once per tap through an L2 that holds only ~4 MB per XCD; groups of
+  // 4 slabs (256 channels x ~4096 pixels in flight per XCD = 2 MB) keep the 9 taps' re-reads in L2.
+  ConvParams q = p;
+  {
+    const int CB = p.Cin / 64, KT = p.KH * p.KW;
+    static const int env_kg = [] { const char* e = getenv("EMP_CONV_KGROUP"); return e ? atoi(e) : 0; }();   // A/B runs
+    if (kg == 0) kg = env_kg;
+    if (kg == 0) kg = (KT > 1 && CB > 4 && CB % 4 == 0) ? 4 : CB;
+    if (kg > CB || CB % kg != 0 || KT == 1) kg = CB;
+    q.kgroup = kg;
+  }
+  if (tile == 0) {
+    // 256x256 tile (conv_igemm256.hip) when it fills the chip: one workgroup per CU, so it needs >= ~1 tile per CU
+    static const bool no256 = [] { const char* e = getenv("EMP_CONV_NO256"); return e && e[0] == '1'; }();   // A/B runs
+    const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * (p.Cout / 256);
+    static const int min_k = [] { const char* e = getenv("EMP_CONV_256_MINK"); return e ? atoi(e) : 512; }();
+    if (!no256 && conv_igemm256_supported(p) && tiles256 >= 192 && p.KH * p.KW * p.Cin >= min_k)
+      return launch_conv_igemm256(p, stream);
+    tile = (p.Cout <= 64) ? 2 : 1;
+  }
   if (v == 0) v = 3;
   if (tile == 1) {
-    if (v == 1) return launch_tpl<128, 128, 2, 2, false, false>(p, stream);
-    if (v == 2) return launch_tpl<128, 128, 2, 2, true, false>(p, stream);
-    return launch_tpl<128, 128, 2, 2, true, true>(p, stream);
+    if (v == 1) return launch_tpl<128, 128, 2, 2, false, false>(q, stream);
+    if (v == 2) return launch_tpl<128, 128, 2, 2, true, false>(q, stream);
+    return launch_tpl<128, 128, 2, 2, true, true>(q, stream);
   }
   if (tile == 2) {
-    if (v == 1) return launch_tpl<128, 64, 2, 2, false, false, 3>(p, stream);
-    if (v == 2) return launch_tpl<128, 64, 2, 2, true, false, 3>(p, stream);
-    return launch_tpl<128, 64, 2, 2, true, true, 3>(p, stream);
+    if (v == 1) return launch_tpl<128, 64, 2, 2, false, false, 3>(q, stream);
+    if (v == 2) return launch_tpl<128, 64, 2, 2, true, false, 3>(q, stream);
+    return launch_tpl<128, 64, 2, 2, true, true, 3>(q, stream);
   }
-  if (v == 1) return launch_tpl<64, 64, 2, 2, false, false, 5>(p, stream);
-  if (v == 2) return launch_tpl<64, 64, 2, 2, true, false, 5>(p, stream);
-  return launch_tpl<64, 64, 2, 2, true, true, 5>(p, stream);
+  if (v == 1) return launch_tpl<64, 64, 2, 2, false, false, 5>(q, stream);
+  if (v == 2) return launch_tpl<64, 64, 2, 2, true, false, 5>(q, stream);
+  return launch_tpl<64, 64, 2, 2, true, true, 5>(q, stream);
 }
 
 }  // namespace emp

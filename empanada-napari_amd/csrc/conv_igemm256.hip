@@ -1,0 +1,268 @@
+// 256 x 256 implicit-GEMM convolution tile for the MFMA-bound layers (K = KH*KW*Cin >= 512, Cout % 256 == 0):
+// NHWC fp16, MFMA 16x16x32 f16, fp32 accumulate, same operands / epilogue semantics as conv_igemm.hip.
+//
+// Why a second tile: with 128 x 128 x 64 tiles every byte of both operands crosses the CU's vector-memory
+// path (64 B/clk) once per 64 FLOP/B x ... = exactly the MFMA peak, i.e. LDS-DMA issue, LDS and the matrix pipe
+// all saturate together and the kernel sits at ~40 % of peak (profiles/r01_layer_roofline.csv).  A 256 x 256
+// tile halves the operand bytes (and LDS-DMA instructions) per MFMA.
+//
+// Structure (one workgroup = 8 waves = 2 groups of 4, one workgroup per CU, 128 KiB LDS):
+//   * K is walked in slabs of 32 channels ("K-tile": 256 pixel rows + 256 cout rows of 64 B = 32 KiB) through
+//     a ring of FOUR LDS slots filled by LDS-DMA three K-tiles ahead; a wave waits for its own DMA pieces with a
+//     counted vmcnt(8) (two younger K-tiles stay in flight) and the barriers fence LDS only.
+//   * wave (g, c): pixels g*128..+127 x couts c*64..+63, accumulators 4 x 8 MFMA tiles = 128 VGPRs.
+//   * the two groups run half a K-tile apart: between two barriers one group issues its 12 fragment reads
+//     and 4 DMA pieces while the other (its SIMD partner) runs its 32 MFMAs, then they swap.
+//     slot 2t  : group 0 LOAD(t) + STAGE(t+3)   | group 1 COMPUTE(t-1)
+//     slot 2t+1: group 0 COMPUTE(t)             | group 1 LOAD(t) + STAGE(t+3)
+//   Hazards: K-tile t is read in slots 2t / 2t+1; its pieces were waited for (vmcnt) by their issuers in LOAD(t-1),
+//   i.e. before the barrier that opens slot 2t.  STAGE(t+3) overwrites the ring slot of K-tile t-1, last read
+//   (lgkmcnt(0) before the closing barrier) in slot 2t-1.
+//   * LDS rows are 64 B; 16-byte chunk c of row r is stored at chunk c ^ ((-(r >> 2)) & 3): conflict-free for the
+//     ds_read_b128 lane groups of gfx950; the swizzle is applied to the DMA source address (lane-linear dest).
+#include "common.h"
+
+namespace emp {
+
+namespace {
+
+constexpr int KS = 32;                    // channels per K-tile
+constexpr int SLOT_BYTES = 512 * 64;      // 256 pixel rows + 256 cout rows
+constexpr int W_OFF = 256 * 64;           // cout rows start
+constexpr int NSLOT = 4;
+
+__device__ __forceinline__ int perm32b(int x) {
+  const int t = x >> 4, i = x & 15;
+  return ((i >> 2) << 3) + (t << 2) + (i & 3);
+}
+__device__ __forceinline__ float act_fn(float x, int act) {
+  if (act == 1) return fmaxf(x, 0.f);
+  if (act == 2) return x / (1.f + __expf(-x));
+  return x;
+}
+__device__ __forceinline__ void lds_barrier() {
+  // Raw barrier that orders LDS traffic only.  A fence (or __syncthreads) would also drain vmcnt: an in-flight
+  // LDS-DMA is a pending LDS write on the VM counter.  The "memory" clobber keeps the compiler from moving
+  // memory accesses across it; DMA completion is handled by the counted vmcnt waits of the issuing waves.
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, j = bid >> 3;
+  const int mtile = xcd * p.mt_per_xcd + j / p.nt;
+  const int ntile = j % p.nt;
+  if (mtile >= p.mt) return;
+  const int m0 = mtile * 256, n0 = ntile * 256;
+
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+  const int grp = wave >> 2, wc = wave & 3;
+  const int HoWo = p.Ho * p.Wo;
+  const int KT = p.KH * p.KW;
+  const int CB = p.Cin / KS;              // 32-channel slabs per tap
+  const int KG = p.kgroup;                // slabs per K-walk group (divides CB)
+  const int KTOT = KT * CB;
+  const bool pointwise = (KT == 1) && p.stride == 1 && p.pad == 0;
+
+  // ---- staging: wave w moves pixel pieces {w, w+8} and cout pieces {w, w+8} (16 rows x 64 B each) ----
+  const int srow = l >> 2;                                   // row within the piece
+  const int schunk = (l & 3) ^ ((-(l >> 4)) & 3);            // logical 16-B chunk this lane fetches
+  const half_t* a_img[2];
+  int a_iy0[2], a_ix0[2];
+  const half_t* a_cur[2];
+  int a_inc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + (wave + 8 * i) * 16 + srow;
+    a_img[i] = p.in;
+    a_iy0[i] = a_ix0[i] = -(1 << 28);
+    a_cur[i] = p.zero;
+    a_inc[i] = 0;
+    if (m < p.M) {
+      if (pointwise) {
+        a_cur[i] = p.in + (size_t)m * p.in_ld + schunk * 8;
+        a_inc[i] = KS;
+      } else {
+        const int n = m / HoWo;
+        const int r = m - n * HoWo;
+        const int oy = r / p.Wo;
+        const int ox = r - oy * p.Wo;
+        a_iy0[i] = oy * p.stride - p.pad;
+        a_ix0[i] = ox * p.stride - p.pad;
+        a_img[i] = p.in + (size_t)n * p.H * p.W * p.in_ld + schunk * 8;
+      }
+    }
+  }
+  const half_t* b_base[2];
+  const half_t* b_cur[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wave + 8 * i) * 16 + srow;
+    const int co = n0 + (row & ~31) + perm32b(row & 31);
+    b_base[i] = b_cur[i] = p.wgt + (size_t)co * KT * p.Cin + schunk * 8;
+  }
+  int st_ky = 0, st_kx = 0, st_cb = 0, st_grp = 0, st_u = 0;
+  auto stage = [&]() {       // issues exactly 4 DMA pieces for K-tile st_u into ring slot st_u & 3
+    char* base = lds + (st_u & (NSLOT - 1)) * SLOT_BYTES;
+    const bool valid = st_u < KTOT;
+    if (valid && st_cb == 0) {
+      const int c0 = st_grp * KG * KS;
+      if (!pointwise) {
+        const int dy = st_ky * p.dil, dx = st_kx * p.dil;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+          const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          a_cur[i] = ok ? a_img[i] + ((size_t)iy * p.W + ix) * p.in_ld + c0 : p.zero;
+          a_inc[i] = ok ? KS : 0;
+        }
+      }
+      if (KG != CB) {
+        const int koff = (st_ky * p.KW + st_kx) * p.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b_cur[i] = b_base[i] + koff;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const half_t* src = valid ? a_cur[i] : p.zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + (wave + 8 * i) * 1024), 16, 0, 0);
+      a_cur[i] += a_inc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const half_t* src = valid ? b_cur[i] : p.zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + W_OFF + (wave + 8 * i) * 1024),
+                                       16, 0, 0);
+      b_cur[i] += KS;
+    }
+    ++st_u;
+    if (++st_cb == KG) {
+      st_cb = 0;
+      if (++st_kx == p.KW) {
+        st_kx = 0;
+        if (++st_ky == p.KH) { st_ky = 0; ++st_grp; }
+      }
+    }
+  };
+
+  // ---- fragment addressing (lane-constant) ----
+  const int fr = l & 15, fq = l >> 4;
+  const int foff = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
+  const int p_off = grp * 128 * 64 + foff;            // + pt*1024
+  const int w_off = W_OFF + wc * 64 * 64 + foff;      // + ct*1024
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: three K-tiles in flight, the first one landed ----
+  stage();
+  stage();
+  stage();
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  lds_barrier();
+  if (grp == 1) lds_barrier();      // group 1 runs one slot behind group 0
+
+  f16x8 pf[8], wf[4];
+  for (int t = 0; t < KTOT; ++t) {
+    // ---- LOAD slot: fragments of K-tile t, DMA of K-tile t+3 ----
+    const char* base = lds + (t & (NSLOT - 1)) * SLOT_BYTES;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wf[c] = *reinterpret_cast<const f16x8*>(base + w_off + c * 1024);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pf[q] = *reinterpret_cast<const f16x8*>(base + p_off + q * 1024);
+    stage();
+    // my pieces of K-tile t+1 have landed (only the 8 pieces of t+2, t+3 may be in flight); my reads are done
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    // ---- COMPUTE slot ----
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[q], acc[c][q], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+  }
+  if (grp == 0) lds_barrier();      // equal barrier count for both groups
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy DMA tail
+
+  // ---- epilogue: lane (fq, fr) owns couts pair*32 + fq*8 + [0,8) of pixel fr of each pixel tile ----
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int m = m0 + grp * 128 + q * 16 + fr;
+    if (m >= p.M) continue;
+    const int n_img = (p.bias_n != nullptr) ? m / HoWo : 0;
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      const int co = n0 + wc * 64 + P * 32 + fq * 8;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[2 * P][q][r];
+        v[4 + r] = acc[2 * P + 1][q][r];
+      }
+      if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (p.bias_n) {
+        const float* bn = p.bias_n + (size_t)n_img * p.Cout + co;
+        const float4 b0 = *reinterpret_cast<const float4*>(bn);
+        const float4 b1 = *reinterpret_cast<const float4*>(bn + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (p.res) {
+        const f16x8 rv = *reinterpret_cast<const f16x8*>(p.res + (size_t)m * p.res_ld + co);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+      }
+      f16x8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = (half_t)act_fn(v[r], p.act);
+      *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + co) = o;
+    }
+  }
+}
+
+}  // namespace
+
+bool conv_igemm256_supported(const ConvParams& p) {
+  return p.Cout % 256 == 0 && p.ps_cout == 0 && p.Cin % KS == 0;
+}
+
+int launch_conv_igemm256(ConvParams p, hipStream_t stream) {
+  EMP_REQUIRE(conv_igemm256_supported(p), "conv256: unsupported shape (Cout=%d)", p.Cout);
+  {
+    const int CB = p.Cin / KS, KT = p.KH * p.KW;
+    int kg = (KT > 1 && CB > 8 && CB % 8 == 0) ? 8 : CB;      // 256-channel groups, see conv_igemm.hip
+    p.kgroup = kg;
+  }
+  p.mt = cdiv(p.M, 256);
+  p.nt = p.Cout / 256;
+  p.mt_per_xcd = cdiv(p.mt, 8);
+  const int grid = 8 * p.mt_per_xcd * p.nt;
+  static bool attr_set = false;
+  if (!attr_set) {
+    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm256_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_igemm256_kernel, dim3(grid), dim3(512), NSLOT * SLOT_BYTES, stream, p);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+}  // namespace emp

@@ -48,11 +48,14 @@ __global__ void __launch_bounds__(256) stem7x7_kernel(const T* __restrict__ img,
 
   const int cg = tid & 3;    // 16-channel group
   const int pl = tid >> 2;   // 0..63
-  float acc[4][16];
+  // fp32 accumulate on channel pairs (v_pk_fma_f32: two FMAs per lane and instruction; the kernel is bound by
+  // VALU issue: 49 taps x 64 channels per output pixel)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc2[4][8];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[k][c] = 0.f;
+    for (int c = 0; c < 8; ++c) acc2[k][c] = f32x2{0.f, 0.f};
   int py[4], px[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -62,21 +65,28 @@ __global__ void __launch_bounds__(256) stem7x7_kernel(const T* __restrict__ img,
   }
   for (int ky = 0; ky < 7; ++ky) {
     for (int kx = 0; kx < 7; ++kx) {
-      float wv[16];
+      f32x2 wv[8];
       const float4* wp = reinterpret_cast<const float4*>(&wl[ky * 7 + kx][cg * 16]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 t = wp[q];
-        wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
+        wv[2 * q] = f32x2{t.x, t.y};
+        wv[2 * q + 1] = f32x2{t.z, t.w};
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        float x = patch[py[k] * 2 + ky][px[k] * 2 + kx];
+        const float x = patch[py[k] * 2 + ky][px[k] * 2 + kx];
+        const f32x2 xx = f32x2{x, x};
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[k][c] = fmaf(x, wv[c], acc[k][c]);
+        for (int c = 0; c < 8; ++c) acc2[k][c] = __builtin_elementwise_fma(xx, wv[c], acc2[k][c]);
       }
     }
   }
+  float acc[4][16];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { acc[k][2 * c] = acc2[k][c][0]; acc[k][2 * c + 1] = acc2[k][c][1]; }
   float bv[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) bv[c] = bias[cg * 16 + c];

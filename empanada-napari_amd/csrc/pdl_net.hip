@@ -56,6 +56,7 @@ struct emp_pdl {
   std::vector<std::string> param_names;
   std::map<std::string, HostParam> params;
   bool finalized = false;
+  FILE* layer_log = [] { const char* e = getenv("EMP_LAYER_LOG"); return e ? fopen(e, "w") : (FILE*)nullptr; }();
   // fused separable convs (sepconv.hip); EMP_FUSE_SEPCONV=0 keeps the dwconv + 1x1 conv + head1x1 launches (A/B runs)
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
 
@@ -78,6 +79,7 @@ struct emp_pdl {
   ~emp_pdl() {
     for (void* p : owned) (void)hipFree(p);
     if (arena) (void)hipFree(arena);
+    if (layer_log) fclose(layer_log);
   }
 };
 
@@ -444,6 +446,9 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
   p.ps_cout = ps_cout;
   p.M = p.N * p.Ho * p.Wo;
   n->flops += 2.0 * (double)p.M * dc.cout * (double)(dc.cin * dc.kh * dc.kw);
+  if (n->layer_log)   // EMP_LAYER_LOG=<file>: one line per MFMA launch, in launch order (tools/layer_roofline.py)
+    fprintf(n->layer_log, "conv,%s,%d,%d,%d,%d,%d,%d,%d,%d\n", wname.c_str(), p.M, dc.cin_pad, dc.cout, dc.kh, stride, dil,
+            res ? 1 : 0, in.N * in.H * in.W);
   return launch_conv_igemm(p, 0, s);
 }
 
@@ -621,6 +626,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
           RC(launch_sepconv5(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), pwc.w, pwc.cin_pad, pwc.b,
                              pwc.cout, 1, so.p, so.ld, nullptr, nullptr, 0, nullptr, 0, rawp<half_t>(n, "zero"), s));
           n->flops += 2.0 * (double)N * cb.H * cb.W * pwc.cout * (double)pwc.cin;
+          if (n->layer_log) fprintf(n->layer_log, "sepconv,%s,%d,%d,%d,5,1,1,0,%d\n", fz.c_str(), N * cb.H * cb.W, cb.ld, pwc.cout, N * cb.H * cb.W);
         } else {
           RC(launch_dwconv(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), 5, A(q + ".dw").p, cb.ld,
                            rawp<half_t>(n, "zero"), s));
@@ -659,6 +665,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
                          pwc.b, pwc.cout, 1, nullptr, 0, n->f32w.at(p + ".head.1.w"), n->f32w.at(p + ".head.1.b"), hc[k],
                          dst, (int64_t)hq * wq, rawp<half_t>(n, "zero"), s));
       n->flops += 2.0 * (double)N * hq * wq * pwc.cout * (double)pwc.cin;
+      if (n->layer_log) fprintf(n->layer_log, "sephead,%s,%d,%d,%d,5,1,1,0,%d\n", p.c_str(), N * hq * wq, n->dec_ch, pwc.cout, N * hq * wq);
     } else {
       RC(launch_dwconv(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f16w.at(p + ".head.0.0.sepconv.0"), 5, A(p + ".dw").p,
                        n->dec_ch, rawp<half_t>(n, "zero"), s));
@@ -899,8 +906,10 @@ int emp_pdl_forward(emp_pdl_t* net, const void* d_image, int image_dtype, float 
     return EMP_ERR_STATE;
   }
   if (N != net->pN || H != net->pH || W != net->pW || render_steps != net->pRS) RC(plan(net, N, H, W, render_steps));
-  return run(net, d_image, image_dtype, sub, mul, N, H, W, H, W, render_steps, interpolate_ins, d_sem_logits, d_ctr_hmp,
+  const int rc = run(net, d_image, image_dtype, sub, mul, N, H, W, H, W, render_steps, interpolate_ins, d_sem_logits, d_ctr_hmp,
              d_offsets, (hipStream_t)stream);
+  if (net->layer_log) { fprintf(net->layer_log, "end\n"); fflush(net->layer_log); }
+  return rc;
 }
 
 double emp_pdl_flops(const emp_pdl_t* net, int, int, int, int) { return net ? net->flops : 0.0; }

@@ -77,9 +77,10 @@ __device__ __forceinline__ void tile_coords(const SepParams& p, int tile, int& n
 
 // workgroup barrier that orders LDS traffic only: global loads / LDS-DMA stay in flight across it
 __device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  // Raw barrier that orders LDS traffic only.  A fence (or __syncthreads) would also drain vmcnt: an in-flight
+  // LDS-DMA is a pending LDS write on the VM counter.  The "memory" clobber keeps the compiler from moving
+  // memory accesses across it; DMA completion is handled by the counted vmcnt waits of the issuing waves.
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // NMW = number of mma waves (4 or 8), MT = 16-cout MFMA row tiles per mma wave: Cout = NMW * 16 * MT.

@@ -26,7 +26,8 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 16 + 3, 32 + 1, 32 + 2, 32 + 3, 48 + 1, 48 + 2, 48 + 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 16 + 3, 32 + 1, 32 + 2, 32 + 3, 48 + 1, 48 + 2, 48 + 3,
+                                     (1 << 8) + 3, (2 << 8) + 19, (4 << 8) + 35])   # bits 8+: K-walk group size
 @pytest.mark.parametrize('case', CASES)
 def test_conv_matches_fp32_reference(case, variant):
     from gpu_common import conv_hip, conv_ref, dev
@@ -66,3 +67,45 @@ def test_conv_rejects_bad_arguments():
     rc = lib.emp_conv2d_nhwc_f16(_abi.ptr(x), 1, 4, 4, 48, 48, _abi.ptr(x), None, None, None, 0, _abi.ptr(x), 8, 8,
                                  1, 1, 1, 0, 1, 0, 0, None)
     assert rc == -1 and b'multiple of 64' in lib.emp_last_error()
+
+
+CASES_256 = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, relu, res, bias_n   (Cout % 256 == 0: the 256x256 tile, variant 64)
+    (1, 16, 24, 64, 256, 1, 1, 0, 1, True, True, False),        # 2 K-tiles only (shorter than the DMA ring)
+    (1, 16, 16, 256, 512, 1, 2, 0, 1, False, False, False),     # strided 1x1, two cout tiles
+    (1, 12, 12, 512, 256, 3, 1, 6, 6, True, False, False),      # ASPP rate 6, group-major K walk (16 slabs)
+    (2, 8, 8, 2048, 256, 3, 1, 2, 2, True, False, False),       # K = 18432
+    (2, 8, 8, 1024, 256, 1, 1, 0, 1, True, False, True),        # per-image bias
+    (1, 1, 300, 288, 256, 1, 1, 0, 1, True, False, False),      # M tail (300 = 256 + 44), Cin padded to 320
+    (3, 24, 24, 128, 256, 3, 1, 1, 1, False, True, False),      # 7 pixel tiles, residual, no relu
+    (1, 40, 40, 512, 1024, 1, 1, 0, 1, True, True, False),      # 4 cout tiles
+]
+
+
+@pytest.mark.parametrize('case', CASES_256)
+def test_conv256_matches_fp32_reference(case):
+    from gpu_common import conv_hip, conv_ref, dev
+    N, H, W, Cin, Cout, k, stride, pad, dil, relu, use_res, use_bn = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = (torch.randn((N, H, W, Cin), generator=g)).to(torch.float16).to(dev())
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (1.0 / np.sqrt(Cin * k * k))
+    b = torch.randn((Cout,), generator=g) * 0.1
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = torch.randn((N, Ho, Wo, Cout), generator=g).to(torch.float16).to(dev()) if use_res else None
+    bn = torch.randn((N, Cout), generator=g) * 0.2 if use_bn else None
+    ref = conv_ref(x, w, b, bn, res, stride, pad, dil, relu)
+    for rep in range(3):      # the pipeline spans barriers with DMA in flight: repeat to catch timing-dependent races
+        y = conv_hip(x, w, b, bn, res, stride, pad, dil, relu, 64).float().cpu()
+        err = (y - ref).abs()
+        tol = 2e-3 + 2e-3 * ref.abs()
+        assert torch.all(err <= tol), f'rep {rep}: max err {err.max():.4e} at ref {ref.flatten()[err.argmax()]:.4f}'
+
+
+def test_conv256_rejects_other_cout():
+    from gpu_common import conv_hip, dev
+    from empanada_napari_amd._abi import EmpError
+    x = torch.zeros((1, 8, 8, 64), dtype=torch.float16, device=dev())
+    w = torch.zeros((64, 64, 1, 1))
+    with pytest.raises(EmpError):
+        conv_hip(x, w, None, None, None, 1, 0, 1, True, 64)
