@@ -71,7 +71,7 @@ def test_conv_rejects_bad_arguments():
 
 CASES_256 = [
     # N, H, W, Cin, Cout, k, stride, pad, dil, relu, res, bias_n   (Cout % 256 == 0: the 256x256 tile, variant 64)
-    (1, 16, 24, 64, 256, 1, 1, 0, 1, True, True, False),        # 2 K-tiles only (shorter than the DMA ring)
+    (1, 16, 24, 128, 256, 1, 1, 0, 1, True, True, False),       # 4 K-tiles: the shortest K the ring accepts
     (1, 16, 16, 256, 512, 1, 2, 0, 1, False, False, False),     # strided 1x1, two cout tiles
     (1, 12, 12, 512, 256, 3, 1, 6, 6, True, False, False),      # ASPP rate 6, group-major K walk (16 slabs)
     (2, 8, 8, 2048, 256, 3, 1, 2, 2, True, False, False),       # K = 18432

@@ -42,7 +42,10 @@ def main():
     lib = _abi.load()
     dev = torch.device('cuda:0')
     rows = []
+    flt = sys.argv[2] if len(sys.argv) > 2 else ''
     for name, H, W, Cin, Cout, k_, s, p, d in SHAPES:
+        if flt not in name:
+            continue
         x = (torch.randn((B, H, W, Cin), device=dev) * 1.0).to(torch.float16)
         w = (torch.randn((Cout, k_ * k_, Cin), device=dev) / np.sqrt(Cin * k_ * k_)).to(torch.float16)
         b = torch.randn((Cout,), device=dev)

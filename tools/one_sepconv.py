@@ -24,10 +24,3 @@ for _ in range(3):
                                            _abi.ptr(hb) if hc else None, hc, _abi.ptr(ho), st), 'fused')
 torch.cuda.synchronize()
 
-if int(os.environ.get('EMP_SEPCONV_DBG', '0')) & 256:
-    t = ho.flatten()[:8 * 256 * 8].cpu().numpy().reshape(8, 256, 8)
-    steps = (B * (H // 8) * (W // 16) // 256) * (Cc // 64)
-    print('steps per WG', steps)
-    print('dw  busy cycles/step', t[0, :, :4].mean() / steps, ' mma busy cycles/step', t[0, :, 4:].mean() / steps,
-          ' mma vmcnt-wait cycles/step', t[1, :, 4:].mean() / steps)
-    print('mma sections [pre, stage, wait, mfma, load_a, epilogue] cycles/step', [round(float(t[2 + i, :, 4:].mean() / steps)) for i in range(6)])
