@@ -46,7 +46,8 @@ PROTOTYPES = {
     'emp_conv2d_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'emp_dwconv_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, vp, c_int, vp]),
-    'emp_sepconv5x5_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, c_int, vp, c_int, c_int, vp,
+    'emp_sepconv5x5_pack_pw': (c_int, [vp, c_int, c_int, c_int, vp, vp]),
+    'emp_sepconv5x5_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_int, c_int, vp,
                                         c_int, vp, vp, c_int, vp, vp]),
     'emp_logits_to_prob': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'emp_median_slices': (c_int, [C.POINTER(vp), c_int, vp, sz, vp]),

@@ -90,8 +90,13 @@ int emp_dwconv_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld,
                        (hipStream_t)stream);
 }
 
+int emp_sepconv5x5_pack_pw(const void* d_pw_w, int pw_ld, int C, int Cout, void* d_packed, void* stream) {
+  EMP_REQUIRE(d_pw_w && d_packed, "sepconv5x5 pack: null pointer");
+  return launch_sepconv5_pack_pw((const half_t*)d_pw_w, pw_ld, C, Cout, (half_t*)d_packed, (hipStream_t)stream);
+}
+
 int emp_sepconv5x5_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld, const void* d_dw_w,
-                            const void* d_pw_w, int pw_ld, const float* d_bias, int Cout, int act, void* d_out,
+                            const void* d_pw_w, const float* d_bias, int Cout, int act, void* d_out,
                             int out_ld, const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
                             void* stream) {
   EMP_REQUIRE(d_in && d_dw_w && d_pw_w, "sepconv5x5: null pointer");
@@ -99,7 +104,7 @@ int emp_sepconv5x5_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in
   EMP_REQUIRE(head_c == 0 || (d_head_w && d_head_out), "sepconv5x5: head pointers missing");
   const half_t* zero = (const half_t*)zero_page();
   EMP_REQUIRE(zero != nullptr, "sepconv5x5: could not allocate the zero page");
-  return launch_sepconv5((const half_t*)d_in, N, H, W, C, in_ld, (const half_t*)d_dw_w, (const half_t*)d_pw_w, pw_ld,
+  return launch_sepconv5((const half_t*)d_in, N, H, W, C, in_ld, (const half_t*)d_dw_w, (const half_t*)d_pw_w,
                          d_bias, Cout, act, head_c ? nullptr : (half_t*)d_out, out_ld, d_head_w, d_head_b, head_c,
                          d_head_out, (int64_t)H * W, zero, (hipStream_t)stream);
 }

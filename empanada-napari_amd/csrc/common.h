@@ -96,8 +96,9 @@ int launch_gemv(const float* in, int N, int K, const float* w, const float* b, i
 // if scatter_idx != null: pix index of row r is scatter_idx[n*P + r] into a plane of plane_size.
 // fused depthwise 5x5 + pointwise (+ optional 1x1 head), sepconv.hip
 bool sepconv5_supported(int C, int Cout, int head_c);
-int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* dww, const half_t* pww,
-                    int pw_ld, const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
+int launch_sepconv5_pack_pw(const half_t* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s);
+int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* dww, const half_t* pww_packed,
+                    const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
                     const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s);
 int launch_head1x1(const half_t* in, int N, int P, int K, int in_ld, const float* w, const float* b, int C,
                    float* out, int64_t plane_size, const int32_t* scatter_idx, hipStream_t s);

@@ -193,6 +193,20 @@ int pack_conv(emp_pdl* n, const std::string& name, int cin_pad_to = 0) {
   return EMP_OK;
 }
 
+// fragment-ordered copy of a pointwise weight for the fused separable conv (sepconv.hip), when its shape qualifies
+int pack_sepconv_pw(emp_pdl* n, const std::string& name) {
+  const DevConv& dc = n->convs.at(name);
+  if (dc.kh != 1 || dc.kw != 1 || !sepconv5_supported(dc.cin_pad, dc.cout, 0)) return EMP_OK;
+  void* d = nullptr;
+  EMP_CHECK_HIP(hipMalloc(&d, (size_t)dc.cin_pad * dc.cout * sizeof(half_t)));
+  n->owned.push_back(d);
+  int rc = launch_sepconv5_pack_pw(dc.w, dc.cin_pad, dc.cin_pad, dc.cout, (half_t*)d, nullptr);
+  if (rc) return rc;
+  EMP_CHECK_HIP(hipStreamSynchronize(nullptr));
+  n->f16w[name + ".packed"] = (half_t*)d;
+  return EMP_OK;
+}
+
 int upload_f32(emp_pdl* n, const std::string& key, const std::vector<float>& v) {
   void* d;
   int rc = dev_upload(n, v.data(), v.size() * sizeof(float), &d);
@@ -621,9 +635,10 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       {
         const DevConv& pwc = n->convs.at(fz + "1");
         const Act& so = A(q + ".out");
-        if (n->fuse_sepconv && pwc.cin_pad == cb.ld && so.ld == pwc.cout && sepconv5_supported(cb.ld, pwc.cout, 0)) {
+        if (n->fuse_sepconv && n->f16w.count(fz + "1.packed") && pwc.cin_pad == cb.ld && so.ld == pwc.cout &&
+            sepconv5_supported(cb.ld, pwc.cout, 0)) {
           // depthwise 5x5 -> pointwise -> bias -> ReLU in one launch (sepconv.hip); the depthwise map stays in LDS
-          RC(launch_sepconv5(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), pwc.w, pwc.cin_pad, pwc.b,
+          RC(launch_sepconv5(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), n->f16w.at(fz + "1.packed"), pwc.b,
                              pwc.cout, 1, so.p, so.ld, nullptr, nullptr, 0, nullptr, 0, rawp<half_t>(n, "zero"), s));
           n->flops += 2.0 * (double)N * cb.H * cb.W * pwc.cout * (double)pwc.cin;
           if (n->layer_log) fprintf(n->layer_log, "sepconv,%s,%d,%d,%d,5,1,1,0,%d\n", fz.c_str(), N * cb.H * cb.W, cb.ld, pwc.cout, N * cb.H * cb.W);
@@ -657,12 +672,13 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
     if (k == 2 && !interp) dst = o_off;
     head_out[k] = dst;
     const DevConv& pwc = n->convs.at(p + ".head.0.0.sepconv.1");
-    if (n->fuse_sepconv && xin.C == n->dec_ch && pwc.cin_pad == n->dec_ch && pwc.cout == n->dec_ch && hc[k] <= 2 &&
+    if (n->fuse_sepconv && n->f16w.count(p + ".head.0.0.sepconv.1.packed") && xin.C == n->dec_ch &&
+        pwc.cin_pad == n->dec_ch && pwc.cout == n->dec_ch && hc[k] <= 2 &&
         sepconv5_supported(n->dec_ch, pwc.cout, hc[k])) {
       // head.0 (depthwise 5x5 -> pointwise -> ReLU) and head.1 (1x1 -> hc planes) in one launch: neither the
       // depthwise nor the dec_ch-channel map reaches HBM (sepconv.hip)
-      RC(launch_sepconv5(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f16w.at(p + ".head.0.0.sepconv.0"), pwc.w, pwc.cin_pad,
-                         pwc.b, pwc.cout, 1, nullptr, 0, n->f32w.at(p + ".head.1.w"), n->f32w.at(p + ".head.1.b"), hc[k],
+      RC(launch_sepconv5(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f16w.at(p + ".head.0.0.sepconv.0"),
+                         n->f16w.at(p + ".head.0.0.sepconv.1.packed"), pwc.b, pwc.cout, 1, nullptr, 0, n->f32w.at(p + ".head.1.w"), n->f32w.at(p + ".head.1.b"), hc[k],
                          dst, (int64_t)hq * wq, rawp<half_t>(n, "zero"), s));
       n->flops += 2.0 * (double)N * hq * wq * pwc.cout * (double)pwc.cin;
       if (n->layer_log) fprintf(n->layer_log, "sephead,%s,%d,%d,%d,5,1,1,0,%d\n", p.c_str(), N * hq * wq, n->dec_ch, pwc.cout, N * hq * wq);
@@ -864,6 +880,7 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       EMP_REQUIRE(n->convs[p + ".project." + std::to_string(i) + ".0"].cout == lp, "%s.project.%d: Cout != %d", p.c_str(), i, lp);
       RC(pack_dw(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.0", cpad));
       RC(pack_conv(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1", cpad));
+      RC(pack_sepconv_pw(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1"));
       xch = n->dec_ch;
     }
   }
@@ -873,6 +890,7 @@ int emp_pdl_finalize(emp_pdl_t* n) {
     std::string p = heads[k];
     RC(pack_dw(n, p + ".head.0.0.sepconv.0", n->dec_ch));
     RC(pack_conv(n, p + ".head.0.0.sepconv.1"));
+    RC(pack_sepconv_pw(n, p + ".head.0.0.sepconv.1"));
     RC(upload_f32(n, p + ".head.1.w", n->params[p + ".head.1"].w));
     RC(upload_f32(n, p + ".head.1.b", n->params[p + ".head.1"].b));
   }

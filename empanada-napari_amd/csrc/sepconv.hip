@@ -44,8 +44,7 @@ struct SepParams {
   const half_t* in;
   int N, H, W, C, in_ld;
   const half_t* dww;     // [25][C] fp16
-  const half_t* pww;     // [Cout][pw_ld] fp16
-  int pw_ld;
+  const half_t* pww;     // pointwise weights in MFMA-fragment order (sepconv5_pack_pw)
   const float* bias;     // [Cout]
   half_t* out;           // (N,H,W,out_ld) or nullptr (head mode)
   int out_ld, act;
@@ -83,10 +82,12 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// NMW = number of mma waves (4 or 8), MT = 16-cout MFMA row tiles per mma wave: Cout = NMW * 16 * MT.
-template <int NMW, int MT, bool HEAD, int ACT>
-__global__ void __launch_bounds__(64 * (4 + NMW), 1) sepconv5_kernel(const SepParams p) {
-  constexpr int NT = 64 * (4 + NMW);        // threads
+// NDW = number of depthwise waves (4 or 8: one or two per SIMD), NMW = number of mma waves (4 or 8),
+// MT = 16-cout MFMA row tiles per mma wave: Cout = NMW * 16 * MT.
+template <int NDW, int NMW, int MT, bool HEAD, int ACT>
+__global__ void __launch_bounds__(64 * (NDW + NMW), 1) sepconv5_kernel(const SepParams p) {
+  constexpr int NT = 64 * (NDW + NMW);      // threads
+  constexpr int R = 16 / NDW;               // output rows per depthwise thread (4 or 2)
   constexpr int COUT = NMW * 16 * MT;
   constexpr int NDMA = 32 / NMW;            // LDS-DMA instructions per mma wave and step (8 or 4)
   extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -117,11 +118,11 @@ __global__ void __launch_bounds__(64 * (4 + NMW), 1) sepconv5_kernel(const SepPa
     for (int i = tid; i < p.hc * COUT; i += NT) hwl[i] = p.hw[i];
   }
 
-  if (wave < 4) {
+  if (wave < NDW) {
     // ------------------------------------------------------------------ dw role
-    // thread = channel pair cp x columns 4cg..4cg+3 x rows 4rg..4rg+3 of the 8x16 tile
+    // thread = channel pair cp x columns 4cg..4cg+3 x rows R*rg..R*rg+R-1 of the 8x16 tile
     const int cp = lane & 31, combo = wave * 2 + (lane >> 5), cg = combo & 3, rg = combo >> 2;
-    const int hoff = ((4 * rg) * SC_IW + 4 * cg) * 128 + cp * 4;
+    const int hoff = ((R * rg) * SC_IW + 4 * cg) * 128 + cp * 4;
     const int sw = (cp >> 2), sub = (cp & 3) * 4;
     __syncthreads();
     f32x2 w[25];            // taps of the chunk of the coming step: read before the barrier, off the critical path
@@ -132,20 +133,20 @@ __global__ void __launch_bounds__(64 * (4 + NMW), 1) sepconv5_kernel(const SepPa
       chn = chn + 1 == NC ? 0 : chn + 1;
       if (g < S) {
         const char* hb = halo + ring * SC_HALO_BYTES + hoff;
-        f32x2 acc[4][4];
+        f32x2 acc[R][4];
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+        for (int y = 0; y < R; ++y)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[y][j] = f32x2{0.f, 0.f};
         f16x2 nxt[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) nxt[c] = *reinterpret_cast<const f16x2*>(hb + c * 128);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < R + 4; ++r) {
           f32x2 x[8];
 #pragma unroll
           for (int c = 0; c < 8; ++c) x[c] = f32x2{(float)nxt[c][0], (float)nxt[c][1]};
-          if (r + 1 < 8) {
+          if (r + 1 < R + 4) {
 #pragma unroll
             for (int c = 0; c < 8; ++c)
               nxt[c] = *reinterpret_cast<const f16x2*>(hb + ((r + 1) * SC_IW + c) * 128);
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(64 * (4 + NMW), 1) sepconv5_kernel(const SepPa
 #pragma unroll
           for (int ky = 0; ky < 5; ++ky) {
             const int y = r - ky;
-            if (y < 0 || y >= 4) continue;
+            if (y < 0 || y >= R) continue;
 #pragma unroll
             for (int kx = 0; kx < 5; ++kx)
 #pragma unroll
@@ -163,10 +164,10 @@ __global__ void __launch_bounds__(64 * (4 + NMW), 1) sepconv5_kernel(const SepPa
         }
         char* bb = bt + (g & 1) * SC_BT_BYTES;
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+        for (int y = 0; y < R; ++y)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int px = (4 * rg + y) * SC_TW + 4 * cg + j;
+            const int px = (R * rg + y) * SC_TW + 4 * cg + j;
             f16x2 h;
             h[0] = (half_t)acc[y][j][0];
             h[1] = (half_t)acc[y][j][1];
@@ -181,15 +182,13 @@ __global__ void __launch_bounds__(64 * (4 + NMW), 1) sepconv5_kernel(const SepPa
     }
   } else {
     // ------------------------------------------------------------------ mma role
-    const int wm = wave - 4, g16 = lane >> 4, n16 = lane & 15;
+    const int wm = wave - NDW, g16 = lane >> 4, n16 = lane & 15;
     __builtin_amdgcn_s_setprio(3);      // few instructions, long latencies: issue ahead of the VALU-bound dw wave
-    const half_t* aptr[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-      const int i = n16, tp = t & 1;
-      const int co = wm * 16 * MT + (t >> 1) * 32 + ((i >> 2) << 3) + (tp << 2) + (i & 3);
-      aptr[t] = p.pww + (size_t)co * p.pw_ld + g16 * 8;
-    }
+    // Pointwise weights, pre-packed in fragment order [chunk][wave][tile][k-half][lane][8]: every load instruction
+    // reads 1 KiB of whole cache lines (fragment-shaped loads of 16 rows x 64 B cost the texture addresser twice
+    // as much, and the addresser is what bounds this role).
+    const half_t* const abase = p.pww + ((size_t)wm * MT * 2 * 64 + lane) * 8;
+    constexpr int A_CHUNK = NMW * MT * 2 * 64 * 8;      // halves per 64-channel chunk
     // Halo DMA: wave wm issues slots i = wm + NMW*k.  Always exactly NDMA instructions per step (the two spare
     // slots repeat slot 29 with the same data; a step without a halo to fetch copies the zero page into the free
     // ring slot), so that every step has the same VM issue sequence and the counted wait is a constant.
@@ -228,8 +227,8 @@ __global__ void __launch_bounds__(64 * (4 + NMW), 1) sepconv5_kernel(const SepPa
     auto load_a = [&](int ch) {
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const half_t* ap = aptr[t] + ch * 64;
-        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
+        const half_t* ap = abase + (size_t)ch * A_CHUNK + t * (2 * 64 * 8);
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:1024"
                      : "=&v"(a[t][0]), "=&v"(a[t][1]) : "v"(ap) : "memory");
       }
     };
@@ -379,24 +378,42 @@ __global__ void __launch_bounds__(64 * (4 + NMW), 1) sepconv5_kernel(const SepPa
   }
 }
 
-template <int NMW, int MT, bool HEAD, int ACT>
+// (Cout, pw_ld) row-major -> fragment order of the kernel above; NMW / MT as chosen by launch_sepconv5 for this Cout
+__global__ void __launch_bounds__(256) sepconv5_pack_pw_kernel(const half_t* __restrict__ w, int pw_ld, int C, int Cout,
+                                                               int NMW, int MT, half_t* __restrict__ out) {
+  const int total = C * Cout / 8;      // 16-byte fragments
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int r = i;
+    const int lane = r & 63; r >>= 6;
+    const int ks = r & 1; r >>= 1;
+    const int t = r % MT; r /= MT;
+    const int wm = r % NMW;
+    const int ch = r / NMW;
+    const int n16 = lane & 15, g16 = lane >> 4, tp = t & 1;
+    const int co = wm * 16 * MT + (t >> 1) * 32 + ((n16 >> 2) << 3) + (tp << 2) + (n16 & 3);
+    const f16x8 v = *reinterpret_cast<const f16x8*>(w + (size_t)co * pw_ld + ch * 64 + ks * 32 + g16 * 8);
+    *reinterpret_cast<f16x8*>(out + (size_t)i * 8) = v;
+  }
+}
+
+template <int NDW, int NMW, int MT, bool HEAD, int ACT>
 int launch_act(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv5_kernel<NMW, MT, HEAD, ACT>),
+    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv5_kernel<NDW, NMW, MT, HEAD, ACT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((sepconv5_kernel<NMW, MT, HEAD, ACT>), dim3(grid), dim3(64 * (4 + NMW)), lds_bytes, s, p);
+  hipLaunchKernelGGL((sepconv5_kernel<NDW, NMW, MT, HEAD, ACT>), dim3(grid), dim3(64 * (NDW + NMW)), lds_bytes, s, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
 
-template <int NMW, int MT, bool HEAD>
+template <int NDW, int NMW, int MT, bool HEAD>
 int launch_one(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
-  if (p.act == 1) return launch_act<NMW, MT, HEAD, 1>(p, lds_bytes, grid, s);
-  if (p.act == 2) return launch_act<NMW, MT, HEAD, 2>(p, lds_bytes, grid, s);
-  return launch_act<NMW, MT, HEAD, 0>(p, lds_bytes, grid, s);
+  if (p.act == 1) return launch_act<NDW, NMW, MT, HEAD, 1>(p, lds_bytes, grid, s);
+  if (p.act == 2) return launch_act<NDW, NMW, MT, HEAD, 2>(p, lds_bytes, grid, s);
+  return launch_act<NDW, NMW, MT, HEAD, 0>(p, lds_bytes, grid, s);
 }
 
 }  // namespace
@@ -414,16 +431,25 @@ bool sepconv5_supported(int C, int Cout, int head_c) {
 
 // out != nullptr: y = act(pw(dw(x)) + bias) -> (N,H,W,out_ld) fp16.
 // head_c > 0   : hout[n][h] = head_w[h] . y + head_b[h] as fp32 planes of `plane` floats; y is not stored.
+int launch_sepconv5_pack_pw(const half_t* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s) {
+  EMP_REQUIRE(C % 64 == 0 && (Cout == 128 || Cout == 256) && pw_ld % 8 == 0 && pw_ld >= C, "sepconv5 pack: bad shape");
+  const int nmw = Cout == 256 ? 8 : 4, mt = 2;
+  const int total = C * Cout / 8;
+  hipLaunchKernelGGL(sepconv5_pack_pw_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, pw_ld, C, Cout, nmw, mt, packed);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
 int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* dww, const half_t* pww,
-                    int pw_ld, const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
+                    const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
                     const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s) {
   EMP_REQUIRE(sepconv5_supported(C, Cout, head_c), "sepconv5: unsupported shape C=%d Cout=%d head=%d", C, Cout, head_c);
   EMP_REQUIRE(act >= 0 && act <= 2, "sepconv5: bad activation %d", act);
   EMP_REQUIRE((head_c > 0) != (out != nullptr), "sepconv5: exactly one of the feature / head outputs");
-  EMP_REQUIRE(in_ld % 8 == 0 && pw_ld % 8 == 0 && (out == nullptr || out_ld % 8 == 0), "sepconv5: 16-byte row alignment");
+  EMP_REQUIRE(in_ld % 8 == 0 && (out == nullptr || out_ld % 8 == 0), "sepconv5: 16-byte row alignment");
   SepParams p{};
   p.in = in; p.N = N; p.H = H; p.W = W; p.C = C; p.in_ld = in_ld;
-  p.dww = dww; p.pww = pww; p.pw_ld = pw_ld; p.bias = bias;
+  p.dww = dww; p.pww = pww; p.bias = bias;
   p.out = out; p.out_ld = out_ld; p.act = act; p.zero = zero;
   p.tiles_x = cdiv(W, SC_TW); p.tiles_y = cdiv(H, SC_TH);
   const int64_t tiles = (int64_t)N * p.tiles_x * p.tiles_y;
@@ -439,8 +465,10 @@ int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, con
   }
   const int grid = n_cu;
   const size_t lds_bytes = sepconv5_lds_bytes(C, Cout, head_c);
-  if (Cout == 256) return head_c ? launch_one<8, 2, true>(p, lds_bytes, grid, s) : launch_one<8, 2, false>(p, lds_bytes, grid, s);
-  return head_c ? launch_one<4, 2, true>(p, lds_bytes, grid, s) : launch_one<4, 2, false>(p, lds_bytes, grid, s);
+  // (two depthwise waves per SIMD, <8, 8, 2>, measured no faster: the mma role's vector-memory issue bounds the step)
+  if (Cout == 256)
+    return head_c ? launch_one<4, 8, 2, true>(p, lds_bytes, grid, s) : launch_one<4, 8, 2, false>(p, lds_bytes, grid, s);
+  return head_c ? launch_one<4, 4, 2, true>(p, lds_bytes, grid, s) : launch_one<4, 4, 2, false>(p, lds_bytes, grid, s);
 }
 
 }  // namespace emp

@@ -158,12 +158,14 @@ EMP_API int emp_dwconv_nhwc_f16(const void* d_in, int N, int H, int W, int C, in
  * replaces the 'depthwise_separable_conv' blocks of the Panoptic-DeepLab decoder / heads
  * (models/decoders/panoptic_deeplab.py fuse convs, models/heads/panoptic_deeplab.py head.0 -> head.1).
  *   d_in    : (N,H,W,in_ld) fp16, channels [0,C), C % 64 == 0, 128 <= C <= 512
- *   d_dw_w  : (25, C) fp16;  d_pw_w: (Cout, pw_ld) fp16, Cout in {128,256};  d_bias: (Cout) fp32 or NULL
+ *   d_dw_w  : (25, C) fp16;  d_bias: (Cout) fp32 or NULL;  Cout in {128,256}
+ *   d_pw_w  : the (Cout, C) pointwise weights re-ordered by emp_sepconv5x5_pack_pw (MFMA fragment order, C*Cout fp16)
  *   act     : 0 none | 1 ReLU | 2 SiLU
  *   head_c == 0: d_out (N,H,W,out_ld) fp16 receives y
  *   head_c  > 0: d_head_out (N,head_c,H,W) fp32 receives d_head_w (head_c,Cout) . y + d_head_b; d_out unused */
+EMP_API int emp_sepconv5x5_pack_pw(const void* d_pw_w, int pw_ld, int C, int Cout, void* d_packed, void* stream);
 EMP_API int emp_sepconv5x5_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld,
-                        const void* d_dw_w, const void* d_pw_w, int pw_ld, const float* d_bias,
+                        const void* d_dw_w, const void* d_pw_w, const float* d_bias,
                         int Cout, int act, void* d_out, int out_ld,
                         const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
                         void* stream);

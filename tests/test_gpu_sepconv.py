@@ -60,11 +60,13 @@ def _fused(x, dw, pw, b, case, head=None):
     N, H, W, Cc, in_ld, Cout, act = case
     xd = x.to(dev())
     dwd = dw.reshape(Cc, 25).t().contiguous().to(dev())          # (25, C)
-    pwd = pw.contiguous().to(dev())
+    pwu = pw.contiguous().to(dev())
+    pwd = torch.empty_like(pwu)
+    _abi.check(lib.emp_sepconv5x5_pack_pw(_abi.ptr(pwu), Cc, Cc, Cout, _abi.ptr(pwd), _abi.stream_ptr(dev())), 'pack')
     bd = b.float().to(dev())
     if head is None:
         out = torch.full((N, H, W, Cout), 7.0, dtype=torch.float16, device=dev())
-        _abi.check(lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(xd), N, H, W, Cc, in_ld, _abi.ptr(dwd), _abi.ptr(pwd), Cc,
+        _abi.check(lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(xd), N, H, W, Cc, in_ld, _abi.ptr(dwd), _abi.ptr(pwd),
                                                _abi.ptr(bd), Cout, act, _abi.ptr(out), Cout, None, None, 0, None,
                                                _abi.stream_ptr(dev())), 'sepconv')
         torch.cuda.synchronize()
@@ -73,7 +75,7 @@ def _fused(x, dw, pw, b, case, head=None):
     hc = hw.shape[0]
     hout = torch.full((N, hc, H, W), 7.0, dtype=torch.float32, device=dev())
     hwd, hbd = hw.float().contiguous().to(dev()), hb.float().to(dev())
-    _abi.check(lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(xd), N, H, W, Cc, in_ld, _abi.ptr(dwd), _abi.ptr(pwd), Cc,
+    _abi.check(lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(xd), N, H, W, Cc, in_ld, _abi.ptr(dwd), _abi.ptr(pwd),
                                            _abi.ptr(bd), Cout, act, None, 0, _abi.ptr(hwd), _abi.ptr(hbd), hc,
                                            _abi.ptr(hout), _abi.stream_ptr(dev())), 'sepconv head')
     torch.cuda.synchronize()
@@ -150,6 +152,6 @@ def test_unsupported_shape_is_rejected():
     w = torch.zeros((25, 64), dtype=torch.float16, device=dev())
     p = torch.zeros((64, 64), dtype=torch.float16, device=dev())
     o = torch.zeros((1, 8, 16, 64), dtype=torch.float16, device=dev())
-    rc = lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(x), 1, 8, 16, 64, 64, _abi.ptr(w), _abi.ptr(p), 64, None, 64, 1,
+    rc = lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(x), 1, 8, 16, 64, 64, _abi.ptr(w), _abi.ptr(p), None, 64, 1,
                                      _abi.ptr(o), 64, None, None, 0, None, _abi.stream_ptr(dev()))
     assert rc != 0 and b'unsupported' in lib.emp_last_error()

@@ -13,13 +13,15 @@ st = _abi.stream_ptr(dev)
 x = torch.randn((B, H, W, Cc), device=dev).to(torch.float16)
 dw = (torch.randn((25, Cc), device=dev) * 0.2).to(torch.float16)
 pw = (torch.randn((Cout, Cc), device=dev) / np.sqrt(Cc)).to(torch.float16)
+pwp = torch.empty_like(pw)
+_abi.check(lib.emp_sepconv5x5_pack_pw(_abi.ptr(pw), Cc, Cc, Cout, _abi.ptr(pwp), st), 'pack')
 b = torch.randn((Cout,), device=dev)
 out = torch.empty((B, H, W, Cout), device=dev, dtype=torch.float16)
 hw = torch.randn((max(hc, 1), Cout), device=dev)
 hb = torch.randn((max(hc, 1),), device=dev)
 ho = torch.empty((B, max(hc, 1), H, W), device=dev)
 for _ in range(3):
-    _abi.check(lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(x), B, H, W, Cc, Cc, _abi.ptr(dw), _abi.ptr(pw), Cc, _abi.ptr(b), Cout, 1,
+    _abi.check(lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(x), B, H, W, Cc, Cc, _abi.ptr(dw), _abi.ptr(pwp), _abi.ptr(b), Cout, 1,
                                            None if hc else _abi.ptr(out), Cout, _abi.ptr(hw) if hc else None,
                                            _abi.ptr(hb) if hc else None, hc, _abi.ptr(ho), st), 'fused')
 torch.cuda.synchronize()

@@ -40,6 +40,8 @@ def main():
         x = torch.randn((B, H, W, Cc), device=dev).to(torch.float16)
         dw = (torch.randn((25, Cc), device=dev) * 0.2).to(torch.float16)
         pw = (torch.randn((Cout, Cc), device=dev) / np.sqrt(Cc)).to(torch.float16)
+        pwp = torch.empty_like(pw)
+        _abi.check(lib.emp_sepconv5x5_pack_pw(_abi.ptr(pw), Cc, Cc, Cout, _abi.ptr(pwp), st), 'pack')
         b = torch.randn((Cout,), device=dev)
         mid = torch.empty((B, H, W, Cc), device=dev, dtype=torch.float16)
         out = torch.empty((B, H, W, Cout), device=dev, dtype=torch.float16)
@@ -53,7 +55,7 @@ def main():
                                                _abi.ptr(out), Cout, Cout, 1, 1, 1, 0, 1, 1, 0, st), 'pw')
 
         def fused():
-            _abi.check(lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(x), B, H, W, Cc, Cc, _abi.ptr(dw), _abi.ptr(pw), Cc,
+            _abi.check(lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(x), B, H, W, Cc, Cc, _abi.ptr(dw), _abi.ptr(pwp),
                                                    _abi.ptr(b), Cout, 1, None if hc else _abi.ptr(out), Cout,
                                                    _abi.ptr(hw) if hc else None, _abi.ptr(hb) if hc else None, hc,
                                                    _abi.ptr(ho) if hc else None, st), 'fused')
