@@ -158,3 +158,34 @@ def test_bifpn_heads_match_reference_golden(golden_dir, tag, ncls, case):
         else:
             # PointRend cell selection can differ on near-ties; the bulk must agree
             assert np.mean(err > 0.05 * scale) < 2e-2
+
+
+def test_fused_launches_equal_unfused_bit_exact(setup):
+    """The fused separable-conv kernel keeps the summation order of the launches it replaces: a network built with
+    the fusion switched off gives identical feature maps."""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    cfg, P, model = setup
+    x = _norm(synth.em_tiles(2, 128, seed=31)).cuda()
+    fused = {k: v.clone() for k, v in model(x, 2, False).items()}
+    taps_f = {t: model.tap(t).clone() for t in ('encoder.layer1.2', 'encoder.layer2.3', 'semantic_decoder.stage0.out')}
+    old = {k: os.environ.get(k) for k in ('EMP_FUSE_SEPCONV',)}
+    try:
+        os.environ['EMP_FUSE_SEPCONV'] = '0'
+        plain_model = HipPanopticDeepLab(P, cfg, folded=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    plain = plain_model(x, 2, False)
+    for t, v in taps_f.items():
+        assert torch.equal(v, plain_model.tap(t)), t
+    # heads: the fused head keeps the 256-channel map in fp32 (the unfused path rounds it to fp16 first)
+    for k in ('ctr_hmp', 'offsets'):
+        d = (fused[k] - plain[k]).abs().max().item()
+        assert d < (2e-2 if k == 'offsets' else 5e-3), (k, d)      # offsets are in pixels (|values| up to tens)
+    # PointRend refines the most uncertain cells: a cell picked by one side only differs by (refined - interpolated)
+    d = (fused['sem_logits'] - plain['sem_logits']).abs()
+    assert (d > 1e-2).float().mean().item() < 5e-3 and d.median().item() < 1e-3
