@@ -10,7 +10,7 @@ import.  Differences, all behind the same results:
     whole chunk of slices; no worker process, no pickled dense maps;
   * ``model_config['model']`` may be a TorchScript file (the reference's export),
     a state dict, or an already built ``HipPanopticDeepLab``.
-Not built yet (raise ``NotImplementedError``): ``tile_size > 0`` (cztile tiler),
+Not built yet (raise ``NotImplementedError``):
 label erosion / dilation / hole
 filling, zarr stores when zarr is not installed.
 """
@@ -188,12 +188,34 @@ class Engine2d:
 
     def infer(self, image):
         if self.tile_size > 0 and any(s > self.tile_size for s in image.shape):
-            raise NotImplementedError('tiled 2-D inference (cztile Tiler + tile consensus) is a next-tier row')
+            return self._infer_tiled(image)
         _require_scale_one(self.inference_scale)
         size = image.shape
         x = self.preprocessor(resize_by_factor(image, self.inference_scale))['image'].unsqueeze(0)
         pan_seg = self.engine(x, size, upsampling=self.inference_scale)
         return self.force_connected(pan_seg.squeeze(0))
+
+
+    def _infer_tiled(self, image):
+        """inference.py:283-318: per tile engine call -> RLE on the GPU -> image frame -> tile consensus -> dense.
+        The tile rectangles come from ``tile.Tiler`` (cztile stand-in, parity unpinned)."""
+        from .tile import Tiler
+        tiler = Tiler(image.shape, tile_size=self.tile_size, overlap_width=min(128, int(self.tile_size * 0.1)))
+        self.last_tiler = tiler
+        rle_segs = []
+        for i in range(len(tiler)):
+            tile = tiler(image, i)
+            x = self.preprocessor(resize_by_factor(tile, self.inference_scale))['image'].unsqueeze(0)
+            pan = self.engine(x, tile.shape, upsampling=self.inference_scale).squeeze(0).to(torch.int32)
+            seg = sparse.pan_seg_to_rle_seg(pan, self.labels, self.label_divisor, self.engine.thing_list)
+            rle_segs.append(tiler.translate_rle_seg(seg, i))
+        rle_seg = {}
+        for label in self.labels:
+            if label in self.engine.thing_list:
+                rle_seg[label] = sparse.merge_objects_from_tiles([rs[label] for rs in rle_segs], tiler.overlap_rle)
+            else:
+                rle_seg[label] = sparse.merge_semantic_from_tiles([rs[label] for rs in rle_segs])
+        return sparse.rle_seg_to_pan_seg(rle_seg, image.shape)
 
 
 class Engine3d:

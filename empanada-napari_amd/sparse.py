@@ -222,6 +222,18 @@ def vote_by_ranges(list_of_ranges, vote_thr=2):
     return out[:n_out.value].copy()
 
 
+def rle_voting(ranges, vote_thr=2):
+    """array_utils.py:563-625 on ONE array of (possibly overlapping) ranges: sub-ranges covered >= vote_thr times."""
+    ranges = np.ascontiguousarray(np.asarray(ranges, dtype=i64).reshape(-1, 2))
+    if len(ranges) == 0:
+        return np.zeros((0, 2), dtype=i64)
+    out = np.empty((2 * len(ranges), 2), dtype=i64)
+    n_out = C.c_int64(0)
+    _abi.check(_lib().emp_ranges_vote(_hp(ranges), len(ranges), int(vote_thr), _hp(out), C.byref(n_out)),
+               'emp_ranges_vote')
+    return out[:n_out.value].copy()
+
+
 def join_ranges(list_of_ranges):
     return vote_by_ranges(list_of_ranges, 1)
 
@@ -596,6 +608,69 @@ def merge_semantic_from_trackers(semantic_trackers, pixel_vote_thr=2):
         box = merge_boxes(box, b)
     v = vote_by_ranges(ranges, pixel_vote_thr)
     return {1: {'box': box, 'starts': v[:, 0], 'runs': v[:, 1] - v[:, 0]}}
+
+
+# ----------------------------------------------------------------------------
+# tile consensus (consensus.py:471-625)
+# ----------------------------------------------------------------------------
+def merge_semantic_from_tiles(tiles):
+    """Union of a semantic class over tiles (consensus.py:471-521)."""
+    label_id, boxes, ranges = None, [], []
+    for t in tiles:
+        for iid, a in t.items():
+            if label_id is None:
+                label_id = iid
+            boxes.append(tuple(int(v) for v in a['box']))
+            ranges.append(np.stack([a['starts'], a['starts'] + a['runs']], axis=1))
+    if not boxes:
+        return {}
+    box = boxes[0]
+    for b in boxes[1:]:
+        box = merge_boxes(box, b)
+    r = join_ranges(ranges)
+    return {label_id: {'box': box, 'starts': r[:, 0], 'runs': r[:, 1] - r[:, 0]}}
+
+
+def merge_objects_from_tiles(tiles, overlap_rle=None):
+    """Objects seen by several tiles become one (union of runs per connected cluster); with ``overlap_rle`` an
+    object seen by a single tile with more than 10 % of its area in the overlap band is dropped
+    (consensus.py:523-625)."""
+    import networkx as nx
+    src, labels, boxes, objs = [], [], [], []
+    for ti, t in enumerate(tiles):
+        for iid, a in t.items():
+            src.append(ti)
+            labels.append(int(iid))
+            boxes.append(tuple(int(v) for v in a['box']))
+            objs.append((np.asarray(a['starts'], dtype=i64), np.asarray(a['runs'], dtype=i64)))
+    if not boxes:
+        return {}
+    src, barr = np.array(src), np.array(boxes)
+    p = box_overlap_pairs(barr, barr)
+    p = p[src[p[:, 0]] != src[p[:, 1]]]
+    p = np.unique(np.sort(p, axis=1), axis=0)
+    inter = rle_pair_intersections([_sorted_runs(s, r) for s, r in objs], p)
+    G = nx.Graph()
+    G.add_nodes_from(range(len(objs)))
+    for (a, b), it in zip(p, inter):
+        if it > 0:
+            G.add_edge(int(a), int(b))
+    out, iid = {}, int(min(labels))
+    for comp in nx.connected_components(G):
+        cluster = list(comp)
+        box = boxes[cluster[0]]
+        for n in cluster[1:]:
+            box = merge_boxes(box, boxes[n])
+        voted = join_ranges([np.stack([objs[n][0], objs[n][0] + objs[n][1]], axis=1) for n in cluster])
+        if overlap_rle is not None and len(cluster) < 2 and np.any(voted):
+            ioa = rle_ioa(np.asarray(overlap_rle[0], dtype=i64), np.asarray(overlap_rle[1], dtype=i64),
+                          voted[:, 0], voted[:, 1] - voted[:, 0])
+            if ioa > 0.1:
+                voted = np.zeros((0, 2), dtype=i64)
+        if np.any(voted):
+            out[iid] = {'box': box, 'starts': voted[:, 0], 'runs': voted[:, 1] - voted[:, 0]}
+            iid += 1
+    return out
 
 
 def create_instance_consensus(class_trackers, pixel_vote_thr=2, cluster_iou_thr=0.75, bypass=False):

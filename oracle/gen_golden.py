@@ -392,3 +392,91 @@ def gen_sparse():
 
 if __name__ == '__main__' and 'sparse' in (sys.argv[1:] or ['sparse']):
     gen_sparse()
+
+
+def _stub_cztile():
+    """inference/tile.py imports cztile (un-vendored) at module level; only Tiler.__init__ uses it.  The golden
+    vectors below never call __init__: tile rectangles are inputs."""
+    import types
+    if 'cztile' not in sys.modules:
+        cz = types.ModuleType('cztile')
+        a = types.ModuleType('cztile.fixed_total_area_strategy_2d')
+        a.AlmostEqualBorderFixedTotalAreaStrategy2D = object
+        b = types.ModuleType('cztile.tiling_strategy')
+        b.Region2D = object
+        sys.modules['cztile'] = cz
+        sys.modules['cztile.fixed_total_area_strategy_2d'] = a
+        sys.modules['cztile.tiling_strategy'] = b
+
+
+def synth_tile_pan_segs(shape, yranges, xranges, divisor, seed):
+    """A global instance map (class 1) + one semantic region (class 2), cropped per tile with per-tile changes:
+    tile-local instance ids, one object removed from a single tile inside the overlap band, one-pixel erosions."""
+    rng = np.random.default_rng(seed)
+    h, w = shape
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    inst = np.zeros(shape, np.int32)
+    for i in range(1, 15):
+        cy, cx = rng.uniform(4, h - 4), rng.uniform(4, w - 4)
+        ry, rx = rng.uniform(3, 9), rng.uniform(3, 9)
+        inst[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1] = i
+    sem = (((yy - h * 0.5) / (h * 0.3)) ** 2 + ((xx - w * 0.45) / (w * 0.42)) ** 2 <= 1) & (inst == 0)
+    tiles = []
+    for ti, ((y0, y1), (x0, x1)) in enumerate(zip(yranges, xranges)):
+        crop = inst[y0:y1, x0:x1].copy()
+        pan = np.zeros(crop.shape, np.int32)
+        ids = [v for v in np.unique(crop) if v > 0]
+        drop = ids[ti % len(ids)] if ids and ti % 2 == 1 else -1      # seen by the other tiles only
+        for k, v in enumerate(ids):
+            if v == drop:
+                continue
+            m = crop == v
+            if (v + ti) % 3 == 0:                                       # tile-dependent boundary
+                m[:, :-1] &= m[:, 1:]
+            pan[m] = divisor + 1 + k
+        pan[sem[y0:y1, x0:x1] & (pan == 0)] = 2 * divisor
+        tiles.append(pan)
+    return tiles
+
+
+def gen_tiles():
+    _stub_numba_skimage()
+    _stub_cztile()
+    from empanada.consensus import merge_objects_from_tiles, merge_semantic_from_tiles
+    from empanada.inference.tile import Tiler, calculate_overlap_rle
+    from oracle import sparse as osp
+    out = {}
+    divisor = 1000
+    for case, (shape, tile, ov) in enumerate((((72, 100), 48, 8), ((64, 64), (40, 36), 6), ((50, 90), 32, 10))):
+        yr, xr = osp.tile_ranges_2d(shape, tile, ov)
+        tiler = object.__new__(Tiler)
+        tiler.image_shape, tiler.yranges, tiler.xranges = shape, yr, xr
+        ovs, ovr = calculate_overlap_rle(yr, xr, shape)
+        pans = synth_tile_pan_segs(shape, yr, xr, divisor, seed=40 + case)
+        out[f'c{case}_shape'] = np.array(shape, np.int64)
+        out[f'c{case}_yranges'] = np.array(yr, np.int64)
+        out[f'c{case}_xranges'] = np.array(xr, np.int64)
+        out[f'c{case}_overlap'] = np.stack([np.asarray(ovs, np.int64), np.asarray(ovr, np.int64)], axis=1).reshape(-1, 2)
+        segs = []
+        for i, pan in enumerate(pans):
+            out[f'c{case}_pan{i}'] = pan
+            seg = osp.pan_seg_to_rle_seg(pan, [1, 2], divisor, [1], force_connected=True)   # skimage-backed: input only
+            # the reference's _join_ranges reads an unbound variable for a single-range input (SURVEY Q9): keep such
+            # slivers out of the vectors
+            seg[1] = {k: v for k, v in seg[1].items() if len(v['starts']) > 1}
+            seg = tiler.translate_rle_seg(seg, i)
+            for lab in (1, 2):
+                for k, v in flatten_instances(seg[lab]).items():
+                    out[f'c{case}_t{i}_l{lab}_{k}'] = v
+            segs.append(seg)
+        for tag, ovl in (('ov', (ovs, ovr)), ('noov', None)):
+            for k, v in flatten_instances(merge_objects_from_tiles([sg[1] for sg in segs], ovl)).items():
+                out[f'c{case}_obj_{tag}_{k}'] = v
+        for k, v in flatten_instances(merge_semantic_from_tiles([sg[2] for sg in segs])).items():
+            out[f'c{case}_sem_{k}'] = v
+    out['n_cases'] = np.int64(3)
+    save('tiles', **out)
+
+
+if __name__ == '__main__' and 'tiles' in (sys.argv[1:] or ['tiles']):
+    gen_tiles()

@@ -754,3 +754,115 @@ def merge_semantic_from_trackers(trackers, pixel_vote_thr=2):
         box = merge_boxes(box, b)
     v = vote_by_ranges([np.stack([s, s + r], axis=1) for s, r in zip(starts, runs)], pixel_vote_thr)
     return {1: {'box': box, 'starts': v[:, 0], 'runs': v[:, 1] - v[:, 0]}}
+
+
+# ----------------------------------------------------------------------------
+# 2-D tiled inference (inference/tile.py:8-195, consensus.py:471-625)
+# ----------------------------------------------------------------------------
+def tile_ranges_1d(length, tile, overlap):
+    """Stand-in for cztile's AlmostEqualBorderFixedTotalAreaStrategy2D along one axis (cztile >= 2.0.0 is an
+    un-vendored dependency, tile.py:2,88-104): PARITY UNPINNED.  Same contract -- every tile has the full size
+    `tile`, neighbours overlap by at least `overlap`, overlaps almost equal: n = ceil((L - ov) / (T - ov)) tiles
+    whose starts are floor(i * (L - T) / (n - 1))."""
+    tile = min(tile, length)
+    if length <= tile:
+        return [(0, length)]
+    n = -(-(length - overlap) // (tile - overlap))
+    return [((i * (length - tile)) // (n - 1), (i * (length - tile)) // (n - 1) + tile) for i in range(n)]
+
+
+def tile_ranges_2d(shape, tile_size, overlap):
+    """Row-major list of (yrange, xrange) tiles (order unpinned, see tile_ranges_1d)."""
+    th, tw = (tile_size, tile_size) if isinstance(tile_size, int) else tile_size
+    ys, xs = tile_ranges_1d(shape[0], th, overlap), tile_ranges_1d(shape[1], tw, overlap)
+    return [y for y in ys for _ in xs], [x for _ in ys for x in xs]
+
+
+def calculate_overlap_rle(yranges, xranges, image_shape):
+    """tile.py:8-52."""
+    y = np.array(rle_voting(np.unique(np.stack(yranges, axis=0), axis=0), vote_thr=2))
+    x = np.array(rle_voting(np.unique(np.stack(xranges, axis=0), axis=0), vote_thr=2))
+    if len(y) > 0:
+        row_starts = y[:, 0] * image_shape[1]
+        row_runs = y[:, 1] * image_shape[1] - row_starts
+    else:
+        row_starts, row_runs = [], []
+    if len(x) > 0:
+        col = np.concatenate([x + r * image_shape[1] for r in range(image_shape[0])], axis=0)
+        col_starts, col_runs = col[:, 0], col[:, 1] - col[:, 0]
+    else:
+        col_starts, col_runs = [], []
+    if len(row_starts) > 0 or len(col_starts) > 0:
+        return merge_rles(row_starts, row_runs, col_starts, col_runs)
+    return [], []
+
+
+def translate_rle_seg(rle_seg, yrange, xrange, image_shape):
+    """Tiler.translate_rle_seg, tile.py:133-172 (in place)."""
+    ys, xs = yrange[0], xrange[0]
+    w = xrange[1] - xrange[0]
+    for labels in rle_seg.values():
+        for a in labels.values():
+            b = list(a['box'])
+            a['box'] = (b[0] + ys, b[1] + xs, b[2] + ys, b[3] + xs)
+            st = a['starts']
+            a['starts'] = np.ravel_multi_index((st // w + ys, st % w + xs), dims=image_shape)
+    return rle_seg
+
+
+def merge_semantic_from_tiles(tiles):
+    """consensus.py:471-521."""
+    label_id, boxes, starts, runs = None, [], [], []
+    for t in tiles:
+        for iid, a in t.items():
+            if label_id is None:
+                label_id = iid
+            boxes.append(a['box'])
+            starts.append(a['starts'])
+            runs.append(a['runs'])
+    if len(boxes) == 0:
+        return {}
+    box = np.array(boxes)[0]
+    for b in np.array(boxes)[1:]:
+        box = merge_boxes(box, b)
+    r = join_ranges([np.stack([s, s + u], axis=1) for s, u in zip(starts, runs)])
+    return {label_id: {'box': tuple(int(v) for v in box), 'starts': r[:, 0], 'runs': r[:, 1] - r[:, 0]}}
+
+
+def merge_objects_from_tiles(tiles, overlap_rle=None):
+    """consensus.py:523-625."""
+    src, labels, boxes, starts, runs = [], [], [], [], []
+    for ti, t in enumerate(tiles):
+        for iid, a in t.items():
+            src.append(ti)
+            labels.append(int(iid))
+            boxes.append(a['box'])
+            starts.append(a['starts'])
+            runs.append(a['runs'])
+    src, labels, boxes = np.array(src), np.array(labels), np.array(boxes)
+    if len(boxes) == 0:
+        return {}
+    G = _Graph()
+    for n in range(len(labels)):
+        G.add_node(n, box=boxes[n], starts=starts[n], runs=runs[n])
+    for r1, r2 in bounding_box_screening(boxes, src):
+        iou, inter = rle_iou(starts[r1], runs[r1], starts[r2], runs[r2], True)
+        if iou > 0:
+            G.add_edge(int(r1), int(r2), iou=iou, overlap=inter)
+    iid = int(np.min(labels))
+    out = {}
+    for comp in G.components():
+        cluster = list(comp)
+        box = G.node[cluster[0]]['box']
+        for n in cluster[1:]:
+            box = merge_boxes(box, G.node[n]['box'])
+        voted = join_ranges([np.stack([G.node[n]['starts'], G.node[n]['starts'] + G.node[n]['runs']], axis=1)
+                             for n in cluster])
+        if overlap_rle is not None and len(cluster) < 2 and np.any(voted):
+            ioa = rle_ioa(overlap_rle[0], overlap_rle[1], voted[:, 0], voted[:, 1] - voted[:, 0])
+            if ioa > 0.1:
+                voted = []
+        if np.any(voted):
+            out[iid] = {'box': tuple(int(v) for v in box), 'starts': voted[:, 0], 'runs': voted[:, 1] - voted[:, 0]}
+            iid += 1
+    return out
