@@ -302,33 +302,53 @@ __global__ void __launch_bounds__(256) fuse_combine_kernel(const half_t* __restr
 // ---------------------------------------------------------------------------
 // bilinear resize, align_corners=True, NHWC fp16 (decoders/panoptic_deeplab.py:75)
 // ---------------------------------------------------------------------------
+// One block iteration = one output row segment: 256 threads = (256 / CG) pixels x CG 8-channel groups, so the
+// index arithmetic is 32-bit and mostly wave-uniform and every pixel's channels are one contiguous store.
 __global__ void __launch_bounds__(256) bilinear_ac_kernel(const half_t* __restrict__ in, int N, int h, int w, int C,
                                                           int in_ld, half_t* __restrict__ out, int H, int W,
-                                                          int out_ld, float sy, float sx, int64_t total) {
+                                                          int out_ld, float sy, float sx, int segs_per_row, int ppb) {
   const int CG = C >> 3;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    int cg = (int)(i % CG);
-    int64_t p = i / CG;
-    int ox = (int)(p % W); p /= W;
-    int oy = (int)(p % H);
-    int n = (int)(p / H);
-    float fy = sy * (float)oy, fx = sx * (float)ox;
-    int y0 = (int)fy, x0 = (int)fx;
-    int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-    float ly = fy - (float)y0, lx = fx - (float)x0;
-    float hy = 1.f - ly, hx = 1.f - lx;
-    const half_t* base = in + (size_t)n * h * w * in_ld + cg * 8;
-    f16x8 v00 = *reinterpret_cast<const f16x8*>(base + ((size_t)y0 * w + x0) * in_ld);
-    f16x8 v01 = *reinterpret_cast<const f16x8*>(base + ((size_t)y0 * w + x1) * in_ld);
-    f16x8 v10 = *reinterpret_cast<const f16x8*>(base + ((size_t)y1 * w + x0) * in_ld);
-    f16x8 v11 = *reinterpret_cast<const f16x8*>(base + ((size_t)y1 * w + x1) * in_ld);
-    f16x8 o;
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;      // channel group, pixel within the segment
+  const int total = N * H * segs_per_row;
+  constexpr int U = 4;                               // row segments in flight per thread (16 loads before any store)
+  for (int b0 = blockIdx.x * U; b0 < total; b0 += gridDim.x * U) {
+    f16x8 v00[U], v01[U], v10[U], v11[U];
+    float ly[U], lx[U];
+    size_t oidx[U];
+    bool ok[U];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float r = hy * (hx * (float)v00[c] + lx * (float)v01[c]) + ly * (hx * (float)v10[c] + lx * (float)v11[c]);
-      o[c] = (half_t)r;
+    for (int u = 0; u < U; ++u) {
+      const int b = b0 + u;
+      const int seg = b % segs_per_row;
+      const int row = b / segs_per_row;
+      const int oy = row % H, n = row / H;
+      const int ox = seg * ppb + pl;
+      ok[u] = b < total && pl < ppb && ox < W;
+      const float fy = sy * (float)oy, fx = sx * (float)ox;
+      int y0 = (int)fy, x0 = (int)fx;
+      if (!ok[u]) { y0 = 0; x0 = 0; }
+      const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      ly[u] = fy - (float)y0;
+      lx[u] = fx - (float)x0;
+      const half_t* base = in + (size_t)(ok[u] ? n : 0) * h * w * in_ld + cg * 8;
+      v00[u] = *reinterpret_cast<const f16x8*>(base + ((size_t)y0 * w + x0) * in_ld);
+      v01[u] = *reinterpret_cast<const f16x8*>(base + ((size_t)y0 * w + x1) * in_ld);
+      v10[u] = *reinterpret_cast<const f16x8*>(base + ((size_t)y1 * w + x0) * in_ld);
+      v11[u] = *reinterpret_cast<const f16x8*>(base + ((size_t)y1 * w + x1) * in_ld);
+      oidx[u] = (((size_t)n * H + oy) * W + ox) * out_ld + cg * 8;
     }
-    *reinterpret_cast<f16x8*>(out + (((size_t)n * H + oy) * W + ox) * out_ld + cg * 8) = o;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float hy = 1.f - ly[u], hx = 1.f - lx[u];
+      f16x8 o;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float r = hy * (hx * (float)v00[u][c] + lx[u] * (float)v01[u][c]) +
+                  ly[u] * (hx * (float)v10[u][c] + lx[u] * (float)v11[u][c]);
+        o[c] = (half_t)r;
+      }
+      if (ok[u]) *reinterpret_cast<f16x8*>(out + oidx[u]) = o;
+    }
   }
 }
 
@@ -554,9 +574,15 @@ int launch_bilinear_ac(const half_t* in, int N, int h, int w, int C, int in_ld, 
   // area_pixel_compute_scale(align_corners=True): (in-1)/(out-1), 0 when out == 1
   float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
   float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-  int64_t total = (int64_t)N * H * W * (C / 8);
-  hipLaunchKernelGGL(bilinear_ac_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, N, h, w, C, in_ld,
-                     out, H, W, out_ld, sy, sx, total);
+  const int CG = C / 8;
+  EMP_REQUIRE(CG >= 1 && CG <= 256, "bilinear: at most 2048 channels");
+  const int ppb = 256 / CG;                         // pixels per block iteration
+  const int segs = cdiv(W, ppb);
+  const int64_t total = (int64_t)N * H * segs;
+  EMP_REQUIRE(total < (1ll << 31), "bilinear: too many row segments");
+  const int grid = (int)(total < 256 * 16 ? total : 256 * 16);
+  hipLaunchKernelGGL(bilinear_ac_kernel, dim3(grid), dim3(256), 0, s, in, N, h, w, C, in_ld, out, H, W, out_ld, sy, sx, segs,
+                     ppb);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
