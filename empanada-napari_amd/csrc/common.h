@@ -77,6 +77,9 @@ int launch_conv_igemm256(ConvParams p, hipStream_t stream);
 int launch_stem7x7(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
                    const float* w /*49x64*/, const float* b /*64*/, half_t* out, hipStream_t s);
 int launch_maxpool3x3s2(const half_t* in, int N, int H, int W, int C, half_t* out, hipStream_t s);
+// conv1 + bn1 + relu + maxpool on MFMA in one launch (stem.hip): img -> (N,H/4,W/4,64)
+int launch_stem_pool(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
+                     const float* w, const float* b, half_t* out, hipStream_t s);
 // depthwise KxK (K = 3 or 5), stride 1, pad K/2; weights fp16 [K*K][C]
 int launch_dwconv(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* w, int K,
                   half_t* out, int out_ld, const half_t* zero, hipStream_t s);

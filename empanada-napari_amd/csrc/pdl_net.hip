@@ -58,6 +58,7 @@ struct emp_pdl {
   bool finalized = false;
   FILE* layer_log = [] { const char* e = getenv("EMP_LAYER_LOG"); return e ? fopen(e, "w") : (FILE*)nullptr; }();
   // fused separable convs (sepconv.hip); EMP_FUSE_SEPCONV=0 keeps the dwconv + 1x1 conv + head1x1 launches (A/B runs)
+  bool fuse_stem = [] { const char* e = getenv("EMP_FUSE_STEM"); return !(e && e[0] == '0'); }();   // stem.hip
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
 
   // device parameters
@@ -479,9 +480,14 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
   auto A = [&](const std::string& k) -> Act& { return n->acts.at(k); };
 
   // ---- encoder ----
-  RC(launch_stem7x7(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("stem").p, s));
+  if (n->fuse_stem) {
+    // conv1 + bn1 + relu + maxpool in one launch on the matrix pipe; the half-resolution map is never written
+    RC(launch_stem_pool(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("p1").p, s));
+  } else {
+    RC(launch_stem7x7(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("stem").p, s));
+    RC(launch_maxpool3x3s2(A("stem").p, N, H / 2, W / 2, 64, A("p1").p, s));
+  }
   n->flops += 2.0 * N * (H / 2) * (W / 2) * 64.0 * 49.0;
-  RC(launch_maxpool3x3s2(A("stem").p, N, H / 2, W / 2, 64, A("p1").p, s));
   std::string xname = "p1";
   std::string pyr[5];
   pyr[0] = "p1";

@@ -1,0 +1,180 @@
+// Stem on the matrix pipe: 7x7 stride-2 pad-3 conv (1 -> 64 channels) + bias + ReLU + 3x3 stride-2 pad-1 max-pool
+// in one launch (reference: encoders/resnet.py:164-168,219-222: conv1 + bn1 + relu + maxpool, BN folded), with the
+// uint8/uint16 -> normalise -> zero-pad preprocessing fused in like layers.hip's VALU stem.
+//
+// The VALU stem is bound by its 49 x 64 fp32 FMAs per output pixel (0.70 ms per 32 tiles) and writes a 1 GiB
+// half-resolution map that the max-pool (0.32 ms) reads straight back.  Here the conv is a GEMM
+//   D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],   k = ky * 8 + kx  (7 x 7 taps padded to 8 x 8 = 64),
+// and fp32 accuracy is kept by splitting both operands into fp16 hi + lo parts (x = hi + lo, |lo| <= 2^-11 |x|):
+//   W.X ~= Wh.Xh + Wh.Xl + Wl.Xh        (three MFMAs, error ~2^-21 relative: below the fp16 rounding of the output).
+// The X fragment of a lane is 8 consecutive input pixels of one patch row, i.e. four ds_read_b32 from the LDS patch.
+//
+// One workgroup = one 8 x 8 tile of POOLED outputs: the 17 x 17 conv outputs it needs (stored fp16 in LDS, -inf
+// outside the conv map so that the pool's padding never wins) from a 40 x 40 input patch; the conv map itself is
+// never written to HBM.
+#include "common.h"
+
+namespace emp {
+
+namespace {
+
+constexpr int PT = 8;                 // pooled tile side
+constexpr int ST = 2 * PT + 1;        // conv ("stem") tile side: 17
+constexpr int NSP = ST * ST;          // 289 conv pixels
+constexpr int NMT = (NSP + 15) / 16;  // 19 MFMA pixel tiles
+constexpr int IP = 40;                // input patch side (2*16 + 7 = 39 rows/cols used, padded to 40)
+
+template <typename T>
+__global__ void __launch_bounds__(256) stem_pool_kernel(const T* __restrict__ img, float sub, float mul, int N, int H,
+                                                        int W, int vh, int vw, const float* __restrict__ wgt,
+                                                        const float* __restrict__ bias, half_t* __restrict__ out,
+                                                        int normalise) {
+  __shared__ __attribute__((aligned(16))) half_t ph[IP][IP];          // patch, hi part
+  __shared__ __attribute__((aligned(16))) half_t pl[IP][IP];          // patch, lo part
+  __shared__ __attribute__((aligned(16))) half_t st[NMT * 16][64];    // conv tile, fp16 after bias + ReLU
+  const int Hs = H >> 1, Ws = W >> 1;       // conv map
+  const int Hp = Hs >> 1, Wp = Ws >> 1;     // pooled map
+  const int tiles_x = (Wp + PT - 1) / PT, tiles_y = (Hp + PT - 1) / PT;
+  const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+  const int total_tiles = N * tiles_y * tiles_x;
+  // weight fragments (MFMA A operand: row = cout, 8 consecutive k per lane), hi / lo -- once per workgroup, the
+  // workgroups are persistent over tiles
+  const int fr = l & 15, fq = l >> 4;
+  f16x8 wh[4][2], wl[4][2];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ky = fq + 4 * ks;
+#pragma unroll
+      for (int kx = 0; kx < 8; ++kx) {
+        const float w = (ky < 7 && kx < 7) ? wgt[(ky * 7 + kx) * 64 + ct * 16 + fr] : 0.f;
+        const half_t h = (half_t)w;
+        wh[ct][ks][kx] = h;
+        wl[ct][ks][kx] = (half_t)(w - (float)h);
+      }
+    }
+  float bv[4][4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[ct][r] = bias[ct * 16 + fq * 4 + r];
+
+  for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+  int b = tile;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y; b /= tiles_y;
+  const int n = b;
+  const int py0 = ty * PT, px0 = tx * PT;
+  const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;        // conv tile origin (may be -1)
+  const int iy0 = 2 * sy0 - 3, ix0 = 2 * sx0 - 3;        // input patch origin
+  const T* src = img + (size_t)n * vh * vw;
+  for (int i = tid; i < IP * IP; i += 256) {
+    const int r = i / IP, c = i - r * IP;
+    const int iy = iy0 + r, ix = ix0 + c;
+    float v = 0.f;
+    if (iy >= 0 && iy < vh && ix >= 0 && ix < vw) {
+      v = (float)src[(size_t)iy * vw + ix];
+      if (normalise) { v -= sub; v *= mul; }
+    }
+    const half_t h = (half_t)v;
+    ph[r][c] = h;
+    pl[r][c] = (half_t)(v - (float)h);
+  }
+  __syncthreads();
+
+  for (int mt = wave; mt < NMT; mt += 4) {
+    const int q = mt * 16 + fr;                       // this lane's conv pixel (B operand column)
+    const int qq = q < NSP ? q : NSP - 1;
+    const int sy = qq / ST, sx = qq - sy * ST;
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r = 2 * sy + fq + 4 * ks;             // patch row of tap ky = fq + 4 ks  (<= 39)
+      const uint32_t* rh = reinterpret_cast<const uint32_t*>(&ph[r][2 * sx]);
+      const uint32_t* rl = reinterpret_cast<const uint32_t*>(&pl[r][2 * sx]);
+      union { uint32_t u[4]; f16x8 v; } xh, xl;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xh.u[i] = rh[i]; xl.u[i] = rl[i]; }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ct][ks], xh.v, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ct][ks], xl.v, acc[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ct][ks], xh.v, acc[ct], 0, 0, 0);
+      }
+    }
+    // conv pixel outside the conv map -> -inf (max-pool padding); lane owns couts ct*16 + fq*4 + [0,4) of pixel q
+    const int gy = sy0 + sy, gx = sx0 + sx;
+    const bool inside = gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      f16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[ct][r] + bv[ct][r];
+        o[r] = inside ? (half_t)(v > 0.f ? v : 0.f) : (half_t)(-INFINITY);
+      }
+      *reinterpret_cast<f16x4*>(&st[q][ct * 16 + fq * 4]) = o;
+    }
+  }
+  __syncthreads();
+
+  // 3x3 stride-2 max-pool of the 17x17 tile -> 8x8 pooled pixels x 8 channel groups of 8
+  for (int i = tid; i < PT * PT * 8; i += 256) {
+    const int cg = i & 7, pp = i >> 3;
+    const int py = pp / PT, px = pp - py * PT;
+    const int oy = py0 + py, ox = px0 + px;
+    if (oy >= Hp || ox >= Wp) continue;
+    float m[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) m[c] = -INFINITY;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(&st[(2 * py + dy) * ST + 2 * px + dx][cg * 8]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) m[c] = fmaxf(m[c], (float)v[c]);
+      }
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (half_t)m[c];
+    *reinterpret_cast<f16x8*>(out + (((size_t)n * Hp + oy) * Wp + ox) * 64 + cg * 8) = o;
+  }
+  __syncthreads();      // the LDS tiles are reused by the next tile
+  }
+}
+
+}  // namespace
+
+// img (N,vh,vw) -> pooled (N,H/4,W/4,64) fp16; H, W = padded size (multiples of 4), pixels outside vh x vw are zero
+int launch_stem_pool(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
+                     const float* w, const float* b, half_t* out, hipStream_t s) {
+  EMP_REQUIRE(H % 4 == 0 && W % 4 == 0, "stem: H, W must be multiples of 4");
+  const int Hp = H / 4, Wp = W / 4;
+  const int64_t tiles = (int64_t)N * cdiv(Hp, PT) * cdiv(Wp, PT);
+  EMP_REQUIRE(tiles < (1ll << 31), "stem: too many tiles");
+  const int64_t grid = tiles < 256 * 12 ? tiles : 256 * 12;      // persistent: 3 workgroups per CU x 4 rounds of slack
+  switch (dtype) {
+    case EMP_IMG_F32:
+      hipLaunchKernelGGL(stem_pool_kernel<float>, dim3((unsigned)grid), dim3(256), 0, s, (const float*)img, sub, mul, N, H, W,
+                         vh, vw, w, b, out, 0);
+      break;
+    case EMP_IMG_U8:
+      hipLaunchKernelGGL(stem_pool_kernel<uint8_t>, dim3((unsigned)grid), dim3(256), 0, s, (const uint8_t*)img, sub, mul, N,
+                         H, W, vh, vw, w, b, out, 1);
+      break;
+    case EMP_IMG_U16:
+      hipLaunchKernelGGL(stem_pool_kernel<uint16_t>, dim3((unsigned)grid), dim3(256), 0, s, (const uint16_t*)img, sub, mul,
+                         N, H, W, vh, vw, w, b, out, 1);
+      break;
+    default:
+      EMP_REQUIRE(false, "stem: unknown image dtype %d", dtype);
+  }
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+}  // namespace emp
