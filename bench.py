@@ -116,6 +116,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
+    model.profile(True)      # HIP-event pairs around every launch of the dominant kernel (256x256 conv tile)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -132,6 +133,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    dom_ms, dom_flops, dom_launches = model.profile_read()
+    model.profile(False)
     fwd_total_ms = sum(a.elapsed_time(b) for a, b in fwd_ms)
     flops_fwd = model.last_flops() * (B / mb)  # per step (last_flops is per forward call of mb tiles)
     ms_per_step = dt * 1e3 / args.steps
@@ -139,13 +142,18 @@ def main():
 
     if rank == 0:
         fwd_ms_per_step = fwd_total_ms / args.steps
-        traffic = None
-        try:  # HBM bytes per step from the committed PMC passes (only valid for the default workload)
+        traffic = step_traffic = None
+        try:  # HBM bytes from the committed PMC passes (only valid for the default workload)
             if B == 32 and S == 1024 and mb == 32:
-                traffic = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))['hbm_bytes_per_step']
+                tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))
+                step_traffic = tj['hbm_bytes_per_step']
+                k = tj['per_kernel']['conv_igemm256_kernel']
+                traffic = (k['fetch_corrected'] + k['write']) / k['launches_per_step']     # per launch, like `achieved`
         except Exception:
-            traffic = None
-        achieved = flops_fwd / (fwd_ms_per_step * 1e-3) / 1e12
+            traffic = step_traffic = None
+        fwd_tflops = flops_fwd / (fwd_ms_per_step * 1e-3) / 1e12
+        # dominant kernel: conv_igemm256_kernel, every launch of the timed region bracketed by HIP events on its stream
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         res = {
             'metric': 'EM tiles/sec (1024^2 fp16)', 'value': round(value, 2), 'unit': 'tiles/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
@@ -157,9 +165,15 @@ def main():
                        'parallelism': f'tile-sharded x{world}, no collective'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
-                         'traffic_note': 'HBM bytes per step (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 PMC passes, '
-                                         'profiles/r01_hbm_traffic.json)',
-                         'kernel': 'network forward (all kernels; implicit-GEMM conv dominates)',
+                         'traffic_note': 'average HBM bytes per launch of this kernel (2*FETCH_SIZE + WRITE_SIZE, separate '
+                                         'rocprofv3 PMC passes, profiles/r01_hbm_traffic.json)',
+                         'step_traffic_all_kernels': step_traffic,
+                         'kernel': 'conv_igemm256_kernel (256x256 implicit-GEMM tile: ASPP 3x3, layer3/4 convs)',
+                         'launches_per_step': dom_launches / max(args.steps, 1),
+                         'kernel_ms_per_step': round(dom_ms / max(args.steps, 1), 3),
+                         'kernel_share_of_step': round(dom_ms / max(args.steps, 1) / ms_per_step, 3),
+                         'kernel_flops_per_step': dom_flops / max(args.steps, 1),
+                         'forward_tflops': round(fwd_tflops, 2), 'forward_frac': round(fwd_tflops / PEAK_F16_TFLOPS, 4),
                          'flops_per_tile': round(flops_fwd / B / 1e9, 2), 'forward_ms_per_step': round(fwd_ms_per_step, 3)},
             'arena_gib': round(model.arena_bytes() / 2 ** 30, 2),
         }

@@ -39,6 +39,8 @@ PROTOTYPES = {
     'emp_pdl_arena_bytes': (sz, [vp]),
     'emp_pdl_forward': (c_int, [vp, vp, c_int, c_f32, c_f32, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp]),
     'emp_pdl_flops': (c_f64, [vp, c_int, c_int, c_int, c_int]),
+    'emp_pdl_profile': (c_int, [vp, c_int]),
+    'emp_pdl_profile_read': (c_int, [vp, C.POINTER(c_f64), C.POINTER(c_f64), C.POINTER(c_int)]),
     'emp_pdl_tap': (c_int, [vp, cp, C.POINTER(vp), C.POINTER(c_i64)]),
     'emp_pdl_num_taps': (c_int, [vp]),
     'emp_pdl_tap_name': (cp, [vp, c_int]),

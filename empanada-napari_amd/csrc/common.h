@@ -68,6 +68,7 @@ struct ConvParams {
 int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream);
 // 256x256 tile for the MFMA-bound layers (conv_igemm256.hip)
 bool conv_igemm256_supported(const ConvParams& p);
+bool conv_uses_256(const ConvParams& p);      // launch_conv_igemm's auto choice
 int launch_conv_igemm256(ConvParams p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------

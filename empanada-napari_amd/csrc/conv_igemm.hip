@@ -386,6 +386,18 @@ int launch_tpl(ConvParams p, hipStream_t stream) {
 
 }  // namespace
 
+// auto dispatch rule: 256x256 tile (conv_igemm256.hip) when it fills the chip -- one workgroup per CU, so it needs
+// >= ~1 tile per CU -- and K is long enough to amortise its prologue / epilogue.
+bool conv_uses_256(const ConvParams& p) {
+  static const bool no256 = [] { const char* e = getenv("EMP_CONV_NO256"); return e && e[0] == '1'; }();   // A/B runs
+  static const int min_k = [] { const char* e = getenv("EMP_CONV_256_MINK"); return e ? atoi(e) : 512; }();
+  const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * (p.Cout / 256);
+  // one workgroup per CU cannot overlap its epilogue with another tile's main loop: with a residual to read the
+  // epilogue moves 256 KB per tile, as long as a K = 512 main loop (layer4 conv3: 0.57 ms vs 0.51 on 128x128)
+  const int k256 = p.KH * p.KW * p.Cin;
+  return !no256 && conv_igemm256_supported(p) && tiles256 >= 192 && k256 >= (p.res ? 2 * min_k : min_k);
+}
+
 int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   EMP_REQUIRE(p.Cin % BK == 0 && p.Cin > 0, "conv: Cin=%d must be a positive multiple of 64", p.Cin);
   EMP_REQUIRE(p.in_ld % 8 == 0 && p.in_ld >= p.Cin, "conv: in_ld=%d must be >= Cin and a multiple of 8", p.in_ld);
@@ -420,15 +432,7 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
     q.kgroup = kg;
   }
   if (tile == 0) {
-    // 256x256 tile (conv_igemm256.hip) when it fills the chip: one workgroup per CU, so it needs >= ~1 tile per CU
-    static const bool no256 = [] { const char* e = getenv("EMP_CONV_NO256"); return e && e[0] == '1'; }();   // A/B runs
-    const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * (p.Cout / 256);
-    static const int min_k = [] { const char* e = getenv("EMP_CONV_256_MINK"); return e ? atoi(e) : 512; }();
-    // one workgroup per CU cannot overlap its epilogue with another tile's main loop: with a residual to read the
-    // epilogue moves 256 KB per tile, as long as a K = 512 main loop (layer4 conv3: 0.57 ms vs 0.51 on 128x128)
-    const int k256 = p.KH * p.KW * p.Cin;
-    if (!no256 && conv_igemm256_supported(p) && tiles256 >= 192 && k256 >= (p.res ? 2 * min_k : min_k))
-      return launch_conv_igemm256(p, stream);
+    if (conv_uses_256(p)) return launch_conv_igemm256(p, stream);
     tile = (p.Cout <= 64) ? 2 : 1;
   }
   if (v == 0) v = 3;

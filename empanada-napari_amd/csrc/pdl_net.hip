@@ -76,11 +76,18 @@ struct emp_pdl {
   std::vector<std::string> act_order;
   std::map<std::string, std::pair<size_t, size_t>> raw;  // name -> (offset, bytes)
   double flops = 0.0;
+  // live timing of the dominant kernel class (256x256 conv tile): HIP event pairs on the launch stream, summed by
+  // emp_pdl_profile_read (bench.py's roofline block)
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  double prof_flops = 0.0;
 
   ~emp_pdl() {
     for (void* p : owned) (void)hipFree(p);
     if (arena) (void)hipFree(arena);
     if (layer_log) fclose(layer_log);
+    for (auto& e : prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   }
 };
 
@@ -464,6 +471,20 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
   if (n->layer_log)   // EMP_LAYER_LOG=<file>: one line per MFMA launch, in launch order (tools/layer_roofline.py)
     fprintf(n->layer_log, "conv,%s,%d,%d,%d,%d,%d,%d,%d,%d\n", wname.c_str(), p.M, dc.cin_pad, dc.cout, dc.kh, stride, dil,
             res ? 1 : 0, in.N * in.H * in.W);
+  if (n->profile && conv_uses_256(p)) {
+    if (n->prof_used == n->prof_events.size()) {
+      hipEvent_t a, b;
+      EMP_CHECK_HIP(hipEventCreate(&a));
+      EMP_CHECK_HIP(hipEventCreate(&b));
+      n->prof_events.emplace_back(a, b);
+    }
+    auto& ev = n->prof_events[n->prof_used++];
+    EMP_CHECK_HIP(hipEventRecord(ev.first, s));
+    const int rc = launch_conv_igemm(p, 0, s);
+    EMP_CHECK_HIP(hipEventRecord(ev.second, s));
+    n->prof_flops += 2.0 * (double)p.M * dc.cout * (double)(dc.cin * dc.kh * dc.kw);
+    return rc;
+  }
   return launch_conv_igemm(p, 0, s);
 }
 
@@ -937,6 +958,31 @@ int emp_pdl_forward(emp_pdl_t* net, const void* d_image, int image_dtype, float 
 }
 
 double emp_pdl_flops(const emp_pdl_t* net, int, int, int, int) { return net ? net->flops : 0.0; }
+
+int emp_pdl_profile(emp_pdl_t* net, int enable) {
+  EMP_REQUIRE(net != nullptr, "profile: null network");
+  net->profile = enable != 0;
+  net->prof_used = 0;
+  net->prof_flops = 0.0;
+  return EMP_OK;
+}
+
+int emp_pdl_profile_read(emp_pdl_t* net, double* ms_total, double* flops_total, int* launches) {
+  EMP_REQUIRE(net && ms_total && flops_total && launches, "profile_read: null pointer");
+  double ms = 0.0;
+  for (size_t i = 0; i < net->prof_used; ++i) {
+    float t = 0.f;
+    EMP_CHECK_HIP(hipEventSynchronize(net->prof_events[i].second));
+    EMP_CHECK_HIP(hipEventElapsedTime(&t, net->prof_events[i].first, net->prof_events[i].second));
+    ms += t;
+  }
+  *ms_total = ms;
+  *flops_total = net->prof_flops;
+  *launches = (int)net->prof_used;
+  net->prof_used = 0;
+  net->prof_flops = 0.0;
+  return EMP_OK;
+}
 
 int emp_pdl_num_taps(const emp_pdl_t* net) { return net ? (int)net->act_order.size() : 0; }
 const char* emp_pdl_tap_name(const emp_pdl_t* net, int i) {

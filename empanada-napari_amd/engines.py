@@ -117,6 +117,17 @@ class HipPanopticDeepLab:
     def arena_bytes(self):
         return int(self.lib.emp_pdl_arena_bytes(self._h))
 
+    def profile(self, enable=True):
+        """Bracket every launch of the dominant kernel class (256x256 conv tile) with HIP events."""
+        _abi.check(self.lib.emp_pdl_profile(self._h, int(enable)), 'emp_pdl_profile')
+
+    def profile_read(self):
+        """-> (milliseconds, algorithmic FLOPs, launches) of those launches since the last read."""
+        import ctypes as C
+        ms, fl, n = C.c_double(0), C.c_double(0), C.c_int(0)
+        _abi.check(self.lib.emp_pdl_profile_read(self._h, C.byref(ms), C.byref(fl), C.byref(n)), 'emp_pdl_profile_read')
+        return ms.value, fl.value, n.value
+
     def last_flops(self):
         return float(self.lib.emp_pdl_flops(self._h, 0, 0, 0, 0))
 

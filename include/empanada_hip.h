@@ -117,6 +117,13 @@ EMP_API int emp_pdl_forward(emp_pdl_t* net, const void* d_image, int image_dtype
 /* Algorithmic FLOPs (2*MAC) of one forward at this shape: conv/GEMM work only. */
 EMP_API double emp_pdl_flops(const emp_pdl_t* net, int N, int H, int W, int render_steps);
 
+/* Live timing of the dominant kernel class (the 256x256 implicit-GEMM conv tile): while enabled every such
+ * launch is bracketed by HIP events on the forward's stream; emp_pdl_profile_read waits for them, returns the summed
+ * duration, the algorithmic FLOPs (2*MAC) and the number of launches since the last read, and resets.  Used by
+ * bench.py for the roofline block; no reference counterpart. */
+EMP_API int emp_pdl_profile(emp_pdl_t* net, int enable);
+EMP_API int emp_pdl_profile_read(emp_pdl_t* net, double* ms_total, double* flops_total, int* launches);
+
 /* Parity/debug taps: keep every intermediate activation addressable by name
  * after a forward ("stem", "encoder.layer1.0", ..., "semantic_x").  Returns
  * the device pointer (fp16 NHWC) and shape {N,H,W,C,ld}. */

@@ -1,0 +1,56 @@
+"""HBM traffic per bench step from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass).
+  python tools/hbm_traffic.py <fetch_dir> <write_dir> <steps_in_trace> [out.json]
+Each dir is the output of  rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py
+--steps S --warmup W --no-cpu-baseline  (steps_in_trace = S + W).  FETCH_SIZE is doubled (gfx950 tallies 128-B requests
+as 64 B, MI355X_MICROARCH.md); both counters are in KiB; Infinity-Cache hits are included."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'emp::\(anonymous namespace\)::', '', name)
+    m = re.match(r'_ZN3emp12_GLOBAL__N_1(\d+)(.*)', name)
+    if m:
+        return m.group(2)[:int(m.group(1))]
+    return re.sub(r'^void ', '', name).split('(')[0].split('<')[0][:60]
+
+
+def collect(d, counter):
+    f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == counter:
+            k = short(r['Kernel_Name'])
+            tot[k] += float(r['Counter_Value']) * 1024.0
+            cnt[k] += 1
+    return tot, cnt
+
+
+def main():
+    fd, wd, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    fe, fc = collect(fd, 'FETCH_SIZE')
+    wr, _ = collect(wd, 'WRITE_SIZE')
+    per = {}
+    for k in sorted(set(fe) | set(wr), key=lambda k: -(2 * fe.get(k, 0) + wr.get(k, 0))):
+        per[k] = {'launches_per_step': fc.get(k, 0) / steps, 'fetch_corrected': 2 * fe.get(k, 0) / steps,
+                  'write': wr.get(k, 0) / steps}
+    setup = {k: per.pop(k) for k in list(per) if 'fillBufferAligned' in k}      # one-time arena zeroing at reserve()
+    out = {'note': __doc__.split('\n')[0] + ' FETCH_SIZE doubled (gfx950), Infinity-Cache hits included; bytes per step; '
+                   'the runtime fill kernel (arena zeroing at reserve, once per process) is listed under setup.',
+           'hbm_bytes_per_step': sum(v['fetch_corrected'] + v['write'] for v in per.values()),
+           'setup': setup,
+           'per_kernel': per}
+    print(json.dumps({k: out[k] for k in ('hbm_bytes_per_step',)}))
+    for k, v in list(per.items())[:12]:
+        print(f"{k:40s} {v['launches_per_step']:6.1f} launches  fetch {v['fetch_corrected'] / 1e9:7.2f} GB  write {v['write'] / 1e9:7.2f} GB")
+    if len(sys.argv) > 4:
+        json.dump(out, open(sys.argv[4], 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
