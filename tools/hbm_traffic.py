@@ -20,25 +20,35 @@ def short(name):
     return re.sub(r'^void ', '', name).split('(')[0].split('<')[0][:60]
 
 
-def collect(d, counter):
-    f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
+def collect(d, counter, steps):
+    """-> {kernel: (launches per step, mean counter bytes per captured launch)}.  Kernel names come from the kernel
+    trace by dispatch id (the counter CSV's own name column is not reliable when a pass drops samples) and the
+    per-step launch count from the trace as well."""
+    fc = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
+    ft = glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)[0]
+    name, launches = {}, defaultdict(int)
+    for r in csv.DictReader(open(ft)):
+        name[r['Dispatch_Id']] = short(r['Kernel_Name'])
+        launches[short(r['Kernel_Name'])] += 1
     tot, cnt = defaultdict(float), defaultdict(int)
-    for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] == counter:
-            k = short(r['Kernel_Name'])
+    for r in csv.DictReader(open(fc)):
+        if r['Counter_Name'] == counter and r['Dispatch_Id'] in name:
+            k = name[r['Dispatch_Id']]
             tot[k] += float(r['Counter_Value']) * 1024.0
             cnt[k] += 1
-    return tot, cnt
+    return {k: (launches[k] / steps, tot[k] / cnt[k]) for k in tot}
 
 
 def main():
     fd, wd, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
-    fe, fc = collect(fd, 'FETCH_SIZE')
-    wr, _ = collect(wd, 'WRITE_SIZE')
+    fe = collect(fd, 'FETCH_SIZE', steps)
+    wr = collect(wd, 'WRITE_SIZE', steps)
     per = {}
-    for k in sorted(set(fe) | set(wr), key=lambda k: -(2 * fe.get(k, 0) + wr.get(k, 0))):
-        per[k] = {'launches_per_step': fc.get(k, 0) / steps, 'fetch_corrected': 2 * fe.get(k, 0) / steps,
-                  'write': wr.get(k, 0) / steps}
+    for k in set(fe) | set(wr):
+        lps = fe[k][0] if k in fe else wr[k][0]
+        per[k] = {'launches_per_step': lps, 'fetch_corrected': 2 * fe.get(k, (0, 0))[1] * lps,
+                  'write': wr.get(k, (0, 0))[1] * lps}
+    per = dict(sorted(per.items(), key=lambda kv: -(kv[1]['fetch_corrected'] + kv[1]['write'])))
     setup = {k: per.pop(k) for k in list(per) if 'fillBufferAligned' in k}      # one-time arena zeroing at reserve()
     out = {'note': __doc__.split('\n')[0] + ' FETCH_SIZE doubled (gfx950), Infinity-Cache hits included; bytes per step; '
                    'the runtime fill kernel (arena zeroing at reserve, once per process) is listed under setup.',
