@@ -38,6 +38,8 @@ PROTOTYPES = {
     'emp_pdl_reserve': (c_int, [vp, c_int, c_int, c_int]),
     'emp_pdl_arena_bytes': (sz, [vp]),
     'emp_pdl_forward': (c_int, [vp, vp, c_int, c_f32, c_f32, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp]),
+    'emp_pdl_forward_padded': (c_int, [vp, vp, c_int, c_f32, c_f32, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp,
+                                       vp, vp, vp]),
     'emp_pdl_flops': (c_f64, [vp, c_int, c_int, c_int, c_int]),
     'emp_pdl_profile': (c_int, [vp, c_int]),
     'emp_pdl_profile_read': (c_int, [vp, C.POINTER(c_f64), C.POINTER(c_f64), C.POINTER(c_int)]),

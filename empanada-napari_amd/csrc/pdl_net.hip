@@ -942,19 +942,27 @@ int emp_pdl_reserve(emp_pdl_t* net, int N, int H, int W) {
 }
 size_t emp_pdl_arena_bytes(const emp_pdl_t* net) { return net ? net->arena_used : 0; }
 
-int emp_pdl_forward(emp_pdl_t* net, const void* d_image, int image_dtype, float sub, float mul, int N, int H, int W,
-                    int render_steps, int interpolate_ins, float* d_sem_logits, float* d_ctr_hmp, float* d_offsets,
-                    void* stream) {
+int emp_pdl_forward_padded(emp_pdl_t* net, const void* d_image, int image_dtype, float sub, float mul, int N, int vh, int vw,
+                           int H, int W, int render_steps, int interpolate_ins, float* d_sem_logits, float* d_ctr_hmp,
+                           float* d_offsets, void* stream) {
   EMP_REQUIRE(net && d_image && d_sem_logits && d_ctr_hmp && d_offsets, "forward: null argument");
+  EMP_REQUIRE(vh > 0 && vw > 0 && vh <= H && vw <= W, "forward: valid size %dx%d must fit the padded size %dx%d", vh, vw, H, W);
   if (!net->finalized) {
     set_error("forward: call emp_pdl_finalize first");
     return EMP_ERR_STATE;
   }
   if (N != net->pN || H != net->pH || W != net->pW || render_steps != net->pRS) RC(plan(net, N, H, W, render_steps));
-  const int rc = run(net, d_image, image_dtype, sub, mul, N, H, W, H, W, render_steps, interpolate_ins, d_sem_logits, d_ctr_hmp,
-             d_offsets, (hipStream_t)stream);
+  const int rc = run(net, d_image, image_dtype, sub, mul, N, H, W, vh, vw, render_steps, interpolate_ins, d_sem_logits,
+                     d_ctr_hmp, d_offsets, (hipStream_t)stream);
   if (net->layer_log) { fprintf(net->layer_log, "end\n"); fflush(net->layer_log); }
   return rc;
+}
+
+int emp_pdl_forward(emp_pdl_t* net, const void* d_image, int image_dtype, float sub, float mul, int N, int H, int W,
+                    int render_steps, int interpolate_ins, float* d_sem_logits, float* d_ctr_hmp, float* d_offsets,
+                    void* stream) {
+  return emp_pdl_forward_padded(net, d_image, image_dtype, sub, mul, N, H, W, H, W, render_steps, interpolate_ins,
+                                d_sem_logits, d_ctr_hmp, d_offsets, stream);
 }
 
 double emp_pdl_flops(const emp_pdl_t* net, int, int, int, int) { return net ? net->flops : 0.0; }

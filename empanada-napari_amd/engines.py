@@ -132,9 +132,10 @@ class HipPanopticDeepLab:
         return float(self.lib.emp_pdl_flops(self._h, 0, 0, 0, 0))
 
     @torch.no_grad()
-    def __call__(self, image, render_steps=2, interpolate_ins=True, sub=0.0, mul=1.0, out=None):
+    def __call__(self, image, render_steps=2, interpolate_ins=True, sub=0.0, mul=1.0, out=None, pad_to=None):
         """image: (N,1,H,W) cuda tensor, float32 (normalised) or uint8/uint16 (raw; then
-        ``sub``/``mul`` are the normalisation constants).  Returns the reference's dict."""
+        ``sub``/``mul`` are the normalisation constants).  ``pad_to=(Hp,Wp)``: run at that padded size with the
+        reference's ``factor_pad`` (zeros after normalisation) fused into the stem.  Returns the reference's dict."""
         assert image.ndim == 4 and image.size(1) == 1, 'expected (N,1,H,W)'
         if image.device != self.device:
             image = image.to(self.device, non_blocking=True)
@@ -142,7 +143,8 @@ class HipPanopticDeepLab:
         dt = IMG_DTYPES.get(image.dtype)
         if dt is None:
             raise TypeError(f'unsupported image dtype {image.dtype}')
-        N, _, H, W = image.shape
+        N, _, vh, vw = image.shape
+        H, W = (vh, vw) if pad_to is None else (int(pad_to[0]), int(pad_to[1]))
         up = 2 ** (render_steps - 2) if render_steps >= 2 else 1.0 / (2 ** (2 - render_steps))
         Hs, Ws = int(H * up), int(W * up)
         hq, wq = (H, W) if interpolate_ins else (H // 4, W // 4)
@@ -152,9 +154,9 @@ class HipPanopticDeepLab:
             off = torch.empty((N, 2, hq, wq), dtype=torch.float32, device=self.device)
         else:
             sem, ctr, off = out
-        _abi.check(self.lib.emp_pdl_forward(self._h, _abi.ptr(image), dt, float(sub), float(mul), N, H, W,
-                                            int(render_steps), int(bool(interpolate_ins)), _abi.ptr(sem),
-                                            _abi.ptr(ctr), _abi.ptr(off), _abi.stream_ptr(self.device)),
+        _abi.check(self.lib.emp_pdl_forward_padded(self._h, _abi.ptr(image), dt, float(sub), float(mul), N, vh, vw, H, W,
+                                                   int(render_steps), int(bool(interpolate_ins)), _abi.ptr(sem),
+                                                   _abi.ptr(ctr), _abi.ptr(off), _abi.stream_ptr(self.device)),
                    'emp_pdl_forward')
         return {'sem_logits': sem, 'ctr_hmp': ctr, 'offsets': off}
 

@@ -327,7 +327,10 @@ class RLEMatcher:
         assert self.target_rle is not None, 'Initialize target rle before running!'
         matched, (tl, ml), _, ioa = rle_matcher(self.target_rle, match_instance_rle, self.merge_iou_thr)
         by_match = {m: t for t, m in zip(matched[0], matched[1])}
-        out = {}
+        # The reference folds every object that lands on an existing label into it pairwise (merge_attrs inside the
+        # loop).  A union of runs is associative, so the objects are grouped per label first (dict order = order of
+        # first occurrence, as in the reference) and each group is joined ONCE.
+        groups = {}
         for col, (m, attrs) in enumerate(match_instance_rle.items()):
             if m in by_match:
                 new = by_match[m]
@@ -340,7 +343,17 @@ class RLEMatcher:
                     self.next_label += 1
                 else:
                     new = m
-            out[new] = attrs if new not in out else merge_attrs(out[new], attrs)
+            groups.setdefault(new, []).append(attrs)
+        out = {}
+        for new, members in groups.items():
+            if len(members) == 1:
+                out[new] = members[0]
+                continue
+            box = members[0]['box']
+            for a in members[1:]:
+                box = merge_boxes(box, a['box'])
+            r = join_ranges([np.stack([a['starts'], a['starts'] + a['runs']], axis=1) for a in members])
+            out[new] = {'box': box, 'starts': r[:, 0], 'runs': r[:, 1] - r[:, 0]}
         if update_target:
             self.update_target(out)
         return out

@@ -114,6 +114,15 @@ EMP_API int emp_pdl_forward(emp_pdl_t* net, const void* d_image, int image_dtype
                     float* d_sem_logits, float* d_ctr_hmp, float* d_offsets,
                     void* stream);
 
+/* Same forward with `factor_pad` (postprocess.py:25-36) fused into the stem: d_image is the tight (N,vh,vw) image,
+ * the network runs at the padded size H x W (multiples of 16, H >= vh, W >= vw) and pixels outside vh x vw are zero
+ * AFTER normalisation, as in the reference.  Outputs have the padded size. */
+EMP_API int emp_pdl_forward_padded(emp_pdl_t* net, const void* d_image, int image_dtype,
+                    float sub, float mul, int N, int vh, int vw, int H, int W,
+                    int render_steps, int interpolate_ins,
+                    float* d_sem_logits, float* d_ctr_hmp, float* d_offsets,
+                    void* stream);
+
 /* Algorithmic FLOPs (2*MAC) of one forward at this shape: conv/GEMM work only. */
 EMP_API double emp_pdl_flops(const emp_pdl_t* net, int N, int H, int W, int render_steps);
 
