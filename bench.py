@@ -60,7 +60,7 @@ def main():
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--micro-batch', type=int, default=0, help='forward in chunks of this many tiles (0 = whole batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-tiles', type=int, default=1)
+    ap.add_argument('--cpu-tiles', type=int, default=8)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
