@@ -53,6 +53,24 @@ PROTOTYPES = {
     'emp_sepconv5x5_pack_pw': (c_int, [vp, c_int, c_int, c_int, vp, vp]),
     'emp_sepconv5x5_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_int, c_int, vp,
                                         c_int, vp, vp, c_int, vp, vp]),
+    'emp_sm_create': (vp, [c_i64, c_i64, c_f64, c_f64, c_int]),
+    'emp_sm_destroy': (None, [vp]),
+    'emp_sm_push_slice_runs': (c_int, [vp, vp, c_i64, c_i64, c_i64]),
+    'emp_sm_push_slice_objects': (c_int, [vp, c_i64, vp, vp, vp, vp, vp]),
+    'emp_sm_num_slices': (c_i64, [vp]),
+    'emp_sm_begin_backward': (c_int, [vp]),
+    'emp_sm_step_begin': (c_int, [vp, c_i64, C.POINTER(c_int), C.POINTER(c_int)]),
+    'emp_sm_iou': (vp, [vp]),
+    'emp_sm_step_apply': (c_int, [vp, vp, vp, c_i64]),
+    'emp_sm_tracker_init': (c_int, [vp, c_int, c_i64, c_i64, c_i64]),
+    'emp_sm_track': (c_int, [vp, c_i64, c_i64]),
+    'emp_sm_tracker_finish': (c_int, [vp]),
+    'emp_sm_num_tracks': (c_i64, [vp]),
+    'emp_sm_track_info': (c_int, [vp, c_i64, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64)]),
+    'emp_sm_track_runs': (c_int, [vp, c_i64, vp, vp]),
+    'emp_sm_slice_num_objects': (c_i64, [vp, c_i64]),
+    'emp_sm_slice_object_info': (c_int, [vp, c_i64, c_i64, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64)]),
+    'emp_sm_slice_object_runs': (c_int, [vp, c_i64, c_i64, vp, vp]),
     'emp_logits_to_prob': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'emp_median_slices': (c_int, [C.POINTER(vp), c_int, vp, sz, vp]),
     'emp_median_recursive': (c_int, [vp, vp, c_int, c_int, c_int, vp, sz, vp]),

@@ -1,0 +1,410 @@
+// Host half of the 3-D stitching path: slice-to-slice label matching and the instance tracker in C++
+// (reference: empanada/inference/matcher.py:136-326, patterns.py:55-121, tracker.py:61-123).
+//
+// The reference walks a stack of slices twice (forward, then backward with assign_new = False) and keeps every
+// slice as a Python dict of {label: {'box','starts','runs'}}; with the network at ~1 ms per slice that bookkeeping
+// was 85 % of the wall time of a 512^3 ortho-plane job.  Here a stack of one class lives in one C++ object: slices
+// arrive as the GPU run extractor's (start, length, label) triples, objects are CSR-free small vectors, and a step is
+//   emp_sm_step_begin  -> dense IoU (float64) / IoA (float32) matrices of target x match objects,
+//   [caller]           -> the assignment on the IoU matrix (scipy.optimize.linear_sum_assignment, as the reference),
+//   emp_sm_step_apply  -> label propagation, IoA merge, new labels, union of the objects that share a label.
+// Exactness notes: IoU = inter / (a + b - inter) in float64, IoA = float32(inter / area_match) as numpy stores it;
+// objects are visited in dict order (ascending component label after extraction, first-occurrence order after a
+// step); an object that keeps a label alone keeps its run list untouched, objects that share one are joined with the
+// reference's join_ranges rule (ranges that touch are merged).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct Obj {
+  int64_t label;
+  int64_t box[4];
+  std::vector<int64_t> starts, runs;
+};
+using Slice = std::vector<Obj>;
+
+struct Track {
+  int64_t label;
+  int64_t box[6];
+  std::vector<int64_t> starts, runs;
+};
+
+int64_t intersection_sorted(const std::vector<int64_t>& s1, const std::vector<int64_t>& r1,
+                            const std::vector<int64_t>& s2, const std::vector<int64_t>& r2) {
+  size_t i = 0, j = 0;
+  int64_t acc = 0;
+  while (i < s1.size() && j < s2.size()) {
+    const int64_t a0 = s1[i], a1 = a0 + r1[i], b0 = s2[j], b1 = b0 + r2[j];
+    const int64_t lo = a0 > b0 ? a0 : b0, hi = a1 < b1 ? a1 : b1;
+    if (hi > lo) acc += hi - lo;
+    if (a1 < b1) ++i; else ++j;
+  }
+  return acc;
+}
+
+void sort_runs(Obj& o) {   // runs of a merged object are produced sorted; extraction output is sorted by construction
+  bool sorted = true;
+  for (size_t i = 1; i < o.starts.size(); ++i) if (o.starts[i] < o.starts[i - 1]) { sorted = false; break; }
+  if (sorted) return;
+  std::vector<size_t> idx(o.starts.size());
+  for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return o.starts[a] < o.starts[b]; });
+  std::vector<int64_t> s(idx.size()), r(idx.size());
+  for (size_t i = 0; i < idx.size(); ++i) { s[i] = o.starts[idx[i]]; r[i] = o.runs[idx[i]]; }
+  o.starts.swap(s);
+  o.runs.swap(r);
+}
+
+}  // namespace
+
+struct emp_stack_matcher {
+  int64_t class_id, divisor;
+  double iou_thr, ioa_thr;
+  bool do_match = true, assign_new = true, has_target = false;
+  int64_t next_label = 0;
+  Slice target;
+  std::vector<Slice> stack;
+  // pending step
+  int pending = -1, nt = 0, nm = 0;
+  std::vector<double> iou;
+  std::vector<float> ioa;
+  // tracker
+  int axis = 0;
+  int64_t D = 0, H = 0, W = 0;
+  std::vector<Track> tracks;
+  std::unordered_map<int64_t, size_t> track_of;
+  bool finished = false;
+};
+
+using namespace emp;
+
+extern "C" {
+
+emp_stack_matcher* emp_sm_create(int64_t class_id, int64_t label_divisor, double iou_thr, double ioa_thr, int do_match) {
+  emp_stack_matcher* h = new emp_stack_matcher();
+  h->class_id = class_id;
+  h->divisor = label_divisor;
+  h->iou_thr = iou_thr;
+  h->ioa_thr = ioa_thr;
+  h->do_match = do_match != 0;
+  h->next_label = class_id * label_divisor + 1;
+  return h;
+}
+
+void emp_sm_destroy(emp_stack_matcher* h) { delete h; }
+
+// Append a slice from the run extractor: `runs` is (n,3) {start, length, label} in raster order, labels > 0; the slice
+// plane is `width` pixels wide.  Objects are created in ascending label order (regionprops order) with half-open boxes,
+// exactly like rle.pan_seg_to_rle_seg; `id_offset` is added to every label (component index -> class id range).
+int emp_sm_push_slice_runs(emp_stack_matcher* h, const int64_t* runs, int64_t n, int64_t width, int64_t id_offset) {
+  EMP_REQUIRE(h && (runs || n == 0) && n >= 0 && width > 0, "sm_push_slice_runs: bad arguments");
+  std::vector<int64_t> order((size_t)n);
+  for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return runs[3 * a + 2] < runs[3 * b + 2]; });
+  Slice sl;
+  for (int64_t k = 0; k < n; ++k) {
+    const int64_t* r = runs + 3 * order[(size_t)k];
+    const int64_t s = r[0], ln = r[1], lab = r[2] + id_offset;
+    const int64_t e = s + ln - 1;
+    const int64_t y0 = s / width, y1 = e / width;
+    const int64_t x0 = y0 == y1 ? s % width : 0, x1 = y0 == y1 ? e % width : width - 1;
+    if (sl.empty() || sl.back().label != lab) {
+      Obj o;
+      o.label = lab;
+      o.box[0] = y0; o.box[1] = x0; o.box[2] = y1 + 1; o.box[3] = x1 + 1;
+      sl.push_back(std::move(o));
+    } else {
+      Obj& o = sl.back();
+      o.box[0] = std::min(o.box[0], y0); o.box[1] = std::min(o.box[1], x0);
+      o.box[2] = std::max(o.box[2], y1 + 1); o.box[3] = std::max(o.box[3], x1 + 1);
+    }
+    sl.back().starts.push_back(s);
+    sl.back().runs.push_back(ln);
+  }
+  h->stack.push_back(std::move(sl));
+  return EMP_OK;
+}
+
+// Append a slice given as objects (labels, (n,4) boxes, CSR runs): the generic form of the above.
+int emp_sm_push_slice_objects(emp_stack_matcher* h, int64_t n, const int64_t* labels, const int64_t* boxes,
+                              const int64_t* off, const int64_t* starts, const int64_t* runs) {
+  EMP_REQUIRE(h && n >= 0, "sm_push_slice_objects: bad arguments");
+  Slice sl((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    Obj& o = sl[(size_t)i];
+    o.label = labels[i];
+    std::memcpy(o.box, boxes + 4 * i, sizeof(o.box));
+    o.starts.assign(starts + off[i], starts + off[i + 1]);
+    o.runs.assign(runs + off[i], runs + off[i + 1]);
+  }
+  h->stack.push_back(std::move(sl));
+  return EMP_OK;
+}
+
+int64_t emp_sm_num_slices(const emp_stack_matcher* h) { return h ? (int64_t)h->stack.size() : 0; }
+
+// patterns.py:102-109: the backward pass starts from a fresh target and never creates labels
+int emp_sm_begin_backward(emp_stack_matcher* h) {
+  EMP_REQUIRE(h != nullptr, "sm_begin_backward: null handle");
+  h->has_target = false;
+  h->target.clear();
+  h->assign_new = false;
+  return EMP_OK;
+}
+
+// First half of RLEMatcher.__call__ / apply_matchers for slice `idx`.  Returns through nt / nm the matrix shape; nt < 0
+// means "no assignment needed" (the slice initialised the target, the class is not matched, or one side is empty:
+// call emp_sm_step_apply with n = 0 in the last case -- reported as nt = 0 or nm = 0).
+int emp_sm_step_begin(emp_stack_matcher* h, int64_t idx, int* nt, int* nm) {
+  EMP_REQUIRE(h && nt && nm && idx >= 0 && idx < (int64_t)h->stack.size(), "sm_step_begin: bad arguments");
+  *nt = -1;
+  *nm = 0;
+  h->pending = -1;
+  if (!h->do_match) return EMP_OK;
+  Slice& cur = h->stack[(size_t)idx];
+  if (!h->has_target) {   // initialize_target (matcher.py:262-268)
+    h->target = cur;
+    h->has_target = true;
+    if (!cur.empty()) {
+      int64_t mx = cur[0].label;
+      for (const Obj& o : cur) mx = std::max(mx, o.label);
+      h->next_label = mx + 1;
+    }
+    return EMP_OK;
+  }
+  for (Obj& o : h->target) sort_runs(o);
+  for (Obj& o : cur) sort_runs(o);
+  h->pending = (int)idx;
+  h->nt = (int)h->target.size();
+  h->nm = (int)cur.size();
+  *nt = h->nt;
+  *nm = h->nm;
+  if (h->nt == 0 || h->nm == 0) return EMP_OK;
+  h->iou.assign((size_t)h->nt * h->nm, 0.0);
+  h->ioa.assign((size_t)h->nt * h->nm, 0.f);
+  std::vector<int64_t> ta((size_t)h->nt), ma((size_t)h->nm);
+  for (int i = 0; i < h->nt; ++i) { int64_t a = 0; for (int64_t r : h->target[(size_t)i].runs) a += r; ta[(size_t)i] = a; }
+  for (int j = 0; j < h->nm; ++j) { int64_t a = 0; for (int64_t r : cur[(size_t)j].runs) a += r; ma[(size_t)j] = a; }
+  for (int i = 0; i < h->nt; ++i) {
+    const Obj& t = h->target[(size_t)i];
+    for (int j = 0; j < h->nm; ++j) {
+      const Obj& m = cur[(size_t)j];
+      // box screen (array_utils.py:148-211): non-empty intersection of the half-open boxes
+      if (std::min(t.box[2], m.box[2]) <= std::max(t.box[0], m.box[0]) ||
+          std::min(t.box[3], m.box[3]) <= std::max(t.box[1], m.box[1]))
+        continue;
+      const int64_t inter = intersection_sorted(t.starts, t.runs, m.starts, m.runs);
+      h->iou[(size_t)i * h->nm + j] = (double)inter / (double)(ta[(size_t)i] + ma[(size_t)j] - inter);
+      h->ioa[(size_t)i * h->nm + j] = (float)((double)inter / (double)ma[(size_t)j]);
+    }
+  }
+  return EMP_OK;
+}
+
+// dense (nt x nm) float64 IoU matrix of the pending step (valid until the next step_begin)
+const double* emp_sm_iou(const emp_stack_matcher* h) { return (h && !h->iou.empty()) ? h->iou.data() : nullptr; }
+
+// Second half: `rows` / `cols` is the assignment on the IoU matrix (all pairs; pairs below the IoU threshold are
+// dropped here, matcher.py:226-229).
+int emp_sm_step_apply(emp_stack_matcher* h, const int64_t* rows, const int64_t* cols, int64_t n) {
+  EMP_REQUIRE(h && h->pending >= 0 && n >= 0, "sm_step_apply: no pending step");
+  Slice& cur = h->stack[(size_t)h->pending];
+  const int nt = h->nt, nm = h->nm;
+  const bool have = nt > 0 && nm > 0;
+  std::vector<int64_t> matched_t((size_t)nm, -1);     // per match object: index of the matched target, or -1
+  if (have)
+    for (int64_t k = 0; k < n; ++k) {
+      const int64_t r = rows[k], c = cols[k];
+      EMP_REQUIRE(r >= 0 && r < nt && c >= 0 && c < nm, "sm_step_apply: assignment out of range");
+      if (h->iou[(size_t)r * nm + c] >= h->iou_thr) matched_t[(size_t)c] = r;
+    }
+  // new label per object, groups in first-occurrence order
+  std::vector<int64_t> group_label;
+  std::vector<std::vector<int>> members;
+  std::unordered_map<int64_t, size_t> gi;
+  for (int c = 0; c < nm; ++c) {
+    int64_t nl;
+    if (matched_t[(size_t)c] >= 0) {
+      nl = h->target[(size_t)matched_t[(size_t)c]].label;
+    } else {
+      float best = 0.f;
+      int arg = 0;
+      if (have) {
+        best = h->ioa[(size_t)c];
+        for (int r = 1; r < nt; ++r)
+          if (h->ioa[(size_t)r * nm + c] > best) { best = h->ioa[(size_t)r * nm + c]; arg = r; }
+      }
+      // numpy >= 2 compares the float32 matrix entry with the Python float threshold in float32 (NEP 50)
+      if (have && best >= (float)h->ioa_thr) nl = h->target[(size_t)arg].label;
+      else if (h->assign_new) nl = h->next_label++;
+      else nl = cur[(size_t)c].label;
+    }
+    auto it = gi.find(nl);
+    if (it == gi.end()) {
+      gi.emplace(nl, members.size());
+      group_label.push_back(nl);
+      members.emplace_back(1, c);
+    } else {
+      members[it->second].push_back(c);
+    }
+  }
+  Slice out(members.size());
+  for (size_t g = 0; g < members.size(); ++g) {
+    Obj& o = out[g];
+    o.label = group_label[g];
+    const std::vector<int>& mem = members[g];
+    if (mem.size() == 1) {
+      Obj& src = cur[(size_t)mem[0]];
+      std::memcpy(o.box, src.box, sizeof(o.box));
+      o.starts.swap(src.starts);
+      o.runs.swap(src.runs);
+      continue;
+    }
+    // merge_attrs folded over the group: box union, join_ranges of all runs (array_utils.py:658-699)
+    std::memcpy(o.box, cur[(size_t)mem[0]].box, sizeof(o.box));
+    std::vector<std::pair<int64_t, int64_t>> rg;
+    for (int c : mem) {
+      const Obj& s = cur[(size_t)c];
+      o.box[0] = std::min(o.box[0], s.box[0]); o.box[1] = std::min(o.box[1], s.box[1]);
+      o.box[2] = std::max(o.box[2], s.box[2]); o.box[3] = std::max(o.box[3], s.box[3]);
+      for (size_t i = 0; i < s.starts.size(); ++i) rg.emplace_back(s.starts[i], s.starts[i] + s.runs[i]);
+    }
+    std::stable_sort(rg.begin(), rg.end(), [](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) {
+      return a.first < b.first;
+    });
+    for (const auto& r : rg) {
+      if (!o.starts.empty() && o.starts.back() + o.runs.back() >= r.first) {
+        const int64_t end = std::max(o.starts.back() + o.runs.back(), r.second);
+        o.runs.back() = end - o.starts.back();
+      } else {
+        o.starts.push_back(r.first);
+        o.runs.push_back(r.second - r.first);
+      }
+    }
+  }
+  cur.swap(out);
+  h->target = cur;      // update_target
+  h->pending = -1;
+  return EMP_OK;
+}
+
+// ---- tracker (tracker.py:61-123) -------------------------------------------------------------------------------
+int emp_sm_tracker_init(emp_stack_matcher* h, int axis, int64_t D, int64_t H, int64_t W) {
+  EMP_REQUIRE(h && axis >= 0 && axis <= 2 && D > 0 && H > 0 && W > 0, "sm_tracker_init: bad arguments");
+  h->axis = axis; h->D = D; h->H = H; h->W = W;
+  h->tracks.clear();
+  h->track_of.clear();
+  h->finished = false;
+  return EMP_OK;
+}
+
+// InstanceTracker.update for slice idx of the stack at position index2d along the axis
+int emp_sm_track(emp_stack_matcher* h, int64_t idx, int64_t index2d) {
+  EMP_REQUIRE(h && !h->finished && idx >= 0 && idx < (int64_t)h->stack.size(), "sm_track: bad arguments");
+  const int64_t H = h->H, W = h->W;
+  for (const Obj& o : h->stack[(size_t)idx]) {
+    int64_t box[6];
+    const int64_t y1 = o.box[0], x1 = o.box[1], y2 = o.box[2], x2 = o.box[3];
+    if (h->axis == 0) { box[0] = index2d; box[1] = y1; box[2] = x1; box[3] = index2d + 1; box[4] = y2; box[5] = x2; }
+    else if (h->axis == 1) { box[0] = y1; box[1] = index2d; box[2] = x1; box[3] = y2; box[4] = index2d + 1; box[5] = x2; }
+    else { box[0] = y1; box[1] = x1; box[2] = index2d; box[3] = y2; box[4] = x2; box[5] = index2d + 1; }
+    auto it = h->track_of.find(o.label);
+    Track* t;
+    if (it == h->track_of.end()) {
+      h->track_of.emplace(o.label, h->tracks.size());
+      h->tracks.emplace_back();
+      t = &h->tracks.back();
+      t->label = o.label;
+      std::memcpy(t->box, box, sizeof(box));
+    } else {
+      t = &h->tracks[it->second];
+      for (int k = 0; k < 3; ++k) { t->box[k] = std::min(t->box[k], box[k]); t->box[3 + k] = std::max(t->box[3 + k], box[3 + k]); }
+    }
+    for (size_t i = 0; i < o.starts.size(); ++i) {
+      const int64_t st = o.starts[i], rn = o.runs[i];
+      if (h->axis == 0) {                     // plane (H,W) at depth index2d
+        t->starts.push_back(st + index2d * (H * W));
+        t->runs.push_back(rn);
+      } else if (h->axis == 1) {              // plane (D,W) at row index2d: runs along x stay runs
+        t->starts.push_back((st / W) * (H * W) + index2d * W + (st % W));
+        t->runs.push_back(rn);
+      } else {                                // plane (D,H) at column index2d: every voxel is its own run
+        for (int64_t f = st; f < st + rn; ++f) {
+          t->starts.push_back((f / H) * (H * W) + (f % H) * W + index2d);
+          t->runs.push_back(1);
+        }
+      }
+    }
+  }
+  return EMP_OK;
+}
+
+int emp_sm_tracker_finish(emp_stack_matcher* h) {
+  EMP_REQUIRE(h != nullptr, "sm_tracker_finish: null handle");
+  if (h->axis == 2) {
+    for (Track& t : h->tracks) {       // tracker.py:113-120: sort the voxels, re-encode
+      std::vector<int64_t> v(t.starts);
+      std::sort(v.begin(), v.end());      // plain integers: a stable sort (as numpy's kind='stable') gives the same order
+      t.starts.clear();
+      t.runs.clear();
+      for (size_t i = 0; i < v.size(); ++i) {
+        if (i > 0 && v[i] == v[i - 1] + 1) ++t.runs.back();
+        else { t.starts.push_back(v[i]); t.runs.push_back(1); }
+      }
+    }
+  }
+  h->finished = true;
+  return EMP_OK;
+}
+
+int64_t emp_sm_num_tracks(const emp_stack_matcher* h) { return h ? (int64_t)h->tracks.size() : 0; }
+
+int emp_sm_track_info(const emp_stack_matcher* h, int64_t k, int64_t* label, int64_t* box6, int64_t* n_runs) {
+  EMP_REQUIRE(h && k >= 0 && k < (int64_t)h->tracks.size() && label && box6 && n_runs, "sm_track_info: bad arguments");
+  const Track& t = h->tracks[(size_t)k];
+  *label = t.label;
+  std::memcpy(box6, t.box, sizeof(t.box));
+  *n_runs = (int64_t)t.starts.size();
+  return EMP_OK;
+}
+
+int emp_sm_track_runs(const emp_stack_matcher* h, int64_t k, int64_t* starts, int64_t* runs) {
+  EMP_REQUIRE(h && k >= 0 && k < (int64_t)h->tracks.size() && starts && runs, "sm_track_runs: bad arguments");
+  const Track& t = h->tracks[(size_t)k];
+  std::memcpy(starts, t.starts.data(), t.starts.size() * sizeof(int64_t));
+  std::memcpy(runs, t.runs.data(), t.runs.size() * sizeof(int64_t));
+  return EMP_OK;
+}
+
+// ---- slice read-back (parity tests, save_panoptic) ----------------------------------------------------------------
+int64_t emp_sm_slice_num_objects(const emp_stack_matcher* h, int64_t idx) {
+  return (h && idx >= 0 && idx < (int64_t)h->stack.size()) ? (int64_t)h->stack[(size_t)idx].size() : -1;
+}
+
+int emp_sm_slice_object_info(const emp_stack_matcher* h, int64_t idx, int64_t k, int64_t* label, int64_t* box4,
+                             int64_t* n_runs) {
+  EMP_REQUIRE(h && idx >= 0 && idx < (int64_t)h->stack.size() && k >= 0 && k < (int64_t)h->stack[(size_t)idx].size(),
+              "sm_slice_object_info: bad arguments");
+  const Obj& o = h->stack[(size_t)idx][(size_t)k];
+  *label = o.label;
+  std::memcpy(box4, o.box, sizeof(o.box));
+  *n_runs = (int64_t)o.starts.size();
+  return EMP_OK;
+}
+
+int emp_sm_slice_object_runs(const emp_stack_matcher* h, int64_t idx, int64_t k, int64_t* starts, int64_t* runs) {
+  EMP_REQUIRE(h && idx >= 0 && idx < (int64_t)h->stack.size() && k >= 0 && k < (int64_t)h->stack[(size_t)idx].size(),
+              "sm_slice_object_runs: bad arguments");
+  const Obj& o = h->stack[(size_t)idx][(size_t)k];
+  std::memcpy(starts, o.starts.data(), o.starts.size() * sizeof(int64_t));
+  std::memcpy(runs, o.runs.data(), o.runs.size() * sizeof(int64_t));
+  return EMP_OK;
+}
+
+}  // extern "C"

@@ -402,21 +402,25 @@ class Engine3d:
             raise NotImplementedError('label erosion / dilation / hole filling are next-tier rows (filters.py:154-210)')
         axis = self.axes[axis_name]
         trackers = self.create_trackers(volume.shape, axis_name)
-        matchers = sparse.create_matchers(self.thing_list, self.label_divisor, self.merge_iou_thr, self.merge_ioa_thr)
         stack = self.create_panoptic_stack(axis_name, volume.shape)
         pan_segs = self.predict_slices(volume, axis)
         assert len(pan_segs) == volume.shape[axis]
-        # forward matching (patterns.py:68-100): dense -> RLE on the GPU in chunks, matching in slice order
-        rle_stack = []
+        # forward matching (patterns.py:68-100), backward matching (:102-121) and tracking (tracker.py:61-123) of every
+        # class in C++ (sparse.StackMatcher): dense -> runs on the GPU in chunks, no Python object per slice object
+        sms = {label: sparse.StackMatcher(label, self.label_divisor, self.merge_iou_thr, self.merge_ioa_thr,
+                                          match=label in self.thing_list) for label in self.labels}
         for i0 in range(0, len(pan_segs), 64):
             chunk = torch.stack(pan_segs[i0:i0 + 64])
-            for seg in sparse.pan_stack_to_rle_segs(chunk, self.labels, self.label_divisor, self.thing_list,
-                                                    force_connected=True):
-                rle_stack.append(sparse.apply_matchers(seg, matchers))
-        axis_len = volume.shape[axis]
-        for index, rle_seg in sparse.backward_matching(rle_stack, matchers, axis_len):
-            sparse.update_trackers(rle_seg, index, trackers)
-        sparse.finish_tracking(trackers)
+            width = chunk.shape[-1]
+            for label, (runs_list, off) in sparse.pan_stack_to_runs(chunk, self.labels, self.label_divisor,
+                                                                   self.thing_list, force_connected=True).items():
+                for runs in runs_list:
+                    sms[label].push_runs(runs, width, off)
+        for tr in trackers:
+            sm = sms[tr.class_id]
+            sm.forward()
+            tr.instances = sm.backward_and_track(axis_name, volume.shape)
+            tr.finished = True
         for tr in trackers:
             sparse.remove_small_objects(tr, min_size=self.min_size)
             sparse.remove_pancakes(tr, min_span=self.min_extent)

@@ -129,6 +129,24 @@ def pan_stack_to_rle_segs(pan, labels, label_divisor, thing_list, force_connecte
     return segs
 
 
+@torch.no_grad()
+def pan_stack_to_runs(pan, labels, label_divisor, thing_list, force_connected=True):
+    """The GPU half of pan_stack_to_rle_segs without building Python objects: pan (N,H,W) ->
+    {class: (list of N (n_i,3) int64 {start, length, label} arrays in raster order, id offset)} for StackMatcher.push_runs."""
+    pan = _as_device_i32(pan)
+    out = {}
+    for label in labels:
+        lo = label * label_divisor
+        hi = lo + label_divisor
+        inst = torch.where((pan >= lo) & (pan < hi), pan, torch.zeros_like(pan))
+        off = 0
+        if force_connected and label in thing_list:
+            inst, _ = ccl8(inst)
+            off = lo
+        out[label] = (extract_runs(inst), off)
+    return out
+
+
 def pan_seg_to_rle_seg(pan_seg, labels, label_divisor, thing_list, force_connected=True):
     """rle.py:26-86 for one (H,W) panoptic map."""
     p = pan_seg if isinstance(pan_seg, torch.Tensor) else np.asarray(pan_seg)
@@ -356,6 +374,102 @@ class RLEMatcher:
             out[new] = {'box': box, 'starts': r[:, 0], 'runs': r[:, 1] - r[:, 0]}
         if update_target:
             self.update_target(out)
+        return out
+
+
+class StackMatcher:
+    """One class of one stack of slices, matched and tracked in C++ (csrc/matcher.hip): the forward pass
+    (patterns.py:68-100), the backward pass (patterns.py:102-121) and the instance tracker (tracker.py:61-123) without
+    a Python object per slice object.  Only the assignment on the IoU matrix stays with scipy, as in the reference
+    (matcher.py:218).  ``match=False`` tracks a semantic class without matching."""
+
+    def __init__(self, class_id, label_divisor, merge_iou_thr=0.25, merge_ioa_thr=0.25, match=True):
+        self.lib = _lib()
+        self.class_id = class_id
+        self.label_divisor = label_divisor
+        self._h = self.lib.emp_sm_create(int(class_id), int(label_divisor), float(merge_iou_thr), float(merge_ioa_thr),
+                                         int(bool(match)))
+        if not self._h:
+            raise _abi.EmpError('emp_sm_create failed')
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self.lib.emp_sm_destroy(h)
+
+    def __len__(self):
+        return int(self.lib.emp_sm_num_slices(self._h))
+
+    def push_runs(self, runs, width, id_offset=0):
+        """runs: (n,3) int64 {start, length, label} in raster order (extract_runs output of one slice)."""
+        runs = np.ascontiguousarray(runs, dtype=i64).reshape(-1, 3)
+        _abi.check(self.lib.emp_sm_push_slice_runs(self._h, _hp(runs), len(runs), int(width), int(id_offset)),
+                   'emp_sm_push_slice_runs')
+
+    def push_objects(self, instance_rles):
+        """instance_rles: {label: {'box','starts','runs'}} of one slice (dict order kept)."""
+        labels = np.array([int(k) for k in instance_rles], dtype=i64)
+        boxes = np.ascontiguousarray(np.array([a['box'] for a in instance_rles.values()], dtype=i64).reshape(-1, 4))
+        starts, runs, off = _csr([(a['starts'], a['runs']) for a in instance_rles.values()]) if len(labels) else \
+            (np.zeros(0, i64), np.zeros(0, i64), np.zeros(1, i64))
+        _abi.check(self.lib.emp_sm_push_slice_objects(self._h, len(labels), _hp(labels), _hp(boxes), _hp(off), _hp(starts),
+                                                      _hp(runs)), 'emp_sm_push_slice_objects')
+
+    def _step(self, idx):
+        from scipy.optimize import linear_sum_assignment
+        nt, nm = C.c_int(0), C.c_int(0)
+        _abi.check(self.lib.emp_sm_step_begin(self._h, int(idx), C.byref(nt), C.byref(nm)), 'emp_sm_step_begin')
+        if nt.value < 0:
+            return
+        if nt.value == 0 or nm.value == 0:
+            _abi.check(self.lib.emp_sm_step_apply(self._h, None, None, 0), 'emp_sm_step_apply')
+            return
+        ptr = self.lib.emp_sm_iou(self._h)
+        iou = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(nt.value, nm.value))
+        rows, cols = linear_sum_assignment(iou, maximize=True)
+        rows = np.ascontiguousarray(rows, dtype=i64)
+        cols = np.ascontiguousarray(cols, dtype=i64)
+        _abi.check(self.lib.emp_sm_step_apply(self._h, _hp(rows), _hp(cols), len(rows)), 'emp_sm_step_apply')
+
+    def forward(self):
+        for idx in range(len(self)):
+            self._step(idx)
+
+    def backward_and_track(self, axis_name, shape3d):
+        """Backward matching with the tracker fed in the same (descending) slice order; returns the finished tracker's
+        ``instances`` dict."""
+        D, H, W = [int(v) for v in shape3d]
+        _abi.check(self.lib.emp_sm_tracker_init(self._h, InstanceTracker.AXES[axis_name], D, H, W), 'emp_sm_tracker_init')
+        _abi.check(self.lib.emp_sm_begin_backward(self._h), 'emp_sm_begin_backward')
+        for idx in range(len(self) - 1, -1, -1):
+            self._step(idx)
+            _abi.check(self.lib.emp_sm_track(self._h, idx, idx), 'emp_sm_track')
+        _abi.check(self.lib.emp_sm_tracker_finish(self._h), 'emp_sm_tracker_finish')
+        return self.instances()
+
+    def instances(self):
+        out = {}
+        lab, n = C.c_int64(0), C.c_int64(0)
+        box = (C.c_int64 * 6)()
+        for k in range(int(self.lib.emp_sm_num_tracks(self._h))):
+            _abi.check(self.lib.emp_sm_track_info(self._h, k, C.byref(lab), box, C.byref(n)), 'emp_sm_track_info')
+            st, rn = np.empty(n.value, dtype=i64), np.empty(n.value, dtype=i64)
+            if n.value:
+                _abi.check(self.lib.emp_sm_track_runs(self._h, k, _hp(st), _hp(rn)), 'emp_sm_track_runs')
+            out[int(lab.value)] = {'box': tuple(int(v) for v in box), 'starts': st, 'runs': rn}
+        return out
+
+    def slice_objects(self, idx):
+        """Current labelling of slice ``idx`` as the reference's dict (tests, save_panoptic)."""
+        out = {}
+        lab, n = C.c_int64(0), C.c_int64(0)
+        box = (C.c_int64 * 4)()
+        for k in range(int(self.lib.emp_sm_slice_num_objects(self._h, int(idx)))):
+            _abi.check(self.lib.emp_sm_slice_object_info(self._h, int(idx), k, C.byref(lab), box, C.byref(n)), 'slice info')
+            st, rn = np.empty(n.value, dtype=i64), np.empty(n.value, dtype=i64)
+            if n.value:
+                _abi.check(self.lib.emp_sm_slice_object_runs(self._h, int(idx), k, _hp(st), _hp(rn)), 'slice runs')
+            out[int(lab.value)] = {'box': tuple(int(v) for v in box), 'starts': st, 'runs': rn}
         return out
 
 

@@ -270,6 +270,40 @@ EMP_API int emp_rle_pair_intersections(const int64_t* h_starts, const int64_t* h
  * replaces vote_by_ranges / rle_voting / join_ranges, array_utils.py:461-699. */
 EMP_API int emp_ranges_vote(const int64_t* h_ranges, int64_t n, int thr, int64_t* h_out, int64_t* n_out);
 
+/* ------------------------------------------------------------------------
+ * 5. HOST: slice-to-slice matching + instance tracking of ONE class over a
+ *    stack of slices.  replaces RLEMatcher / rle_matcher (matcher.py:136-326),
+ *    forward_matching / backward_matching / apply_matchers (patterns.py:55-121)
+ *    and InstanceTracker.update / finish (tracker.py:61-123).  The assignment on
+ *    the IoU matrix stays with the caller (scipy.optimize.linear_sum_assignment,
+ *    matcher.py:218):  step_begin -> [assignment] -> step_apply, per slice.
+ * ---------------------------------------------------------------------- */
+typedef struct emp_stack_matcher emp_stack_matcher_t;
+EMP_API emp_stack_matcher_t* emp_sm_create(int64_t class_id, int64_t label_divisor, double iou_thr, double ioa_thr,
+                                   int do_match);
+EMP_API void emp_sm_destroy(emp_stack_matcher_t* h);
+/* append a slice: (n,3) {start, length, label} runs in raster order (emp_rle_extract output), plane width, id offset */
+EMP_API int emp_sm_push_slice_runs(emp_stack_matcher_t* h, const int64_t* h_runs, int64_t n, int64_t width, int64_t id_offset);
+/* append a slice as objects: labels (n), boxes (n,4), CSR offsets (n+1), starts, runs */
+EMP_API int emp_sm_push_slice_objects(emp_stack_matcher_t* h, int64_t n, const int64_t* labels, const int64_t* boxes,
+                              const int64_t* off, const int64_t* starts, const int64_t* runs);
+EMP_API int64_t emp_sm_num_slices(const emp_stack_matcher_t* h);
+EMP_API int emp_sm_begin_backward(emp_stack_matcher_t* h);
+/* nt < 0: nothing to assign (target initialised / class not matched); nt == 0 or nm == 0: call step_apply with n = 0 */
+EMP_API int emp_sm_step_begin(emp_stack_matcher_t* h, int64_t idx, int* nt, int* nm);
+EMP_API const double* emp_sm_iou(const emp_stack_matcher_t* h);          /* (nt,nm) float64, valid until the next step */
+EMP_API int emp_sm_step_apply(emp_stack_matcher_t* h, const int64_t* rows, const int64_t* cols, int64_t n);
+EMP_API int emp_sm_tracker_init(emp_stack_matcher_t* h, int axis /* 0 xy, 1 xz, 2 yz */, int64_t D, int64_t H, int64_t W);
+EMP_API int emp_sm_track(emp_stack_matcher_t* h, int64_t idx, int64_t index2d);
+EMP_API int emp_sm_tracker_finish(emp_stack_matcher_t* h);
+EMP_API int64_t emp_sm_num_tracks(const emp_stack_matcher_t* h);
+EMP_API int emp_sm_track_info(const emp_stack_matcher_t* h, int64_t k, int64_t* label, int64_t* box6, int64_t* n_runs);
+EMP_API int emp_sm_track_runs(const emp_stack_matcher_t* h, int64_t k, int64_t* starts, int64_t* runs);
+EMP_API int64_t emp_sm_slice_num_objects(const emp_stack_matcher_t* h, int64_t idx);
+EMP_API int emp_sm_slice_object_info(const emp_stack_matcher_t* h, int64_t idx, int64_t k, int64_t* label, int64_t* box4,
+                             int64_t* n_runs);
+EMP_API int emp_sm_slice_object_runs(const emp_stack_matcher_t* h, int64_t idx, int64_t k, int64_t* starts, int64_t* runs);
+
 #ifdef __cplusplus
 }
 #endif

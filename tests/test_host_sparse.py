@@ -113,3 +113,91 @@ def test_filters_and_relabel(trackers):
     for k in a:
         np.testing.assert_array_equal(a[k]['starts'], b[k]['starts'])
         np.testing.assert_array_equal(a[k]['runs'], b[k]['runs'])
+
+
+def _stack_matcher_trackers(push):
+    """The sparse_case pipeline through the C++ stack matcher (csrc/matcher.hip)."""
+    vol = sparse_case.synth_label_volume(sparse_case.SHAPE, 7, seed=5)
+    out = []
+    for axis, name in enumerate(('xy', 'xz', 'yz')):
+        slices = sparse_case.axis_pan_slices(vol, axis, sparse_case.DIVISOR, seed=100 + axis)
+        sm = ps.StackMatcher(1, sparse_case.DIVISOR, 0.25, 0.25)
+        for pan in slices:
+            push(sm, pan)
+        sm.forward()
+        fwd = [sm.slice_objects(i) for i in range(len(slices))]
+        inst = sm.backward_and_track(name, sparse_case.SHAPE)
+        out.append((name, slices, fwd, inst, sm))
+    return out
+
+
+def _push_objects(sm, pan):
+    sm.push_objects(osp.pan_seg_to_rle_seg(pan, [1], sparse_case.DIVISOR, [1], force_connected=True)[1])
+
+
+def _push_runs(sm, pan):
+    """raw (start, length, label) triples in raster order, as the GPU run extractor emits them"""
+    cc = osp.connected_components(np.where((pan >= sparse_case.DIVISOR) & (pan < 2 * sparse_case.DIVISOR), pan, 0))
+    flat = cc.ravel()
+    W = pan.shape[1]
+    runs = []
+    for y in range(pan.shape[0]):
+        row = flat[y * W:(y + 1) * W]
+        x = 0
+        while x < W:
+            if row[x] > 0:
+                x0 = x
+                while x < W and row[x] == row[x0]:
+                    x += 1
+                runs.append((y * W + x0, x - x0, int(row[x0])))
+            else:
+                x += 1
+    sm.push_runs(np.array(runs, dtype=np.int64).reshape(-1, 3), W, sparse_case.DIVISOR)
+
+
+@pytest.mark.parametrize('push', [_push_objects, _push_runs])
+def test_cpp_stack_matcher_matches_reference(golden_dir, push):
+    g = np.load(os.path.join(golden_dir, 'sparse.npz'))
+    for name, slices, fwd, inst, sm in _stack_matcher_trackers(push):
+        for k, v in _flat(inst).items():
+            np.testing.assert_array_equal(v, g[f'trk_{name}_{k}'], err_msg=f'{name} {k}')
+
+
+def test_cpp_stack_matcher_equals_python_matcher_per_slice():
+    """every slice after the forward pass and after the backward pass: same labels, boxes and runs as RLEMatcher"""
+    for name, slices, fwd, inst, sm in _stack_matcher_trackers(_push_objects):
+        m = ps.RLEMatcher(1, sparse_case.DIVISOR, 0.25, 0.25)
+        stack = []
+        for i, pan in enumerate(slices):
+            seg = osp.pan_seg_to_rle_seg(pan, [1], sparse_case.DIVISOR, [1], force_connected=True)[1]
+            seg = seg if m.target_rle is None and not m.initialize_target(seg) else m(seg)
+            stack.append(seg)
+            assert list(seg) == list(fwd[i]), (name, i)
+            for k in seg:
+                assert tuple(seg[k]['box']) == fwd[i][k]['box']
+                np.testing.assert_array_equal(seg[k]['starts'], fwd[i][k]['starts'])
+                np.testing.assert_array_equal(seg[k]['runs'], fwd[i][k]['runs'])
+        m.target_rle, m.assign_new = None, False
+        for i in range(len(slices) - 1, -1, -1):
+            seg = stack[i] if m.target_rle is None and not m.initialize_target(stack[i]) else m(stack[i])
+            got = sm.slice_objects(i)
+            assert list(seg) == list(got), (name, i)
+            for k in seg:
+                np.testing.assert_array_equal(seg[k]['starts'], got[k]['starts'])
+
+
+def test_cpp_stack_matcher_empty_slices_and_semantic_class():
+    sm = ps.StackMatcher(1, 1000, 0.25, 0.25)
+    a = {1001: {'box': (0, 0, 2, 4), 'starts': np.array([0, 8]), 'runs': np.array([4, 4])}}
+    for seg in ({}, a, {}, a):
+        sm.push_objects(seg)
+    sm.forward()
+    assert [list(sm.slice_objects(i)) for i in range(4)] == [[], [1001], [], [1002]]      # new label after an empty slice
+    inst = sm.backward_and_track('xy', (4, 2, 8))
+    assert sorted(inst) == [1001, 1002] and inst[1001]['box'] == (1, 0, 0, 2, 2, 4)
+    st = ps.StackMatcher(2, 1000, match=False)
+    st.push_objects({2000: {'box': (0, 0, 1, 3), 'starts': np.array([1]), 'runs': np.array([2])}})
+    st.push_objects({2000: {'box': (1, 0, 2, 2), 'starts': np.array([8]), 'runs': np.array([2])}})
+    st.forward()
+    inst = st.backward_and_track('xy', (2, 2, 8))
+    assert list(inst) == [2000] and inst[2000]['starts'].tolist() == [24, 1] and inst[2000]['box'] == (0, 0, 0, 2, 2, 3)

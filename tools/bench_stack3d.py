@@ -43,22 +43,28 @@ def main():
         # same as infer_on_axis from here (re-using the predicted slices keeps the breakdown honest)
         from empanada_napari_amd import sparse
         trs = eng.create_trackers(vol.shape, name)
-        matchers = sparse.create_matchers(eng.thing_list, eng.label_divisor, eng.merge_iou_thr, eng.merge_ioa_thr)
-        rle_stack = []
+        sms = {label: sparse.StackMatcher(label, eng.label_divisor, eng.merge_iou_thr, eng.merge_ioa_thr,
+                                          match=label in eng.thing_list) for label in eng.labels}
         for i0 in range(0, len(pans), 64):
-            for seg in sparse.pan_stack_to_rle_segs(torch.stack(pans[i0:i0 + 64]), eng.labels, eng.label_divisor,
-                                                    eng.thing_list, True):
-                rle_stack.append(sparse.apply_matchers(seg, matchers))
+            chunk = torch.stack(pans[i0:i0 + 64])
+            for label, (runs_list, off) in sparse.pan_stack_to_runs(chunk, eng.labels, eng.label_divisor, eng.thing_list,
+                                                                   True).items():
+                for runs in runs_list:
+                    sms[label].push_runs(runs, chunk.shape[-1], off)
+        tb2 = time.perf_counter()
+        for tr in trs:
+            sms[tr.class_id].forward()
         tc = time.perf_counter()
-        for index, seg in sparse.backward_matching(rle_stack, matchers, vol.shape[axis]):
-            sparse.update_trackers(seg, index, trs)
-        sparse.finish_tracking(trs)
+        for tr in trs:
+            tr.instances = sms[tr.class_id].backward_and_track(name, vol.shape)
+            tr.finished = True
         for tr in trs:
             sparse.remove_small_objects(tr, eng.min_size)
             sparse.remove_pancakes(tr, eng.min_extent)
         td = time.perf_counter()
         trackers[name] = trs
-        t[name] = {'forward_post_s': round(tb - ta, 3), 'rle_forward_match_s': round(tc - tb, 3),
+        t[name] = {'forward_post_s': round(tb - ta, 3), 'dense_to_runs_s': round(tb2 - tb, 3),
+                   'forward_match_s': round(tc - tb2, 3),
                    'backward_track_s': round(td - tc, 3), 'objects': len(trs[0].instances)}
     te = time.perf_counter()
     out = list(tracker_consensus(trackers, None, mc, label_divisor=10000, pixel_vote_thr=2, cluster_iou_thr=0.75,
