@@ -190,11 +190,15 @@ class MultiGPUEngine3d:
         if segs is None:
             return None, None
         trackers = e3.create_trackers(volume.shape, axis_name)
-        matchers = sparse.create_matchers(e3.thing_list, e3.label_divisor, e3.merge_iou_thr, e3.merge_ioa_thr)
-        rle_stack = [sparse.apply_matchers(s, matchers) for s in segs]
-        for index, rle_seg in sparse.backward_matching(rle_stack, matchers, n):
-            sparse.update_trackers(rle_seg, index, trackers)
-        sparse.finish_tracking(trackers)
+        # sequential matching + tracking of the gathered run lists on rank 0, in C++ (sparse.StackMatcher)
+        for tr in trackers:
+            sm = sparse.StackMatcher(tr.class_id, e3.label_divisor, e3.merge_iou_thr, e3.merge_ioa_thr,
+                                     match=tr.class_id in e3.thing_list)
+            for s in segs:
+                sm.push_objects(s[tr.class_id])
+            sm.forward()
+            tr.instances = sm.backward_and_track(axis_name, volume.shape)
+            tr.finished = True
         for tr in trackers:
             sparse.remove_small_objects(tr, min_size=e3.min_size)
             sparse.remove_pancakes(tr, min_span=e3.min_extent)
