@@ -288,6 +288,39 @@ __global__ void __launch_bounds__(256) rle_fill_kernel(const int64_t* __restrict
   }
 }
 
+// ordered fill, pass 1: every voxel of run r remembers the highest order[r] that covers it
+__global__ void __launch_bounds__(256) rle_prio_kernel(const int64_t* __restrict__ starts, const int64_t* __restrict__ lens,
+                                                       const int32_t* __restrict__ order, int64_t nruns,
+                                                       int32_t* __restrict__ prio, int64_t size) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t r = wave0; r < nruns; r += nw) {
+    const int64_t s = starts[r], e = min(size, s + lens[r]);
+    const int32_t o = order[r];
+    for (int64_t p = s + lane; p < e; p += 64) atomicMax(prio + p, o);
+  }
+}
+// pass 2: only the winning run writes its value
+template <typename T>
+__global__ void __launch_bounds__(256) rle_fill_ordered_kernel(const int64_t* __restrict__ starts,
+                                                               const int64_t* __restrict__ lens,
+                                                               const int64_t* __restrict__ vals,
+                                                               const int32_t* __restrict__ order, int64_t nruns,
+                                                               const int32_t* __restrict__ prio, T* __restrict__ vol,
+                                                               int64_t size) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t r = wave0; r < nruns; r += nw) {
+    const int64_t s = starts[r], e = min(size, s + lens[r]);
+    const T v = (T)vals[r];
+    const int32_t o = order[r];
+    for (int64_t p = s + lane; p < e; p += 64)
+      if (prio[p] == o) vol[p] = v;
+  }
+}
+
 }  // namespace
 }  // namespace emp
 
@@ -367,6 +400,29 @@ int emp_rle_fill(const int64_t* d_starts, const int64_t* d_lens, const int64_t* 
     case 4: hipLaunchKernelGGL(rle_fill_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_vals, nruns, (uint32_t*)d_volume, size); break;
     case 8: hipLaunchKernelGGL(rle_fill_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_vals, nruns, (uint64_t*)d_volume, size); break;
     default: EMP_REQUIRE(false, "rle_fill: element size %d unsupported", elem_bytes);
+  }
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+// Same with the reference's overwrite rule for overlapping objects (numpy_fill_instances fills the instances one after
+// the other, array_utils.py:754-766): where runs overlap the one with the highest d_order wins.  d_prio is a scratch
+// volume of `size` int32 that this call initialises.  Runs of equal order must not overlap each other.
+int emp_rle_fill_ordered(const int64_t* d_starts, const int64_t* d_lens, const int64_t* d_vals, const int32_t* d_order,
+                         int64_t nruns, void* d_volume, int64_t size, int elem_bytes, int32_t* d_prio, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  EMP_REQUIRE(d_volume && d_prio && d_order && nruns >= 0 && size > 0, "rle_fill_ordered: bad arguments");
+  if (nruns == 0) return EMP_OK;
+  EMP_CHECK_HIP(hipMemsetAsync(d_prio, 0xff, (size_t)size * sizeof(int32_t), s));     // -1
+  const int grid = grid_for(nruns * 64, 256, 256 * 32);
+  hipLaunchKernelGGL(rle_prio_kernel, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_order, nruns, d_prio, size);
+  EMP_LAUNCH_CHECK();
+  switch (elem_bytes) {
+    case 1: hipLaunchKernelGGL(rle_fill_ordered_kernel<uint8_t>, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_vals, d_order, nruns, d_prio, (uint8_t*)d_volume, size); break;
+    case 2: hipLaunchKernelGGL(rle_fill_ordered_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_vals, d_order, nruns, d_prio, (uint16_t*)d_volume, size); break;
+    case 4: hipLaunchKernelGGL(rle_fill_ordered_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_vals, d_order, nruns, d_prio, (uint32_t*)d_volume, size); break;
+    case 8: hipLaunchKernelGGL(rle_fill_ordered_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, d_starts, d_lens, d_vals, d_order, nruns, d_prio, (uint64_t*)d_volume, size); break;
+    default: EMP_REQUIRE(false, "rle_fill_ordered: element size %d unsupported", elem_bytes);
   }
   EMP_LAUNCH_CHECK();
   return EMP_OK;

@@ -79,10 +79,8 @@ def _class_volume(zarr_store, name, shape, dtype, chunks):
 def _fill(volume, instances):
     if isinstance(volume, np.ndarray):
         sparse.fill_volume(volume, instances)
-    else:  # zarr array: fill a host copy chunk-free, then assign
-        tmp = np.zeros(volume.shape, dtype=volume.dtype)
-        sparse.fill_volume(tmp, instances)
-        volume[...] = tmp
+    else:  # chunked store (zarr): stream slab by slab
+        sparse.chunked_fill(volume, instances)
 
 
 @thread_worker

@@ -818,25 +818,71 @@ def create_semantic_consensus(class_trackers, pixel_vote_thr=2):
 # RLE -> dense (patterns.py:204-220, array_utils.py:754-766)
 # ----------------------------------------------------------------------------
 @torch.no_grad()
-def fill_volume(volume, instances, device=None):
-    """Fills ``volume`` (numpy array or cuda tensor) in place with the instances' ids."""
+def _fill_device(dvol, starts, lens, vals, order):
+    """Ordered run fill of a contiguous device tensor (later instances overwrite earlier ones where they overlap)."""
     lib = _lib()
+    dev = dvol.device
+    ds, dl, dv = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (starts, lens, vals))
+    do = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)).to(dev)
+    prio = torch.empty(dvol.numel(), dtype=torch.int32, device=dev)
+    _abi.check(lib.emp_rle_fill_ordered(_abi.ptr(ds), _abi.ptr(dl), _abi.ptr(dv), _abi.ptr(do), len(starts), _abi.ptr(dvol),
+                                        dvol.numel(), dvol.element_size(), _abi.ptr(prio), _abi.stream_ptr(dev)),
+               'emp_rle_fill_ordered')
+
+
+def _instance_runs(instances):
     ids = list(instances)
-    if not ids:
-        return volume
     starts = np.concatenate([np.asarray(instances[k]['starts'], dtype=i64) for k in ids])
     lens = np.concatenate([np.asarray(instances[k]['runs'], dtype=i64) for k in ids])
-    vals = np.concatenate([np.full(len(instances[k]['starts']), int(k), dtype=i64) for k in ids])
+    n = [len(instances[k]['starts']) for k in ids]
+    vals = np.repeat(np.array([int(k) for k in ids], dtype=i64), n)
+    order = np.repeat(np.arange(len(ids), dtype=np.int32), n)
+    return starts, lens, vals, order
+
+
+@torch.no_grad()
+def fill_volume(volume, instances, device=None):
+    """Fills ``volume`` (numpy array or cuda tensor) in place with the instances' ids; where instances overlap the
+    later one in the dict wins, as in the reference's sequential fill (array_utils.py:754-766)."""
+    if not instances:
+        return volume
+    starts, lens, vals, order = _instance_runs(instances)
     is_np = isinstance(volume, np.ndarray)
     dev = _dev(device) if is_np else volume.device
     dvol = torch.from_numpy(volume).to(dev) if is_np else volume
     assert dvol.is_contiguous()
-    ds, dl, dv = (torch.from_numpy(a).to(dev) for a in (starts, lens, vals))
-    _abi.check(lib.emp_rle_fill(_abi.ptr(ds), _abi.ptr(dl), _abi.ptr(dv), len(starts), _abi.ptr(dvol), dvol.numel(),
-                                dvol.element_size(), _abi.stream_ptr(dev)), 'emp_rle_fill')
+    _fill_device(dvol, starts, lens, vals, order)
     if is_np:
         volume[...] = dvol.cpu().numpy()
     return volume
+
+
+@torch.no_grad()
+def chunked_fill(array, instances, slab_depth=None, device=None):
+    """Streaming RLE -> dense writer for chunked stores (zarr arrays or anything with ``.shape``, ``.dtype`` and slab
+    assignment ``array[z0:z1] = block``): replaces zarr_fill_instances (zarr_utils.py:97-184).  The volume is
+    produced one slab of ``slab_depth`` (default: the store's chunk depth) z-planes at a time on the GPU -- runs that
+    cross a slab are clipped -- so the dense volume never has to fit in host or device memory at once."""
+    d, h, w = [int(v) for v in array.shape]
+    if slab_depth is None:
+        slab_depth = int(getattr(array, 'chunks', (64,))[0])
+    dt = np.dtype(array.dtype)
+    tdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[dt.itemsize]
+    starts, lens, vals, order = _instance_runs(instances) if instances else (np.zeros(0, i64),) * 3 + (np.zeros(0, np.int32),)
+    ends = starts + lens
+    plane = h * w
+    dev = _dev(device)
+    for z0 in range(0, d, slab_depth):
+        z1 = min(d, z0 + slab_depth)
+        lo, hi = z0 * plane, z1 * plane
+        sel = np.flatnonzero((ends > lo) & (starts < hi))
+        block = torch.zeros((z1 - z0, h, w), dtype=tdt, device=dev)
+        if len(sel):
+            s = np.maximum(starts[sel], lo) - lo
+            e = np.minimum(ends[sel], hi) - lo
+            _fill_device(block, s, e - s, vals[sel], order[sel])
+        array[z0:z1] = block.cpu().numpy().view(dt)
+    return array
 
 
 def fill_panoptic_volume(volume, trackers):

@@ -262,6 +262,13 @@ EMP_API int emp_rle_extract(const int32_t* d_labels, int N, int H, int W, int32_
 EMP_API int emp_rle_fill(const int64_t* d_starts, const int64_t* d_lens, const int64_t* d_vals,
                  int64_t nruns, void* d_volume, int64_t size, int elem_bytes, void* stream);
 
+/* The same with the reference's overwrite order for overlapping objects: where runs overlap, the run with the highest
+ * d_order (position of its instance in the dict) wins, as numpy_fill_instances' sequential fill does.  d_prio: scratch
+ * of `size` int32, initialised by the call. */
+EMP_API int emp_rle_fill_ordered(const int64_t* d_starts, const int64_t* d_lens, const int64_t* d_vals,
+                 const int32_t* d_order, int64_t nruns, void* d_volume, int64_t size, int elem_bytes,
+                 int32_t* d_prio, void* stream);
+
 /* HOST: intersections of pairs of run-length objects stored CSR-style (object k owns runs
  * [h_off[k], h_off[k+1])).  replaces rle_intersection, array_utils.py:344-407. */
 EMP_API int emp_rle_pair_intersections(const int64_t* h_starts, const int64_t* h_runs, const int64_t* h_off,
