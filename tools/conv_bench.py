@@ -53,7 +53,7 @@ def main():
         Wo = (W + 2 * p - d * (k_ - 1) - 1) // s + 1
         out = torch.empty((B, Ho, Wo, Cout), device=dev, dtype=torch.float16)
         flops = 2.0 * B * Ho * Wo * Cout * Cin * k_ * k_
-        VARS = [('128x128', 16 + 3), ('256x256', 64 if Cout % 256 == 0 else 16 + 3), ('auto', 0)]
+        VARS = [('128x128', 16 + 3), ('256x256', 64 if Cout % 256 == 0 and Cin * k_ * k_ >= 128 else 16 + 3), ('auto', 0)]
         times = {k: [] for k, _ in VARS}
         for rnd in range(5):
             for k, v in VARS:
