@@ -622,10 +622,22 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
         x = dp + ".cat" + std::to_string(i);
       }
       const Act& cat = A(x);
-      RC(launch_dwconv(cat.p, N, cat.H, cat.W, 2 * F, cat.ld, n->f16w.at(dp + ".fusion.0.sepconv.0"), 5, A(dp + ".dw").p,
-                       2 * F, zero, s));
       n->flops += 2.0 * 25.0 * (double)N * cat.H * cat.W * 2 * F;
-      RC(conv(n, dp + ".fusion.0.sepconv.1", A(dp + ".dw"), 0, A(dp + ".out"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+      {
+        const DevConv& pwc = n->convs.at(dp + ".fusion.0.sepconv.1");
+        const Act& so = A(dp + ".out");
+        if (n->fuse_sepconv && n->f16w.count(dp + ".fusion.0.sepconv.1.packed") && cat.ld == 2 * F && pwc.cin_pad == 2 * F &&
+            so.ld == pwc.cout && sepconv5_supported(2 * F, pwc.cout, 0)) {
+          RC(launch_sepconv5(cat.p, N, cat.H, cat.W, 2 * F, cat.ld, n->f16w.at(dp + ".fusion.0.sepconv.0"),
+                             n->f16w.at(dp + ".fusion.0.sepconv.1.packed"), pwc.b, pwc.cout, 1, so.p, so.ld, nullptr, nullptr,
+                             0, nullptr, 0, zero, s));
+          n->flops += 2.0 * (double)N * cat.H * cat.W * pwc.cout * (double)pwc.cin;
+        } else {
+          RC(launch_dwconv(cat.p, N, cat.H, cat.W, 2 * F, cat.ld, n->f16w.at(dp + ".fusion.0.sepconv.0"), 5, A(dp + ".dw").p,
+                           2 * F, zero, s));
+          RC(conv(n, dp + ".fusion.0.sepconv.1", A(dp + ".dw"), 0, so, 0, 1, 0, 1, 1, nullptr, nullptr, s));
+        }
+      }
       dec_out[d] = dp + ".out";
     }
   } else {
@@ -869,6 +881,7 @@ int emp_pdl_finalize(emp_pdl_t* n) {
         EMP_REQUIRE(n->convs[nm].cout == 4 * F, "%s: transposed conv must produce fpn_dim channels", nm.c_str());
       } else {
         RC(pack_conv(n, nm));
+        if (nm.size() > 19 && nm.compare(nm.size() - 19, 19, ".fusion.0.sepconv.1") == 0) RC(pack_sepconv_pw(n, nm));
       }
     }
   } else {
