@@ -1,0 +1,79 @@
+"""Race screens for the kernels whose pipelines keep LDS-DMA in flight across barriers (counted vmcnt waits, raw
+s_barrier): at full-chip sizes, many repetitions must give bit-identical outputs, and those must agree with a
+differently structured kernel computing the same op.  A schedule-dependent hazard shows up as rare wrong tiles
+that come and go between runs (cdna_hip_programming.md, 8-phase template notes)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_conv256_repeatable_and_equal_to_128_tile():
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    N, H, W, Cin, Cout, k, d = 8, 64, 64, 512, 512, 3, 2            # 128 pixel tiles x 2 cout tiles, 144 K-tiles
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.float16).to(dev())
+    w = (torch.randn((Cout, k * k, Cin), generator=g) / np.sqrt(Cin * k * k)).to(torch.float16).to(dev())
+    b = torch.randn((Cout,), generator=g).to(dev())
+    res = torch.randn((N, H, W, Cout), generator=g).to(torch.float16).to(dev())
+
+    def run(variant):
+        out = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev())
+        _abi.check(lib.emp_conv2d_nhwc_f16(_abi.ptr(x), N, H, W, Cin, Cin, _abi.ptr(w), _abi.ptr(b), None, _abi.ptr(res),
+                                           Cout, _abi.ptr(out), Cout, Cout, k, k, 1, d, d, 1, variant,
+                                           _abi.stream_ptr(dev())), 'conv')
+        return out
+
+    first = run(64)
+    for _ in range(20):
+        assert torch.equal(run(64), first)
+    ref = run(16 + 3).float()
+    err = (first.float() - ref).abs()
+    assert torch.all(err <= 2e-3 + 4e-3 * ref.abs()), err.max()      # different K order: fp32 summation noise only
+
+
+def test_sepconv_repeatable_and_equal_to_unfused():
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    N, H, W, Cc, Cout = 8, 256, 256, 320, 256                         # 16 tiles per workgroup
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((N, H, W, Cc), generator=g).to(torch.float16).to(dev())
+    dw = (torch.randn((25, Cc), generator=g) * 0.2).to(torch.float16).to(dev())
+    pw = (torch.randn((Cout, Cc), generator=g) / np.sqrt(Cc)).to(torch.float16).to(dev())
+    b = torch.randn((Cout,), generator=g).to(dev())
+    pwp = torch.empty_like(pw)
+    st = _abi.stream_ptr(dev())
+    _abi.check(lib.emp_sepconv5x5_pack_pw(_abi.ptr(pw), Cc, Cc, Cout, _abi.ptr(pwp), st), 'pack')
+
+    def fused():
+        out = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev())
+        _abi.check(lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(x), N, H, W, Cc, Cc, _abi.ptr(dw), _abi.ptr(pwp), _abi.ptr(b), Cout,
+                                               1, _abi.ptr(out), Cout, None, None, 0, None, st), 'sepconv')
+        return out
+
+    mid = torch.empty((N, H, W, Cc), dtype=torch.float16, device=dev())
+    ref = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev())
+    _abi.check(lib.emp_dwconv_nhwc_f16(_abi.ptr(x), N, H, W, Cc, Cc, _abi.ptr(dw), 5, _abi.ptr(mid), Cc, st), 'dw')
+    _abi.check(lib.emp_conv2d_nhwc_f16(_abi.ptr(mid), N, H, W, Cc, Cc, _abi.ptr(pw), _abi.ptr(b), None, None, 0,
+                                       _abi.ptr(ref), Cout, Cout, 1, 1, 1, 0, 1, 1, 0, st), 'pw')
+    for _ in range(20):
+        assert torch.equal(fused(), ref)
+
+
+def test_stem_pool_repeatable():
+    from gpu_common import dev
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    x = torch.from_numpy(synth.em_tiles(4, 512, seed=9))[:, None].to(dev())
+    model(x, 2, False, sub=146.8, mul=0.0307)
+    first = model.tap('p1').clone()
+    for _ in range(5):
+        model(x, 2, False, sub=146.8, mul=0.0307)
+        assert torch.equal(model.tap('p1'), first)
