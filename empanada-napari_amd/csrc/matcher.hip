@@ -33,6 +33,7 @@ struct Track {
   int64_t label;
   int64_t box[6];
   std::vector<int64_t> starts, runs;
+  std::vector<int64_t> yz;   // yz stacks before finish(): (start in the (D,H) plane, length, x) triples
 };
 
 int64_t intersection_sorted(const std::vector<int64_t>& s1, const std::vector<int64_t>& r1,
@@ -334,11 +335,10 @@ int emp_sm_track(emp_stack_matcher* h, int64_t idx, int64_t index2d) {
       } else if (h->axis == 1) {              // plane (D,W) at row index2d: runs along x stay runs
         t->starts.push_back((st / W) * (H * W) + index2d * W + (st % W));
         t->runs.push_back(rn);
-      } else {                                // plane (D,H) at column index2d: every voxel is its own run
-        for (int64_t f = st; f < st + rn; ++f) {
-          t->starts.push_back((f / H) * (H * W) + (f % H) * W + index2d);
-          t->runs.push_back(1);
-        }
+      } else {                                // plane (D,H) at column index2d: every voxel is its own run;
+        t->yz.push_back(st);                  // kept as the 2-D run until finish() turns the object around
+        t->yz.push_back(rn);
+        t->yz.push_back(index2d);
       }
     }
   }
@@ -348,15 +348,85 @@ int emp_sm_track(emp_stack_matcher* h, int64_t idx, int64_t index2d) {
 int emp_sm_tracker_finish(emp_stack_matcher* h) {
   EMP_REQUIRE(h != nullptr, "sm_tracker_finish: null handle");
   if (h->axis == 2) {
-    for (Track& t : h->tracks) {       // tracker.py:113-120: sort the voxels, re-encode
-      std::vector<int64_t> v(t.starts);
-      std::sort(v.begin(), v.end());      // plain integers: a stable sort (as numpy's kind='stable') gives the same order
+    // tracker.py:84-88,111-120: every voxel of a yz object becomes a run of 1 at its raveled (z,y,x) index, the
+    // indices are sorted and re-encoded.  Same result without the sort: the object's voxels are marked in a bitmap
+    // over its bounding box (rows = (z,y), bits = x) and the rows are scanned in order; a run that ends at the last
+    // column continues into column 0 of the next row exactly when the raveled indices are consecutive.
+    const int64_t H = h->H, W = h->W;
+    std::vector<uint64_t> bits;
+    for (Track& t : h->tracks) {
+      const int64_t z0 = t.box[0], y0 = t.box[1], x0 = t.box[2];
+      const int64_t nz = t.box[3] - z0, ny = t.box[4] - y0, nx = t.box[5] - x0;
+      const int64_t wpr = (nx + 63) / 64;                    // words per row
+      const int64_t words = nz * ny * wpr;
       t.starts.clear();
       t.runs.clear();
-      for (size_t i = 0; i < v.size(); ++i) {
-        if (i > 0 && v[i] == v[i - 1] + 1) ++t.runs.back();
-        else { t.starts.push_back(v[i]); t.runs.push_back(1); }
+      if (words > ((int64_t)1 << 27)) {                      // > 1 GiB of bitmap: sort the voxels instead
+        std::vector<int64_t> v;
+        for (size_t i = 0; i < t.yz.size(); i += 3)
+          for (int64_t f = t.yz[i]; f < t.yz[i] + t.yz[i + 1]; ++f) v.push_back((f / H) * (H * W) + (f % H) * W + t.yz[i + 2]);
+        std::sort(v.begin(), v.end());
+        for (size_t i = 0; i < v.size(); ++i) {
+          if (i > 0 && v[i] == v[i - 1] + 1) ++t.runs.back();
+          else { t.starts.push_back(v[i]); t.runs.push_back(1); }
+        }
+      } else {
+        bits.assign((size_t)words, 0);
+        for (size_t i = 0; i < t.yz.size(); i += 3) {
+          const int64_t f0 = t.yz[i], len = t.yz[i + 1], bx = t.yz[i + 2] - x0;
+          int64_t z = f0 / H, y = f0 % H;
+          int64_t row = (z - z0) * ny + (y - y0);
+          const int64_t wofs = bx >> 6;
+          const uint64_t bit = (uint64_t)1 << (bx & 63);
+          for (int64_t k = 0; k < len; ++k) {
+            bits[(size_t)(row * wpr + wofs)] |= bit;
+            if (++y == H) { y = 0; ++z; row = (z - z0) * ny - y0; }   // a 2-D run may wrap into the next z row
+            else ++row;
+          }
+        }
+        const uint64_t* wp = bits.data();
+        for (int64_t z = 0; z < nz; ++z)
+          for (int64_t y = 0; y < ny; ++y, wp += wpr) {
+            const int64_t row0 = (z + z0) * (H * W) + (y + y0) * W + x0;
+            int64_t open = -1;                               // first column of the run being scanned
+            for (int64_t wi = 0; wi < wpr; ++wi) {
+              uint64_t m = wp[wi];
+              const int64_t c0 = wi * 64;
+              if (m == 0) {
+                if (open >= 0) { t.starts.push_back(row0 + open); t.runs.push_back(c0 - open); open = -1; }
+                continue;
+              }
+              if (m == ~(uint64_t)0) { if (open < 0) open = c0; continue; }
+              int64_t pos = 0;
+              while (pos < 64) {
+                if (open < 0) {                               // look for the next set bit
+                  const uint64_t rest = m >> pos;
+                  if (rest == 0) break;
+                  pos += __builtin_ctzll(rest);
+                  open = c0 + pos;
+                } else {                                      // look for the next clear bit
+                  const uint64_t inv = (~m) >> pos;
+                  if (inv == 0) break;                        // the run continues into the next word
+                  pos += __builtin_ctzll(inv);
+                  t.starts.push_back(row0 + open);
+                  t.runs.push_back(c0 + pos - open);
+                  open = -1;
+                }
+              }
+            }
+            if (open >= 0) { t.starts.push_back(row0 + open); t.runs.push_back(wpr * 64 - open); }
+          }
+        // (padding bits of a row are never set, so a run is still open at the end of a row only when nx % 64 == 0)
+        // runs that touch in raveled order (column W-1 -> column 0 of the next row) are joined here
+        size_t o = 0;
+        for (size_t i = 0; i < t.starts.size(); ++i) {
+          if (o > 0 && t.starts[o - 1] + t.runs[o - 1] == t.starts[i]) t.runs[o - 1] += t.runs[i];
+          else { t.starts[o] = t.starts[i]; t.runs[o] = t.runs[i]; ++o; }
+        }
+        t.starts.resize(o);
+        t.runs.resize(o);
       }
+      std::vector<int64_t>().swap(t.yz);
     }
   }
   h->finished = true;

@@ -454,23 +454,46 @@ int emp_rle_pair_intersections(const int64_t* h_starts, const int64_t* h_runs, c
 // output ranges through *n_out; h_out must hold n ranges.
 int emp_ranges_vote(const int64_t* h_ranges, int64_t n, int thr, int64_t* h_out, int64_t* n_out) {
   EMP_REQUIRE(h_ranges && h_out && n_out && n >= 0 && thr >= 1, "ranges_vote: bad arguments");
-  std::vector<std::pair<int64_t, int>> ev;
-  ev.reserve((size_t)n * 2);
+  // starts and ends are swept as two sorted sequences (the coverage right of a coordinate does not depend on the order
+  // of the events AT that coordinate).  The callers concatenate a few already sorted run lists, so the sort is a
+  // merge of the ascending stretches found in the input; arbitrary input falls back to std::sort.
+  std::vector<int64_t> st, en;
+  st.reserve((size_t)n);
+  en.reserve((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
     if (h_ranges[2 * i + 1] <= h_ranges[2 * i]) continue;
-    ev.emplace_back(h_ranges[2 * i], +1);
-    ev.emplace_back(h_ranges[2 * i + 1], -1);
+    st.push_back(h_ranges[2 * i]);
+    en.push_back(h_ranges[2 * i + 1]);
   }
-  // at equal coordinates starts (+1) sort before ends (-1): touching ranges stay chained
-  std::sort(ev.begin(), ev.end(), [](const std::pair<int64_t, int>& x, const std::pair<int64_t, int>& y) {
-    return x.first != y.first ? x.first < y.first : x.second > y.second;
-  });
+  auto natural_sort = [](std::vector<int64_t>& v) {
+    std::vector<size_t> cut{0};
+    for (size_t i = 1; i < v.size(); ++i)
+      if (v[i] < v[i - 1]) {
+        cut.push_back(i);
+        if (cut.size() > 64) { std::sort(v.begin(), v.end()); return; }
+      }
+    cut.push_back(v.size());
+    while (cut.size() > 2) {              // merge neighbouring stretches pairwise
+      std::vector<size_t> next{0};
+      for (size_t k = 0; k + 2 < cut.size(); k += 2) {
+        std::inplace_merge(v.begin() + cut[k], v.begin() + cut[k + 1], v.begin() + cut[k + 2]);
+        next.push_back(cut[k + 2]);
+      }
+      if (next.back() != v.size()) next.push_back(v.size());
+      cut.swap(next);
+    }
+  };
+  natural_sort(st);
+  natural_sort(en);
   int64_t cnt = 0, m = 0, open_at = 0;
   bool open = false;
-  for (size_t k = 0; k < ev.size();) {
-    const int64_t pos = ev[k].first;
-    while (k < ev.size() && ev[k].first == pos) cnt += ev[k++].second;  // net coverage just right of pos
-    const bool ok = cnt >= thr;
+  size_t i = 0, j = 0;
+  const size_t N = st.size();
+  while (j < N) {                         // every start is followed by its end, so the ends run out last
+    const int64_t pos = (i < N && st[i] <= en[j]) ? st[i] : en[j];
+    while (i < N && st[i] == pos) { ++cnt; ++i; }
+    while (j < N && en[j] == pos) { --cnt; ++j; }
+    const bool ok = cnt >= thr;           // net coverage just right of pos: touching ranges stay chained
     if (ok && !open) { open = true; open_at = pos; }
     else if (!ok && open) {
       open = false;

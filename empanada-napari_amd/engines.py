@@ -333,6 +333,21 @@ class PanopticDeepLabRenderEngine(_Engine):
         pan_seg = self.panoptic_merge_int(model_out['sem'], cells, kmax)
         return pan_seg[..., :h, :w]
 
+    @torch.no_grad()
+    def call_raw(self, image, sub, mul):
+        """``__call__`` for a raw integer image (1,1,h,w) uint8/uint16 at native scale: Preprocessor's
+        (x - mean*max) * 1/(std*max) and ``factor_pad`` run inside the stem kernel (1-2 bytes per pixel uploaded
+        instead of 4).  Same result as ``self(preprocessor(image), (h, w))``."""
+        assert image.ndim == 4 and image.size(0) == 1
+        h, w = image.shape[-2:]
+        pf = self.padding_factor
+        pad_to = (-(-h // pf) * pf, -(-w // pf) * pf)
+        out = self.model(self.to_model_device(image), 2, interpolate_ins=not self.coarse_boundaries, sub=float(sub),
+                         mul=float(mul), pad_to=pad_to)
+        sem = logits_to_prob(out['sem_logits'])
+        cells, _, _, kmax = self.instance_cells_int(out['ctr_hmp'], out['offsets'], 1)
+        return self.panoptic_merge_int(sem, cells, kmax)[..., :h, :w]
+
     # ---- batched extension (config 2: "equal to N sequential reference calls") ----
     @torch.no_grad()
     def infer_batch(self, images, sizes=None, upsampling=1, sub=0.0, mul=1.0):

@@ -73,12 +73,12 @@ def _open_zarr(store_url, mode=None):
 def _class_volume(zarr_store, name, shape, dtype, chunks):
     if zarr_store is not None:
         return zarr_store.create_array(name, shape=shape, dtype=dtype, overwrite=True, chunks=chunks)
-    return np.zeros(shape, dtype=dtype)
+    return np.empty(shape, dtype=dtype)      # every voxel is written by _fill(..., fresh=True)
 
 
 def _fill(volume, instances):
     if isinstance(volume, np.ndarray):
-        sparse.fill_volume(volume, instances)
+        sparse.fill_volume(volume, instances, fresh=True)
     else:  # chunked store (zarr): stream slab by slab
         sparse.chunked_fill(volume, instances)
 
@@ -182,13 +182,20 @@ class Engine2d:
             cc, _ = sparse.ccl8(inst[None])
             cc = cc[0]
             pan = torch.where(cc > 0, cc + lo, pan)
-        return pan.cpu().numpy().astype(np.int32)
+        return pan.cpu().numpy().astype(np.int32, copy=False)
 
     def infer(self, image):
         if self.tile_size > 0 and any(s > self.tile_size for s in image.shape):
             return self._infer_tiled(image)
         _require_scale_one(self.inference_scale)
         size = image.shape
+        if (isinstance(image, np.ndarray) and image.ndim == 2 and image.dtype in (np.uint8, np.uint16)
+                and self.inference_scale == 1):
+            # raw integers go up (1-2 B/pixel); normalisation + factor_pad are fused into the stem kernel
+            from .preprocess import normalize_params
+            sub, mul = normalize_params(self.preprocessor.mean, self.preprocessor.std, np.iinfo(image.dtype).max)
+            x = torch.from_numpy(np.ascontiguousarray(image))[None, None]
+            return self.force_connected(self.engine.call_raw(x, sub, mul).squeeze(0))
         x = self.preprocessor(resize_by_factor(image, self.inference_scale))['image'].unsqueeze(0)
         pan_seg = self.engine(x, size, upsampling=self.inference_scale)
         return self.force_connected(pan_seg.squeeze(0))

@@ -12,10 +12,14 @@ calls (matcher.py:213, consensus.py:2).  Dict schema is the reference's:
 """
 import ctypes as C
 import math
+import os
+from concurrent.futures import ThreadPoolExecutor
 from itertools import combinations
 
+import networkx as nx
 import numpy as np
 import torch
+from scipy.optimize import linear_sum_assignment
 
 from . import _abi
 
@@ -293,7 +297,6 @@ def _unpack(rles):
 
 def rle_matcher(target_rles, match_rles, iou_thr=0.5):
     """matcher.py:136-232 (return_ioa=True form) -> (matched, [target_labels, match_labels], ious, ioa_matrix)."""
-    from scipy.optimize import linear_sum_assignment
     tl, tb, tobj = _unpack(target_rles)
     ml, mb, mobj = _unpack(match_rles)
     if len(tl) == 0 or len(ml) == 0:
@@ -416,7 +419,6 @@ class StackMatcher:
                                                       _hp(runs)), 'emp_sm_push_slice_objects')
 
     def _step(self, idx):
-        from scipy.optimize import linear_sum_assignment
         nt, nm = C.c_int(0), C.c_int(0)
         _abi.check(self.lib.emp_sm_step_begin(self._h, int(idx), C.byref(nt), C.byref(nm)), 'emp_sm_step_begin')
         if nt.value < 0:
@@ -604,7 +606,6 @@ def _avg_weight(G, c1, c2, key):
 
 
 def _cluster_graph(G, thr):
-    import networkx as nx
     H = G.copy()
     H.remove_edges_from([(u, v) for u, v, d in G.edges(data=True) if d['iou'] <= thr])
     CG = nx.Graph()
@@ -645,7 +646,6 @@ def _merge_clusters(G):
 
 def _merge_overlapping(cluster_instances):
     """consensus.py:166-197."""
-    import networkx as nx
     if len(cluster_instances) < 2:
         return list(cluster_instances.values())
     ids = list(cluster_instances)
@@ -670,7 +670,6 @@ def _merge_overlapping(cluster_instances):
 
 def merge_objects_from_trackers(object_trackers, pixel_vote_thr=2, cluster_iou_thr=0.75, bypass=False):
     """consensus.py:348-469."""
-    import networkx as nx
     n_votes = len(object_trackers)
     min_cluster = 1 if bypass else n_votes // 2 + 1
     if pixel_vote_thr < min_cluster:
@@ -696,12 +695,14 @@ def merge_objects_from_trackers(object_trackers, pixel_vote_thr=2, cluster_iou_t
     for (a, b), it in zip(p, inter):
         if it > 0:
             G.add_edge(int(a), int(b), iou=it / (area[a] + area[b] - it), overlap=it)
-    instances, next_id = {}, 1
+    # graph work first (sequential, order defines the output ids), then the per-cluster pixel votes -- independent
+    # range sweeps in C++ that release the GIL -- on a small thread pool, then the per-component assembly
+    comps = []
     for comp in nx.connected_components(G):
         if len(comp) < min_cluster:
             continue
         CG = _merge_clusters(_cluster_graph(G.subgraph(comp), cluster_iou_thr))
-        cluster_instances, cid = {}, 1
+        clusters = []
         for node in CG.nodes:
             cluster = list(CG.nodes[node]['cluster'])
             if len(cluster) < min_cluster:
@@ -709,8 +710,23 @@ def merge_objects_from_trackers(object_trackers, pixel_vote_thr=2, cluster_iou_t
             box = tuple(int(v) for v in boxes[cluster[0]])
             for n in cluster[1:]:
                 box = merge_boxes(box, tuple(int(v) for v in boxes[n]))
-            voted = vote_by_ranges([np.stack([objs[n][0], objs[n][0] + objs[n][1]], axis=1) for n in cluster],
-                                   pixel_vote_thr)
+            clusters.append((box, cluster))
+        comps.append(clusters)
+
+    def vote(cluster):
+        return vote_by_ranges([np.stack([objs[n][0], objs[n][0] + objs[n][1]], axis=1) for n in cluster], pixel_vote_thr)
+
+    jobs = [cluster for clusters in comps for _, cluster in clusters]
+    if len(jobs) > 1:
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1, len(jobs))) as pool:
+            votes = iter(list(pool.map(vote, jobs)))
+    else:
+        votes = iter([vote(c) for c in jobs])
+    instances, next_id = {}, 1
+    for clusters in comps:
+        cluster_instances, cid = {}, 1
+        for box, _ in clusters:
+            voted = next(votes)
             if len(voted) > 0:
                 cluster_instances[cid] = {'box': box, 'starts': voted[:, 0], 'runs': voted[:, 1] - voted[:, 0]}
                 cid += 1
@@ -762,7 +778,6 @@ def merge_objects_from_tiles(tiles, overlap_rle=None):
     """Objects seen by several tiles become one (union of runs per connected cluster); with ``overlap_rle`` an
     object seen by a single tile with more than 10 % of its area in the overlap band is dropped
     (consensus.py:523-625)."""
-    import networkx as nx
     src, labels, boxes, objs = [], [], [], []
     for ti, t in enumerate(tiles):
         for iid, a in t.items():
@@ -841,19 +856,27 @@ def _instance_runs(instances):
 
 
 @torch.no_grad()
-def fill_volume(volume, instances, device=None):
+def fill_volume(volume, instances, device=None, fresh=False):
     """Fills ``volume`` (numpy array or cuda tensor) in place with the instances' ids; where instances overlap the
-    later one in the dict wins, as in the reference's sequential fill (array_utils.py:754-766)."""
+    later one in the dict wins, as in the reference's sequential fill (array_utils.py:754-766).  ``fresh``: the
+    caller just allocated the (numpy) volume and wants zeros elsewhere -- its current content is not uploaded."""
+    is_np = isinstance(volume, np.ndarray)
     if not instances:
+        if fresh:
+            volume[...] = 0
         return volume
     starts, lens, vals, order = _instance_runs(instances)
-    is_np = isinstance(volume, np.ndarray)
     dev = _dev(device) if is_np else volume.device
-    dvol = torch.from_numpy(volume).to(dev) if is_np else volume
+    if is_np:
+        host = torch.from_numpy(volume)
+        assert host.is_contiguous()
+        dvol = torch.zeros(host.shape, dtype=host.dtype, device=dev) if fresh else host.to(dev)
+    else:
+        dvol = volume.zero_() if fresh else volume
     assert dvol.is_contiguous()
     _fill_device(dvol, starts, lens, vals, order)
     if is_np:
-        volume[...] = dvol.cpu().numpy()
+        host.copy_(dvol)       # one device -> host copy straight into the caller's array
     return volume
 
 

@@ -57,8 +57,21 @@ def blob_image(h, w, seed=0, n_blobs=8):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-def blob_volume(d, h, w, seed=0, n_blobs=8):
+def blob_volume(d, h, w, seed=0, n_blobs=8, fast=False):
+    """Gaussian blobs + noise, uint8 (the reference's test volumes, test_button_widgets.py:119-140, at any size).
+    ``fast``: the same blobs summed as one GEMM of separable factors (float32 rounding differs in isolated voxels from
+    the plain form the small test fixtures were made with); for the 512^3 bench volume this is seconds, not minutes."""
     rng = np.random.default_rng(seed)
+    if fast:
+        s = max(d, h, w) / 100.0
+        par = np.array([[rng.uniform(0, w), rng.uniform(0, h), rng.uniform(0, d), rng.uniform(4, 10) * s,
+                         rng.uniform(120, 255)] for _ in range(n_blobs)], dtype=np.float64)
+        g = lambda n, c: np.exp(-((np.arange(n)[None, :] - c[:, None]) ** 2) / (2 * par[:, 3:4] ** 2)).astype(np.float32)
+        ez, ey, ex = g(d, par[:, 2]), g(h, par[:, 1]), g(w, par[:, 0])
+        plane = (ey[:, :, None] * ex[:, None, :]).reshape(n_blobs, h * w)
+        vol = ((ez * par[:, 4:5].astype(np.float32)).T @ plane).reshape(d, h, w)
+        vol += rng.normal(0, 10, size=vol.shape).astype(np.float32)
+        return np.clip(vol, 0, 255).astype(np.uint8)
     z, y, x = np.mgrid[0:d, 0:h, 0:w]
     vol = np.zeros((d, h, w), dtype=np.float32)
     s = max(d, h, w) / 100.0

@@ -102,6 +102,12 @@ def test_engine2d_force_connected(model_config):
     np.testing.assert_array_equal(got, osp.force_connected_pan(raw.copy(), [1], DIV))
     with pytest.raises(Exception, match='float'):
         eng.infer(img.astype(np.float32))                     # Preprocessor contract, utils.py:196-197
+    # uint16 input is normalised by 65535 (utils.py:199-200); the raw-integer upload (normalisation fused into the
+    # stem) must give the same labels as the host Preprocessor + factor_pad route
+    img16 = img.astype(np.uint16) * 257
+    x16 = eng.preprocessor(img16)['image'].unsqueeze(0)
+    raw16 = eng.engine(x16, img16.shape, 1).squeeze(0).cpu().numpy().astype(np.int32)
+    np.testing.assert_array_equal(eng.infer(img16), osp.force_connected_pan(raw16.copy(), [1], DIV))
 
 
 def test_batched_slices_equal_single_slice_calls(model_config):

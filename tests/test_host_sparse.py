@@ -201,3 +201,33 @@ def test_cpp_stack_matcher_empty_slices_and_semantic_class():
     st.forward()
     inst = st.backward_and_track('xy', (2, 2, 8))
     assert list(inst) == [2000] and inst[2000]['starts'].tolist() == [24, 1] and inst[2000]['box'] == (0, 0, 0, 2, 2, 3)
+
+
+@pytest.mark.parametrize('shape,density', [((5, 7, 128), 0.6), ((3, 4, 64), 1.0), ((4, 6, 70), 0.9), ((2, 3, 200), 0.5),
+                                           ((6, 5, 1), 0.7)])
+def test_cpp_yz_tracker_bitmap_equals_sort_and_encode(shape, density):
+    """yz stacks: the C++ tracker turns each object around through a bitmap over its box; the reference decodes to
+    voxels, sorts and re-encodes (tracker.py:84-88,111-120).  Dense / full-width masks make runs continue across
+    rows of the raveled volume, widths of 64k exercise the open-run-at-row-end case, 2-D runs wrap across plane rows."""
+    rng = np.random.default_rng(hash(shape) % 1000)
+    mask = rng.random(shape) < density
+    D, H, W = shape
+    sm = ps.StackMatcher(2, 1000, match=False)
+    ot = osp.InstanceTracker(2, 1000, shape, 'yz')
+    for x in range(W):
+        flat = np.flatnonzero(mask[:, :, x].ravel())
+        seg = {}
+        if len(flat):
+            st, rn = osp.rle_encode(flat)
+            zz, yy = np.unravel_index(flat, (D, H))
+            seg = {2000: {'box': (int(zz.min()), int(yy.min()), int(zz.max()) + 1, int(yy.max()) + 1), 'starts': st, 'runs': rn}}
+        sm.push_objects(seg)
+        ot.update(seg, x)
+    ot.finish()
+    sm.forward()
+    inst = sm.backward_and_track('yz', shape)
+    assert list(inst) == list(ot.instances) == [2000]
+    np.testing.assert_array_equal(inst[2000]['starts'], ot.instances[2000]['starts'])
+    np.testing.assert_array_equal(inst[2000]['runs'], ot.instances[2000]['runs'])
+    assert tuple(inst[2000]['box']) == tuple(ot.instances[2000]['box'])
+    np.testing.assert_array_equal(np.sort(osp.rle_decode(inst[2000]['starts'], inst[2000]['runs'])), np.flatnonzero(mask.ravel()))

@@ -27,10 +27,10 @@ def main():
     model = HipPanopticDeepLab(P, cfg, folded=True)
     mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
           'norms': {'mean': 0.57571, 'std': 0.12765}}
-    vol = synth.blob_volume(size, size, size, seed=0, n_blobs=max(8, (size // 32) ** 2))
+    vol = synth.blob_volume(size, size, size, seed=0, n_blobs=max(8, (size // 32) ** 2), fast=True)
     eng = Engine3d(mc, label_divisor=10000, median_kernel_size=3, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5,
                    min_size=500, min_extent=5, batch_size=batch)
-    eng.predict_slices(vol[:batch], 0)  # warm-up (arena allocation, first-touch)
+    eng.infer_on_axis(vol[:batch], 'xy')  # warm-up: arena allocation, first launches of every kernel on the path
     torch.cuda.synchronize()
     t = {}
     t0 = time.perf_counter()
