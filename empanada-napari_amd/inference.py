@@ -230,7 +230,7 @@ class Engine3d:
                  void_label=0, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.3, force_connected=True,
                  min_size=500, min_extent=4, fine_boundaries=False, semantic_only=False, use_gpu=True,
                  use_quantized=False, store_url=None, chunk_size=(256, 256, 256), save_panoptic=False,
-                 label_erosion=0, label_dilation=0, fill_holes_in_segmentation=False, batch_size=8):
+                 label_erosion=0, label_dilation=0, fill_holes_in_segmentation=False, batch_size=None):
         if not (torch.cuda.is_available() and use_gpu):
             raise RuntimeError('Engine3d: the MI355X engine has no CPU path (use_gpu=True and a HIP device required)')
         device = torch.device('cuda:0')
@@ -301,6 +301,13 @@ class Engine3d:
         return None
 
     @torch.no_grad()
+    def slice_batch(self, padded_hw):
+        """Slices per forward launch group: ``batch_size`` if given, else about 16 Mpixel per batch (64 slices of 512^2,
+        16 of 1024^2, one of 4096^2) -- enough pixels to fill 256 CUs in the deep layers without growing the arena."""
+        if self.batch_size:
+            return int(self.batch_size)
+        return int(max(1, min(64, (1 << 24) // max(1, int(padded_hw[0]) * int(padded_hw[1])))))
+
     def predict_slices(self, volume, axis):
         """Per-slice panoptic maps (device, int64 (h,w)) in slice order.
 
@@ -379,15 +386,20 @@ class Engine3d:
             vh, vw = moved.shape[1:]
             pad_to = (-(-vh // pf) * pf, -(-vw // pf) * pf)
             size = (vh, vw)
-        for i0 in range(0, n, self.batch_size):
+        if raw_path:
+            bs = self.slice_batch(pad_to)
+        else:
+            shp = [s for i, s in enumerate(volume.shape) if i != axis]
+            bs = self.slice_batch((math.ceil(shp[0] / ups), math.ceil(shp[1] / ups)))
+        for i0 in range(0, n, bs):
             if raw_path:
-                xb = (moved[i0:i0 + self.batch_size].contiguous() if on_dev else
-                      torch.from_numpy(np.ascontiguousarray(moved[i0:i0 + self.batch_size])))[:, None]
+                xb = (moved[i0:i0 + bs].contiguous() if on_dev else
+                      torch.from_numpy(np.ascontiguousarray(moved[i0:i0 + bs])))[:, None]
                 mo = eng.model(xb.to(eng.model.device, non_blocking=True), rs, interpolate_ins=not eng.coarse_boundaries,
                                sub=float(sub), mul=float(mul), pad_to=pad_to)
                 nb = xb.shape[0]
             else:
-                raws = [np.asarray(take(volume, i, axis)) for i in range(i0, min(n, i0 + self.batch_size))]
+                raws = [np.asarray(take(volume, i, axis)) for i in range(i0, min(n, i0 + bs))]
                 size = tuple(raws[0].shape[-2:])          # label maps come back at the ORIGINAL slice size
                 imgs = [self.preprocessor(resize_by_factor(r, ups))['image'] for r in raws]
                 x = factor_pad(torch.stack(imgs), eng.padding_factor)

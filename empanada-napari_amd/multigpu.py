@@ -95,12 +95,14 @@ def distributed_filtered_sem(raw, ks, median_fn, group=None):
     return out
 
 
-def distributed_stack_inference(n_slices, forward_fn, median_fn, segment_fn, to_rle_fn, ks, group=None):
+def distributed_stack_inference(n_slices, forward_fn, median_fn, segment_fn, to_rle_fn, ks, group=None,
+                                segment_batch_fn=None):
     """SPMD body of one axis.
 
     forward_fn(lo, hi)  -> list of per-slice dicts with at least 'sem' (tensor) for slices [lo, hi)
     median_fn(list)     -> per-pixel median of an odd number of 'sem' tensors
     segment_fn(item)    -> panoptic map of one slice (any array type to_rle_fn accepts)
+    segment_batch_fn(items) -> the same for a list of slices at once (optional; replaces segment_fn)
     to_rle_fn(list)     -> list of rle_seg dicts for a list of panoptic maps
     Returns on rank 0 the list of rle_seg dicts of ALL slices in order, elsewhere None.
     """
@@ -109,11 +111,8 @@ def distributed_stack_inference(n_slices, forward_fn, median_fn, segment_fn, to_
     lo, hi = slab_bounds(n_slices, world)[rank]
     items = forward_fn(lo, hi)
     sems = distributed_filtered_sem([it['sem'] for it in items], ks, median_fn, group)
-    pans = []
-    for it, s in zip(items, sems):
-        it = dict(it)
-        it['sem'] = s
-        pans.append(segment_fn(it))
+    items = [dict(it, sem=s) for it, s in zip(items, sems)]
+    pans = segment_batch_fn(items) if segment_batch_fn is not None else [segment_fn(it) for it in items]
     segs = to_rle_fn(pans) if pans else []
     gathered = [None] * world if rank == 0 else None
     dist.gather_object(segs, gathered, dst=0, group=group)
@@ -127,15 +126,16 @@ class MultiGPUEngine3d:
     every rank of an initialised ``torch.distributed`` group (``torchrun``, backend ``nccl`` = RCCL)
     constructs the engine and calls ``infer_on_axis``; rank 0 gets ``(stack, trackers)``, the others
     ``(None, None)``."""
+    MIN_WORLD = 2
 
     def __init__(self, model_config, inference_scale=1, label_divisor=1000, median_kernel_size=5, stuff_area=64,
                  void_label=0, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.3, force_connected=True,
                  min_size=500, min_extent=4, fine_boundaries=False, semantic_only=False, store_url=None,
-                 chunk_size=(256, 256, 256), save_panoptic=False, batch_size=8, group=None):
+                 chunk_size=(256, 256, 256), save_panoptic=False, batch_size=None, group=None):
         from .inference import Engine3d
         if not dist.is_initialized():
             raise Exception('MultiGPUEngine3d needs an initialised torch.distributed process group')
-        if dist.get_world_size(group) < 2:
+        if dist.get_world_size(group) < self.MIN_WORLD:
             raise Exception('MultiGPU inference requires 2 or more GPUs!')   # multigpu.py:143-144
         self.group = group
         self.local = Engine3d(model_config, inference_scale, label_divisor, median_kernel_size, stuff_area, void_label,
@@ -152,18 +152,39 @@ class MultiGPUEngine3d:
         axis = e3.axes[axis_name]
         rs = int(2 + math.log(e3.inference_scale, 2))
 
+        raw_path = isinstance(volume, np.ndarray) and volume.dtype in (np.uint8, np.uint16) and e3.inference_scale == 1
+        if raw_path:   # as Engine3d.predict_slices: raw integers go up, normalisation + factor_pad run in the stem kernel
+            from .preprocess import normalize_params
+            sub, mul = normalize_params(e3.preprocessor.mean, e3.preprocessor.std, np.iinfo(volume.dtype).max)
+            moved = np.moveaxis(volume, axis, 0)
+            pf = eng.padding_factor
+            size = tuple(moved.shape[1:])
+            pad_to = (-(-size[0] // pf) * pf, -(-size[1] // pf) * pf)
+            bs = e3.slice_batch(pad_to)
+
         def forward_fn(lo, hi):
+            from .inference import take
             items = []
-            for i0 in range(lo, hi, e3.batch_size):
-                from .inference import take
-                imgs = [e3.preprocessor(np.asarray(take(volume, i, axis)))['image'] for i in range(i0, min(hi, i0 + e3.batch_size))]
-                size = tuple(imgs[0].shape[-2:])
+            if raw_path:
+                for i0 in range(lo, hi, bs):
+                    xb = torch.from_numpy(np.ascontiguousarray(moved[i0:min(hi, i0 + bs)]))[:, None]
+                    mo = eng.model(xb.to(eng.model.device, non_blocking=True), rs, interpolate_ins=not eng.coarse_boundaries,
+                                   sub=float(sub), mul=float(mul), pad_to=pad_to)
+                    sem = logits_to_prob(mo['sem_logits'])
+                    for j in range(xb.shape[0]):
+                        items.append({'ctr_hmp': mo['ctr_hmp'][j:j + 1], 'offsets': mo['offsets'][j:j + 1],
+                                      'sem': sem[j:j + 1], 'size': size})
+                return items
+            for i0 in range(lo, hi, e3.batch_size or 8):
+                imgs = [e3.preprocessor(np.asarray(take(volume, i, axis)))['image']
+                        for i in range(i0, min(hi, i0 + (e3.batch_size or 8)))]
+                size_ = tuple(imgs[0].shape[-2:])
                 x = eng.to_model_device(factor_pad(torch.stack(imgs), eng.padding_factor))
                 mo = eng.model(x, rs, interpolate_ins=not eng.coarse_boundaries)
                 sem = logits_to_prob(mo['sem_logits'])
                 for j in range(x.shape[0]):
-                    items.append({'ctr_hmp': mo['ctr_hmp'][j:j + 1].clone(), 'offsets': mo['offsets'][j:j + 1].clone(),
-                                  'sem': sem[j:j + 1].clone(), 'size': size})
+                    items.append({'ctr_hmp': mo['ctr_hmp'][j:j + 1], 'offsets': mo['offsets'][j:j + 1],
+                                  'sem': sem[j:j + 1], 'size': size_})
             return items
 
         def median_fn(maps):
@@ -178,6 +199,19 @@ class MultiGPUEngine3d:
             h, w = item['size']
             return eng._segment(item, e3.inference_scale)[0, :h, :w]
 
+        def segment_batch_fn(items):
+            """voting + merge of the slab in launch groups of up to 64 slices (one host sync per group)"""
+            pans = []
+            for i0 in range(0, len(items), 64):
+                grp = items[i0:i0 + 64]
+                cells, _, _, kmax = eng.instance_cells_int(torch.cat([it['ctr_hmp'] for it in grp]),
+                                                           torch.cat([it['offsets'] for it in grp]), e3.inference_scale)
+                pan = eng.panoptic_merge_int(torch.cat([it['sem'] for it in grp]), cells, kmax)
+                for j, it in enumerate(grp):
+                    h, w = it['size']
+                    pans.append(pan[j, :h, :w])
+            return pans
+
         def to_rle_fn(pans):
             out = []
             for i0 in range(0, len(pans), 64):
@@ -186,7 +220,8 @@ class MultiGPUEngine3d:
             return out
 
         n = volume.shape[axis]
-        segs = distributed_stack_inference(n, forward_fn, median_fn, segment_fn, to_rle_fn, eng.ks, self.group)
+        segs = distributed_stack_inference(n, forward_fn, median_fn, segment_fn, to_rle_fn, eng.ks, self.group,
+                                           segment_batch_fn=segment_batch_fn)
         if segs is None:
             return None, None
         trackers = e3.create_trackers(volume.shape, axis_name)

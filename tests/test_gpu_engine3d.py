@@ -178,3 +178,37 @@ def test_engine2d_tiled_inference_equals_oracle_pipeline(model_config):
     want = osp.rle_seg_to_pan_seg(ref, img.shape)
     assert np.array_equal(out, want)
     assert len(np.unique(out)) > 2, 'degenerate test image: no instances'
+
+
+@pytest.mark.parametrize('dtype', [np.uint8, np.int16])
+def test_multigpu_engine_single_rank_equals_engine3d(model_config, monkeypatch, dtype):
+    """MultiGPUEngine3d on a one-rank group (the slab driver with no neighbours) must give Engine3d's trackers: same
+    forward (raw-integer upload for uint8; the host Preprocessor route otherwise), per-slice recursive median instead
+    of the run kernel, batched voting / merge, run lists through gather_object, C++ matcher on rank 0.
+    The N > 1 exchange logic is covered on CPU with gloo (tests/test_multigpu_cpu.py)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from empanada_napari_amd import multigpu, synth
+    from empanada_napari_amd.inference import Engine3d
+    vol = synth.blob_volume(10, 40, 56, seed=11)
+    if dtype is not np.uint8:
+        vol = vol.astype(np.int16) * 128           # an integer type that goes through the host Preprocessor route
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        monkeypatch.setattr(multigpu.MultiGPUEngine3d, 'MIN_WORLD', 1)
+        kw = dict(label_divisor=DIV, median_kernel_size=3, nms_kernel=3, confidence_thr=0.5, min_size=20, min_extent=2)
+        mg = multigpu.MultiGPUEngine3d(model_config, **kw)
+        e3 = Engine3d(model_config, **kw)
+        for axis in ('xy', 'yz'):
+            _, ta = mg.infer_on_axis(vol, axis)
+            _, tb = e3.infer_on_axis(vol, axis)
+            assert len(tb[0].instances) > 0
+            _same_instances(ta[0].instances, tb[0].instances)
+        with pytest.raises(Exception, match='2 or more'):
+            monkeypatch.setattr(multigpu.MultiGPUEngine3d, 'MIN_WORLD', 2)
+            multigpu.MultiGPUEngine3d(model_config, **kw)
+    finally:
+        dist.destroy_process_group()

@@ -21,7 +21,7 @@ from empanada_napari_amd.inference import Engine3d, tracker_consensus  # noqa: E
 
 def main():
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # 0: the engine picks (about 16 Mpixel per batch)
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
     model = HipPanopticDeepLab(P, cfg, folded=True)
@@ -29,8 +29,8 @@ def main():
           'norms': {'mean': 0.57571, 'std': 0.12765}}
     vol = synth.blob_volume(size, size, size, seed=0, n_blobs=max(8, (size // 32) ** 2), fast=True)
     eng = Engine3d(mc, label_divisor=10000, median_kernel_size=3, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5,
-                   min_size=500, min_extent=5, batch_size=batch)
-    eng.infer_on_axis(vol[:batch], 'xy')  # warm-up: arena allocation, first launches of every kernel on the path
+                   min_size=500, min_extent=5, batch_size=batch or None)
+    eng.infer_on_axis(vol[:batch or 64], 'xy')  # warm-up: arena allocation, first launches of every kernel on the path
     torch.cuda.synchronize()
     t = {}
     t0 = time.perf_counter()
