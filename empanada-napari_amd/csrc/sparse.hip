@@ -13,6 +13,8 @@
 //   emp_rle_pair_intersections   array_utils.py:344-407 (two-pointer merge)
 //   emp_ranges_vote              array_utils.py:461-639 (k-of-n vote; thr 1 = join_ranges :658-699)
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -434,7 +436,7 @@ int emp_rle_fill_ordered(const int64_t* d_starts, const int64_t* d_lens, const i
 int emp_rle_pair_intersections(const int64_t* h_starts, const int64_t* h_runs, const int64_t* h_off,
                                const int64_t* h_pairs, int64_t n_pairs, int64_t* h_out) {
   EMP_REQUIRE(h_starts && h_runs && h_off && h_pairs && h_out && n_pairs >= 0, "rle_pair_intersections: null argument");
-  for (int64_t k = 0; k < n_pairs; ++k) {
+  auto one = [&](int64_t k) {
     const int64_t a = h_pairs[2 * k], b = h_pairs[2 * k + 1];
     int64_t i = h_off[a], ie = h_off[a + 1], j = h_off[b], je = h_off[b + 1];
     int64_t tot = 0;
@@ -445,7 +447,25 @@ int emp_rle_pair_intersections(const int64_t* h_starts, const int64_t* h_runs, c
       if (e1 < e2) ++i; else ++j;
     }
     h_out[k] = tot;
+  };
+  // pairs are independent two-pointer merges: big jobs (consensus of whole-volume trackers) are spread over threads
+  int64_t work = 0;
+  for (int64_t k = 0; k < n_pairs; ++k)
+    work += (h_off[h_pairs[2 * k] + 1] - h_off[h_pairs[2 * k]]) + (h_off[h_pairs[2 * k + 1] + 1] - h_off[h_pairs[2 * k + 1]]);
+  unsigned nthr = std::thread::hardware_concurrency();
+  nthr = nthr > 16 ? 16 : nthr;
+  if ((int64_t)nthr > n_pairs) nthr = (unsigned)n_pairs;
+  if (work < (1 << 18) || nthr < 2) {
+    for (int64_t k = 0; k < n_pairs; ++k) one(k);
+    return EMP_OK;
   }
+  std::atomic<int64_t> next{0};
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nthr; ++t)
+    pool.emplace_back([&] {
+      for (int64_t k = next.fetch_add(1); k < n_pairs; k = next.fetch_add(1)) one(k);
+    });
+  for (auto& th : pool) th.join();
   return EMP_OK;
 }
 

@@ -16,6 +16,7 @@ filling, zarr stores when zarr is not installed.
 """
 import math
 import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -309,7 +310,11 @@ class Engine3d:
         return int(max(1, min(64, (1 << 24) // max(1, int(padded_hw[0]) * int(padded_hw[1])))))
 
     def predict_slices(self, volume, axis):
-        """Per-slice panoptic maps (device, int64 (h,w)) in slice order.
+        """Per-slice panoptic maps (device, int64 (h,w)) in slice order (see ``iter_slice_chunks``)."""
+        return [p for chunk in self.iter_slice_chunks(volume, axis) for p in chunk]
+
+    def iter_slice_chunks(self, volume, axis):
+        """Generator over consecutive groups of per-slice panoptic maps (device, int64 (h,w)), in slice order.
 
         Same arithmetic as feeding PanopticDeepLabRenderEngine3d.__call__ slice by slice
         (engines.py:363-394): f[z] = raw[z] for the first / last ``mid`` slices, otherwise
@@ -323,7 +328,6 @@ class Engine3d:
         ks, mid = eng.ks, eng.mid_idx
         ups = self.inference_scale
         rs = int(2 + math.log(ups, 2))
-        out = []
         fhist = []            # last `mid` filtered maps, each (1,C,H,W)
         pend = []             # raw (sem, ctr, off) of slices not yet emitted, each with batch dim 1..B
         zp = 0                # global index of the first pending slice
@@ -334,13 +338,13 @@ class Engine3d:
             cells, _, _, kmax = eng.instance_cells_int(ctr, off, ups)
             pan = eng.panoptic_merge_int(sem_f, cells, kmax)
             h, w = size
-            out.extend(pan[:, :h, :w].unbind(0))
+            return list(pan[:, :h, :w].unbind(0))
 
         def process(upto):
             """emit slices zp .. upto-1 (their look-ahead is available or they are tail slices)"""
             nonlocal zp, pend, fhist
             if upto <= zp:
-                return
+                return []
             sem = torch.cat([p[0] for p in pend])
             ctr = torch.cat([p[1] for p in pend])
             off = torch.cat([p[2] for p in pend])
@@ -365,10 +369,11 @@ class Engine3d:
                 filt.append(res)
                 fhist = (fhist + list(res[-mid:].split(1)))[-mid:]
                 z += run
-            emit(torch.cat(filt), ctr[:cnt], off[:cnt])
+            chunk = emit(torch.cat(filt), ctr[:cnt], off[:cnt])
             rest = sem.shape[0] - cnt
             pend = [(sem[cnt:], ctr[cnt:], off[cnt:])] if rest > 0 else []
             zp = upto
+            return chunk
 
         # Fast path for integer numpy volumes at native scale: the batch is cut out of the volume in one strided copy,
         # uploaded as raw integers (1-2 bytes per pixel instead of 4) and normalised + zero-padded inside the stem
@@ -407,10 +412,13 @@ class Engine3d:
                 nb = x.shape[0]
             pend.append((logits_to_prob(mo['sem_logits']), mo['ctr_hmp'].clone(), mo['offsets'].clone()))
             avail += nb
-            process(min(avail - mid, n - mid) if avail < n else n)
-        process(n)
+            chunk = process(min(avail - mid, n - mid) if avail < n else n)
+            if chunk:
+                yield chunk
+        chunk = process(n)
+        if chunk:
+            yield chunk
         eng.reset()
-        return out
 
     def infer_on_axis(self, volume, axis_name):
         """:491-578 -> (stack, trackers)."""
@@ -420,19 +428,33 @@ class Engine3d:
         axis = self.axes[axis_name]
         trackers = self.create_trackers(volume.shape, axis_name)
         stack = self.create_panoptic_stack(axis_name, volume.shape)
-        pan_segs = self.predict_slices(volume, axis)
-        assert len(pan_segs) == volume.shape[axis]
         # forward matching (patterns.py:68-100), backward matching (:102-121) and tracking (tracker.py:61-123) of every
-        # class in C++ (sparse.StackMatcher): dense -> runs on the GPU in chunks, no Python object per slice object
+        # class in C++ (sparse.StackMatcher): dense -> runs on the GPU in chunks, no Python object per slice object.
+        # The forward matching of a chunk runs on a worker thread (its C++ / scipy calls release the GIL) while this
+        # thread drives the GPU through the next chunk, as the reference overlaps them with a process (patterns.py:68).
         sms = {label: sparse.StackMatcher(label, self.label_divisor, self.merge_iou_thr, self.merge_ioa_thr,
                                           match=label in self.thing_list) for label in self.labels}
-        for i0 in range(0, len(pan_segs), 64):
-            chunk = torch.stack(pan_segs[i0:i0 + 64])
-            width = chunk.shape[-1]
-            for label, (runs_list, off) in sparse.pan_stack_to_runs(chunk, self.labels, self.label_divisor,
-                                                                   self.thing_list, force_connected=True).items():
+        n_seen = 0
+
+        def match_chunk(per_label, width):
+            for label, (runs_list, off) in per_label.items():
+                sm = sms[label]
                 for runs in runs_list:
-                    sms[label].push_runs(runs, width, off)
+                    sm.push_runs(runs, width, off)
+                    sm.step(len(sm) - 1)
+
+        with ThreadPoolExecutor(max_workers=1) as worker:
+            jobs = []
+            for pans in self.iter_slice_chunks(volume, axis):
+                n_seen += len(pans)
+                for i0 in range(0, len(pans), 64):
+                    chunk = torch.stack(pans[i0:i0 + 64])
+                    per_label = sparse.pan_stack_to_runs(chunk, self.labels, self.label_divisor, self.thing_list,
+                                                         force_connected=True)
+                    jobs.append(worker.submit(match_chunk, per_label, chunk.shape[-1]))
+            for j in jobs:
+                j.result()
+        assert n_seen == volume.shape[axis]
         for tr in trackers:
             sm = sms[tr.class_id]
             sm.forward()

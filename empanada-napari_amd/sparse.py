@@ -394,6 +394,7 @@ class StackMatcher:
                                          int(bool(match)))
         if not self._h:
             raise _abi.EmpError('emp_sm_create failed')
+        self._stepped = 0
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -433,9 +434,16 @@ class StackMatcher:
         cols = np.ascontiguousarray(cols, dtype=i64)
         _abi.check(self.lib.emp_sm_step_apply(self._h, _hp(rows), _hp(cols), len(rows)), 'emp_sm_step_apply')
 
+    def step(self, idx):
+        """Forward matching of slice ``idx`` (the next unmatched one): lets the caller match slices as they arrive."""
+        assert idx == self._stepped, f'forward matching is sequential: expected slice {self._stepped}, got {idx}'
+        self._step(idx)
+        self._stepped += 1
+
     def forward(self):
-        for idx in range(len(self)):
-            self._step(idx)
+        """Forward matching of every slice not matched yet."""
+        while self._stepped < len(self):
+            self.step(self._stepped)
 
     def backward_and_track(self, axis_name, shape3d):
         """Backward matching with the tracker fed in the same (descending) slice order; returns the finished tracker's
@@ -718,7 +726,7 @@ def merge_objects_from_trackers(object_trackers, pixel_vote_thr=2, cluster_iou_t
 
     jobs = [cluster for clusters in comps for _, cluster in clusters]
     if len(jobs) > 1:
-        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1, len(jobs))) as pool:
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1, len(jobs))) as pool:
             votes = iter(list(pool.map(vote, jobs)))
     else:
         votes = iter([vote(c) for c in jobs])
