@@ -1,3 +1,5 @@
+"""cProfile of one axis (yz) and of tracker_consensus on the 512^3 bench volume (host-side hot spots of the 3-D job).
+    python tools/profile_stack3d.py"""
 import sys, time, cProfile, pstats, os
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
