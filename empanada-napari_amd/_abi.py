@@ -79,6 +79,9 @@ PROTOTYPES = {
     'emp_panoptic_merge_work_bytes': (sz, [c_int, c_int, c_int]),
     'emp_ccl8_work_bytes': (sz, [c_int, c_int, c_int]),
     'emp_ccl8': (c_int, [vp, c_int, c_int, c_int, vp, vp, vp, vp]),
+    'emp_ccl26': (c_int, [vp, c_int, c_int, c_int, vp, vp, vp, vp]),
+    'emp_morph_cross3d': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
+    'emp_fill_holes_slices': (c_int, [vp, c_i64, c_i64, c_i64]),
     'emp_rle_extract_work_bytes': (sz, [c_int, c_int, c_int]),
     'emp_rle_extract': (c_int, [vp, c_int, c_int, c_int, vp, vp, c_int, vp, vp]),
     'emp_rle_fill': (c_int, [vp, vp, vp, c_i64, vp, c_i64, c_int, vp]),

@@ -105,6 +105,62 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(const int32_t* __restric
   }
 }
 
+// 26-connected components of a volume (skimage.measure.label on a 3-D array, full connectivity): the 13 neighbours
+// that precede a voxel in raster order
+__global__ void __launch_bounds__(256) ccl_merge3d_kernel(const int32_t* __restrict__ im, int* __restrict__ parent,
+                                                          int d, int h, int w) {
+  const int64_t total = (int64_t)d * h * w;
+  const int64_t p64 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p64 >= total) return;
+  const int p = (int)p64;
+  const int32_t v = im[p];
+  if (v == 0) return;
+  const int hw = h * w;
+  const int z = p / hw, r = p - z * hw;
+  const int y = r / w, x = r - y * w;
+  if (x > 0 && im[p - 1] == v) uf_union(parent, p, p - 1);
+  if (y > 0) {
+    if (im[p - w] == v) uf_union(parent, p, p - w);
+    if (x > 0 && im[p - w - 1] == v) uf_union(parent, p, p - w - 1);
+    if (x + 1 < w && im[p - w + 1] == v) uf_union(parent, p, p - w + 1);
+  }
+  if (z > 0) {
+    const int q = p - hw;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      if ((unsigned)(y + dy) >= (unsigned)h) continue;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        if ((unsigned)(x + dx) >= (unsigned)w) continue;
+        const int n = q + dy * w + dx;
+        if (im[n] == v) uf_union(parent, p, n);
+      }
+    }
+  }
+}
+
+// grey erosion (op 0: min) / dilation (op 1: max) of a label volume with the 3-D cross (skimage.morphology.erosion /
+// dilation defaults: footprint = generate_binary_structure(3, 1), border mode 'reflect' == the edge voxel itself)
+__global__ void __launch_bounds__(256) morph_cross3d_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                            int d, int h, int w, int op) {
+  const int64_t total = (int64_t)d * h * w;
+  const int64_t hw = (int64_t)h * w;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < total; p += (int64_t)gridDim.x * 256) {
+    const int z = (int)(p / hw);
+    const int r = (int)(p - z * hw);
+    const int y = r / w, x = r - y * w;
+    uint32_t v = in[p];
+    auto acc = [&](uint32_t u) { v = op ? (u > v ? u : v) : (u < v ? u : v); };
+    if (x > 0) acc(in[p - 1]);
+    if (x + 1 < w) acc(in[p + 1]);
+    if (y > 0) acc(in[p - w]);
+    if (y + 1 < h) acc(in[p + w]);
+    if (z > 0) acc(in[p - hw]);
+    if (z + 1 < d) acc(in[p + hw]);
+    out[p] = v;
+  }
+}
+
 __global__ void __launch_bounds__(256) ccl_flatten_kernel(int* __restrict__ parent_all, int hw) {
   const int n = blockIdx.y;
   const int p = blockIdx.x * 256 + threadIdx.x;
@@ -336,11 +392,12 @@ size_t emp_ccl8_work_bytes(int N, int H, int W) {
   return (size_t)N * (hw * 8 + nb * 8) + 512;
 }
 
-int emp_ccl8(const int32_t* d_in, int N, int H, int W, int32_t* d_out, int32_t* d_num, void* d_work, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  EMP_REQUIRE(d_in && d_out && d_work && N > 0 && H > 0 && W > 0, "ccl8: bad arguments");
-  EMP_REQUIRE((int64_t)H * W < (1ll << 30), "ccl8: image too large");
-  const int hw = H * W;
+// depth == 0: N images of H x W, 8-connected; depth > 0: ONE volume depth x H x W, 26-connected
+static int ccl_run(const int32_t* d_in, int N, int depth, int H, int W, int32_t* d_out, int32_t* d_num, void* d_work,
+                   hipStream_t s) {
+  const int64_t hw64 = (int64_t)(depth > 0 ? depth : 1) * H * W;
+  EMP_REQUIRE(hw64 < (1ll << 30), "ccl: image / volume too large (< 2^30 elements)");
+  const int hw = (int)hw64;
   const int nb = cdiv(hw, CHUNK);
   int* parent = (int*)d_work;
   int32_t* rank = (int32_t*)(parent + (size_t)N * hw);
@@ -349,7 +406,10 @@ int emp_ccl8(const int32_t* d_in, int N, int H, int W, int32_t* d_out, int32_t* 
   const int64_t total = (int64_t)N * hw;
   hipLaunchKernelGGL(ccl_init_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_in, parent, total, hw);
   EMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ccl_merge_kernel, dim3(cdiv(hw, 256), N), dim3(256), 0, s, d_in, parent, H, W);
+  if (depth > 0)
+    hipLaunchKernelGGL(ccl_merge3d_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, s, d_in, parent, depth, H, W);
+  else
+    hipLaunchKernelGGL(ccl_merge_kernel, dim3(cdiv(hw, 256), N), dim3(256), 0, s, d_in, parent, H, W);
   EMP_LAUNCH_CHECK();
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(hw, 256), N), dim3(256), 0, s, parent, hw);
   EMP_LAUNCH_CHECK();
@@ -360,6 +420,25 @@ int emp_ccl8(const int32_t* d_in, int N, int H, int W, int32_t* d_out, int32_t* 
   hipLaunchKernelGGL(ccl_rank_kernel, dim3(nb, N), dim3(256), 0, s, parent, hw, blockoff, nb, rank);
   EMP_LAUNCH_CHECK();
   hipLaunchKernelGGL(ccl_relabel_kernel, dim3(grid_for(total)), dim3(256), 0, s, parent, rank, d_out, total, hw);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int emp_ccl8(const int32_t* d_in, int N, int H, int W, int32_t* d_out, int32_t* d_num, void* d_work, void* stream) {
+  EMP_REQUIRE(d_in && d_out && d_work && N > 0 && H > 0 && W > 0, "ccl8: bad arguments");
+  return ccl_run(d_in, N, 0, H, W, d_out, d_num, d_work, (hipStream_t)stream);
+}
+
+// work buffer: emp_ccl8_work_bytes(1, D * H, W)
+int emp_ccl26(const int32_t* d_in, int D, int H, int W, int32_t* d_out, int32_t* d_num, void* d_work, void* stream) {
+  EMP_REQUIRE(d_in && d_out && d_work && D > 0 && H > 0 && W > 0, "ccl26: bad arguments");
+  return ccl_run(d_in, 1, D, H, W, d_out, d_num, d_work, (hipStream_t)stream);
+}
+
+int emp_morph_cross3d(const uint32_t* d_in, uint32_t* d_out, int D, int H, int W, int op, void* stream) {
+  EMP_REQUIRE(d_in && d_out && d_in != d_out && D > 0 && H > 0 && W > 0 && (op == 0 || op == 1), "morph_cross3d: bad arguments");
+  hipLaunchKernelGGL(morph_cross3d_kernel, dim3(grid_for((int64_t)D * H * W)), dim3(256), 0, (hipStream_t)stream, d_in,
+                     d_out, D, H, W, op);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
@@ -523,6 +602,84 @@ int emp_ranges_vote(const int64_t* h_ranges, int64_t n, int thr, int64_t* h_out,
     }
   }
   *n_out = m;
+  return EMP_OK;
+}
+
+// fill_holes_in_segmentation (filters.py:178-210) on a host label volume, slice by slice (slices are independent and
+// run on threads).  Bug-compatible with the reference loop: labels of the slice in ascending order (regionprops), each
+// with the bounding box it had BEFORE the loop; the box is cut out of the CURRENT slice, every non-zero pixel and every
+// hole of the cut-out (scipy.ndimage.binary_fill_holes: background not 4-connected to the cut-out's border) becomes
+// that label -- including pixels of other objects inside the box.
+int emp_fill_holes_slices(uint32_t* h_vol, int64_t D, int64_t H, int64_t W) {
+  EMP_REQUIRE(h_vol && D > 0 && H > 0 && W > 0, "fill_holes_slices: bad arguments");
+  auto one_slice = [&](int64_t z) {
+    uint32_t* m = h_vol + z * H * W;
+    std::vector<uint32_t> labels;
+    {
+      uint32_t last = 0;
+      for (int64_t i = 0; i < H * W; ++i) {
+        const uint32_t v = m[i];
+        if (v != 0 && v != last) { labels.push_back(v); last = v; }
+      }
+      std::sort(labels.begin(), labels.end());
+      labels.erase(std::unique(labels.begin(), labels.end()), labels.end());
+    }
+    if (labels.empty()) return;
+    const size_t nl = labels.size();
+    std::vector<int64_t> box(nl * 4);
+    for (size_t k = 0; k < nl; ++k) { box[4 * k] = H; box[4 * k + 1] = W; box[4 * k + 2] = -1; box[4 * k + 3] = -1; }
+    for (int64_t y = 0; y < H; ++y)
+      for (int64_t x = 0; x < W; ++x) {
+        const uint32_t v = m[y * W + x];
+        if (v == 0) continue;
+        const size_t k = std::lower_bound(labels.begin(), labels.end(), v) - labels.begin();
+        int64_t* b = &box[4 * k];
+        if (y < b[0]) b[0] = y;
+        if (x < b[1]) b[1] = x;
+        if (y > b[2]) b[2] = y;
+        if (x > b[3]) b[3] = x;
+      }
+    std::vector<uint8_t> outside;
+    std::vector<int64_t> stack;
+    for (size_t k = 0; k < nl; ++k) {
+      const int64_t y0 = box[4 * k], x0 = box[4 * k + 1], bh = box[4 * k + 2] - y0 + 1, bw = box[4 * k + 3] - x0 + 1;
+      outside.assign((size_t)(bh * bw), 0);
+      stack.clear();
+      auto push = [&](int64_t yy, int64_t xx) {
+        if (m[(y0 + yy) * W + x0 + xx] == 0 && !outside[(size_t)(yy * bw + xx)]) {
+          outside[(size_t)(yy * bw + xx)] = 1;
+          stack.push_back(yy * bw + xx);
+        }
+      };
+      for (int64_t xx = 0; xx < bw; ++xx) { push(0, xx); push(bh - 1, xx); }
+      for (int64_t yy = 0; yy < bh; ++yy) { push(yy, 0); push(yy, bw - 1); }
+      while (!stack.empty()) {
+        const int64_t q = stack.back();
+        stack.pop_back();
+        const int64_t yy = q / bw, xx = q - yy * bw;
+        if (yy > 0) push(yy - 1, xx);
+        if (yy + 1 < bh) push(yy + 1, xx);
+        if (xx > 0) push(yy, xx - 1);
+        if (xx + 1 < bw) push(yy, xx + 1);
+      }
+      const uint32_t L = labels[k];
+      for (int64_t yy = 0; yy < bh; ++yy)
+        for (int64_t xx = 0; xx < bw; ++xx)
+          m[(y0 + yy) * W + x0 + xx] = outside[(size_t)(yy * bw + xx)] ? 0u : L;
+    }
+  };
+  unsigned nthr = std::thread::hardware_concurrency();
+  nthr = nthr > 32 ? 32 : (nthr < 1 ? 1 : nthr);
+  if ((int64_t)nthr > D) nthr = (unsigned)D;
+  if (nthr < 2) {
+    for (int64_t z = 0; z < D; ++z) one_slice(z);
+    return EMP_OK;
+  }
+  std::atomic<int64_t> next{0};
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nthr; ++t)
+    pool.emplace_back([&] { for (int64_t z = next.fetch_add(1); z < D; z = next.fetch_add(1)) one_slice(z); });
+  for (auto& th : pool) th.join();
   return EMP_OK;
 }
 

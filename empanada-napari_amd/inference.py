@@ -423,8 +423,6 @@ class Engine3d:
     def infer_on_axis(self, volume, axis_name):
         """:491-578 -> (stack, trackers)."""
         _require_scale_one(self.inference_scale)
-        if self.label_erosion or self.label_dilation or self.fill_holes_in_segmentation:
-            raise NotImplementedError('label erosion / dilation / hole filling are next-tier rows (filters.py:154-210)')
         axis = self.axes[axis_name]
         trackers = self.create_trackers(volume.shape, axis_name)
         stack = self.create_panoptic_stack(axis_name, volume.shape)
@@ -463,6 +461,17 @@ class Engine3d:
         for tr in trackers:
             sparse.remove_small_objects(tr, min_size=self.min_size)
             sparse.remove_pancakes(tr, min_span=self.min_extent)
+        # optional morphology, in the reference's order (inference.py:560-570)
+        margs = (volume.shape, self.labels, self.label_divisor, self.thing_list)
+        if self.label_erosion > 0:
+            for tr in trackers:
+                sparse.erode(tr, *margs, iterations=self.label_erosion)
+        if self.label_dilation > 0:
+            for tr in trackers:
+                sparse.dilate(tr, *margs, iterations=self.label_dilation)
+        if self.fill_holes_in_segmentation:
+            for tr in trackers:
+                sparse.fill_holes_in_segmentation(tr, *margs)
         if stack is not None:
             if isinstance(stack, np.ndarray):
                 sparse.fill_panoptic_volume(stack, trackers)

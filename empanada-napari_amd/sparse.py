@@ -592,6 +592,115 @@ def remove_pancakes(object_tracker, min_span=4):
             del object_tracker.instances[k]
 
 
+# ----------------------------------------------------------------------------
+# optional morphology on a finished tracker (empanada/inference/filters.py:118-210): the tracker becomes a dense label
+# volume on the GPU, is eroded / dilated there (or hole-filled slice by slice in the C++ host half) and goes back to
+# runs through 26-connected components + run extraction on the GPU.
+# ----------------------------------------------------------------------------
+@torch.no_grad()
+def ccl26(volume):
+    """volume (D,H,W) int32 cuda -> 26-connected components of equal non-zero label, numbered in raster order."""
+    lib = _lib()
+    volume = volume.contiguous()
+    D, H, W = volume.shape
+    out = torch.empty_like(volume)
+    num = torch.empty((1,), dtype=torch.int32, device=volume.device)
+    work = torch.empty((int(lib.emp_ccl8_work_bytes(1, D * H, W)),), dtype=torch.uint8, device=volume.device)
+    _abi.check(lib.emp_ccl26(_abi.ptr(volume), D, H, W, _abi.ptr(out), _abi.ptr(num), _abi.ptr(work),
+                             _abi.stream_ptr(volume.device)), 'emp_ccl26')
+    return out
+
+
+def _runs_to_attrs3d(runs, shape, id_offset=0):
+    """(n,3) {start,len,label} over the raveled volume -> {label: attrs} with 6-tuple boxes, labels ascending."""
+    if len(runs) == 0:
+        return {}
+    D, H, W = shape
+    HW = H * W
+    order = np.argsort(runs[:, 2], kind='stable')
+    r = runs[order]
+    s, ln, lab = r[:, 0], r[:, 1], r[:, 2]
+    e = s + ln - 1
+    z0, z1 = s // HW, e // HW
+    y0, y1 = (s % HW) // W, (e % HW) // W
+    planes = z0 != z1                                  # a run over a plane border covers rows H-1 and 0
+    rows = planes | (y0 != y1)                         # a run over a row border covers columns W-1 and 0
+    ya, yb = np.where(planes, 0, y0), np.where(planes, H - 1, y1)
+    xa, xb = np.where(rows, 0, s % W), np.where(rows, W - 1, e % W)
+    bounds = np.concatenate([[0], np.flatnonzero(np.diff(lab)) + 1, [len(lab)]])
+    idx = bounds[:-1]
+    lo = [np.minimum.reduceat(v, idx) for v in (z0, ya, xa)]
+    hi = [np.maximum.reduceat(v, idx) for v in (z1, yb, xb)]
+    out = {}
+    for k, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+        out[int(lab[a]) + id_offset] = {'box': tuple(int(v[k]) for v in lo) + tuple(int(v[k]) + 1 for v in hi),
+                                        'starts': s[a:b].copy(), 'runs': ln[a:b].copy()}
+    return out
+
+
+@torch.no_grad()
+def volume_to_instances(volume, labels, label_divisor, thing_list, force_connected=True):
+    """filters.pan_seg_to_rle_seg (filters.py:58-116) for a (D,H,W) label volume (numpy or cuda tensor): one flat
+    {instance_id: attrs} dict; instance classes are split into 26-connected components first."""
+    vol = _as_device_i32(volume)
+    D, H, W = vol.shape
+    out = {}
+    for label in labels:
+        lo = label * label_divisor
+        hi = lo + label_divisor
+        inst = torch.where((vol >= lo) & (vol < hi), vol, torch.zeros_like(vol))
+        off = 0
+        if force_connected and label in thing_list:
+            inst = ccl26(inst)
+            off = lo
+        runs = extract_runs(inst.view(1, D * H, W), max_runs=1 << 20)[0]
+        out.update(_runs_to_attrs3d(runs, (D, H, W), off))
+    return out
+
+
+@torch.no_grad()
+def tracker_to_volume(object_tracker, shape, device=None):
+    """filters.rle_seg_to_pan_seg (filters.py:118-152) on the device: int32 (D,H,W), later instances overwrite."""
+    vol = torch.zeros(tuple(int(v) for v in shape), dtype=torch.int32, device=_dev(device))
+    return fill_volume(vol, object_tracker.instances)
+
+
+@torch.no_grad()
+def _morph(object_tracker, volume_shape, labels, label_divisor, thing_list, iterations, op):
+    lib = _lib()
+    a = tracker_to_volume(object_tracker, volume_shape)
+    b = torch.empty_like(a)
+    D, H, W = a.shape
+    for _ in range(int(iterations)):
+        _abi.check(lib.emp_morph_cross3d(_abi.ptr(a), _abi.ptr(b), D, H, W, op, _abi.stream_ptr(a.device)),
+                   'emp_morph_cross3d')
+        a, b = b, a
+    object_tracker.instances = volume_to_instances(a, labels, label_divisor, thing_list)
+    return object_tracker
+
+
+def erode(object_tracker, volume_shape, labels, label_divisor, thing_list, iterations=1):
+    """filters.py:154-164."""
+    return _morph(object_tracker, volume_shape, labels, label_divisor, thing_list, iterations, 0)
+
+
+def dilate(object_tracker, volume_shape, labels, label_divisor, thing_list, iterations=1):
+    """filters.py:166-176."""
+    return _morph(object_tracker, volume_shape, labels, label_divisor, thing_list, iterations, 1)
+
+
+@torch.no_grad()
+def fill_holes_in_segmentation(object_tracker, volume_shape, labels, label_divisor, thing_list):
+    """filters.py:178-210: the per-slice, per-label fill is sequential by construction (each label's cut-out sees what
+    the previous labels wrote), so it runs in the C++ host half, one thread per slice."""
+    host = np.empty(tuple(int(v) for v in volume_shape), dtype=np.uint32)
+    fill_volume(host, object_tracker.instances, fresh=True)
+    D, H, W = host.shape
+    _abi.check(_lib().emp_fill_holes_slices(_hp(host), D, H, W), 'emp_fill_holes_slices')
+    object_tracker.instances = volume_to_instances(host.view(np.int32), labels, label_divisor, thing_list)
+    return object_tracker
+
+
 def instance_relabel(tracker):
     """empanada_napari/inference.py:31-54: ids 1..n, runs stably sorted by start."""
     out = {}

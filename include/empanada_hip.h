@@ -250,6 +250,24 @@ EMP_API size_t emp_ccl8_work_bytes(int N, int H, int W);
 EMP_API int emp_ccl8(const int32_t* d_in, int N, int H, int W, int32_t* d_out, int32_t* d_num,
              void* d_work, void* stream);
 
+/* 26-connected components of EQUAL non-zero label of ONE volume (skimage.measure.label on a 3-D array, default
+ * full connectivity), numbered in raster order of first voxels.  replaces filters.connected_components,
+ * empanada/inference/filters.py:14-20, as used by filters.pan_seg_to_rle_seg (:58-116) after erode / dilate /
+ * fill_holes.  d_in, d_out (D,H,W) int32, D*H*W < 2^30; work buffer: emp_ccl8_work_bytes(1, D*H, W). */
+EMP_API int emp_ccl26(const int32_t* d_in, int D, int H, int W, int32_t* d_out, int32_t* d_num,
+              void* d_work, void* stream);
+
+/* One grey erosion (op 0) / dilation (op 1) of a uint32 label volume with the 3-D cross footprint, border mode
+ * 'reflect'.  replaces skimage.morphology.erosion / dilation as called by filters.erode / filters.dilate,
+ * empanada/inference/filters.py:154-176 (one call per iteration; d_out != d_in). */
+EMP_API int emp_morph_cross3d(const uint32_t* d_in, uint32_t* d_out, int D, int H, int W, int op, void* stream);
+
+/* (host) filters.fill_holes_in_segmentation, empanada/inference/filters.py:178-210, on a host uint32 label volume in
+ * place: per slice, per label in ascending order, the label's original bounding box is cut out of the current
+ * slice and scipy.ndimage.binary_fill_holes of the cut-out (any label counts as foreground) is written back as
+ * that label.  Slices run on threads. */
+EMP_API int emp_fill_holes_slices(uint32_t* h_vol, int64_t D, int64_t H, int64_t W);
+
 /* Runs of equal non-zero label over the raveled image, in raster order.  replaces
  * regionprops(...).coords -> rle_encode, rle.py:73-81 + array_utils.py:213-239.
  *   d_runs (N, max_runs, 3) int32 {start, length, label}; d_num_runs (N) int32 (un-clamped). */

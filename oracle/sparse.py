@@ -507,6 +507,111 @@ def remove_pancakes(tracker, min_span=4):
             del tracker.instances[k]
 
 
+# ----------------------------------------------------------------------------
+# optional morphology on a finished tracker (inference/filters.py:14-210).  erosion / dilation / binary_fill_holes
+# are the scipy.ndimage calls skimage and the reference make themselves; measure.label / regionprops are restated.
+# ----------------------------------------------------------------------------
+def label_nd(seg):
+    """filters.connected_components (filters.py:14-20) = skimage.measure.label(seg): regions of EQUAL non-zero value under
+    full connectivity (8 in 2-D, 26 in 3-D), numbered 1.. in raster order of each region's first element."""
+    from scipy import ndimage as ndi
+    seg = np.asarray(seg)
+    struct = np.ones((3,) * seg.ndim, dtype=bool)
+    comps = []
+    per_value = {}
+    for v in np.unique(seg):
+        if v == 0:
+            continue
+        lab, n = ndi.label(seg == v, structure=struct)
+        per_value[v] = lab
+        ids, first = np.unique(lab.ravel(), return_index=True)
+        comps += [(int(f), v, int(i)) for i, f in zip(ids, first) if i != 0]
+    out = np.zeros(seg.shape, dtype=i64)
+    for number, (_, v, i) in enumerate(sorted(comps), start=1):
+        out[per_value[v] == i] = number
+    return out
+
+
+def regionprops_rle_nd(instance_seg):
+    """regionprops on an n-D label array -> {label: {'box' (mins..., maxs+1...), 'starts', 'runs'}}, labels ascending."""
+    attrs = {}
+    flat = instance_seg.reshape(-1)
+    for lab in np.unique(flat):
+        if lab == 0:
+            continue
+        idx = np.flatnonzero(flat == lab)
+        coords = np.unravel_index(idx, instance_seg.shape)
+        starts, runs = rle_encode(idx)
+        attrs[int(lab)] = {'box': tuple(int(c.min()) for c in coords) + tuple(int(c.max()) + 1 for c in coords),
+                           'starts': starts.astype(i64), 'runs': runs.astype(i64)}
+    return attrs
+
+
+def filters_pan_seg_to_rle_seg(pan_seg, labels, label_divisor, thing_list, force_connected=True):
+    """filters.py:58-116: like rle.pan_seg_to_rle_seg on an n-D array, but ONE flat dict of instance attrs comes back."""
+    instance_attrs = {}
+    for label in labels:
+        lo, hi = label * label_divisor, label * label_divisor + label_divisor
+        inst = pan_seg.astype(i64)
+        inst[(pan_seg < lo) | (pan_seg >= hi)] = 0
+        if force_connected and label in thing_list:
+            inst = label_nd(inst)
+            inst[inst > 0] += lo
+        instance_attrs.update(regionprops_rle_nd(inst))
+    return instance_attrs
+
+
+def filters_rle_seg_to_pan_seg(tracker, shape):
+    """filters.py:118-152: tracker instances -> dense uint32 volume (later instances overwrite earlier ones)."""
+    pan = np.zeros(shape, dtype=np.uint32).ravel()
+    for oid, a in tracker.instances.items():
+        for st, r in zip(a['starts'], a['runs']):
+            pan[st:st + r] = oid
+    return pan.reshape(shape)
+
+
+def _cross(ndim):
+    from scipy import ndimage as ndi
+    return ndi.generate_binary_structure(ndim, 1)
+
+
+def erode(tracker, volume_shape, labels, label_divisor, thing_list, iterations=1):
+    """filters.py:154-164; skimage.morphology.erosion(mask) = ndi.grey_erosion(mask, footprint=cross) (mode 'reflect')."""
+    from scipy import ndimage as ndi
+    mask = filters_rle_seg_to_pan_seg(tracker, volume_shape)
+    for _ in range(iterations):
+        mask = ndi.grey_erosion(mask, footprint=_cross(mask.ndim))
+    tracker.instances = filters_pan_seg_to_rle_seg(mask, labels, label_divisor, thing_list)
+    return tracker
+
+
+def dilate(tracker, volume_shape, labels, label_divisor, thing_list, iterations=1):
+    """filters.py:166-176."""
+    from scipy import ndimage as ndi
+    mask = filters_rle_seg_to_pan_seg(tracker, volume_shape)
+    for _ in range(iterations):
+        mask = ndi.grey_dilation(mask, footprint=_cross(mask.ndim))
+    tracker.instances = filters_pan_seg_to_rle_seg(mask, labels, label_divisor, thing_list)
+    return tracker
+
+
+def fill_holes_in_segmentation(tracker, volume_shape, labels, label_divisor, thing_list):
+    """filters.py:178-210 (3-D only; the reference just prints for other ranks)."""
+    from scipy.ndimage import binary_fill_holes
+    mask_3d = filters_rle_seg_to_pan_seg(tracker, volume_shape)
+    assert mask_3d.ndim == 3
+    for idx in range(mask_3d.shape[0]):
+        mask = mask_3d[idx]
+        boxes = {lab: a['box'] for lab, a in regionprops_rle_nd(mask).items()}     # boxes of the slice BEFORE the loop
+        for lab in sorted(boxes):
+            minr, minc, maxr, maxc = boxes[lab]
+            tmp = mask[minr:maxr, minc:maxc]
+            tmp = binary_fill_holes(tmp.astype(bool))
+            mask[minr:maxr, minc:maxc] = tmp.astype(mask.dtype) * lab
+    tracker.instances = filters_pan_seg_to_rle_seg(mask_3d, labels, label_divisor, thing_list)
+    return tracker
+
+
 def instance_relabel(tracker):
     """empanada_napari/inference.py:31-54."""
     out = {}

@@ -212,3 +212,24 @@ def test_multigpu_engine_single_rank_equals_engine3d(model_config, monkeypatch, 
             multigpu.MultiGPUEngine3d(model_config, **kw)
     finally:
         dist.destroy_process_group()
+
+
+def test_engine3d_morphology_options(model_config):
+    """label_erosion / label_dilation / fill_holes_in_segmentation run after the size filters, in the reference's order
+    (empanada_napari/inference.py:560-570): same trackers as the oracle's filters applied to the plain engine's output"""
+    import copy
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine3d
+    from oracle import sparse as osp
+    vol = synth.blob_volume(10, 48, 56, seed=21)
+    kw = dict(label_divisor=DIV, median_kernel_size=3, nms_kernel=3, confidence_thr=0.5, min_size=20, min_extent=2)
+    _, plain = Engine3d(model_config, **kw).infer_on_axis(vol, 'xy')
+    _, got = Engine3d(model_config, label_erosion=1, label_dilation=2, fill_holes_in_segmentation=True,
+                      **kw).infer_on_axis(vol, 'xy')
+    want = osp.InstanceTracker(1, DIV, vol.shape, 'xy')
+    want.instances = copy.deepcopy(plain[0].instances)
+    assert len(want.instances) > 0
+    osp.erode(want, vol.shape, [1], DIV, [1], 1)
+    osp.dilate(want, vol.shape, [1], DIV, [1], 2)
+    osp.fill_holes_in_segmentation(want, vol.shape, [1], DIV, [1])
+    _same_instances(got[0].instances, want.instances)

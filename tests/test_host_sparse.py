@@ -231,3 +231,52 @@ def test_cpp_yz_tracker_bitmap_equals_sort_and_encode(shape, density):
     np.testing.assert_array_equal(inst[2000]['runs'], ot.instances[2000]['runs'])
     assert tuple(inst[2000]['box']) == tuple(ot.instances[2000]['box'])
     np.testing.assert_array_equal(np.sort(osp.rle_decode(inst[2000]['starts'], inst[2000]['runs'])), np.flatnonzero(mask.ravel()))
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_fill_holes_slices_equals_reference_loop(seed):
+    """emp_fill_holes_slices (C++ host, threaded over slices) vs the reference's loop restated with scipy's
+    binary_fill_holes (filters.py:178-210), including its overwrite of foreign labels inside a bounding box."""
+    import ctypes as C
+    from empanada_napari_amd import _abi
+    from scipy.ndimage import binary_fill_holes
+    rng = np.random.default_rng(seed)
+    D, H, W = 5, 40, 48
+    vol = np.zeros((D, H, W), np.uint32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for z in range(D):
+        for lab in rng.permutation(np.arange(1001, 1009)):
+            cy, cx, r = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(3, 12)
+            d = np.hypot(yy - cy, xx - cx)
+            vol[z][(d < r) & (d > r * rng.uniform(0.2, 0.7))] = lab      # rings: holes, overlaps, border contacts
+        vol[z][rng.random((H, W)) < 0.05] = 0
+    want = vol.copy()
+    for z in range(D):
+        m = want[z]
+        boxes = {}
+        for lab in np.unique(m[m > 0]):
+            ys, xs = np.nonzero(m == lab)
+            boxes[int(lab)] = (ys.min(), xs.min(), ys.max() + 1, xs.max() + 1)
+        for lab in sorted(boxes):
+            y0, x0, y1, x1 = boxes[lab]
+            m[y0:y1, x0:x1] = binary_fill_holes(m[y0:y1, x0:x1].astype(bool)).astype(m.dtype) * lab
+    got = vol.copy()
+    _abi.check(_abi.load().emp_fill_holes_slices(got.ctypes.data_as(C.c_void_p), D, H, W), 'emp_fill_holes_slices')
+    assert (want != vol).any()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_oracle_morphology_restatement_basics():
+    """oracle erode / dilate / label_nd on hand-checkable input (filters.py:14-20,154-176)"""
+    vol = np.zeros((5, 7, 7), np.uint32)
+    vol[1:4, 2:5, 2:5] = 1003          # a 3x3x3 cube ...
+    vol[0, 0, 0] = 1001                # ... and a corner voxel (border mode: reflect keeps it under dilation only)
+    tr = osp.InstanceTracker(1, 1000, vol.shape, 'xy')
+    tr.instances = osp.filters_pan_seg_to_rle_seg(vol, [1], 1000, [1])
+    assert sorted(tr.instances) == [1001, 1002] and tr.instances[1002]['box'] == (1, 2, 2, 4, 5, 5)
+    osp.erode(tr, vol.shape, [1], 1000, [1], 1)
+    assert list(tr.instances) == [1001] and tr.instances[1001]['starts'].tolist() == [2 * 49 + 3 * 7 + 3]   # cube centre
+    osp.dilate(tr, vol.shape, [1], 1000, [1], 1)
+    assert int(tr.instances[1001]['runs'].sum()) == 7                                                       # a 3-D cross
+    diag = np.zeros((2, 2, 2), np.int64); diag[0, 0, 0] = diag[1, 1, 1] = 5
+    assert osp.label_nd(diag).max() == 1                                                                    # 26-connectivity
