@@ -66,7 +66,7 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    dist_on = world > 1
+    dist_on = world > 1 or os.environ.get('EMP_BENCH_FORCE_DIST') == '1'   # the env switch runs the RCCL path on one GPU
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
