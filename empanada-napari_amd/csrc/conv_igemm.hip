@@ -415,7 +415,12 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   //   staging: 0 auto | 1 register staging | 2 LDS-DMA | 3 LDS-DMA + LDS-transposed epilogue
   //   tile   : 0 auto | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x256 (conv_igemm256.hip; Cout % 256 == 0)
   // (tried and removed, slower on MI355X: a persistent cross-tile pipeline, and a 256x128 8-wave tile with
-  //  three LDS stages + counted vmcnt / raw barriers: 865 vs 990 TF/s on the ASPP shape -- DESIGN.md section 4)
+  //  three LDS stages + counted vmcnt / raw barriers: 865 vs 990 TF/s on the ASPP shape -- DESIGN.md section 4;
+  //  a 128x128 4-wave tile with the 256x256 kernel's four-slot ring of 32-channel K-tiles, LDS-DMA three tiles ahead,
+  //  register-double-buffered fragments and one LDS-only barrier per K-tile, two workgroups per CU: bit-identical
+  //  results but 5-15 % SLOWER than the two-stage kernel on every layer shape (e.g. 512->2048 1x1: 0.547 vs 0.502 ms,
+  //  128->512: 0.316 vs 0.278) -- with two workgroups per CU the global-load latency is already covered and the
+  //  second barrier per 64 channels costs more than the deeper prefetch saves)
   int v = variant & 15, tile = (variant >> 4) & 15, kg = variant >> 8;
   EMP_REQUIRE(v <= 3 && tile <= 4, "conv: bad variant %d", variant);
   if (tile == 4) return launch_conv_igemm256(p, stream);
