@@ -632,6 +632,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
                              n->f16w.at(dp + ".fusion.0.sepconv.1.packed"), pwc.b, pwc.cout, 1, so.p, so.ld, nullptr, nullptr,
                              0, nullptr, 0, zero, s));
           n->flops += 2.0 * (double)N * cat.H * cat.W * pwc.cout * (double)pwc.cin;
+          if (n->layer_log) fprintf(n->layer_log, "sepconv,%s,%d,%d,%d,5,1,1,0,%d\n", (dp + ".fusion.0").c_str(), N * cat.H * cat.W, 2 * F, pwc.cout, N * cat.H * cat.W);
         } else {
           RC(launch_dwconv(cat.p, N, cat.H, cat.W, 2 * F, cat.ld, n->f16w.at(dp + ".fusion.0.sepconv.0"), 5, A(dp + ".dw").p,
                            2 * F, zero, s));

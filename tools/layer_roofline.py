@@ -22,7 +22,7 @@ def run(B, S):
     from empanada_napari_amd.engines import HipPanopticDeepLab
     from empanada_napari_amd.preprocess import normalize_params
     dev = torch.device('cuda:0')
-    cfg = dict(weights.MITONET_PDL_CFG)
+    cfg = dict(weights.MITONET_MINI_CFG if os.environ.get('EMP_MODEL') == 'bifpn' else weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
     model = HipPanopticDeepLab(P, cfg, device=dev, folded=True)
     base = synth.em_tiles(min(B, 4), S, seed=1234)
