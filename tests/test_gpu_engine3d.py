@@ -233,3 +233,60 @@ def test_engine3d_morphology_options(model_config):
     osp.dilate(want, vol.shape, [1], DIV, [1], 2)
     osp.fill_holes_in_segmentation(want, vol.shape, [1], DIV, [1])
     _same_instances(got[0].instances, want.instances)
+
+
+def test_multiclass_bifpn_orthoplane_consensus():
+    """BASELINE configs[4] in small: PanopticBiFPN with 4 outputs (background + two instance classes + one semantic
+    class), softmax / argmax hardening, one matcher + tracker per class, instance consensus for the thing classes and
+    the pixel vote for the semantic class -- all against the oracle pipeline fed with the same per-slice label maps."""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.inference import Engine3d, tracker_consensus
+    from oracle import sparse as osp
+    cfg = dict(weights.MITONET_MINI_CFG, num_classes=4)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
+    w, b = P['ins_center.head.1']
+    P['ins_center.head.1'] = (w, b + np.float32(0.75))         # centres on small slices (see model_config above)
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    labels, things = [1, 2, 3], [1, 2]
+    mc = {'model': model, 'thing_list': things, 'labels': labels, 'class_names': {1: 'mito', 2: 'nucleus', 3: 'droplet'},
+          'padding_factor': 128, 'norms': {'mean': 0.57571, 'std': 0.12765}}
+    vol = synth.blob_volume(12, 40, 36, seed=8, n_blobs=6)
+    eng = Engine3d(mc, label_divisor=DIV, median_kernel_size=3, nms_kernel=3, confidence_thr=0.3, min_size=8, min_extent=1)
+    trackers, otrackers = {}, {}
+    seen = set()
+    for axis_name, axis in (('xy', 0), ('xz', 1), ('yz', 2)):
+        pans = [p.cpu().numpy() for p in eng.predict_slices(vol, axis)]
+        seen |= set(int(v) // DIV for v in np.unique(np.stack(pans)) if v > 0)
+        _, trs = eng.infer_on_axis(vol, axis_name)
+        ms = [osp.RLEMatcher(c, DIV, 0.25, 0.25) for c in things]
+        stack = [osp.apply_matchers(osp.pan_seg_to_rle_seg(p, labels, DIV, things, force_connected=True), ms) for p in pans]
+        for m in ms:
+            m.target_rle, m.assign_new = None, False
+        otrs = [osp.InstanceTracker(c, DIV, vol.shape, axis_name) for c in labels]
+        for idx in range(len(pans) - 1, -1, -1):
+            seg = osp.apply_matchers(stack[idx], ms)
+            for t in otrs:
+                t.update(seg[t.class_id], idx)
+        for t, got in zip(otrs, trs):
+            t.finish()
+            osp.remove_small_objects(t, 8)      # the size filters apply to every tracker (inference.py:556-558)
+            osp.remove_pancakes(t, 1)
+            assert got.class_id == t.class_id
+            _same_instances(got.instances, t.instances)
+        trackers[axis_name], otrackers[axis_name] = trs, otrs
+    assert len(seen) >= 2, f'the seeded network should produce several classes on this volume, got {seen}'
+    out = list(tracker_consensus(trackers, None, mc, label_divisor=DIV, pixel_vote_thr=2, cluster_iou_thr=0.75,
+                                 allow_one_view=False, min_size=8, min_extent=1, dtype=np.uint32))
+    assert [name for _, name, _ in out] == ['mito', 'nucleus', 'droplet']
+    for (cvol, name, inst), c in zip(out, labels):
+        cls = [t for ts in otrackers.values() for t in ts if t.class_id == c]
+        want = osp.InstanceTracker(c, DIV, vol.shape, 'xy')
+        if c in things:
+            want.instances = osp.merge_objects_from_trackers(cls, 2, 0.75, False)
+            osp.remove_small_objects(want, 8)
+            osp.remove_pancakes(want, 1)
+        else:
+            want.instances = osp.merge_semantic_from_trackers(cls, 2)
+        _same_instances(inst, want.instances)
+        np.testing.assert_array_equal(cvol, osp.numpy_fill_instances(np.zeros(vol.shape, np.uint32), want.instances))
