@@ -49,6 +49,8 @@ PROTOTYPES = {
     'emp_copy_d2d': (c_int, [vp, vp, sz, vp]),
     'emp_conv2d_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+    'emp_conv1x1_dual_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp,
+                                  c_int, c_int, c_int, c_int, vp]),
     'emp_dwconv_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, vp, c_int, vp]),
     'emp_sepconv5x5_pack_pw': (c_int, [vp, c_int, c_int, c_int, vp, vp]),
     'emp_sepconv5x5_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_int, c_int, vp,

@@ -81,6 +81,30 @@ int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_l
   return launch_conv_igemm(p, variant, (hipStream_t)stream);
 }
 
+int emp_conv1x1_dual_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_ld, const void* d_in2, int H2, int W2,
+                              int Cin2, int in2_ld, int stride2, const void* d_w, const float* d_bias, void* d_out,
+                              int out_ld, int Cout, int relu, int variant, void* stream) {
+  EMP_REQUIRE(d_in && d_in2 && d_w && d_out, "conv1x1_dual: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && H2 > 0 && W2 > 0, "conv1x1_dual: bad geometry");
+  EMP_REQUIRE(variant >= 0 && (variant & 15) <= 3 && ((variant >> 4) & 15) <= 4, "conv1x1_dual: bad variant %d", variant);
+  ConvParams p{};
+  p.in = (const half_t*)d_in;
+  p.in2 = (const half_t*)d_in2;
+  p.wgt = (const half_t*)d_w;
+  p.bias = d_bias;
+  p.out = (half_t*)d_out;
+  p.zero = (const half_t*)zero_page();
+  EMP_REQUIRE(p.zero != nullptr, "conv1x1_dual: could not allocate the zero page");
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.in_ld = in_ld;
+  p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.in2_ld = in2_ld; p.stride2 = stride2;
+  p.Cout = Cout; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1;
+  p.Ho = H; p.Wo = W;
+  p.out_ld = out_ld;
+  p.act = relu;
+  p.M = N * H * W;
+  return launch_conv_igemm(p, variant, (hipStream_t)stream);
+}
+
 int emp_dwconv_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld, const void* d_w, int K, void* d_out,
                         int out_ld, void* stream) {
   EMP_REQUIRE(d_in && d_w && d_out, "dwconv: null pointer");

@@ -62,6 +62,11 @@ struct ConvParams {
   int mt, nt;      // tiles along pixels / couts
   int mt_per_xcd;  // ceil(mt/8)
   int kgroup;      // channel slabs (64 ch) per K-walk group, set by launch_conv_igemm
+  // optional second source, K-concatenated behind the first one (1x1 main conv only): a strided 1x1 conv of `in2`
+  // summed into the same accumulators -- the bottleneck's downsample branch folded into conv3.
+  // Weight rows are then [KH*KW*Cin | Cin2] long.
+  const half_t* in2;  // (N,H2,W2,in2_ld) or null
+  int Cin2, in2_ld, H2, W2, stride2;
 };
 
 // variant: 0 = auto, 1 = register-staged, 2 = LDS-DMA staged

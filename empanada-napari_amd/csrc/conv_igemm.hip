@@ -98,13 +98,15 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
   const int HoWo = p.Ho * p.Wo;
   const int KT = p.KH * p.KW;
   const int CB = p.Cin / BK;
-  const int S = KT * CB;
+  const int S1 = KT * CB;                    // K-steps of the main source
+  const int S = S1 + (p.in2 ? p.Cin2 / BK : 0);
   const bool pointwise = (KT == 1) && p.stride == 1 && p.pad == 0;
 
   const half_t* a_img[A_ITERS];   // image base (+ chunk) of the row's pixel, general path
   int a_iy0[A_ITERS], a_ix0[A_ITERS];
   const half_t* a_cur[A_ITERS];   // source of the next K-slab (or the zero page)
   int a_inc[A_ITERS];             // BK, or 0 while parked on the zero page
+  const half_t* a_two[A_ITERS];   // second source: the row's pixel in `in2` (or the zero page)
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) {
     const int m = m0 + 8 * (w + 4 * i) + srow;
@@ -112,7 +114,15 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
     a_iy0[i] = a_ix0[i] = -(1 << 28);
     a_cur[i] = p.zero;
     a_inc[i] = 0;
+    a_two[i] = p.zero;
     if (m < p.M) {
+      if (p.in2) {
+        const int n = m / HoWo;
+        const int r = m - n * HoWo;
+        const int oy = r / p.Wo;
+        const int ox = r - oy * p.Wo;
+        a_two[i] = p.in2 + (((size_t)n * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.in2_ld + schunk * 8;
+      }
       if (pointwise) {
         a_cur[i] = p.in + (size_t)m * p.in_ld + schunk * 8;
         a_inc[i] = BK;
@@ -135,7 +145,7 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
     const int row = 8 * (w + 4 * i) + srow;                  // LDS row in the B tile
     const int co = n0 + (row & ~31) + perm32(row & 31);      // cout staged into that row
     const bool ok = co < p.Cout;
-    b_base[i] = b_cur[i] = ok ? p.wgt + (size_t)co * KT * p.Cin + schunk * 8 : p.zero;
+    b_base[i] = b_cur[i] = ok ? p.wgt + (size_t)co * (KT * p.Cin + (p.in2 ? p.Cin2 : 0)) + schunk * 8 : p.zero;
     b_inc[i] = ok ? BK : 0;
   }
   const int KG = p.kgroup;          // channel slabs per group (divides CB); KG == CB: plain tap-major walk
@@ -157,11 +167,20 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
 
   f16x8 ra[A_ITERS], rb[B_ITERS];
   int st_ky = 0, st_kx = 0, st_cb = 0, st_grp = 0;  // tap / slab within the group / group of the step being staged
+  int st_n = 0;                                     // index of the step being staged
 
   auto stage_issue = [&](int buf) {
     char* a_s = lds + buf * (A_BYTES + B_BYTES);
     char* b_s = a_s + A_BYTES;
-    if (!pointwise && st_cb == 0) {  // uniform: new tap (or group) -> re-derive the row sources once
+    if (st_n == S1 && p.in2) {       // uniform: the main source is exhausted, continue along K in the second one
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) {
+        a_cur[i] = a_two[i];
+        a_inc[i] = (a_two[i] != p.zero) ? BK : 0;
+      }
+    }
+    ++st_n;
+    if (!pointwise && st_cb == 0 && st_n <= S1) {  // uniform: new tap (or group) -> re-derive the row sources once
       const int dy = st_ky * p.dil, dx = st_kx * p.dil;
       const int c0 = st_grp * KG * BK;
 #pragma unroll
@@ -394,7 +413,7 @@ bool conv_uses_256(const ConvParams& p) {
   const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * (p.Cout / 256);
   // one workgroup per CU cannot overlap its epilogue with another tile's main loop: with a residual to read the
   // epilogue moves 256 KB per tile, as long as a K = 512 main loop (layer4 conv3: 0.57 ms vs 0.51 on 128x128)
-  const int k256 = p.KH * p.KW * p.Cin;
+  const int k256 = p.KH * p.KW * p.Cin + (p.in2 ? p.Cin2 : 0);
   return !no256 && conv_igemm256_supported(p) && tiles256 >= 192 && k256 >= (p.res ? 2 * min_k : min_k);
 }
 
@@ -411,6 +430,14 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
                   ((uintptr_t)p.res % 16) == 0 && ((uintptr_t)p.zero % 256) == 0 && p.zero != nullptr,
               "conv: pointers must be 16-byte aligned (zero page 256)");
   EMP_REQUIRE((int64_t)p.N * p.Ho * p.Wo < (1ll << 31), "conv: too many output pixels");
+  if (p.in2) {
+    EMP_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.ps_cout == 0,
+                "conv: a second source needs a 1x1 / stride 1 main convolution");
+    EMP_REQUIRE(p.Cin2 > 0 && p.Cin2 % BK == 0 && p.in2_ld % 8 == 0 && p.in2_ld >= p.Cin2 && ((uintptr_t)p.in2 % 16) == 0,
+                "conv: second source: Cin2=%d must be a positive multiple of 64, in2_ld=%d >= Cin2", p.Cin2, p.in2_ld);
+    EMP_REQUIRE(p.stride2 >= 1 && (p.Ho - 1) * p.stride2 < p.H2 && (p.Wo - 1) * p.stride2 < p.W2,
+                "conv: second source %dx%d / stride %d does not cover the %dx%d output", p.H2, p.W2, p.stride2, p.Ho, p.Wo);
+  }
   // variant = staging + 16 * tile
   //   staging: 0 auto | 1 register staging | 2 LDS-DMA | 3 LDS-DMA + LDS-transposed epilogue
   //   tile   : 0 auto | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x256 (conv_igemm256.hip; Cout % 256 == 0)

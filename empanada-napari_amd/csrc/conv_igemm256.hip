@@ -69,7 +69,8 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
   const int KT = p.KH * p.KW;
   const int CB = p.Cin / KS;              // 32-channel slabs per tap
   const int KG = p.kgroup;                // slabs per K-walk group (divides CB)
-  const int KTOT = KT * CB;
+  const int KT1 = KT * CB;                // K-tiles of the main source
+  const int KTOT = KT1 + (p.in2 ? p.Cin2 / KS : 0);
   const bool pointwise = (KT == 1) && p.stride == 1 && p.pad == 0;
 
   // ---- staging: wave w moves pixel pieces {w, w+8} and cout pieces {w, w+8} (16 rows x 64 B each) ----
@@ -79,6 +80,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
   int a_iy0[2], a_ix0[2];
   const half_t* a_cur[2];
   int a_inc[2];
+  const half_t* a_two[2];                 // second source (ConvParams::in2): the row's pixel there, or the zero page
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + (wave + 8 * i) * 16 + srow;
@@ -86,7 +88,15 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
     a_iy0[i] = a_ix0[i] = -(1 << 28);
     a_cur[i] = p.zero;
     a_inc[i] = 0;
+    a_two[i] = p.zero;
     if (m < p.M) {
+      if (p.in2) {
+        const int n = m / HoWo;
+        const int r = m - n * HoWo;
+        const int oy = r / p.Wo;
+        const int ox = r - oy * p.Wo;
+        a_two[i] = p.in2 + (((size_t)n * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.in2_ld + schunk * 8;
+      }
       if (pointwise) {
         a_cur[i] = p.in + (size_t)m * p.in_ld + schunk * 8;
         a_inc[i] = KS;
@@ -107,12 +117,19 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
   for (int i = 0; i < 2; ++i) {
     const int row = (wave + 8 * i) * 16 + srow;
     const int co = n0 + (row & ~31) + perm32b(row & 31);
-    b_base[i] = b_cur[i] = p.wgt + (size_t)co * KT * p.Cin + schunk * 8;
+    b_base[i] = b_cur[i] = p.wgt + (size_t)co * (KT * p.Cin + (p.in2 ? p.Cin2 : 0)) + schunk * 8;
   }
   int st_ky = 0, st_kx = 0, st_cb = 0, st_grp = 0, st_u = 0;
   const half_t* src[4];      // sources of the next K-tile's 4 pieces (2 pixel, 2 cout)
   auto stage_prep = [&]() {   // address work of K-tile st_u (kept out of the MFMA slot)
-    if (st_cb == 0) {
+    if (st_u == KT1 && p.in2) {      // the main source is exhausted: continue along K in the second one
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a_cur[i] = a_two[i];
+        a_inc[i] = (a_two[i] != p.zero) ? KS : 0;
+      }
+    }
+    if (st_cb == 0 && st_u < KT1) {
       const int c0 = st_grp * KG * KS;
       if (!pointwise) {
         const int dy = st_ky * p.dil, dx = st_kx * p.dil;
@@ -271,7 +288,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
 }  // namespace
 
 bool conv_igemm256_supported(const ConvParams& p) {
-  return p.Cout % 256 == 0 && p.ps_cout == 0 && p.Cin % KS == 0 && p.KH * p.KW * (p.Cin / KS) >= 4;
+  return p.Cout % 256 == 0 && p.ps_cout == 0 && p.Cin % KS == 0 && p.KH * p.KW * (p.Cin / KS) + (p.in2 ? p.Cin2 / KS : 0) >= 4;
 }
 
 int launch_conv_igemm256(ConvParams p, hipStream_t stream) {

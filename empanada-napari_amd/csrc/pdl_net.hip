@@ -41,6 +41,7 @@ struct DevConv {  // packed conv weights
   half_t* w = nullptr;
   float* b = nullptr;
   int cout = 0, cin = 0, cin_pad = 0, kh = 1, kw = 1;
+  int cin2 = 0, cin2_pad = 0;     // K-concatenated second source (conv3 + projection shortcut)
 };
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -59,6 +60,7 @@ struct emp_pdl {
   FILE* layer_log = [] { const char* e = getenv("EMP_LAYER_LOG"); return e ? fopen(e, "w") : (FILE*)nullptr; }();
   // fused separable convs (sepconv.hip); EMP_FUSE_SEPCONV=0 keeps the dwconv + 1x1 conv + head1x1 launches (A/B runs)
   bool fuse_stem = [] { const char* e = getenv("EMP_FUSE_STEM"); return !(e && e[0] == '0'); }();   // stem.hip
+  bool fuse_ds = [] { const char* e = getenv("EMP_FUSE_DS"); return !(e && e[0] == '0'); }();       // conv3 + downsample in one GEMM
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
 
   // device parameters
@@ -198,6 +200,38 @@ int pack_conv(emp_pdl* n, const std::string& name, int cin_pad_to = 0) {
   if (rc) return rc;
   dc.b = (float*)d;
   n->convs[name] = dc;
+  return EMP_OK;
+}
+
+// conv3 and the projection shortcut of a bottleneck as one weight matrix [Cout][cin3_pad | cin_ds_pad] with the summed
+// (folded BN) bias: relu(conv3(c2) + downsample(x)) becomes a single GEMM over the concatenated K (ConvParams::in2)
+int pack_conv3_ds(emp_pdl* n, const std::string& block) {
+  const HostParam& h3 = n->params.at(block + ".conv3");
+  const HostParam& hd = n->params.at(block + ".downsample.0");
+  EMP_REQUIRE(h3.shape.size() == 4 && hd.shape.size() == 4 && h3.shape[0] == hd.shape[0] && h3.shape[2] == 1 &&
+                  hd.shape[2] == 1 && h3.b.size() == hd.b.size(), "%s: conv3 / downsample shapes do not match", block.c_str());
+  DevConv dc;
+  dc.cout = (int)h3.shape[0];
+  dc.cin = (int)h3.shape[1];
+  dc.cin_pad = round_up(dc.cin, 64);
+  dc.cin2 = (int)hd.shape[1];
+  dc.cin2_pad = round_up(dc.cin2, 64);
+  const size_t K = (size_t)dc.cin_pad + dc.cin2_pad;
+  std::vector<half_t> pk((size_t)dc.cout * K, (half_t)0.f);
+  std::vector<float> b((size_t)dc.cout);
+  for (int o = 0; o < dc.cout; ++o) {
+    for (int i = 0; i < dc.cin; ++i) pk[o * K + i] = (half_t)h3.w[(size_t)o * dc.cin + i];
+    for (int i = 0; i < dc.cin2; ++i) pk[o * K + dc.cin_pad + i] = (half_t)hd.w[(size_t)o * dc.cin2 + i];
+    b[o] = h3.b[o] + hd.b[o];
+  }
+  void* d;
+  int rc = dev_upload(n, pk.data(), pk.size() * sizeof(half_t), &d);
+  if (rc) return rc;
+  dc.w = (half_t*)d;
+  rc = dev_upload(n, b.data(), b.size() * sizeof(float), &d);
+  if (rc) return rc;
+  dc.b = (float*)d;
+  n->convs[block + ".conv3+ds"] = dc;
   return EMP_OK;
 }
 
@@ -443,9 +477,16 @@ T* rawp(emp_pdl* n, const std::string& name) {
 
 // conv helper: in (channels [0,Cin_pad) of `in`), out channels [coff, coff+Cout) of `out`
 int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const Act& out, int out_coff, int stride,
-         int pad, int dil, int act, const Act* res, const float* bias_n, hipStream_t s, int ps_cout = 0) {
+         int pad, int dil, int act, const Act* res, const float* bias_n, hipStream_t s, int ps_cout = 0,
+         const Act* in2 = nullptr, int stride2 = 1) {
   const DevConv& dc = n->convs.at(wname);
   ConvParams p{};
+  if (in2) {      // K-concatenated second source (ConvParams::in2)
+    EMP_REQUIRE(dc.cin2_pad > 0 && dc.cin2_pad <= in2->ld && in2->N == in.N, "%s: second source mismatch", wname.c_str());
+    p.in2 = in2->p; p.Cin2 = dc.cin2_pad; p.in2_ld = in2->ld; p.H2 = in2->H; p.W2 = in2->W; p.stride2 = stride2;
+  } else {
+    EMP_REQUIRE(dc.cin2_pad == 0, "%s: packed for two sources", wname.c_str());
+  }
   p.in = in.p + in_coff;
   p.wgt = dc.w;
   p.bias = dc.b;
@@ -467,10 +508,11 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
   p.act = act;
   p.ps_cout = ps_cout;
   p.M = p.N * p.Ho * p.Wo;
-  n->flops += 2.0 * (double)p.M * dc.cout * (double)(dc.cin * dc.kh * dc.kw);
+  const double kflop = (double)(dc.cin * dc.kh * dc.kw + dc.cin2);
+  n->flops += 2.0 * (double)p.M * dc.cout * kflop;
   if (n->layer_log)   // EMP_LAYER_LOG=<file>: one line per MFMA launch, in launch order (tools/layer_roofline.py)
-    fprintf(n->layer_log, "conv,%s,%d,%d,%d,%d,%d,%d,%d,%d\n", wname.c_str(), p.M, dc.cin_pad, dc.cout, dc.kh, stride, dil,
-            res ? 1 : 0, in.N * in.H * in.W);
+    fprintf(n->layer_log, "conv,%s,%d,%d,%d,%d,%d,%d,%d,%d\n", wname.c_str(), p.M, dc.cin_pad + dc.cin2_pad, dc.cout, dc.kh,
+            stride, dil, res ? 1 : 0, in.N * in.H * in.W);
   if (n->profile && conv_uses_256(p)) {
     if (n->prof_used == n->prof_events.size()) {
       hipEvent_t a, b;
@@ -482,7 +524,7 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
     EMP_CHECK_HIP(hipEventRecord(ev.first, s));
     const int rc = launch_conv_igemm(p, 0, s);
     EMP_CHECK_HIP(hipEventRecord(ev.second, s));
-    n->prof_flops += 2.0 * (double)p.M * dc.cout * (double)(dc.cin * dc.kh * dc.kw);
+    n->prof_flops += 2.0 * (double)p.M * dc.cout * kflop;
     return rc;
   }
   return launch_conv_igemm(p, 0, s);
@@ -521,6 +563,13 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       RC(conv(n, p + ".conv1", A(xname), 0, A(p + ".c1"), 0, 1, 0, 1, true, nullptr, nullptr, s));
       RC(conv(n, p + ".conv2", A(p + ".c1"), 0, A(p + ".c2"), 0, sb, dil, dil, true, nullptr, nullptr, s));
       const Act* idn = &A(xname);
+      if (b == 0 && n->fuse_ds) {
+        // relu(bn3(conv3(c2)) + bn(downsample(x))) as ONE GEMM whose K runs over c2's channels and then over x's
+        // (sampled with the block's stride): the shortcut map is neither written nor read back
+        RC(conv(n, p + ".conv3+ds", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, true, nullptr, nullptr, s, 0, &A(xname), sb));
+        xname = p;
+        continue;
+      }
       if (b == 0) {
         RC(conv(n, p + ".downsample.0", A(xname), 0, A(p + ".ds"), 0, sb, 0, 1, false, nullptr, nullptr, s));
         idn = &A(p + ".ds");
@@ -858,7 +907,10 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       RC(pack_conv(n, p + ".conv1"));
       RC(pack_conv(n, p + ".conv2"));
       RC(pack_conv(n, p + ".conv3"));
-      if (b == 0) RC(pack_conv(n, p + ".downsample.0"));
+      if (b == 0) {
+        RC(pack_conv(n, p + ".downsample.0"));
+        RC(pack_conv3_ds(n, p));
+      }
     }
   if (c.arch == 1) {
     const int F = c.fpn_dim;

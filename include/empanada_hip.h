@@ -162,6 +162,17 @@ EMP_API int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, 
                         int KH, int KW, int stride, int pad, int dil, int relu,
                         int variant, void* stream);
 
+/* out = act( in . W[:, :Cin] + in2(strided) . W[:, Cin:] + bias ): a 1x1 convolution whose reduction continues over a
+ * second tensor sampled with stride2.  replaces the tail of a ResNet bottleneck with a projection shortcut,
+ * `out = relu(bn3(conv3(x)) + downsample(identity))`, empanada/models/encoders/resnet.py:109-129 with
+ * downsample = Conv2d(1x1, stride) + BN (:176-181): both branches accumulate in fp32 in one launch, the shortcut map is
+ * never written.  d_w (Cout, Cin + Cin2) fp16, rows K-contiguous; in (N,H,W,in_ld), in2 (N,H2,W2,in2_ld) with
+ * (H-1)*stride2 < H2; Cin, Cin2 multiples of 64. */
+EMP_API int emp_conv1x1_dual_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_ld, const void* d_in2,
+                              int H2, int W2, int Cin2, int in2_ld, int stride2, const void* d_w,
+                              const float* d_bias, void* d_out, int out_ld, int Cout, int relu, int variant,
+                              void* stream);
+
 /* NHWC fp16 depthwise KxK convolution (K in {3,5}, stride 1, pad K/2, no bias), fp32 accumulate.
  * replaces nn.Conv2d(C, C, K, groups=C, bias=False): the first half of the decoder's separable convs
  * (models/blocks.py separable conv, models/decoders/bifpn.py SeparableConv2d).

@@ -109,3 +109,56 @@ def test_conv256_rejects_other_cout():
     w = torch.zeros((64, 64, 1, 1))
     with pytest.raises(EmpError):
         conv_hip(x, w, None, None, None, 1, 0, 1, True, 64)
+
+
+CASES_DUAL = [
+    # N, H, W, Cin, H2, W2, Cin2, stride2, Cout, variant
+    (1, 24, 40, 64, 24, 40, 64, 1, 256, 0),          # layer1.0: conv3 (64) + shortcut (64), same resolution
+    (1, 24, 40, 64, 24, 40, 64, 1, 256, 64),         # the same on the 256x256 tile (2 + 2 K-tiles: the shortest ring)
+    (2, 12, 20, 128, 24, 40, 256, 2, 512, 0),        # layer2.0: the shortcut samples every second pixel
+    (2, 12, 20, 128, 23, 39, 256, 2, 512, 64),       # odd source size ((H-1)*2 < H2)
+    (1, 8, 8, 512, 8, 8, 1024, 1, 2048, 0),          # layer4.0 (output stride 16): auto -> 256x256 tile, 48 K-tiles
+    (1, 9, 7, 64, 9, 7, 128, 1, 64, 0),              # Cout 64 -> the 128x64 tile; M tail
+    (1, 16, 16, 192, 31, 31, 64, 2, 128, 16 + 1),    # register-staged variant of the 128x128 tile
+]
+
+
+@pytest.mark.parametrize('case', CASES_DUAL)
+def test_conv1x1_dual_source_matches_fp32_reference(case):
+    """out = relu(x . W1 + x2[::s, ::s] . W2 + b): the bottleneck's conv3 with the projection shortcut K-concatenated"""
+    import ctypes as C
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    N, H, W, Cin, H2, W2, Cin2, s2, Cout, variant = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.float16)
+    x2 = torch.randn((N, H2, W2, Cin2), generator=g).to(torch.float16)
+    w = (torch.randn((Cout, Cin + Cin2), generator=g) / np.sqrt(Cin + Cin2)).to(torch.float16)
+    b = torch.randn((Cout,), generator=g) * 0.1
+    ref = x.float() @ w[:, :Cin].float().T + x2[:, ::s2, ::s2][:, :H, :W].float() @ w[:, Cin:].float().T + b
+    ref = torch.relu(ref)
+    xd, x2d, wd, bd = x.to(dev()), x2.to(dev()), w.to(dev()).contiguous(), b.float().to(dev())
+    lib = _abi.load()
+    for rep in range(3):
+        out = torch.full((N, H, W, Cout), 7.0, dtype=torch.float16, device=dev())
+        _abi.check(lib.emp_conv1x1_dual_nhwc_f16(_abi.ptr(xd), N, H, W, Cin, Cin, _abi.ptr(x2d), H2, W2, Cin2, Cin2, s2,
+                                                 _abi.ptr(wd), _abi.ptr(bd), _abi.ptr(out), Cout, Cout, 1, variant,
+                                                 _abi.stream_ptr(dev())), 'emp_conv1x1_dual_nhwc_f16')
+        torch.cuda.synchronize()
+        err = (out.float().cpu() - ref).abs()
+        tol = 2e-3 + 2e-3 * ref.abs()
+        assert torch.all(err <= tol), f'rep {rep}: max err {err.max():.4e}'
+
+
+def test_conv1x1_dual_source_rejects_bad_geometry():
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    from empanada_napari_amd._abi import EmpError
+    lib = _abi.load()
+    x = torch.zeros((1, 8, 8, 64), dtype=torch.float16, device=dev())
+    x2 = torch.zeros((1, 8, 8, 64), dtype=torch.float16, device=dev())
+    w = torch.zeros((64, 128), dtype=torch.float16, device=dev())
+    out = torch.zeros((1, 8, 8, 64), dtype=torch.float16, device=dev())
+    with pytest.raises(EmpError, match='does not cover'):        # stride 2 over an 8x8 source cannot feed 8x8 outputs
+        _abi.check(lib.emp_conv1x1_dual_nhwc_f16(_abi.ptr(x), 1, 8, 8, 64, 64, _abi.ptr(x2), 8, 8, 64, 64, 2, _abi.ptr(w), None,
+                                                 _abi.ptr(out), 64, 64, 1, 0, _abi.stream_ptr(dev())), 'dual')

@@ -174,10 +174,11 @@ def test_fused_launches_equal_unfused_bit_exact(setup):
     x = _norm(synth.em_tiles(2, 128, seed=31)).cuda()
     fused = {k: v.clone() for k, v in model(x, 2, False).items()}
     taps_f = {t: model.tap(t).clone() for t in ('encoder.layer1.2', 'encoder.layer2.3', 'semantic_decoder.stage0.out')}
-    old = {k: os.environ.get(k) for k in ('EMP_FUSE_SEPCONV', 'EMP_FUSE_STEM')}
+    old = {k: os.environ.get(k) for k in ('EMP_FUSE_SEPCONV', 'EMP_FUSE_STEM', 'EMP_FUSE_DS')}
     try:
         os.environ['EMP_FUSE_SEPCONV'] = '0'
         os.environ['EMP_FUSE_STEM'] = '0'
+        os.environ['EMP_FUSE_DS'] = '0'      # conv3 + projection shortcut as two launches (shortcut rounded to fp16)
         plain_model = HipPanopticDeepLab(P, cfg, folded=True)
     finally:
         for k, v in old.items():
