@@ -67,6 +67,10 @@ struct ConvParams {
   // Weight rows are then [KH*KW*Cin | Cin2] long.
   const half_t* in2;  // (N,H2,W2,in2_ld) or null
   int Cin2, in2_ld, H2, W2, stride2;
+  // optional second destination: couts [split, Cout) go to out2 (channel 0 of out2 = cout `split`); split % 8 == 0.
+  // Two convolutions of the same input (the two decoders' low-level projections) share one pass over it.
+  half_t* out2;
+  int out2_ld, split;
 };
 
 // variant: 0 = auto, 1 = register-staged, 2 = LDS-DMA staged

@@ -57,6 +57,12 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 // output element offset of pixel m / cout co.  ps_cout > 0: the GEMM computes a k=2,s=2 transposed
 // convolution as 4 sub-pixel 1x1 convs (cout blocks q = dy*2+dx of ps_cout channels each) and the
 // store does the pixel shuffle: (n,y,x,q*C+c) -> (n, 2y+dy, 2x+dx, c)   (blocks.py:154-171)
+__device__ __forceinline__ size_t out_offset(const ConvParams& p, int m, int co, int HoWo);
+// destination of the 8 couts starting at `co` of output pixel m (second destination: ConvParams::out2)
+__device__ __forceinline__ half_t* out_ptr(const ConvParams& p, int m, int co, int HoWo) {
+  if (p.out2 && co >= p.split) return p.out2 + (size_t)m * p.out2_ld + (co - p.split);
+  return p.out + out_offset(p, m, co, HoWo);
+}
 __device__ __forceinline__ size_t out_offset(const ConvParams& p, int m, int co, int HoWo) {
   if (p.ps_cout == 0) return (size_t)m * p.out_ld + co;
   const int q = co / p.ps_cout, c = co - q * p.ps_cout;
@@ -344,7 +350,7 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
       f16x8 o;
 #pragma unroll
       for (int r = 0; r < 8; ++r) o[r] = (half_t)apply_act(v[r], p.act);
-      *reinterpret_cast<f16x8*>(p.out + out_offset(p, m, co_l, HoWo)) = o;
+      *reinterpret_cast<f16x8*>(out_ptr(p, m, co_l, HoWo)) = o;
     }
     return;
   } else {
@@ -386,7 +392,7 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
         f16x8 o;
 #pragma unroll
         for (int r = 0; r < 8; ++r) o[r] = (half_t)apply_act(v[r], p.act);
-        *reinterpret_cast<f16x8*>(p.out + out_offset(p, m, co, HoWo)) = o;
+        *reinterpret_cast<f16x8*>(out_ptr(p, m, co, HoWo)) = o;
       }
     }
   }
@@ -414,14 +420,14 @@ bool conv_uses_256(const ConvParams& p) {
   // one workgroup per CU cannot overlap its epilogue with another tile's main loop: with a residual to read the
   // epilogue moves 256 KB per tile, as long as a K = 512 main loop (layer4 conv3: 0.57 ms vs 0.51 on 128x128)
   const int k256 = p.KH * p.KW * p.Cin + (p.in2 ? p.Cin2 : 0);
-  return !no256 && conv_igemm256_supported(p) && tiles256 >= 192 && k256 >= (p.res ? 2 * min_k : min_k);
+  return !no256 && !p.out2 && conv_igemm256_supported(p) && tiles256 >= 192 && k256 >= (p.res ? 2 * min_k : min_k);
 }
 
 int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   EMP_REQUIRE(p.Cin % BK == 0 && p.Cin > 0, "conv: Cin=%d must be a positive multiple of 64", p.Cin);
   EMP_REQUIRE(p.in_ld % 8 == 0 && p.in_ld >= p.Cin, "conv: in_ld=%d must be >= Cin and a multiple of 8", p.in_ld);
   EMP_REQUIRE(p.Cout % 8 == 0 && p.Cout > 0, "conv: Cout=%d must be a positive multiple of 8", p.Cout);
-  EMP_REQUIRE(p.out_ld % 8 == 0 && p.out_ld >= (p.ps_cout ? p.ps_cout : p.Cout), "conv: out_ld=%d invalid", p.out_ld);
+  EMP_REQUIRE(p.out_ld % 8 == 0 && p.out_ld >= (p.ps_cout ? p.ps_cout : (p.out2 ? p.split : p.Cout)), "conv: out_ld=%d invalid", p.out_ld);
   EMP_REQUIRE(p.ps_cout == 0 || (p.ps_cout % 8 == 0 && p.Cout == 4 * p.ps_cout && p.res == nullptr),
               "conv: pixel-shuffle store needs Cout == 4*ps_cout, ps_cout %% 8 == 0, no residual");
   EMP_REQUIRE(p.act >= 0 && p.act <= 2, "conv: act must be 0 (none), 1 (ReLU) or 2 (SiLU)");
@@ -430,6 +436,11 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
                   ((uintptr_t)p.res % 16) == 0 && ((uintptr_t)p.zero % 256) == 0 && p.zero != nullptr,
               "conv: pointers must be 16-byte aligned (zero page 256)");
   EMP_REQUIRE((int64_t)p.N * p.Ho * p.Wo < (1ll << 31), "conv: too many output pixels");
+  if (p.out2) {
+    EMP_REQUIRE(p.split > 0 && p.split < p.Cout && p.split % 8 == 0 && p.out2_ld % 8 == 0 && p.out2_ld >= p.Cout - p.split &&
+                    p.out_ld >= p.split && ((uintptr_t)p.out2 % 16) == 0 && p.ps_cout == 0 && p.res == nullptr,
+                "conv: second destination: split=%d must be a multiple of 8 inside (0, Cout=%d)", p.split, p.Cout);
+  }
   if (p.in2) {
     EMP_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.ps_cout == 0,
                 "conv: a second source needs a 1x1 / stride 1 main convolution");
@@ -450,7 +461,10 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   //  second barrier per 64 channels costs more than the deeper prefetch saves)
   int v = variant & 15, tile = (variant >> 4) & 15, kg = variant >> 8;
   EMP_REQUIRE(v <= 3 && tile <= 4, "conv: bad variant %d", variant);
-  if (tile == 4) return launch_conv_igemm256(p, stream);
+  if (tile == 4) {
+    EMP_REQUIRE(p.out2 == nullptr, "conv: the 256x256 tile has no second destination");
+    return launch_conv_igemm256(p, stream);
+  }
   // K walk (variant bits 8+: 0 auto | g = channel slabs per group): with many input channels and several taps a
   // tap-major walk streams the whole input once per tap through an L2 that holds only ~4 MB per XCD; groups of
   // 4 slabs (256 channels x ~4096 pixels in flight per XCD = 2 MB) keep the 9 taps' re-reads in L2.

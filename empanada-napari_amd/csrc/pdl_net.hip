@@ -478,9 +478,14 @@ T* rawp(emp_pdl* n, const std::string& name) {
 // conv helper: in (channels [0,Cin_pad) of `in`), out channels [coff, coff+Cout) of `out`
 int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const Act& out, int out_coff, int stride,
          int pad, int dil, int act, const Act* res, const float* bias_n, hipStream_t s, int ps_cout = 0,
-         const Act* in2 = nullptr, int stride2 = 1) {
+         const Act* in2 = nullptr, int stride2 = 1, const Act* out2 = nullptr, int out2_coff = 0, int split = 0) {
   const DevConv& dc = n->convs.at(wname);
   ConvParams p{};
+  if (out2) {     // couts [split, Cout) go to a second tensor (ConvParams::out2)
+    EMP_REQUIRE(out2->N == out.N && out2->H == out.H && out2->W == out.W && out2_coff + dc.cout - split <= out2->ld,
+                "%s: second destination mismatch", wname.c_str());
+    p.out2 = out2->p + out2_coff; p.out2_ld = out2->ld; p.split = split;
+  }
   if (in2) {      // K-concatenated second source (ConvParams::in2)
     EMP_REQUIRE(dc.cin2_pad > 0 && dc.cin2_pad <= in2->ld && in2->N == in.N, "%s: second source mismatch", wname.c_str());
     p.in2 = in2->p; p.Cin2 = dc.cin2_pad; p.in2_ld = in2->ld; p.H2 = in2->H; p.W2 = in2->W; p.stride2 = stride2;
@@ -502,7 +507,7 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
   const int up = ps_cout ? 2 : 1;
   EMP_REQUIRE(p.Ho * up == out.H && p.Wo * up == out.W && in.N == out.N, "%s: output shape mismatch (%dx%d vs %dx%d)",
               wname.c_str(), p.Ho * up, p.Wo * up, out.H, out.W);
-  EMP_REQUIRE(in_coff + dc.cin_pad <= in.ld && out_coff + (ps_cout ? ps_cout : dc.cout) <= out.ld,
+  EMP_REQUIRE(in_coff + dc.cin_pad <= in.ld && out_coff + (ps_cout ? ps_cout : (out2 ? split : dc.cout)) <= out.ld,
               "%s: channel slice out of range", wname.c_str());
   p.out_ld = out.ld;
   p.act = act;
@@ -718,7 +723,17 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       const Act& cb = A(q + ".cat");
       const Act& xa = A(x);
       RC(launch_bilinear_ac(xa.p, N, xa.H, xa.W, xch, xa.ld, cb.p, cb.H, cb.W, cb.ld, s));
-      RC(conv(n, p + ".project." + std::to_string(i) + ".0", A(pyr[st]), 0, cb, xch, 1, 0, 1, true, nullptr, nullptr, s));
+      const std::string pm = "decoders.project." + std::to_string(i);
+      if (n->convs.count(pm)) {
+        // the two decoders project the same low-level map: one pass over it writes both concat buffers (d == 0)
+        if (d == 0) {
+          const Act& cb2 = A(std::string(decs[1]) + ".stage" + std::to_string(i) + ".cat");
+          RC(conv(n, pm, A(pyr[st]), 0, cb, xch, 1, 0, 1, true, nullptr, nullptr, s, 0, nullptr, 1, &cb2, xch,
+                  c.low_level_proj_sem[i]));
+        }
+      } else {
+        RC(conv(n, p + ".project." + std::to_string(i) + ".0", A(pyr[st]), 0, cb, xch, 1, 0, 1, true, nullptr, nullptr, s));
+      }
       const std::string fz = p + ".fuse." + std::to_string(i) + ".0.sepconv.";
       n->flops += 2.0 * 25.0 * (double)N * cb.H * cb.W * (xch + n->convs.at(p + ".project." + std::to_string(i) + ".0").cout);
       {
@@ -977,6 +992,24 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       xch = n->dec_ch;
     }
   }
+  // the two decoders' low-level projections of one pyramid level as ONE conv with two destinations
+  if (n->fuse_ds && c.ins_decoder)
+    for (int i = 0; i < c.n_stages; ++i) {
+      const HostParam& hs = n->params.at("semantic_decoder.project." + std::to_string(i) + ".0");
+      const HostParam& hi = n->params.at("instance_decoder.project." + std::to_string(i) + ".0");
+      if (hs.shape[1] != hi.shape[1] || hs.shape[0] % 8 != 0) continue;
+      HostParam m;
+      m.shape = {hs.shape[0] + hi.shape[0], hs.shape[1], 1, 1};
+      m.w = hs.w;
+      m.w.insert(m.w.end(), hi.w.begin(), hi.w.end());
+      m.b = hs.b;
+      m.b.insert(m.b.end(), hi.b.begin(), hi.b.end());
+      const std::string pm = "decoders.project." + std::to_string(i);
+      n->params[pm] = m;
+      int rc = pack_conv(n, pm);
+      n->params.erase(pm);
+      if (rc) return rc;
+    }
   }
   const char* heads[3] = {"semantic_head", "ins_center", "ins_xy"};
   for (int k = 0; k < 3; ++k) {
