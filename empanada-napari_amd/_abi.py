@@ -64,6 +64,8 @@ PROTOTYPES = {
     'emp_sm_step_begin': (c_int, [vp, c_i64, C.POINTER(c_int), C.POINTER(c_int)]),
     'emp_sm_iou': (vp, [vp]),
     'emp_sm_step_apply': (c_int, [vp, vp, vp, c_i64]),
+    'emp_sm_run': (c_int, [vp, c_i64, c_int, c_i64, c_int, vp]),
+    'emp_sm_pending_shape': (c_int, [vp, vp, vp]),
     'emp_sm_tracker_init': (c_int, [vp, c_int, c_i64, c_i64, c_i64]),
     'emp_sm_track': (c_int, [vp, c_i64, c_i64]),
     'emp_sm_tracker_finish': (c_int, [vp]),

@@ -295,6 +295,61 @@ int emp_sm_step_apply(emp_stack_matcher* h, const int64_t* rows, const int64_t* 
   return EMP_OK;
 }
 
+// Runs `count` consecutive steps from slice idx in direction dir (+1 forward pass, -1 backward pass; `track`: feed the
+// tracker after every step, as backward_matching does) and stops BEFORE the assignment of the first slice whose IoU
+// matrix needs a real linear_sum_assignment: *stopped_at = that slice (its step is pending: the caller fetches
+// emp_sm_iou, solves, calls emp_sm_step_apply [+ emp_sm_track] and resumes behind it), or -1 when all steps ran.
+// A step needs no solver when every row and every column of the matrix holds at most one non-zero entry: an optimal
+// assignment then contains all of those pairs (any other entry adds 0), and pairs with IoU 0 never pass the
+// threshold (matcher.py:226-229), so the kept matches equal scipy's.
+int emp_sm_track(emp_stack_matcher* h, int64_t idx, int64_t index2d);
+int emp_sm_run(emp_stack_matcher* h, int64_t idx, int dir, int64_t count, int track, int64_t* stopped_at) {
+  EMP_REQUIRE(h && stopped_at && (dir == 1 || dir == -1) && count >= 0, "sm_run: bad arguments");
+  *stopped_at = -1;
+  std::vector<int64_t> rows, cols;
+  for (int64_t k = 0; k < count; ++k) {
+    const int64_t i = idx + k * dir;
+    int nt = 0, nm = 0;
+    int rc = emp_sm_step_begin(h, i, &nt, &nm);
+    if (rc) return rc;
+    if (nt >= 0) {
+      if (nt == 0 || nm == 0) {
+        rc = emp_sm_step_apply(h, nullptr, nullptr, 0);
+      } else {
+        rows.clear();
+        cols.clear();
+        std::vector<char> col_used((size_t)nm, 0);
+        bool simple = true;
+        for (int r = 0; r < nt && simple; ++r) {
+          int found = -1;
+          for (int c = 0; c < nm; ++c)
+            if (h->iou[(size_t)r * nm + c] > 0.0) {
+              if (found >= 0 || col_used[(size_t)c]) { simple = false; break; }
+              found = c;
+              col_used[(size_t)c] = 1;
+            }
+          if (found >= 0) { rows.push_back(r); cols.push_back(found); }
+        }
+        if (!simple) { *stopped_at = i; return EMP_OK; }
+        rc = emp_sm_step_apply(h, rows.data(), cols.data(), (int64_t)rows.size());
+      }
+      if (rc) return rc;
+    }
+    if (track) {
+      rc = emp_sm_track(h, i, i);
+      if (rc) return rc;
+    }
+  }
+  return EMP_OK;
+}
+
+int emp_sm_pending_shape(const emp_stack_matcher* h, int* nt, int* nm) {
+  EMP_REQUIRE(h && nt && nm && h->pending >= 0, "sm_pending_shape: no pending step");
+  *nt = h->nt;
+  *nm = h->nm;
+  return EMP_OK;
+}
+
 // ---- tracker (tracker.py:61-123) -------------------------------------------------------------------------------
 int emp_sm_tracker_init(emp_stack_matcher* h, int axis, int64_t D, int64_t H, int64_t W) {
   EMP_REQUIRE(h && axis >= 0 && axis <= 2 && D > 0 && H > 0 && W > 0, "sm_tracker_init: bad arguments");

@@ -439,7 +439,7 @@ class Engine3d:
                 sm = sms[label]
                 for runs in runs_list:
                     sm.push_runs(runs, width, off)
-                    sm.step(len(sm) - 1)
+                sm.step_to(len(sm))
 
         with ThreadPoolExecutor(max_workers=1) as worker:
             jobs = []

@@ -434,6 +434,37 @@ class StackMatcher:
         cols = np.ascontiguousarray(cols, dtype=i64)
         _abi.check(self.lib.emp_sm_step_apply(self._h, _hp(rows), _hp(cols), len(rows)), 'emp_sm_step_apply')
 
+    def _solve_pending(self):
+        cnt, cnm = C.c_int(0), C.c_int(0)
+        _abi.check(self.lib.emp_sm_pending_shape(self._h, C.byref(cnt), C.byref(cnm)), 'emp_sm_pending_shape')
+        nt, nm = cnt.value, cnm.value
+        iou = np.ctypeslib.as_array(C.cast(self.lib.emp_sm_iou(self._h), C.POINTER(C.c_double)), shape=(nt, nm))
+        rows, cols = linear_sum_assignment(iou, maximize=True)
+        rows = np.ascontiguousarray(rows, dtype=i64)
+        cols = np.ascontiguousarray(cols, dtype=i64)
+        _abi.check(self.lib.emp_sm_step_apply(self._h, _hp(rows), _hp(cols), len(rows)), 'emp_sm_step_apply')
+
+    def _run(self, idx, direction, count, track):
+        """``count`` steps from ``idx`` in C++ (emp_sm_run); only slices whose IoU matrix really needs an assignment
+        solver come back to scipy, as the reference solves every slice (matcher.py:218)."""
+        stopped = C.c_int64(-1)
+        while count > 0:
+            _abi.check(self.lib.emp_sm_run(self._h, int(idx), int(direction), int(count), int(track), C.byref(stopped)),
+                       'emp_sm_run')
+            if stopped.value < 0:
+                return
+            self._solve_pending()
+            if track:
+                _abi.check(self.lib.emp_sm_track(self._h, stopped.value, stopped.value), 'emp_sm_track')
+            done = abs(stopped.value - idx) + 1
+            idx, count = stopped.value + direction, count - done
+
+    def step_to(self, n):
+        """Forward matching of the slices pushed so far up to (not including) ``n``."""
+        if n > self._stepped:
+            self._run(self._stepped, 1, n - self._stepped, False)
+            self._stepped = n
+
     def step(self, idx):
         """Forward matching of slice ``idx`` (the next unmatched one): lets the caller match slices as they arrive."""
         assert idx == self._stepped, f'forward matching is sequential: expected slice {self._stepped}, got {idx}'
@@ -442,8 +473,7 @@ class StackMatcher:
 
     def forward(self):
         """Forward matching of every slice not matched yet."""
-        while self._stepped < len(self):
-            self.step(self._stepped)
+        self.step_to(len(self))
 
     def backward_and_track(self, axis_name, shape3d):
         """Backward matching with the tracker fed in the same (descending) slice order; returns the finished tracker's
@@ -451,9 +481,7 @@ class StackMatcher:
         D, H, W = [int(v) for v in shape3d]
         _abi.check(self.lib.emp_sm_tracker_init(self._h, InstanceTracker.AXES[axis_name], D, H, W), 'emp_sm_tracker_init')
         _abi.check(self.lib.emp_sm_begin_backward(self._h), 'emp_sm_begin_backward')
-        for idx in range(len(self) - 1, -1, -1):
-            self._step(idx)
-            _abi.check(self.lib.emp_sm_track(self._h, idx, idx), 'emp_sm_track')
+        self._run(len(self) - 1, -1, len(self), True)
         _abi.check(self.lib.emp_sm_tracker_finish(self._h), 'emp_sm_tracker_finish')
         return self.instances()
 

@@ -329,6 +329,14 @@ EMP_API int emp_sm_begin_backward(emp_stack_matcher_t* h);
 EMP_API int emp_sm_step_begin(emp_stack_matcher_t* h, int64_t idx, int* nt, int* nm);
 EMP_API const double* emp_sm_iou(const emp_stack_matcher_t* h);          /* (nt,nm) float64, valid until the next step */
 EMP_API int emp_sm_step_apply(emp_stack_matcher_t* h, const int64_t* rows, const int64_t* cols, int64_t n);
+/* Runs `count` steps from slice idx in direction dir (+1 / -1), feeding the tracker after each when `track`, and stops
+ * before the first slice whose IoU matrix has a row or column with more than one non-zero entry (*stopped_at = its
+ * index, step pending: solve emp_sm_iou with linear_sum_assignment, emp_sm_step_apply, emp_sm_track, resume), or runs to
+ * the end (*stopped_at = -1).  Matrices without such conflicts need no solver: every non-zero pair is in any optimal
+ * assignment.  Replaces the per-slice Python loop of forward_matching / backward_matching, patterns.py:68-121. */
+EMP_API int emp_sm_run(emp_stack_matcher_t* h, int64_t idx, int dir, int64_t count, int track, int64_t* stopped_at);
+/* shape (targets x objects) of the pending step's IoU matrix */
+EMP_API int emp_sm_pending_shape(const emp_stack_matcher_t* h, int* nt, int* nm);
 EMP_API int emp_sm_tracker_init(emp_stack_matcher_t* h, int axis /* 0 xy, 1 xz, 2 yz */, int64_t D, int64_t H, int64_t W);
 EMP_API int emp_sm_track(emp_stack_matcher_t* h, int64_t idx, int64_t index2d);
 EMP_API int emp_sm_tracker_finish(emp_stack_matcher_t* h);

@@ -280,3 +280,16 @@ def test_oracle_morphology_restatement_basics():
     assert int(tr.instances[1001]['runs'].sum()) == 7                                                       # a 3-D cross
     diag = np.zeros((2, 2, 2), np.int64); diag[0, 0, 0] = diag[1, 1, 1] = 5
     assert osp.label_nd(diag).max() == 1                                                                    # 26-connectivity
+
+
+def test_cpp_stack_matcher_solver_only_where_needed(monkeypatch):
+    """emp_sm_run: slices whose IoU matrix has at most one non-zero per row and column are assigned in C++ (every such
+    pair is in any optimal assignment); the others still go through scipy.  Both kinds occur in the reference case whose
+    trackers are compared with the reference's goldens above."""
+    calls = []
+    orig = ps.StackMatcher._solve_pending
+    monkeypatch.setattr(ps.StackMatcher, '_solve_pending', lambda self: (calls.append(1), orig(self))[1])
+    n_slices = 0
+    for name, slices, fwd, inst, sm in _stack_matcher_trackers(_push_objects):
+        n_slices += 2 * len(slices)
+    assert 0 < len(calls) < n_slices // 2, (len(calls), n_slices)
