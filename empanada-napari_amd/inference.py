@@ -290,6 +290,13 @@ class Engine3d:
         self.chunk_size = chunk_size
         self.zarr_store = _open_zarr(store_url, mode='w') if store_url is not None else None
 
+    def _host_worker(self):
+        """one worker thread per engine: forward-matching jobs and deferred backward passes run in submission order"""
+        w = self.__dict__.get('_worker')
+        if w is None:
+            w = self.__dict__['_worker'] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='emp-match')
+        return w
+
     def create_trackers(self, shape3d, axis_name):
         return [sparse.InstanceTracker(label, self.label_divisor, shape3d, axis_name) for label in self.labels]
 
@@ -441,43 +448,64 @@ class Engine3d:
                     sm.push_runs(runs, width, off)
                 sm.step_to(len(sm))
 
-        with ThreadPoolExecutor(max_workers=1) as worker:
-            jobs = []
-            for pans in self.iter_slice_chunks(volume, axis):
-                n_seen += len(pans)
-                for i0 in range(0, len(pans), 64):
-                    chunk = torch.stack(pans[i0:i0 + 64])
-                    per_label = sparse.pan_stack_to_runs(chunk, self.labels, self.label_divisor, self.thing_list,
-                                                         force_connected=True)
-                    jobs.append(worker.submit(match_chunk, per_label, chunk.shape[-1]))
+        worker = self._host_worker()
+        jobs = []
+        for pans in self.iter_slice_chunks(volume, axis):
+            n_seen += len(pans)
+            for i0 in range(0, len(pans), 64):
+                chunk = torch.stack(pans[i0:i0 + 64])
+                per_label = sparse.pan_stack_to_runs(chunk, self.labels, self.label_divisor, self.thing_list,
+                                                     force_connected=True)
+                jobs.append(worker.submit(match_chunk, per_label, chunk.shape[-1]))
+        assert n_seen == volume.shape[axis]
+        needs_gpu = bool(self.label_erosion > 0 or self.label_dilation > 0 or self.fill_holes_in_segmentation
+                         or stack is not None)
+
+        def tail():
+            """backward matching + tracking + filters of the axis (host only unless morphology / a dense stack is asked for);
+            works on private trackers and publishes the result at the end"""
             for j in jobs:
                 j.result()
-        assert n_seen == volume.shape[axis]
-        for tr in trackers:
-            sm = sms[tr.class_id]
-            sm.forward()
-            tr.instances = sm.backward_and_track(axis_name, volume.shape)
-            tr.finished = True
-        for tr in trackers:
-            sparse.remove_small_objects(tr, min_size=self.min_size)
-            sparse.remove_pancakes(tr, min_span=self.min_extent)
-        # optional morphology, in the reference's order (inference.py:560-570)
-        margs = (volume.shape, self.labels, self.label_divisor, self.thing_list)
-        if self.label_erosion > 0:
+            priv = self.create_trackers(volume.shape, axis_name)
+            for tr in priv:
+                sm = sms[tr.class_id]
+                sm.forward()
+                tr.instances = sm.backward_and_track(axis_name, volume.shape)
+                tr.finished = True
+            for tr in priv:
+                sparse.remove_small_objects(tr, min_size=self.min_size)
+                sparse.remove_pancakes(tr, min_span=self.min_extent)
+            # optional morphology, in the reference's order (inference.py:560-570)
+            margs = (volume.shape, self.labels, self.label_divisor, self.thing_list)
+            if self.label_erosion > 0:
+                for tr in priv:
+                    sparse.erode(tr, *margs, iterations=self.label_erosion)
+            if self.label_dilation > 0:
+                for tr in priv:
+                    sparse.dilate(tr, *margs, iterations=self.label_dilation)
+            if self.fill_holes_in_segmentation:
+                for tr in priv:
+                    sparse.fill_holes_in_segmentation(tr, *margs)
+            if stack is not None:
+                if isinstance(stack, np.ndarray):
+                    sparse.fill_panoptic_volume(stack, priv)
+                else:
+                    tmp = np.zeros(stack.shape, dtype=stack.dtype)
+                    sparse.fill_panoptic_volume(tmp, priv)
+                    stack[...] = tmp
+            for tr, pv in zip(trackers, priv):
+                tr.__dict__['_instances'] = pv.instances
+                tr.finished = True
+
+        if needs_gpu:
+            for j in jobs:
+                j.result()
+            tail()                       # GPU work stays on this thread
+        else:
+            # the backward pass needs no GPU: it runs behind the queued forward-matching jobs on the worker while the
+            # caller moves on (the next axis' forward, typically); reading ``tracker.instances`` joins it
+            fut = worker.submit(tail)
             for tr in trackers:
-                sparse.erode(tr, *margs, iterations=self.label_erosion)
-        if self.label_dilation > 0:
-            for tr in trackers:
-                sparse.dilate(tr, *margs, iterations=self.label_dilation)
-        if self.fill_holes_in_segmentation:
-            for tr in trackers:
-                sparse.fill_holes_in_segmentation(tr, *margs)
-        if stack is not None:
-            if isinstance(stack, np.ndarray):
-                sparse.fill_panoptic_volume(stack, trackers)
-            else:
-                tmp = np.zeros(stack.shape, dtype=stack.dtype)
-                sparse.fill_panoptic_volume(tmp, trackers)
-                stack[...] = tmp
+                tr.__dict__['_pending'] = fut
         self.engine.reset()
         return stack, trackers

@@ -553,6 +553,20 @@ class InstanceTracker:
     def reset(self):
         self.instances = {}
 
+    # ``instances`` may still be in the making: Engine3d.infer_on_axis hands the trackers back while the backward
+    # pass of the axis finishes on a worker thread (so that it overlaps the next axis' GPU work); the first read joins.
+    @property
+    def instances(self):
+        fut = self.__dict__.get('_pending')
+        if fut is not None:
+            self.__dict__['_pending'] = None
+            fut.result()          # re-raises what the deferred pass raised
+        return self.__dict__['_instances']
+
+    @instances.setter
+    def instances(self, value):
+        self.__dict__['_instances'] = value
+
     def update(self, instance_rles, index2d):
         """tracker.py:61-100: lift a slice's 2-D runs into raveled 3-D indices."""
         assert self.class_id is not None and self.label_divisor is not None and self.shape3d is not None
