@@ -290,3 +290,35 @@ def test_multiclass_bifpn_orthoplane_consensus():
             want.instances = osp.merge_semantic_from_trackers(cls, 2)
         _same_instances(inst, want.instances)
         np.testing.assert_array_equal(cvol, osp.numpy_fill_instances(np.zeros(vol.shape, np.uint32), want.instances))
+
+
+def test_config0_bifpn_single_512_tile_through_engine2d():
+    """BASELINE configs[0]: MitoNet_mini-class (PanopticBiFPN) 2-D inference on one 512 x 512 tile through Engine2d.
+    The label map must equal the oracle's post-processing (instance voting, merge, force_connected) of the engine's own
+    head outputs bit for bit; the heads themselves are checked against the reference goldens in test_gpu_model.py."""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab, logits_to_prob
+    from empanada_napari_amd.inference import Engine2d
+    from oracle import postprocess as opp
+    from oracle import sparse as osp
+    cfg = dict(weights.MITONET_MINI_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    w, b = P['ins_center.head.1']
+    P['ins_center.head.1'] = (w, b + np.float32(0.5))
+    w, b = P['semantic_head.head.1']
+    P['semantic_head.head.1'] = (w, b + np.float32(1.0))
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 128,
+          'norms': {'mean': 0.57571, 'std': 0.12765}}
+    img = synth.em_tiles(1, 512, seed=40)[0]
+    eng = Engine2d(mc, label_divisor=DIV, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5)
+    got = eng.infer(img)
+    assert got.shape == (512, 512) and got.dtype == np.int32 and got.max() > DIV
+    x = eng.preprocessor(img)['image'].unsqueeze(0).cuda()
+    out = model(x, 2, interpolate_ins=False)
+    sem = logits_to_prob(out['sem_logits']).cpu().numpy()
+    oeng = opp.RenderEngine(None, [1], label_divisor=DIV, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                            coarse_boundaries=True)
+    cells = oeng.cells(out['ctr_hmp'].cpu().numpy(), out['offsets'].cpu().numpy(), 1)
+    pan = oeng.postprocess(sem, cells)[0].astype(np.int32)
+    np.testing.assert_array_equal(got, osp.force_connected_pan(pan.copy(), [1], DIV))
