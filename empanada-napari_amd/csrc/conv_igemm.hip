@@ -460,7 +460,15 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   //  128->512: 0.316 vs 0.278) -- with two workgroups per CU the global-load latency is already covered and the
   //  second barrier per 64 channels costs more than the deeper prefetch saves)
   int v = variant & 15, tile = (variant >> 4) & 15, kg = variant >> 8;
-  EMP_REQUIRE(v <= 3 && tile <= 4, "conv: bad variant %d", variant);
+  EMP_REQUIRE(v <= 3 && tile <= 6, "conv: bad variant %d", variant);
+  if (tile == 6) return launch_conv3x3_c64(p, stream);
+  {
+    // 64 -> 64 channel 3x3 (ResNet layer1 conv2): weights in registers, halo tile in LDS (conv3x3c64.hip), once there
+    // are enough 8 x 16 tiles for its 256 persistent workgroups
+    static const bool no_c64 = [] { const char* e = getenv("EMP_CONV_NO_C64"); return e && e[0] == '1'; }();   // A/B runs
+    if (tile == 0 && !no_c64 && conv3x3_c64_supported(p) && (int64_t)p.N * cdiv(p.H, 8) * cdiv(p.W, 16) >= 1024)
+      return launch_conv3x3_c64(p, stream);
+  }
   if (tile == 4) {
     EMP_REQUIRE(p.out2 == nullptr, "conv: the 256x256 tile has no second destination");
     return launch_conv_igemm256(p, stream);

@@ -77,3 +77,29 @@ def test_stem_pool_repeatable():
     for _ in range(5):
         model(x, 2, False, sub=146.8, mul=0.0307)
         assert torch.equal(model.tap('p1'), first)
+
+
+def test_conv3x3_c64_repeatable_and_equal_to_implicit_gemm():
+    """the register-weight 3x3 kernel at the bench's layer1 size: ~16 tiles per persistent workgroup through the ring of
+    three halo slots; 20 repetitions bit-identical and equal to the implicit-GEMM kernel (same K order).  [A first
+    version let the 24th, dummy LDS-DMA of a tile land zeros on top of piece 22 -- caught by exactly this kind of run.]"""
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    N, H, W = 8, 256, 256
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, H, W, 64), generator=g).to(torch.float16).to(dev())
+    w = (torch.randn((64, 9, 64), generator=g) / 24.0).to(torch.float16).to(dev())
+    b = torch.randn((64,), generator=g).to(dev())
+
+    def run(variant):
+        out = torch.empty((N, H, W, 64), dtype=torch.float16, device=dev())
+        _abi.check(lib.emp_conv2d_nhwc_f16(_abi.ptr(x), N, H, W, 64, 64, _abi.ptr(w), _abi.ptr(b), None, None, 0,
+                                           _abi.ptr(out), 64, 64, 3, 3, 1, 1, 1, 1, variant, _abi.stream_ptr(dev())), 'conv')
+        return out
+
+    first = run(96)
+    for _ in range(20):
+        assert torch.equal(run(96), first)
+    assert torch.equal(first, run(32 + 3))          # the 128x64 implicit-GEMM tile
+    assert torch.equal(first, run(0))               # auto picks the register-weight kernel at this size
