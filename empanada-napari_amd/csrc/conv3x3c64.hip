@@ -169,10 +169,138 @@ __global__ void __launch_bounds__(512, 1) conv3x3_c64_kernel(const C64Params p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the dummy DMA batches
 }
 
+// ---------------------------------------------------------------------------
+// 128 -> 128 channels (ResNet layer2 conv2, stride 1): same scheme with one MFMA row tile per wave -- wave w keeps
+// couts 16w..16w+15 x 1152 K = 36 fragments = 144 VGPRs and multiplies them with ALL eight pixel rows of the tile.
+// A halo row's fragment (120 ds_read_b128 per tile and wave) feeds the up to three output rows it belongs to, in an
+// order that keeps every output's K walk tap-major / channel-ascending (bit-identical to conv_igemm_kernel).
+// Halo rows are 256 B (4 pixels per LDS-DMA instruction, 45 pieces + 3 dump pieces = 6 per wave); a wave's 16 couts
+// are 32 B per pixel, so the finished tile is transposed through the just-consumed halo slot into whole 256-byte rows.
+// ---------------------------------------------------------------------------
+constexpr int C128_NDMA = 6;                                // per wave and tile: 48 >= 45
+constexpr int C128_SLOT = 8 * C128_NDMA * 1024;             // 48 KB incl. 3 dump pieces
+
+template <int ACT>
+__global__ void __launch_bounds__(512, 1) conv3x3_c128_kernel(const C64Params p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];     // 3 x C128_SLOT
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, nx = gridDim.x >> 3;
+  auto tile_of = [&](int it) { return (it * 8 + xcd) * nx + jx; };
+  int my_tiles = 0;
+  while (tile_of(my_tiles) < p.tiles) ++my_tiles;
+
+  f16x8 wreg[9][4];
+  {
+    const half_t* wr = p.wgt + (size_t)(16 * wave + fr) * (9 * 128) + fq * 8;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) wreg[t][kk] = *reinterpret_cast<const f16x8*>(wr + t * 128 + kk * 32);
+  }
+  float bv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bv[r] = p.bias ? p.bias[16 * wave + fq * 4 + r] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  auto tile_xy = [&](int it, int& n, int& y0, int& x0) {
+    const int tile = tile_of(it);
+    const int tx = tile % p.tiles_x, r = tile / p.tiles_x;
+    const int ty = r % p.tiles_y;
+    n = r / p.tiles_y;
+    y0 = ty * C64_TH;
+    x0 = tx * C64_TW;
+  };
+  auto stage = [&](int it, int slot) {
+    const bool valid = it < my_tiles;
+    int n = 0, y0 = 0, x0 = 0;
+    if (valid) tile_xy(it, n, y0, x0);
+    char* hb = lds + slot * C128_SLOT;
+#pragma unroll
+    for (int k = 0; k < C128_NDMA; ++k) {
+      const int piece = wave + 8 * k;                           // 0..47; pieces 45..47 are dump blocks
+      const int hp = piece * 4 + (lane >> 4);
+      const int hy = hp / C64_IW, hx = hp - hy * C64_IW;
+      const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+      const bool ok = valid && hp < C64_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const half_t* src = ok ? p.in + (((size_t)n * p.H + iy) * p.W + ix) * p.in_ld + (((lane & 15) ^ (hp & 7)) << 3)
+                             : p.zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(hb + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  stage(0, 0);
+  stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  c64_barrier();
+
+  int slot = 0;
+  for (int it = 0; it < my_tiles; ++it) {
+    stage(it + 2, slot == 0 ? 2 : slot - 1);
+    char* hb = lds + slot * C128_SLOT;
+    f32x4 acc[8];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) acc[y] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 30 groups (halo row r, column shift dx) of four 32-channel fragments, each feeding up to twelve MFMAs; the scheduler
+    // must not hoist the reads of later groups (144 VGPRs hold the weights) -- the SIMD's second wave covers their latency
+    int frv = fr;                      // laundered per tile: the 120 swizzled fragment offsets are recomputed next to
+    asm volatile("" : "+v"(frv));      // their reads instead of being hoisted out of the tile loop into 120 VGPRs
+#pragma unroll
+    for (int g = 0; g < 3 * C64_IH; ++g) {
+      const int r = g / 3, dx = g - r * 3;
+      const int hp = r * C64_IW + frv + dx;
+      f16x8 pf[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        pf[kk] = *reinterpret_cast<const f16x8*>(hb + hp * 256 + (((kk * 4 + fq) ^ (hp & 7)) << 4));
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const int y = r - dy;
+          if (y >= 0 && y < 8) acc[y] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wreg[dy * 3 + dx][kk], pf[kk], acc[y], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // [DMA(it+1) x6, one tile ago] [stores(it-1)] [DMA(it+2) x6]: loads retire in order -> tile it+1 has landed
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    c64_barrier();                 // every wave is done with the halo of tile `it`: the slot becomes the output tile
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      const int px = y * 16 + fr;
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      f16x4 o;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) o[r4] = (half_t)c64_act<ACT>(acc[y][r4] + bv[r4]);
+      const int chunk = 2 * wave + (fq >> 1);                   // 16-byte chunk of couts 16w + 4fq .. +3
+      *reinterpret_cast<f16x4*>(hb + px * 256 + ((chunk ^ (px & 7)) << 4) + (fq & 1) * 8) = o;
+    }
+    c64_barrier();
+    {
+      int n, y0, x0;
+      tile_xy(it, n, y0, x0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = k * 512 + tid;                            // 2048 chunks: pixel q >> 4, chunk q & 15
+        const int px = q >> 4, c = q & 15;
+        const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
+        const f16x8 v = *reinterpret_cast<const f16x8*>(hb + px * 256 + ((c ^ (px & 7)) << 4));
+        if (oy < p.H && ox < p.W)
+          *reinterpret_cast<f16x8*>(p.out + (((size_t)n * p.H + oy) * p.W + ox) * p.out_ld + c * 8) = v;
+      }
+    }
+    c64_barrier();                 // the slot is free for the DMA of tile it+3; tile it+1 is visible
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 bool conv3x3_c64_supported(const ConvParams& p) {
-  return p.Cin == 64 && p.Cout == 64 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
+  return ((p.Cin == 64 && p.Cout == 64) || (p.Cin == 128 && p.Cout == 128)) && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
          p.res == nullptr && p.bias_n == nullptr && p.ps_cout == 0 && p.in2 == nullptr && p.out2 == nullptr;
 }
 
@@ -192,8 +320,18 @@ int launch_conv3x3_c64(const ConvParams& q, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 3 * C64_SLOT, stream, p);
     return EMP_OK;
   };
+  auto go128 = [&](auto kern) -> int {
+    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      3 * C128_SLOT));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 3 * C128_SLOT, stream, p);
+    return EMP_OK;
+  };
   int rc;
-  if (q.act == 1) rc = go(&conv3x3_c64_kernel<1>);
+  if (q.Cin == 128) {
+    if (q.act == 1) rc = go128(&conv3x3_c128_kernel<1>);
+    else if (q.act == 2) rc = go128(&conv3x3_c128_kernel<2>);
+    else rc = go128(&conv3x3_c128_kernel<0>);
+  } else if (q.act == 1) rc = go(&conv3x3_c64_kernel<1>);
   else if (q.act == 2) rc = go(&conv3x3_c64_kernel<2>);
   else rc = go(&conv3x3_c64_kernel<0>);
   if (rc) return rc;

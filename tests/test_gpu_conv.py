@@ -166,15 +166,16 @@ def test_conv1x1_dual_source_rejects_bad_geometry():
 
 @pytest.mark.parametrize('shape', [(1, 8, 16), (1, 16, 32), (2, 20, 37), (3, 64, 64), (1, 9, 250), (5, 40, 48)])
 @pytest.mark.parametrize('relu', [True, False])
-def test_conv3x3_c64_register_weights_equals_implicit_gemm(shape, relu):
+@pytest.mark.parametrize('C', [64, 128])
+def test_conv3x3_c64_register_weights_equals_implicit_gemm(shape, relu, C):
     """variant 96: the 64 -> 64 channel 3x3 kernel with register-resident weights and an LDS halo tile; same K order as
     the implicit-GEMM kernel, so the outputs are identical (image borders, tile tails, several tiles per workgroup)"""
     from gpu_common import conv_hip, conv_ref, dev
     N, H, W = shape
     g = torch.Generator().manual_seed(N * 1000 + H * 10 + W)
-    x = torch.randn((N, H, W, 64), generator=g).to(torch.float16).to(dev())
-    w = torch.randn((64, 64, 3, 3), generator=g) / 24.0
-    b = torch.randn((64,), generator=g) * 0.1
+    x = torch.randn((N, H, W, C), generator=g).to(torch.float16).to(dev())
+    w = torch.randn((C, C, 3, 3), generator=g) / (3.0 * np.sqrt(C))
+    b = torch.randn((C,), generator=g) * 0.1
     base = conv_hip(x, w, b, None, None, 1, 1, 1, relu, 16 + 3)
     ref = conv_ref(x, w, b, None, None, 1, 1, 1, relu)
     for rep in range(3):

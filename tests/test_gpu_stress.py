@@ -103,3 +103,19 @@ def test_conv3x3_c64_repeatable_and_equal_to_implicit_gemm():
         assert torch.equal(run(96), first)
     assert torch.equal(first, run(32 + 3))          # the 128x64 implicit-GEMM tile
     assert torch.equal(first, run(0))               # auto picks the register-weight kernel at this size
+    # the 128-channel variant (layer2 conv2): 16 tiles per workgroup, output transposed through the consumed halo slot
+    N2, H2 = 16, 128
+    x2 = torch.randn((N2, H2, H2, 128), generator=g).to(torch.float16).to(dev())
+    w2 = (torch.randn((128, 9, 128), generator=g) / 34.0).to(torch.float16).to(dev())
+    b2 = torch.randn((128,), generator=g).to(dev())
+
+    def run2(variant):
+        out = torch.empty((N2, H2, H2, 128), dtype=torch.float16, device=dev())
+        _abi.check(lib.emp_conv2d_nhwc_f16(_abi.ptr(x2), N2, H2, H2, 128, 128, _abi.ptr(w2), _abi.ptr(b2), None, None, 0,
+                                           _abi.ptr(out), 128, 128, 3, 3, 1, 1, 1, 1, variant, _abi.stream_ptr(dev())), 'conv')
+        return out
+
+    first2 = run2(96)
+    for _ in range(20):
+        assert torch.equal(run2(96), first2)
+    assert torch.equal(first2, run2(16 + 3))
