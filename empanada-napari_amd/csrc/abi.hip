@@ -133,4 +133,15 @@ int emp_sepconv5x5_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in
                          d_head_out, (int64_t)H * W, zero, (hipStream_t)stream);
 }
 
+int emp_sepconv3x3_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld, const void* d_dw_w, const void* d_pw_w,
+                            const float* d_bias, int Cout, int act, void* d_out, int out_ld, void* stream) {
+  EMP_REQUIRE(d_in && d_dw_w && d_pw_w && d_out, "sepconv3x3: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0, "sepconv3x3: bad geometry");
+  const half_t* zero = (const half_t*)zero_page();
+  EMP_REQUIRE(zero != nullptr, "sepconv3x3: could not allocate the zero page");
+  return launch_sepconv5((const half_t*)d_in, N, H, W, C, in_ld, (const half_t*)d_dw_w, (const half_t*)d_pw_w, d_bias, Cout,
+                         act, (half_t*)d_out, out_ld, nullptr, nullptr, 0, nullptr, (int64_t)H * W, zero,
+                         (hipStream_t)stream, 3);
+}
+
 }  // extern "C"

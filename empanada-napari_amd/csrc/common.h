@@ -115,7 +115,8 @@ bool sepconv5_supported(int C, int Cout, int head_c);
 int launch_sepconv5_pack_pw(const half_t* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s);
 int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* dww, const half_t* pww_packed,
                     const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
-                    const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s);
+                    const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s,
+                    int ks = 5);
 int launch_head1x1(const half_t* in, int N, int P, int K, int in_ld, const float* w, const float* b, int C,
                    float* out, int64_t plane_size, const int32_t* scatter_idx, hipStream_t s);
 int launch_bilinear_ac_f32_nchw(const float* in, int NC, int h, int w, float* out, int scale, hipStream_t s);

@@ -609,11 +609,23 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
                         const half_t* c3, float ca, float cb, float cc, int mode, const std::string& outname) -> int {
           const Act& fz = A(q + ".fuse");
           RC(launch_fuse_combine(a, b2, c3, ca, cb, cc, mode, N, fz.H, fz.W, F, fz.p, s));
+          n->flops += 2.0 * 9.0 * (double)N * fz.H * fz.W * F;
+          const std::string pwn = dirpre + ".after_combines.0.0.sepconv.1";
+          const DevConv& pwc = n->convs.at(pwn);
+          const Act& on = A(outname);
+          // depthwise 3x3 -> pointwise -> BN -> SiLU in one launch (sepconv.hip, KS = 3) once the map has a tile per CU
+          if (n->fuse_sepconv && n->f16w.count(pwn + ".packed") && pwc.cin_pad == F && fz.ld == F && on.ld == pwc.cout &&
+              sepconv5_supported(F, pwc.cout, 0) && (int64_t)N * ((fz.H + 7) / 8) * ((fz.W + 15) / 16) >= 256) {
+            RC(launch_sepconv5(fz.p, N, fz.H, fz.W, F, fz.ld, n->f16w.at(dirpre + ".after_combines.0.0.sepconv.0"),
+                               n->f16w.at(pwn + ".packed"), pwc.b, pwc.cout, 2, on.p, on.ld, nullptr, nullptr, 0, nullptr, 0,
+                               zero, s, 3));
+            n->flops += 2.0 * (double)N * fz.H * fz.W * pwc.cout * (double)pwc.cin;
+            if (n->layer_log) fprintf(n->layer_log, "sepconv,%s,%d,%d,%d,3,1,1,0,%d\n", pwn.c_str(), N * fz.H * fz.W, F, pwc.cout, N * fz.H * fz.W);
+            return EMP_OK;
+          }
           RC(launch_dwconv(fz.p, N, fz.H, fz.W, F, F, n->f16w.at(dirpre + ".after_combines.0.0.sepconv.0"), 3,
                            A(q + ".dw").p, F, zero, s));
-          n->flops += 2.0 * 9.0 * (double)N * fz.H * fz.W * F;
-          return conv(n, dirpre + ".after_combines.0.0.sepconv.1", A(q + ".dw"), 0, A(outname), 0, 1, 0, 1, 2, nullptr,
-                      nullptr, s);
+          return conv(n, pwn, A(q + ".dw"), 0, on, 0, 1, 0, 1, 2, nullptr, nullptr, s);
         };
         // top-down: P7 -> P3 (bifpn.py:47-69); level index lv: 0=P3 .. 4=P7
         {
@@ -950,6 +962,7 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       } else {
         RC(pack_conv(n, nm));
         if (nm.size() > 19 && nm.compare(nm.size() - 19, 19, ".fusion.0.sepconv.1") == 0) RC(pack_sepconv_pw(n, nm));
+        if (nm.find(".after_combines.0.0.sepconv.1") != std::string::npos) RC(pack_sepconv_pw(n, nm));   // BiFPN nodes
       }
     }
   } else {

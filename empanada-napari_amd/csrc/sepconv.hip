@@ -34,10 +34,11 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SC_TH = 8, SC_TW = 16;                  // output tile (rows x cols) = 128 pixels
-constexpr int SC_IH = SC_TH + 4, SC_IW = SC_TW + 4;   // halo tile 12 x 20
-constexpr int SC_NPIX = SC_IH * SC_IW;                // 240 pixels = 30 LDS-DMA instructions of 8 pixels
-constexpr int SC_NST = SC_NPIX / 8;
-constexpr int SC_HALO_BYTES = SC_NPIX * 128;          // 30720
+// halo tile of a KS x KS depthwise kernel: (8 + KS - 1) rows x 20 columns (KS = 5: 12 x 20 = 240 pixels = 30 LDS-DMA
+// instructions of 8 pixels; KS = 3: 10 x 20 = 200 pixels = 25 instructions, the two right-most columns unused)
+constexpr int SC_IW = SC_TW + 4;
+constexpr int sc_npix(int ks) { return (SC_TH + ks - 1) * SC_IW; }
+constexpr int sc_halo_bytes(int ks) { return sc_npix(ks) * 128; }
 constexpr int SC_BT_BYTES = 128 * 128;                // 16384
 
 struct SepParams {
@@ -84,8 +85,10 @@ __device__ __forceinline__ void lds_barrier() {
 
 // NDW = number of depthwise waves (4 or 8: one or two per SIMD), NMW = number of mma waves (4 or 8),
 // MT = 16-cout MFMA row tiles per mma wave: Cout = NMW * 16 * MT.
-template <int NDW, int NMW, int MT, bool HEAD, int ACT>
+template <int KS, int NDW, int NMW, int MT, bool HEAD, int ACT>
 __global__ void __launch_bounds__(64 * (NDW + NMW), 1) sepconv5_kernel(const SepParams p) {
+  constexpr int KK = KS * KS, PAD = KS / 2;
+  constexpr int SC_NPIX = sc_npix(KS), SC_NST = SC_NPIX / 8, SC_HALO_BYTES = sc_halo_bytes(KS);
   constexpr int NT = 64 * (NDW + NMW);      // threads
   constexpr int R = 16 / NDW;               // output rows per depthwise thread (4 or 2)
   constexpr int COUT = NMW * 16 * MT;
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(64 * (NDW + NMW), 1) sepconv5_kernel(const Sep
   char* const halo = lds;                                   // 3 x SC_HALO_BYTES (ring)
   char* const bt = lds + 3 * SC_HALO_BYTES;                 // 2 x SC_BT_BYTES
   float* const dwl = reinterpret_cast<float*>(bt + 2 * SC_BT_BYTES);   // [C/64][25][64] fp32
-  float* const biasl = dwl + p.C * 25;                      // [Cout] epilogue bias
+  float* const biasl = dwl + p.C * KK;                      // [Cout] epilogue bias
   float* const hwl = biasl + COUT;                          // HEAD: [2][Cout] head weights,
   float* const red = hwl + 2 * COUT;                        //       [NMW waves][128 px][2] partial sums
 
@@ -109,9 +112,9 @@ __global__ void __launch_bounds__(64 * (NDW + NMW), 1) sepconv5_kernel(const Sep
   const int LAST = S + (HEAD ? 1 : 0);      // last step index (HEAD: one more to finish the last tile's head)
 
   // depthwise taps -> LDS, fp32, chunk-major; epilogue constants
-  for (int i = tid; i < p.C * 25; i += NT) {
+  for (int i = tid; i < p.C * KK; i += NT) {
     const int t = i / p.C, c = i - t * p.C;
-    dwl[((c >> 6) * 25 + t) * 64 + (c & 63)] = (float)p.dww[i];
+    dwl[((c >> 6) * KK + t) * 64 + (c & 63)] = (float)p.dww[i];
   }
   for (int i = tid; i < COUT; i += NT) biasl[i] = p.bias ? p.bias[i] : 0.f;
   if (HEAD) {
@@ -125,9 +128,9 @@ __global__ void __launch_bounds__(64 * (NDW + NMW), 1) sepconv5_kernel(const Sep
     const int hoff = ((R * rg) * SC_IW + 4 * cg) * 128 + cp * 4;
     const int sw = (cp >> 2), sub = (cp & 3) * 4;
     __syncthreads();
-    f32x2 w[25];            // taps of the chunk of the coming step: read before the barrier, off the critical path
+    f32x2 w[KK];            // taps of the chunk of the coming step: read before the barrier, off the critical path
 #pragma unroll
-    for (int t = 0; t < 25; ++t) w[t] = reinterpret_cast<const f32x2*>(dwl)[t * 32 + cp];
+    for (int t = 0; t < KK; ++t) w[t] = reinterpret_cast<const f32x2*>(dwl)[t * 32 + cp];
     int ring = 0, chn = 0;   // g % 3, (g + 1) % NC
     for (int g = 0; g <= LAST; ++g) {
       chn = chn + 1 == NC ? 0 : chn + 1;
@@ -138,27 +141,27 @@ __global__ void __launch_bounds__(64 * (NDW + NMW), 1) sepconv5_kernel(const Sep
         for (int y = 0; y < R; ++y)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[y][j] = f32x2{0.f, 0.f};
-        f16x2 nxt[8];
+        f16x2 nxt[4 + KS - 1];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) nxt[c] = *reinterpret_cast<const f16x2*>(hb + c * 128);
+        for (int c = 0; c < 4 + KS - 1; ++c) nxt[c] = *reinterpret_cast<const f16x2*>(hb + c * 128);
 #pragma unroll
-        for (int r = 0; r < R + 4; ++r) {
-          f32x2 x[8];
+        for (int r = 0; r < R + KS - 1; ++r) {
+          f32x2 x[4 + KS - 1];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) x[c] = f32x2{(float)nxt[c][0], (float)nxt[c][1]};
-          if (r + 1 < R + 4) {
+          for (int c = 0; c < 4 + KS - 1; ++c) x[c] = f32x2{(float)nxt[c][0], (float)nxt[c][1]};
+          if (r + 1 < R + KS - 1) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+            for (int c = 0; c < 4 + KS - 1; ++c)
               nxt[c] = *reinterpret_cast<const f16x2*>(hb + ((r + 1) * SC_IW + c) * 128);
           }
 #pragma unroll
-          for (int ky = 0; ky < 5; ++ky) {
+          for (int ky = 0; ky < KS; ++ky) {
             const int y = r - ky;
             if (y < 0 || y >= R) continue;
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx)
+            for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
-              for (int j = 0; j < 4; ++j) acc[y][j] = __builtin_elementwise_fma(x[j + kx], w[ky * 5 + kx], acc[y][j]);
+              for (int j = 0; j < 4; ++j) acc[y][j] = __builtin_elementwise_fma(x[j + kx], w[ky * KS + kx], acc[y][j]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -173,9 +176,9 @@ __global__ void __launch_bounds__(64 * (NDW + NMW), 1) sepconv5_kernel(const Sep
             h[1] = (half_t)acc[y][j][1];
             *reinterpret_cast<f16x2*>(bb + px * 128 + ((sw ^ (px & 7)) << 4) + sub) = h;
           }
-        const f32x2* wl = reinterpret_cast<const f32x2*>(dwl + chn * 25 * 64) + cp;
+        const f32x2* wl = reinterpret_cast<const f32x2*>(dwl + chn * KK * 64) + cp;
 #pragma unroll
-        for (int t = 0; t < 25; ++t) w[t] = wl[t * 32];
+        for (int t = 0; t < KK; ++t) w[t] = wl[t * 32];
       }
       ring = ring == 2 ? 0 : ring + 1;
       lds_barrier();
@@ -208,7 +211,7 @@ __global__ void __launch_bounds__(64 * (NDW + NMW), 1) sepconv5_kernel(const Sep
           const int i = min(wm + NMW * k, SC_NST - 1);
           const int q = i * 8 + (lane >> 3);
           const int py = q / SC_IW, px = q - py * SC_IW;
-          const int iy = y0 + py - 2, ix = x0 + px - 2;
+          const int iy = y0 + py - PAD, ix = x0 + px - PAD;
           const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
           sptr[k] = ok ? src + ((size_t)iy * p.W + ix) * p.in_ld : p.zero;
         }
@@ -396,31 +399,31 @@ __global__ void __launch_bounds__(256) sepconv5_pack_pw_kernel(const half_t* __r
   }
 }
 
-template <int NDW, int NMW, int MT, bool HEAD, int ACT>
+template <int KS, int NDW, int NMW, int MT, bool HEAD, int ACT>
 int launch_act(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv5_kernel<NDW, NMW, MT, HEAD, ACT>),
+    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv5_kernel<KS, NDW, NMW, MT, HEAD, ACT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((sepconv5_kernel<NDW, NMW, MT, HEAD, ACT>), dim3(grid), dim3(64 * (NDW + NMW)), lds_bytes, s, p);
+  hipLaunchKernelGGL((sepconv5_kernel<KS, NDW, NMW, MT, HEAD, ACT>), dim3(grid), dim3(64 * (NDW + NMW)), lds_bytes, s, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
 
-template <int NDW, int NMW, int MT, bool HEAD>
+template <int KS, int NDW, int NMW, int MT, bool HEAD>
 int launch_one(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
-  if (p.act == 1) return launch_act<NDW, NMW, MT, HEAD, 1>(p, lds_bytes, grid, s);
-  if (p.act == 2) return launch_act<NDW, NMW, MT, HEAD, 2>(p, lds_bytes, grid, s);
-  return launch_act<NDW, NMW, MT, HEAD, 0>(p, lds_bytes, grid, s);
+  if (p.act == 1) return launch_act<KS, NDW, NMW, MT, HEAD, 1>(p, lds_bytes, grid, s);
+  if (p.act == 2) return launch_act<KS, NDW, NMW, MT, HEAD, 2>(p, lds_bytes, grid, s);
+  return launch_act<KS, NDW, NMW, MT, HEAD, 0>(p, lds_bytes, grid, s);
 }
 
 }  // namespace
 
-static size_t sepconv5_lds_bytes(int C, int Cout, int head_c) {
+static size_t sepconv5_lds_bytes(int C, int Cout, int head_c, int ks = 5) {
   const int nmw = Cout == 256 ? 8 : 4;
-  return 3 * SC_HALO_BYTES + 2 * SC_BT_BYTES + (size_t)C * 25 * 4 + (size_t)Cout * 4 +
+  return 3 * sc_halo_bytes(ks) + 2 * SC_BT_BYTES + (size_t)C * ks * ks * 4 + (size_t)Cout * 4 +
          (head_c ? (size_t)2 * Cout * 4 + (size_t)nmw * 128 * 2 * 4 : 0);
 }
 
@@ -442,7 +445,9 @@ int launch_sepconv5_pack_pw(const half_t* w, int pw_ld, int C, int Cout, half_t*
 
 int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* dww, const half_t* pww,
                     const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
-                    const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s) {
+                    const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s,
+                    int ks) {
+  EMP_REQUIRE(ks == 5 || (ks == 3 && head_c == 0), "sepconv: depthwise kernel %d unsupported", ks);
   EMP_REQUIRE(sepconv5_supported(C, Cout, head_c), "sepconv5: unsupported shape C=%d Cout=%d head=%d", C, Cout, head_c);
   EMP_REQUIRE(act >= 0 && act <= 2, "sepconv5: bad activation %d", act);
   EMP_REQUIRE((head_c > 0) != (out != nullptr), "sepconv5: exactly one of the feature / head outputs");
@@ -464,11 +469,15 @@ int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, con
     n_cu = n_cu >= 8 ? (n_cu / 8) * 8 : 8;
   }
   const int grid = n_cu;
-  const size_t lds_bytes = sepconv5_lds_bytes(C, Cout, head_c);
+  const size_t lds_bytes = sepconv5_lds_bytes(C, Cout, head_c, ks);
+  if (ks == 3) {     // BiFPN nodes (depthwise 3x3 -> pointwise -> BN -> SiLU); no head mode
+    if (Cout == 256) return launch_one<3, 4, 8, 2, false>(p, lds_bytes, grid, s);
+    return launch_one<3, 4, 4, 2, false>(p, lds_bytes, grid, s);
+  }
   // (two depthwise waves per SIMD, <8, 8, 2>, measured no faster: the mma role's vector-memory issue bounds the step)
   if (Cout == 256)
-    return head_c ? launch_one<4, 8, 2, true>(p, lds_bytes, grid, s) : launch_one<4, 8, 2, false>(p, lds_bytes, grid, s);
-  return head_c ? launch_one<4, 4, 2, true>(p, lds_bytes, grid, s) : launch_one<4, 4, 2, false>(p, lds_bytes, grid, s);
+    return head_c ? launch_one<5, 4, 8, 2, true>(p, lds_bytes, grid, s) : launch_one<5, 4, 8, 2, false>(p, lds_bytes, grid, s);
+  return head_c ? launch_one<5, 4, 4, 2, true>(p, lds_bytes, grid, s) : launch_one<5, 4, 4, 2, false>(p, lds_bytes, grid, s);
 }
 
 }  // namespace emp

@@ -196,6 +196,11 @@ EMP_API int emp_sepconv5x5_nhwc_f16(const void* d_in, int N, int H, int W, int C
                         int Cout, int act, void* d_out, int out_ld,
                         const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
                         void* stream);
+/* The same with a 3x3 depthwise kernel (d_dw_w [9][C]) and no head mode: depthwise 3x3 -> pointwise -> BN -> SiLU, the
+ * `SeparableConv2d` after every BiFPN fusion node, empanada/models/decoders/bifpn.py:24-45 as used at :63-69,128-134. */
+EMP_API int emp_sepconv3x3_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld, const void* d_dw_w,
+                            const void* d_pw_w, const float* d_bias, int Cout, int act, void* d_out, int out_ld,
+                            void* stream);
 
 /* ------------------------------------------------------------------------
  * 3. Instance post-processing (hot loop 2), one launch group per batch

@@ -155,3 +155,49 @@ def test_unsupported_shape_is_rejected():
     rc = lib.emp_sepconv5x5_nhwc_f16(_abi.ptr(x), 1, 8, 16, 64, 64, _abi.ptr(w), _abi.ptr(p), None, 64, 1,
                                      _abi.ptr(o), 64, None, None, 0, None, _abi.stream_ptr(dev()))
     assert rc != 0 and b'unsupported' in lib.emp_last_error()
+
+
+CASES3 = [
+    # N, H, W, C, in_ld, Cout, act   (depthwise 3x3: the BiFPN node's separable conv, SiLU after the folded BN)
+    (2, 16, 32, 128, 128, 128, 2),
+    (3, 13, 21, 128, 128, 128, 2),       # ragged rows and columns
+    (1, 64, 128, 128, 128, 128, 2),      # one tile per workgroup and more
+    (1, 8, 16, 128, 192, 256, 0),        # channel slice, Cout 256
+    (2, 40, 48, 256, 256, 256, 1),
+]
+
+
+@pytest.mark.parametrize('case', CASES3)
+def test_fused_3x3_equals_unfused_pair_and_reference(case):
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    N, H, W, Cc, in_ld, Cout, act = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn((N, H, W, in_ld), generator=g).to(torch.float16)
+    dw = (torch.randn((Cc, 3, 3), generator=g) * 0.3).to(torch.float16)
+    pw = (torch.randn((Cout, Cc), generator=g) / np.sqrt(Cc)).to(torch.float16)
+    b = torch.randn((Cout,), generator=g) * 0.1
+    xd = x.to(dev())
+    dwd = dw.reshape(Cc, 9).t().contiguous().to(dev())           # (9, C)
+    pwu = pw.contiguous().to(dev())
+    pwd = torch.empty_like(pwu)
+    _abi.check(lib.emp_sepconv5x5_pack_pw(_abi.ptr(pwu), Cc, Cc, Cout, _abi.ptr(pwd), _abi.stream_ptr(dev())), 'pack')
+    bd = b.float().to(dev())
+    mid = torch.empty((N, H, W, Cc), dtype=torch.float16, device=dev())
+    _abi.check(lib.emp_dwconv_nhwc_f16(_abi.ptr(xd), N, H, W, Cc, in_ld, _abi.ptr(dwd), 3, _abi.ptr(mid), Cc,
+                                       _abi.stream_ptr(dev())), 'dwconv')
+    u = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev())
+    _abi.check(lib.emp_conv2d_nhwc_f16(_abi.ptr(mid), N, H, W, Cc, Cc, _abi.ptr(pwu), _abi.ptr(bd), None, None, 0,
+                                       _abi.ptr(u), Cout, Cout, 1, 1, 1, 0, 1, act, 0, _abi.stream_ptr(dev())), 'conv')
+    for rep in range(3):
+        y = torch.full((N, H, W, Cout), 7.0, dtype=torch.float16, device=dev())
+        _abi.check(lib.emp_sepconv3x3_nhwc_f16(_abi.ptr(xd), N, H, W, Cc, in_ld, _abi.ptr(dwd), _abi.ptr(pwd), _abi.ptr(bd),
+                                               Cout, act, _abi.ptr(y), Cout, _abi.stream_ptr(dev())), 'sepconv3')
+        torch.cuda.synchronize()
+        assert torch.equal(y, u), f'rep {rep}: {(y.float() - u.float()).abs().max().item():.3e} max difference to dwconv + conv'
+    xin = x[..., :Cc].float().permute(0, 3, 1, 2)
+    d = F.conv2d(xin, dw.float()[:, None], padding=1, groups=Cc).to(torch.float16).float()
+    ref = _apply_act(F.conv2d(d, pw.float()[:, :, None, None], b), act)
+    err = (y.float().cpu().permute(0, 3, 1, 2) - ref).abs()
+    assert torch.all(err <= 2e-3 + 2e-3 * ref.abs()), err.max()
