@@ -26,3 +26,9 @@ t = timeit(lambda: b.zero_()); print(f'fill 1GiB       : {t:.3f} ms  {n*2/t/1e9:
 t = timeit(lambda: a.sum()); print(f'reduce 1GiB     : {t:.3f} ms  {n*2/t/1e9:.2f} TB/s (r)')
 c = torch.empty(n // 4, dtype=torch.float16, device=dev)
 t = timeit(lambda: torch.add(a[:n // 4], c, out=b[:n // 4])); print(f'add 0.25GiB x2->1: {t:.3f} ms  {3*(n//4)*2/t/1e9:.2f} TB/s')
+# write rate against the share of reads in the stream (finding 10 in DESIGN.md): pure fill, broadcast copies that read
+# 1/8, 1/4, 1/2 as many bytes as they write, plain copy (1:1), add (2:1)
+for k in (8, 4, 2):
+    src = a[:n // k]
+    t = timeit(lambda: b.view(k, n // k).copy_(src.unsqueeze(0).expand(k, n // k)))
+    print(f'broadcast copy read 1/{k} : {t:.3f} ms  write {n*2/t/1e9:.2f} TB/s, read {n*2/k/t/1e9:.2f} TB/s')
