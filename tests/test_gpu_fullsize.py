@@ -93,3 +93,26 @@ def test_volume_morphology_round_trip_at_512():
         assert np.all(np.diff(a['starts']) > 0)
         z, y, x = np.unravel_index(a['starts'], shape)
         assert a['box'][0] == z.min() and a['box'][1] == y.min() and a['box'][3] == z.max() + 1
+
+
+def test_bifpn_batch_of_1024_tiles_is_repeatable_and_image_independent():
+    """PanopticBiFPN at 1024^2: every fused path runs at a size where it is chosen (register-weight 3x3 convs, shortcut
+    GEMMs, 3x3 and 5x5 separable-conv kernels with several tiles per workgroup); two runs agree bit for bit and an image's
+    outputs do not depend on its neighbours in the batch"""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize_params
+    cfg = dict(weights.MITONET_MINI_CFG, num_classes=4)
+    model = HipPanopticDeepLab(weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg), cfg, folded=True)
+    tiles = torch.from_numpy(synth.em_tiles(4, 1024, seed=5))[:, None].cuda()
+    sub, mul = normalize_params(0.57571, 0.12765, 255)
+    a = {k: v.clone() for k, v in model(tiles, 2, interpolate_ins=False, sub=float(sub), mul=float(mul)).items()}
+    b = {k: v.clone() for k, v in model(tiles, 2, interpolate_ins=False, sub=float(sub), mul=float(mul)).items()}
+    for k in a:
+        assert torch.isfinite(a[k]).all(), k
+        assert torch.equal(a[k], b[k]), f'{k}: two runs differ'
+    one = model(tiles[2:3], 2, interpolate_ins=False, sub=float(sub), mul=float(mul))
+    for k in ('ctr_hmp', 'offsets'):
+        # a batch of one takes the small-problem kernels for the deepest maps (fewer tiles than workgroups): same
+        # arithmetic and K order, so still identical
+        assert torch.equal(one[k][0], a[k][2]), k
