@@ -32,6 +32,12 @@ def test_batch_of_1024_tiles_equals_sequential_calls_and_is_repeatable(engine):
     b = engine.infer_batch(tiles, sub=float(sub), mul=float(mul)).clone()
     assert torch.equal(a, b), 'two runs of the same batch differ'
     assert a.shape == (6, 1024, 1024) and a.dtype == torch.int64
+    # head outputs too: a batch of six and a batch of one pick different conv tiles for the deep layers (256x256 needs
+    # enough tiles to fill the chip), and every kernel variant keeps the same K order -- bit-identical
+    full = {k: v.clone() for k, v in engine.model(tiles, 2, interpolate_ins=False, sub=float(sub), mul=float(mul)).items()}
+    single = engine.model(tiles[4:5], 2, interpolate_ins=False, sub=float(sub), mul=float(mul))
+    for k in full:
+        assert torch.equal(single[k][0], full[k][4]), f'{k}: batch-1 forward differs from the batched one'
     for i in range(6):
         one = engine.call_raw(tiles[i:i + 1], sub, mul)           # the reference-style batch-1 call
         assert torch.equal(one[0], a[i]), f'tile {i}: batched result differs from the single call'

@@ -30,9 +30,9 @@ def test_conv256_repeatable_and_equal_to_128_tile():
     first = run(64)
     for _ in range(20):
         assert torch.equal(run(64), first)
-    ref = run(16 + 3).float()
-    err = (first.float() - ref).abs()
-    assert torch.all(err <= 2e-3 + 4e-3 * ref.abs()), err.max()      # different K order: fp32 summation noise only
+    # the 128x128 kernel walks K in the same order (256-channel groups, tap-major, ascending 32-channel MFMA steps) and
+    # applies the same fp32 epilogue: the choice of tile -- which depends on the batch size -- does not change a bit
+    assert torch.equal(first, run(16 + 3))
 
 
 def test_sepconv_repeatable_and_equal_to_unfused():
