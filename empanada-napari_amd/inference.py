@@ -460,30 +460,33 @@ class Engine3d:
         assert n_seen == volume.shape[axis]
         needs_gpu = bool(self.label_erosion > 0 or self.label_dilation > 0 or self.fill_holes_in_segmentation
                          or stack is not None)
+        # the deferred pass must not see a later update_params(): freeze what it reads
+        min_size, min_extent = self.min_size, self.min_extent
+        erosion, dilation, fill_holes = self.label_erosion, self.label_dilation, self.fill_holes_in_segmentation
+        margs = (tuple(volume.shape), list(self.labels), self.label_divisor, list(self.thing_list))
+        priv = self.create_trackers(volume.shape, axis_name)      # filled by the deferred pass, published at its end
 
         def tail():
             """backward matching + tracking + filters of the axis (host only unless morphology / a dense stack is asked for);
             works on private trackers and publishes the result at the end"""
             for j in jobs:
                 j.result()
-            priv = self.create_trackers(volume.shape, axis_name)
             for tr in priv:
                 sm = sms[tr.class_id]
                 sm.forward()
                 tr.instances = sm.backward_and_track(axis_name, volume.shape)
                 tr.finished = True
             for tr in priv:
-                sparse.remove_small_objects(tr, min_size=self.min_size)
-                sparse.remove_pancakes(tr, min_span=self.min_extent)
+                sparse.remove_small_objects(tr, min_size=min_size)
+                sparse.remove_pancakes(tr, min_span=min_extent)
             # optional morphology, in the reference's order (inference.py:560-570)
-            margs = (volume.shape, self.labels, self.label_divisor, self.thing_list)
-            if self.label_erosion > 0:
+            if erosion > 0:
                 for tr in priv:
-                    sparse.erode(tr, *margs, iterations=self.label_erosion)
-            if self.label_dilation > 0:
+                    sparse.erode(tr, *margs, iterations=erosion)
+            if dilation > 0:
                 for tr in priv:
-                    sparse.dilate(tr, *margs, iterations=self.label_dilation)
-            if self.fill_holes_in_segmentation:
+                    sparse.dilate(tr, *margs, iterations=dilation)
+            if fill_holes:
                 for tr in priv:
                     sparse.fill_holes_in_segmentation(tr, *margs)
             if stack is not None:
