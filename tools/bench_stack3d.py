@@ -1,5 +1,5 @@
 """BASELINE configs[2]: ortho-plane 3-D inference + consensus on a synthetic cube, one MI355X.
-    python tools/bench_stack3d.py [size=256] [batch=16]
+    python tools/bench_stack3d.py [size=256] [batch=0] [--cpu]
 Prints one JSON line: voxels/s over the whole job (3 axes + consensus + fill) and a time breakdown."""
 import json
 import os
@@ -17,6 +17,39 @@ graft.load_package()
 from empanada_napari_amd import synth, weights  # noqa: E402
 from empanada_napari_amd.engines import HipPanopticDeepLab  # noqa: E402
 from empanada_napari_amd.inference import Engine3d, tracker_consensus  # noqa: E402
+
+
+def cpu_baseline(cfg, P, vol, n_slices):
+    """The reference's per-axis control flow on the host cores, restated with the oracle (3-D engine with recursive
+    median, dense -> RLE, matcher, tracker) on the first ``n_slices`` xy slices: voxels per second of ONE axis pass.
+    The full job is three such passes + consensus, so the job-level CPU rate is about a third of this figure."""
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model, postprocess as opp, sparse as osp
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+
+    def model(x, rs, interp):
+        o = pdl_model.pdl_forward(P, torch.from_numpy(x), cfg, rs, interp)
+        return {k: v.numpy() for k, v in o.items()}
+
+    eng = opp.RenderEngine3d(model, [1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                             padding_factor=16, coarse_boundaries=True, median_kernel_size=3)
+    t0 = time.perf_counter()
+    pans = []
+    for z in range(n_slices):
+        r = eng(normalize(vol[z], 0.57571, 0.12765)[None, None], vol[z].shape, 1)
+        if r is not None:
+            pans.append(r[0])
+    pans += [s[0] for s in eng.end(1)]
+    m = osp.RLEMatcher(1, 10000, 0.25, 0.25)
+    stack = [osp.apply_matchers(osp.pan_seg_to_rle_seg(p, [1], 10000, [1], force_connected=True), [m]) for p in pans]
+    m.target_rle, m.assign_new = None, False
+    tr = osp.InstanceTracker(1, 10000, (n_slices,) + vol.shape[1:], 'xy')
+    for idx in range(len(pans) - 1, -1, -1):
+        tr.update(osp.apply_matchers(stack[idx], [m])[1], idx)
+    tr.finish()
+    dt = time.perf_counter() - t0
+    return {'value': round(n_slices * vol.shape[1] * vol.shape[2] / dt, 1), 'unit': 'voxels/s (one axis pass)', 'kind': 'port',
+            'cores': torch.get_num_threads(), 'sample': f'{n_slices} xy slices of {vol.shape[1]}x{vol.shape[2]} ({dt:.1f} s)'}
 
 
 def main():
@@ -89,7 +122,8 @@ def main():
     print(json.dumps({'metric': 'voxels/sec, 3-D ortho-plane stack + consensus', 'value': round(vol.size / job_s, 1),
                       'unit': 'voxels/s', 'volume': list(vol.shape), 'job': job,
                       'staged_seconds': round(total, 3), 'axes': t,
-                      'consensus_fill_s': round(tf - te, 3), 'consensus_objects': len(out[0][2]), 'batch': batch}))
+                      'consensus_fill_s': round(tf - te, 3), 'consensus_objects': len(out[0][2]), 'batch': batch,
+                      'cpu_baseline': cpu_baseline(cfg, P, vol, 12) if '--cpu' in sys.argv else None}))
 
 
 if __name__ == '__main__':
