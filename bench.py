@@ -51,6 +51,28 @@ def cpu_baseline(cfg, P, tile_size, n_tiles, seed):
                       f'({dt:.1f} s)'}
 
 
+def stack3d_line(model, size):
+    """Second half of BASELINE's metric (configs[2]): ortho-plane 3-D inference + consensus on a synthetic size^3 uint8
+    cube, one GPU -- Engine3d.infer_on_axis x 3 + tracker_consensus as a user runs it (tools/bench_stack3d.py has the
+    stage breakdown and the CPU port beside it)."""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine3d, tracker_consensus
+    mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.57571, 'std': 0.12765}}
+    vol = synth.blob_volume(size, size, size, seed=0, n_blobs=max(8, (size // 32) ** 2), fast=True)
+    eng = Engine3d(mc, label_divisor=10000, median_kernel_size=3, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5,
+                   min_size=500, min_extent=5)
+    eng.infer_on_axis(vol[:64], 'xy')[1][0].instances          # warm-up of every kernel on the path
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    trackers = {name: eng.infer_on_axis(vol, name)[1] for name in ('xy', 'xz', 'yz')}
+    out = list(tracker_consensus(trackers, None, mc, label_divisor=10000, pixel_vote_thr=2, cluster_iou_thr=0.75,
+                                 allow_one_view=False, min_size=500, min_extent=5, dtype=np.uint32))
+    dt = time.perf_counter() - t0
+    return {'metric': 'voxels/sec, 3-D ortho-plane stack + consensus', 'value': round(vol.size / dt, 1), 'unit': 'voxels/s',
+            'volume': [size] * 3, 'seconds': round(dt, 3), 'consensus_objects': len(out[0][2]), 'n_gpus': 1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -61,6 +83,7 @@ def main():
     ap.add_argument('--micro-batch', type=int, default=0, help='forward in chunks of this many tiles (0 = whole batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-tiles', type=int, default=8)
+    ap.add_argument('--stack3d', type=int, default=512, help='side of the 3-D cube of the second metric line (0 = skip)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -181,6 +204,8 @@ def main():
             res['cpu_baseline'] = cpu_baseline(cfg, P, S, args.cpu_tiles, 1234)
         else:
             res['cpu_baseline'] = None
+        # the 3-D half of the headline metric, outside the timed region of `value` (rank 0, one GPU)
+        res['stack3d'] = stack3d_line(model, args.stack3d) if (world == 1 and args.stack3d > 0) else None
         print(json.dumps(res), flush=True)
     if dist_on:
         dist.barrier()
