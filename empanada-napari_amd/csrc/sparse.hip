@@ -14,6 +14,7 @@
 //   emp_ranges_vote              array_utils.py:461-639 (k-of-n vote; thr 1 = join_ranges :658-699)
 #include <algorithm>
 #include <atomic>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -564,12 +565,29 @@ int emp_ranges_vote(const int64_t* h_ranges, int64_t n, int thr, int64_t* h_out,
     st.push_back(h_ranges[2 * i]);
     en.push_back(h_ranges[2 * i + 1]);
   }
-  auto natural_sort = [](std::vector<int64_t>& v) {
+  // many stretches (a tracker appends its runs slice by slice in descending slice order): LSD radix sort, 11 bits per
+  // pass over the significant bits of the non-negative keys (3 passes for a 512^3 volume) instead of a comparison sort
+  auto radix_sort = [](std::vector<int64_t>& v) {
+    int64_t mx = 0;
+    for (int64_t x : v) { if (x < 0) { std::sort(v.begin(), v.end()); return; } mx = x > mx ? x : mx; }
+    std::vector<int64_t> tmp(v.size());
+    int64_t* a = v.data();
+    int64_t* b = tmp.data();
+    for (int shift = 0; shift < 63 && (mx >> shift) != 0; shift += 11) {
+      size_t cnt[2049] = {0};
+      for (size_t i = 0; i < v.size(); ++i) ++cnt[((a[i] >> shift) & 2047) + 1];
+      for (int k = 0; k < 2048; ++k) cnt[k + 1] += cnt[k];
+      for (size_t i = 0; i < v.size(); ++i) b[cnt[(a[i] >> shift) & 2047]++] = a[i];
+      std::swap(a, b);
+    }
+    if (a != v.data()) std::memcpy(v.data(), a, v.size() * sizeof(int64_t));
+  };
+  auto natural_sort = [&](std::vector<int64_t>& v) {
     std::vector<size_t> cut{0};
     for (size_t i = 1; i < v.size(); ++i)
       if (v[i] < v[i - 1]) {
         cut.push_back(i);
-        if (cut.size() > 64) { std::sort(v.begin(), v.end()); return; }
+        if (cut.size() > 64) { radix_sort(v); return; }
       }
     cut.push_back(v.size());
     while (cut.size() > 2) {              // merge neighbouring stretches pairwise

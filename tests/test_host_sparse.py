@@ -293,3 +293,19 @@ def test_cpp_stack_matcher_solver_only_where_needed(monkeypatch):
     for name, slices, fwd, inst, sm in _stack_matcher_trackers(_push_objects):
         n_slices += 2 * len(slices)
     assert 0 < len(calls) < n_slices // 2, (len(calls), n_slices)
+
+
+def test_vote_with_many_unsorted_stretches_uses_radix_sort_and_matches_oracle():
+    """tracker run lists arrive slice block by slice block in descending order (hundreds of ascending stretches): the
+    C++ vote then radix-sorts starts and ends; same ranges as the oracle's restatement of vote_by_ranges"""
+    rng = np.random.default_rng(0)
+    lists = []
+    for t in range(3):
+        st = np.sort(rng.choice(1_500_000, 30000, replace=False))
+        ln = rng.integers(1, 20, len(st))
+        keep = np.r_[True, st[1:] >= st[:-1] + ln[:-1]]
+        st, ln = st[keep], ln[keep]
+        idx = np.concatenate(np.array_split(np.arange(len(st)), 300)[::-1])
+        lists.append(np.stack([st[idx], st[idx] + ln[idx]], axis=1))
+    for thr in (1, 2, 3):
+        np.testing.assert_array_equal(ps.vote_by_ranges(lists, thr), osp.vote_by_ranges([l.copy() for l in lists], thr))
