@@ -45,6 +45,7 @@ PROTOTYPES = {
     'emp_pdl_profile_read': (c_int, [vp, C.POINTER(c_f64), C.POINTER(c_f64), C.POINTER(c_int)]),
     'emp_pdl_tap': (c_int, [vp, cp, C.POINTER(vp), C.POINTER(c_i64)]),
     'emp_pdl_num_taps': (c_int, [vp]),
+    'emp_pdl_tap_raw': (c_int, [vp, cp, C.POINTER(vp), C.POINTER(c_i64)]),
     'emp_pdl_tap_name': (cp, [vp, c_int]),
     'emp_copy_d2d': (c_int, [vp, vp, sz, vp]),
     'emp_conv2d_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,

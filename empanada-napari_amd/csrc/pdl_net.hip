@@ -1119,4 +1119,13 @@ int emp_pdl_tap(emp_pdl_t* net, const char* name, void** d_ptr, int64_t shape5[5
   return EMP_OK;
 }
 
+int emp_pdl_tap_raw(emp_pdl_t* net, const char* name, void** d_ptr, int64_t* bytes) {
+  EMP_REQUIRE(net && name && d_ptr && bytes, "tap_raw: null argument");
+  auto it = net->raw.find(name);
+  EMP_REQUIRE(it != net->raw.end(), "tap_raw: unknown buffer '%s'", name);
+  *d_ptr = net->arena + it->second.first;
+  *bytes = (int64_t)it->second.second;
+  return EMP_OK;
+}
+
 }  // extern "C"

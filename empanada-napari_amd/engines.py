@@ -170,6 +170,15 @@ class HipPanopticDeepLab:
         _abi.check(self.lib.emp_copy_d2d(_abi.ptr(t), p, t.numel() * 2, _abi.stream_ptr(self.device)), 'emp_copy_d2d')
         return t[..., :Cc]
 
+    def tap_raw(self, name, shape):
+        """fp32 buffer of the last forward (``emp_pdl_tap_raw``) as a torch tensor of ``shape`` (parity tests)."""
+        p, nb = C.c_void_p(), C.c_int64()
+        _abi.check(self.lib.emp_pdl_tap_raw(self._h, name.encode(), C.byref(p), C.byref(nb)), f'tap_raw({name})')
+        t = torch.empty(shape, dtype=torch.float32, device=self.device)
+        assert t.numel() * 4 <= nb.value, (name, shape, nb.value)
+        _abi.check(self.lib.emp_copy_d2d(_abi.ptr(t), p, t.numel() * 4, _abi.stream_ptr(self.device)), 'emp_copy_d2d')
+        return t
+
     def tap_names(self):
         n = self.lib.emp_pdl_num_taps(self._h)
         return [self.lib.emp_pdl_tap_name(self._h, i).decode() for i in range(n)]
@@ -313,8 +322,25 @@ class PanopticDeepLabRenderEngine(_Engine):
         return cells.float()[:, None]  # (1,1,H,W) float, as engines.py:271-275
 
     @torch.no_grad()
+    def _harden_seg(self, sem):
+        """engines.py:114-121: (N,C,H,W) probabilities -> (N,1,H,W) int64 class map.  API surface only: the hot path
+        hardens inside the merge kernel (``panoptic_merge_int``) and never materialises this map."""
+        if sem.size(1) > 1:
+            return torch.argmax(sem, dim=1, keepdim=True)
+        return (sem >= self.confidence_thr).long()
+
+    @torch.no_grad()
     def get_panoptic_seg(self, sem, instance_cells):
-        raise NotImplementedError('use postprocess(sem, instance_cells)')
+        """engines.py:277-292: ``sem`` is the HARDENED class map (1,H,W) int64, ``instance_cells`` (1,1,H,W).
+        The class map re-enters the merge kernel as an exact one-hot 'probability' (argmax / >= 0.5 give it back)."""
+        sem = sem.reshape(-1, sem.shape[-2], sem.shape[-1]).long()
+        ncls = int(max([int(sem.max().item())] + list(self.thing_list))) + 1
+        if ncls <= 2 and self.confidence_thr <= 1.0 and self.confidence_thr > 0.0:
+            onehot = (sem == 1).float()[:, None]
+        else:
+            onehot = torch.stack([(sem == c).float() for c in range(ncls)], dim=1)
+        cells = instance_cells.reshape(sem.shape).to(torch.int32)
+        return self.panoptic_merge_int(onehot, cells, int(cells.max().item()))
 
     @torch.no_grad()
     def postprocess(self, sem, instance_cells):

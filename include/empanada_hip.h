@@ -138,6 +138,10 @@ EMP_API int emp_pdl_profile_read(emp_pdl_t* net, double* ms_total, double* flops
  * the device pointer (fp16 NHWC) and shape {N,H,W,C,ld}. */
 EMP_API int emp_pdl_tap(emp_pdl_t* net, const char* name, void** d_ptr, int64_t shape5[5]);
 EMP_API int emp_pdl_num_taps(const emp_pdl_t* net);
+/* the fp32 buffers of the last forward that are not NHWC fp16 maps ("semantic_head.out": the coarse logits the
+ * PointRend subdivision starts from, (N,C,H/4,W/4); "ins_center.out", "ins_xy.out" when interpolate_ins): device
+ * pointer + size in bytes */
+EMP_API int emp_pdl_tap_raw(emp_pdl_t* net, const char* name, void** d_ptr, int64_t* bytes);
 /* device-to-device copy on `stream` (lets a host language without a HIP binding read a tap) */
 EMP_API int emp_copy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
 EMP_API const char* emp_pdl_tap_name(const emp_pdl_t* net, int i);

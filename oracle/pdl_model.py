@@ -17,18 +17,76 @@ def _t(a):
     return None if a is None else torch.from_numpy(a)
 
 
-def _conv(x, p, stride=1, padding=0, dilation=1, groups=1, relu=False):
+class Fp16Emu:
+    """Storage-format emulation of the HIP engine for the error budget and the 'kernels are exact up to
+    the fp16 format' parity test: fp32 arithmetic as everywhere in this oracle, but the tensors the engine
+    keeps in fp16 (conv / depthwise weights, every activation map written to HBM or
+    handed to the matrix pipe) are rounded to fp16 (round to nearest even) where the engine rounds them.
+
+    ``weights`` / ``acts``: True (every site), False (none) or a set of site names.  Weight sites are the
+    parameter names; activation sites are the name of the producing layer (a bottleneck block rounds once,
+    after the residual add + ReLU, under the block's name), ``bilinear:<decoder>``, ``pr.features``.
+    ``split_weights``: parameter names whose weights the engine carries as an fp16 hi + lo pair (exact to
+    ~2^-22 relative): rounded to that pair instead of to one fp16."""
+
+    def __init__(self, weights=True, acts=True, split_weights=()):
+        self.weights, self.acts, self.split_weights = weights, acts, set(split_weights)
+        self.names = {}
+        self.sites_w, self.sites_a = [], []
+
+    def bind(self, P):
+        self.names = {id(v[0]): k for k, v in P.items()}
+        return self
+
+    @staticmethod
+    def r16(t):
+        return t.to(torch.float16).to(torch.float32)
+
+    def w(self, w):
+        name = self.names.get(id(w))
+        t = _t(w)
+        if name is None:
+            return t
+        if name not in self.sites_w:
+            self.sites_w.append(name)
+        if name in self.split_weights:
+            hi = self.r16(t)
+            return hi + self.r16(t - hi)
+        on = self.weights is True or (self.weights and name in self.weights)
+        return self.r16(t) if on else t
+
+    def a(self, site, x):
+        if site not in self.sites_a:
+            self.sites_a.append(site)
+        on = self.acts is True or (self.acts and site in self.acts)
+        return self.r16(x) if on else x
+
+
+_EMU = None          # set by model_forward(..., emu=...) for the duration of one forward
+
+
+def _conv(x, p, stride=1, padding=0, dilation=1, groups=1, relu=False, site=None, w32=False):
+    """site: activation-rounding site of the output (None: the engine does not round here);
+    w32: the engine keeps this layer's weights in fp32."""
     w, b = p
-    y = F.conv2d(x, _t(w), _t(b), stride, padding, dilation, groups)
-    return F.relu(y) if relu else y
+    wt = _t(w) if (_EMU is None or w32) else _EMU.w(w)
+    y = F.conv2d(x, wt, _t(b), stride, padding, dilation, groups)
+    y = F.relu(y) if relu else y
+    if _EMU is not None and site is not None:
+        y = _EMU.a(site if site is not True else _EMU.names.get(id(w)), y)
+    return y
+
+
+def _round(site, x):
+    return x if _EMU is None else _EMU.a(site, x)
 
 
 def resnet50_forward(P, x, output_stride=16, taps=None):
     """encoders/resnet.py:217-229 with Bottleneck blocks (:109-129); BN folded."""
-    x = _conv(x, P['encoder.conv1'], stride=2, padding=3, relu=True)
+    x = _conv(x, P['encoder.conv1'], stride=2, padding=3, relu=True, w32=True)   # stem.hip: fp16 hi/lo split, fp32-exact
     if taps is not None:
         taps['stem'] = x
-    p1 = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    p1 = _round('encoder.conv1', F.max_pool2d(x, kernel_size=3, stride=2, padding=1))
     pyr = [p1]
     x = p1
     for li, nblocks in enumerate(RESNET50_LAYERS, start=1):
@@ -40,12 +98,12 @@ def resnet50_forward(P, x, output_stride=16, taps=None):
             pre = f'encoder.layer{li}.{b}'
             s = stride if b == 0 else 1
             identity = x
-            out = _conv(x, P[f'{pre}.conv1'], relu=True)
-            out = _conv(out, P[f'{pre}.conv2'], stride=s, padding=dilation, dilation=dilation, relu=True)
+            out = _conv(x, P[f'{pre}.conv1'], relu=True, site=True)
+            out = _conv(out, P[f'{pre}.conv2'], stride=s, padding=dilation, dilation=dilation, relu=True, site=True)
             out = _conv(out, P[f'{pre}.conv3'])
             if b == 0:
                 identity = _conv(x, P[f'{pre}.downsample.0'], stride=s)
-            x = F.relu(out + identity)
+            x = _round(pre, F.relu(out + identity))       # one rounding per block: conv3 (+ shortcut) epilogue
             if taps is not None:
                 taps[pre] = x
         pyr.append(x)
@@ -54,12 +112,19 @@ def resnet50_forward(P, x, output_stride=16, taps=None):
 
 def aspp_forward(P, pre, x, rates):
     """decoders/aspp.py:96-102 (+ ASPPPooling.forward :45-48)."""
-    res = [_conv(x, P[f'{pre}.convs.0.0'], relu=True)]
+    res = [_conv(x, P[f'{pre}.convs.0.0'], relu=True, site=True)]
     for i, r in enumerate(rates, start=1):
-        res.append(_conv(x, P[f'{pre}.convs.{i}.0'], padding=r, dilation=r, relu=True))
+        res.append(_conv(x, P[f'{pre}.convs.{i}.0'], padding=r, dilation=r, relu=True, site=True))
     size = x.shape[-2:]
     pooled = F.adaptive_avg_pool2d(x, 1)
-    pooled = _conv(pooled, P[f'{pre}.convs.4.aspp_pooling.1'], relu=True)
+    pooled = _conv(pooled, P[f'{pre}.convs.4.aspp_pooling.1'], relu=True, w32=True)
+    if _EMU is not None:
+        # the engine's form (pdl_net.hip): the pooled branch is a per-image constant, its slice of the projection
+        # stays fp32 and enters as a per-image bias; the other four branches go through the fp16 GEMM
+        w, b = P[f'{pre}.project.0']
+        c4 = sum(r.shape[1] for r in res)
+        y = F.conv2d(torch.cat(res, dim=1), _EMU.w(w)[:, :c4], _t(b)) + F.conv2d(pooled, _t(w)[:, c4:])
+        return _EMU.a(f'{pre}.project.0', F.relu(y))
     res.append(F.interpolate(pooled, size=size, mode='bilinear', align_corners=True))
     return _conv(torch.cat(res, dim=1), P[f'{pre}.project.0'], relu=True)
 
@@ -70,19 +135,19 @@ def decoder_forward(P, pre, pyr, low_level_stages, rates, taps=None):
     if taps is not None:
         taps[f'{pre}.aspp'] = x
     for i, stage in enumerate(low_level_stages):
-        l = _conv(pyr[stage], P[f'{pre}.project.{i}.0'], relu=True)
-        x = F.interpolate(x, size=l.shape[2:], mode='bilinear', align_corners=True)
+        l = _conv(pyr[stage], P[f'{pre}.project.{i}.0'], relu=True, site=True)
+        x = _round(f'bilinear:{pre}.{i}', F.interpolate(x, size=l.shape[2:], mode='bilinear', align_corners=True))
         x = torch.cat((x, l), dim=1)
-        x = _conv(x, (P[f'{pre}.fuse.{i}.0.sepconv.0'][0], None), padding=2, groups=x.shape[1])
-        x = _conv(x, P[f'{pre}.fuse.{i}.0.sepconv.1'], relu=True)
+        x = _conv(x, (P[f'{pre}.fuse.{i}.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=True)
+        x = _conv(x, P[f'{pre}.fuse.{i}.0.sepconv.1'], relu=True, site=True)
     return x
 
 
 def head_forward(P, pre, x):
     """heads.py:12-19."""
-    x = _conv(x, (P[f'{pre}.head.0.0.sepconv.0'][0], None), padding=2, groups=x.shape[1])
-    x = _conv(x, P[f'{pre}.head.0.0.sepconv.1'], relu=True)
-    return _conv(x, P[f'{pre}.head.1'])
+    x = _conv(x, (P[f'{pre}.head.0.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=True)
+    x = _conv(x, P[f'{pre}.head.0.0.sepconv.1'], relu=True)      # fused head: this map stays fp32 on chip (sepconv.hip)
+    return _conv(x, P[f'{pre}.head.1'], w32=True)
 
 
 def calculate_uncertainty(logits):
@@ -114,13 +179,16 @@ def uncertain_points_on_grid(uncertainty_map, num_points):
 
 def point_head_forward(P, fine, coarse, num_fc):
     """point_rend.py:181-188 (Conv1d k=1 MLP, coarse concatenated at every layer)."""
+    if _EMU is not None:   # the engine's MLP input rows are fp16: sampled features and the coarse logits beside them
+        fine, coarse = _EMU.a('pr.features', fine), _EMU.a('pr.coarse', coarse)
     x = torch.cat([fine, coarse], dim=1)
     for k in range(num_fc):
         w, b = P[f'semantic_pr.point_head.fc_layers.{k}.0']
-        x = F.relu(F.conv1d(x, _t(w), _t(b)))
+        wt = _t(w) if _EMU is None else _EMU.w(w)
+        x = _round(f'semantic_pr.point_head.fc_layers.{k}.0', F.relu(F.conv1d(x, wt, _t(b))))
         x = torch.cat([x, coarse], dim=1)
     w, b = P['semantic_pr.point_head.predictor']
-    return F.conv1d(x, _t(w), _t(b))
+    return F.conv1d(x, _t(w), _t(b))       # fp32 weights in the engine (head1x1)
 
 
 def point_rend_forward(P, coarse_logits, features, steps, num_points, num_fc, taps=None):
@@ -142,12 +210,21 @@ def point_rend_forward(P, coarse_logits, features, steps, num_points, num_fc, ta
 
 
 @torch.no_grad()
-def pdl_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None):
+def pdl_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None, emu=None):
     """QuantizablePanopticDeepLabPR.forward, eval (quantization/panoptic_deeplab.py:238-250).
 
     P: folded params (numpy), x: (N,1,H,W) fp32 torch tensor, H,W % 16 == 0.
     Returns dict(sem_logits, ctr_hmp, offsets) of fp32 torch tensors.
+    emu: None = the reference's fp32 forward; an Fp16Emu = the same forward with the HIP engine's
+    fp16 storage roundings (class docstring).
     """
+    global _EMU
+    if emu is not None:
+        _EMU = emu.bind(P)
+        try:
+            return pdl_forward(P, x, cfg, render_steps, interpolate_ins, taps, None)
+        finally:
+            _EMU = None
     pyr = resnet50_forward(P, x, cfg['stage4_stride'], taps)
     stages, rates = cfg['low_level_stages'], cfg['atrous_rates']
     semantic_x = decoder_forward(P, 'semantic_decoder', pyr, stages, rates, taps)
@@ -255,7 +332,8 @@ def bifpn_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None):
     return {'sem_logits': sem_logits, 'ctr_hmp': ctr, 'offsets': off}
 
 
-def model_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None):
+def model_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None, emu=None):
     if 'BiFPN' in cfg.get('arch', ''):
+        assert emu is None, 'fp16 emulation is written for the Panoptic-DeepLab forward only'
         return bifpn_forward(P, x, cfg, render_steps, interpolate_ins, taps)
-    return pdl_forward(P, x, cfg, render_steps, interpolate_ins, taps)
+    return pdl_forward(P, x, cfg, render_steps, interpolate_ins, taps, emu)

@@ -1,0 +1,179 @@
+"""Full-size float parity of the network forward, at the north-star tolerance.
+
+One 1024 x 1024 tile (BASELINE configs[1] size: the 256 x 256 conv tile and the register-weight 3x3 kernels ARE
+selected in-network here, unlike the 64^2-160^2 reference goldens) through ``HipPanopticDeepLab`` against
+
+  (A) the oracle with the engine's storage formats (``oracle.pdl_model.Fp16Emu``: same fp32 arithmetic, weights and
+      activation maps rounded to fp16 where the engine keeps them in fp16).  This isolates KERNEL error from FORMAT
+      error: the tolerance is the north star's 1e-3 on the centre heat-map and the semantic probability.
+  (B) the plain fp32 oracle (= the reference forward, pinned by tests/golden/pdl_forward.npz).  The gap to it is the
+      fp16 format itself (profiles/r02_error_budget.csv: no subset of layers holds it, weights and activations
+      contribute alike); asserted at 1e-3 in rms, the max norm is REPORTED (and bounded loosely).
+  (C) end to end: HIP heads -> HIP voting/merge vs fp32-oracle heads -> oracle voting/merge; the label FLIP COUNT is
+      reported (pixels whose foreground differs, pixels whose instance differs after matching ids by overlap).
+
+PointRend refines the 8192 most uncertain cells per step; a cell selected on one side only differs by
+(refined - interpolated).  (A) therefore checks the subdivision separately on IDENTICAL inputs (the engine's own
+coarse logits and feature map handed to the oracle's PointRend), where selection is identical up to fp32 ties.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # BASELINE.json north_star: "within 1e-3 on the float semantic/center heatmaps"
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'parity_fullsize.json')
+
+
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def _report(key, val):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    d = {}
+    if os.path.exists(REPORT):
+        try:
+            d = json.load(open(REPORT))
+        except Exception:
+            d = {}
+    d[key] = val
+    json.dump(d, open(REPORT, 'w'), indent=1, sort_keys=True)
+
+
+@pytest.fixture(scope='module')
+def case():
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model
+    torch.set_num_threads(os.cpu_count())
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    # the seeded network's centre head stays below the NMS threshold on most of a tile: lift the two head biases so
+    # that the end-to-end comparison has instances and foreground (same parameters on both sides)
+    for name, shift in (('ins_center.head.1', 0.75), ('semantic_head.head.1', 1.0), ('semantic_pr.point_head.predictor', 1.0)):
+        w, b = P[name]
+        P[name] = (w, b + np.float32(shift))
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    img = synth.em_tiles(1, 1024, seed=2024)
+    x = torch.from_numpy(normalize(img, 0.57571, 0.12765))[:, None]
+    out = {k: v.cpu().numpy() for k, v in model(x.cuda(), 2, False).items()}
+    torch.cuda.synchronize()
+    semx = model.tap('semantic_decoder.stage0.out').float().cpu().permute(0, 3, 1, 2).contiguous()
+    coarse = model.tap_raw('semantic_head.out', (1, 1, 256, 256)).cpu()
+    taps32, taps16 = {}, {}
+    ref32 = pdl_model.pdl_forward(P, x, cfg, 2, False, taps32)
+    ref16 = pdl_model.pdl_forward(P, x, cfg, 2, False, taps16, emu=pdl_model.Fp16Emu())
+    return dict(cfg=cfg, P=P, model=model, img=img, x=x, out=out, semx=semx, coarse=coarse, ref32=ref32, ref16=ref16,
+                taps32=taps32, taps16=taps16)
+
+
+def test_heads_match_format_emulating_oracle_at_1e3(case):
+    """(A): kernels vs the same forward in fp32 arithmetic with the engine's fp16 storage points."""
+    o, r, t = case['out'], case['ref16'], case['taps16']
+    e_ctr = np.abs(o['ctr_hmp'] - r['ctr_hmp'].numpy())
+    e_off = np.abs(o['offsets'] - r['offsets'].numpy())
+    e_sem = np.abs(_sig(case['coarse'].numpy()) - _sig(t['sem_coarse'].numpy()))
+    e_fx = (case['semx'] - t['semantic_x']).abs()
+    rep = dict(ctr_max=float(e_ctr.max()), ctr_rms=float(np.sqrt((e_ctr ** 2).mean())), off_max=float(e_off.max()),
+               off_rms=float(np.sqrt((e_off ** 2).mean())), sem_coarse_prob_max=float(e_sem.max()),
+               semantic_x_max=float(e_fx.max()), semantic_x_rms=float(e_fx.pow(2).mean().sqrt()),
+               off_abs_max=float(np.abs(r['offsets'].numpy()).max()))
+    print('HIP vs fp16-format oracle @1024^2:', rep)
+    _report('vs_format_oracle', rep)
+    assert e_ctr.max() < TOL, f'centre heat-map: {e_ctr.max():.3e}'
+    assert e_sem.max() < TOL, f'coarse semantic probability: {e_sem.max():.3e}'
+    # offsets are pixels (|values| up to tens, rounded into integer votes): 1e-3 relative to their range
+    assert e_off.max() < TOL * max(1.0, rep['off_abs_max']), f'offsets: {e_off.max():.3e}'
+
+
+def test_pointrend_on_identical_inputs_at_1e3(case):
+    """(A) for the subdivision: the oracle's PointRend on the ENGINE's coarse logits and features."""
+    from oracle import pdl_model
+    cfg, P = case['cfg'], case['P']
+    emu = pdl_model.Fp16Emu().bind(P)
+    pdl_model._EMU = emu
+    try:
+        want = pdl_model.point_rend_forward(P, case['coarse'], case['semx'], 2, cfg['subdivision_num_points'], cfg['num_fc'])
+    finally:
+        pdl_model._EMU = None
+    d = np.abs(_sig(case['out']['sem_logits']) - _sig(want.numpy()))
+    flips = int((d > TOL).sum())
+    rep = dict(prob_max=float(d.max()), cells_over_1e3=flips, cells=int(d.size))
+    print('PointRend on identical inputs:', rep)
+    _report('pointrend_identical_inputs', rep)
+    # a cell whose uncertainty ties with the 8192nd one in fp32 may be picked by one side only
+    assert flips <= 16, f'{flips} cells differ by more than 1e-3 in probability'
+    assert np.sort(d.ravel())[-17 if flips else -1] < TOL
+
+
+def test_heads_vs_fp32_reference_forward(case):
+    """(B): gap to the fp32 forward = the fp16 format (error budget in profiles/): rms within 1e-3, max reported."""
+    o, r, t = case['out'], case['ref32'], case['taps32']
+    e_ctr = np.abs(o['ctr_hmp'] - r['ctr_hmp'].numpy())
+    e_off = np.abs(o['offsets'] - r['offsets'].numpy())
+    e_semc = np.abs(_sig(case['coarse'].numpy()) - _sig(t['sem_coarse'].numpy()))
+    e_prob = np.abs(_sig(o['sem_logits']) - _sig(r['sem_logits'].numpy()))
+    fmt = dict(ctr_max=float(np.abs(case['ref16']['ctr_hmp'].numpy() - r['ctr_hmp'].numpy()).max()))
+    rep = dict(ctr_max=float(e_ctr.max()), ctr_rms=float(np.sqrt((e_ctr ** 2).mean())),
+               off_max=float(e_off.max()), off_rms=float(np.sqrt((e_off ** 2).mean())),
+               sem_coarse_prob_max=float(e_semc.max()), sem_coarse_prob_rms=float(np.sqrt((e_semc ** 2).mean())),
+               prob_max=float(e_prob.max()), prob_rms=float(np.sqrt((e_prob ** 2).mean())),
+               prob_frac_over_1e3=float((e_prob > TOL).mean()), prob_frac_over_1e2=float((e_prob > 1e-2).mean()),
+               format_oracle_ctr_max=fmt['ctr_max'])
+    print('HIP vs fp32 oracle @1024^2:', rep)
+    _report('vs_fp32_oracle', rep)
+    assert rep['ctr_rms'] < TOL and rep['sem_coarse_prob_rms'] < TOL
+    assert rep['ctr_max'] < 1e-2 and rep['sem_coarse_prob_max'] < 1e-2      # loose bound; the budget explains the rest
+    # the engine must sit where the format puts it, not beyond: its distance to fp32 is that of the emulated formats
+    assert rep['ctr_max'] < 1.5 * fmt['ctr_max'] + 1e-4
+
+
+def _match_ids(a, b):
+    """relabel the instances of ``a`` with the id of the instance of ``b`` they overlap most (0 stays 0)."""
+    out = np.zeros_like(a)
+    ids = np.unique(a)
+    for i in ids[ids > 0]:
+        m = a == i
+        vals, cnt = np.unique(b[m], return_counts=True)
+        keep = vals > 0
+        out[m] = vals[keep][np.argmax(cnt[keep])] if keep.any() else -int(i)
+    return out
+
+
+def test_end_to_end_label_flips_vs_fp32_pipeline(case):
+    """(C): label maps after BOTH pipelines: flip counts reported, foreground flips bounded."""
+    from empanada_napari_amd.engines import PanopticDeepLabRenderEngine
+    from oracle import postprocess as opp
+    eng = PanopticDeepLabRenderEngine(case['model'], [1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3,
+                                      confidence_thr=0.5, padding_factor=16, coarse_boundaries=True)
+    pan = eng(case['x'], case['img'].shape[-2:], 1).cpu().numpy()[0]
+    r = {k: v.numpy() for k, v in case['ref32'].items()}
+    r['sem'] = opp.logits_to_prob(r['sem_logits'])
+    oeng = opp.RenderEngine(lambda *_: r, [1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3,
+                            confidence_thr=0.5, coarse_boundaries=True)
+    want = oeng.postprocess(r['sem'], oeng.cells(r['ctr_hmp'], r['offsets'], 1))[0]
+    # and the post-processing alone on the engine's own heads (bit-exact, as in test_gpu_postprocess.py)
+    o = dict(case['out'])
+    o['sem'] = opp.logits_to_prob(o['sem_logits'])
+    own = oeng.postprocess(o['sem'], oeng.cells(o['ctr_hmp'], o['offsets'], 1))[0]
+    near_thr = np.abs(o['sem'][0, 0] - 0.5) < 1e-6
+    assert np.all((pan == own) | near_thr), f'{int((pan != own).sum())} flips with identical head tensors'
+    n_hip, n_ref = len(np.unique(pan)) - 1, len(np.unique(want)) - 1
+    fg_flip = int(((pan > 0) != (want > 0)).sum())
+    verbatim = int((pan != want).sum())
+    matched = _match_ids(pan, want)
+    ins_flip = int((matched != want).sum())
+    rep = dict(instances_hip=n_hip, instances_ref=n_ref, pixels=int(pan.size), foreground_flips=fg_flip,
+               verbatim_label_diffs=verbatim, instance_flips_after_id_matching=ins_flip,
+               foreground_fraction=float((want > 0).mean()))
+    print('end-to-end label flips (HIP fp16 pipeline vs fp32 oracle pipeline):', rep)
+    _report('label_flips', rep)
+    assert n_ref > 0 and n_hip > 0
+    assert fg_flip < 2e-3 * pan.size, f'{fg_flip} foreground flips'
+    assert abs(n_hip - n_ref) <= max(2, 0.02 * n_ref)

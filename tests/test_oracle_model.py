@@ -85,3 +85,29 @@ def test_bifpn_forward_matches_reference(golden_dir, tag, ncls, case):
         bad = np.abs(got - ref) > tol
         # multi-class PointRend: a top-2 tie in the uncertainty ranking may pick a different cell
         assert bad.mean() < (2e-3 if name == 'sem_logits' else 1e-12), (name, bad.mean(), np.abs(got - ref).max())
+
+
+def test_fp16_format_emulation_brackets_the_fp32_forward():
+    """oracle.pdl_model.Fp16Emu (the checker of tests/test_gpu_parity_fullsize.py): with every rounding site off it
+    is the fp32 forward (up to the re-associated ASPP projection); with the engine's sites on it moves the heads by
+    the fp16-format amount (1e-4 .. 1e-2), never more."""
+    import torch
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    x = torch.from_numpy(normalize(synth.em_tiles(1, 64, seed=4), 0.57571, 0.12765))[:, None]
+    ref = pdl_model.pdl_forward(P, x, cfg, 2, False)
+    off = pdl_model.pdl_forward(P, x, cfg, 2, False, emu=pdl_model.Fp16Emu(False, False))
+    emu = pdl_model.Fp16Emu()
+    on = pdl_model.pdl_forward(P, x, cfg, 2, False, emu=emu)
+    assert pdl_model._EMU is None
+    assert float((off['ctr_hmp'] - ref['ctr_hmp']).abs().max()) < 2e-5
+    d = float((on['ctr_hmp'] - ref['ctr_hmp']).abs().max())
+    assert 1e-4 < d < 1e-2, d
+    # every conv of the spec except the fp32-kept ones is a weight site; every block output an activation site
+    assert 'encoder.layer3.2.conv2' in emu.sites_w and 'encoder.conv1' not in emu.sites_w
+    assert 'semantic_head.head.1' not in emu.sites_w and 'encoder.layer4.2' in emu.sites_a
+    split = pdl_model.pdl_forward(P, x, cfg, 2, False, emu=pdl_model.Fp16Emu(True, False, split_weights=emu.sites_w))
+    assert float((split['ctr_hmp'] - ref['ctr_hmp']).abs().max()) < 2e-5     # hi + lo pairs carry 22 bits
