@@ -73,7 +73,8 @@ struct emp_pdl {
   // arena
   char* arena = nullptr;
   size_t arena_cap = 0, arena_used = 0;
-  int pN = 0, pH = 0, pW = 0, pRS = 0;  // planned shape
+  int pN = 0, pH = 0, pW = 0, pRS = 0;  // planned shape (pN: the batch of the current forward)
+  int capN = 0;                         // batch the arena layout was planned for (pN <= capN)
   std::map<std::string, Act> acts;
   std::vector<std::string> act_order;
   std::map<std::string, std::pair<size_t, size_t>> raw;  // name -> (offset, bytes)
@@ -328,7 +329,7 @@ void add_raw(emp_pdl* n, Planner& pl, const std::string& name, size_t bytes) {
 
 
 
-int plan(emp_pdl* n, int N, int H, int W, int RS) {
+int plan(emp_pdl* n, int N, int H, int W, int RS, hipStream_t stream) {
   const emp_pdl_config& c = n->cfg;
   EMP_REQUIRE(N > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0,
               "forward: H=%d W=%d must be positive multiples of 16 (factor_pad first)", H, W);
@@ -462,12 +463,22 @@ int plan(emp_pdl* n, int N, int H, int W, int RS) {
     }
     n->arena_cap = need;
   }
-  // channel-padding regions must read as exact zeros
-  EMP_CHECK_HIP(hipMemset(n->arena, 0, need));
+  // channel-padding regions must read as exact zeros; ordered on the caller's stream behind whatever still runs on
+  // the previous layout (a hipFree above has synchronised the device already)
+  EMP_CHECK_HIP(hipMemsetAsync(n->arena, 0, need, stream));
   n->arena_used = need;
   for (auto& kv : n->acts) kv.second.p = (half_t*)(n->arena + kv.second.off);
   n->pN = N; n->pH = H; n->pW = W; n->pRS = RS;
+  n->capN = N;
   return EMP_OK;
+}
+
+// A smaller batch at the planned image size runs in the SAME layout: every buffer is batch-major, so the first N
+// images are a prefix of it and the zero padding stays valid -- no re-plan, no re-zeroing of a multi-GB arena for
+// the last partial slice chunk of a stack (and none when the full batch comes back).
+void rebatch(emp_pdl* n, int N) {
+  for (auto& kv : n->acts) kv.second.N = N;
+  n->pN = N;
 }
 
 template <typename T>
@@ -1050,7 +1061,7 @@ int emp_pdl_finalize(emp_pdl_t* n) {
 
 int emp_pdl_reserve(emp_pdl_t* net, int N, int H, int W) {
   EMP_REQUIRE(net, "reserve: null network");
-  return plan(net, N, H, W, net->pRS > 2 ? net->pRS : 2);
+  return plan(net, N, H, W, net->pRS > 2 ? net->pRS : 2, nullptr);
 }
 size_t emp_pdl_arena_bytes(const emp_pdl_t* net) { return net ? net->arena_used : 0; }
 
@@ -1063,7 +1074,11 @@ int emp_pdl_forward_padded(emp_pdl_t* net, const void* d_image, int image_dtype,
     set_error("forward: call emp_pdl_finalize first");
     return EMP_ERR_STATE;
   }
-  if (N != net->pN || H != net->pH || W != net->pW || render_steps != net->pRS) RC(plan(net, N, H, W, render_steps));
+  if (H != net->pH || W != net->pW || render_steps != net->pRS || N > net->capN) {
+    RC(plan(net, N, H, W, render_steps, (hipStream_t)stream));
+  } else if (N != net->pN) {
+    rebatch(net, N);
+  }
   const int rc = run(net, d_image, image_dtype, sub, mul, N, H, W, vh, vw, render_steps, interpolate_ins, d_sem_logits,
                      d_ctr_hmp, d_offsets, (hipStream_t)stream);
   if (net->layer_log) { fprintf(net->layer_log, "end\n"); fflush(net->layer_log); }

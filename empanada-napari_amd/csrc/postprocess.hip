@@ -439,7 +439,7 @@ int emp_median_slices(const float* const* h_slice_ptrs, int ks, float* d_out, si
 int emp_median_recursive(const float* d_hist, const float* d_raw, int n_raw, int ks, int n_out, float* d_out,
                          size_t count, void* stream) {
   EMP_REQUIRE(d_hist && d_raw && d_out && count > 0, "median_recursive: null argument");
-  EMP_REQUIRE((ks & 1) && ks >= 3 && ks <= 9, "median_recursive: kernel size %d must be odd, 3..9", ks);
+  EMP_REQUIRE((ks & 1) && ks >= 3 && ks <= MAX_KS, "median_recursive: kernel size %d must be odd, 3..%d", ks, MAX_KS);
   EMP_REQUIRE(n_out >= 1 && n_raw >= n_out + (ks - 1) / 2, "median_recursive: need n_out + mid raw maps");
   hipStream_t s = (hipStream_t)stream;
   const int grid = grid_for((int64_t)count);
@@ -447,7 +447,10 @@ int emp_median_recursive(const float* d_hist, const float* d_raw, int n_raw, int
     case 3: hipLaunchKernelGGL(median_recursive_kernel<3>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
     case 5: hipLaunchKernelGGL(median_recursive_kernel<5>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
     case 7: hipLaunchKernelGGL(median_recursive_kernel<7>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
-    default: hipLaunchKernelGGL(median_recursive_kernel<9>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
+    case 9: hipLaunchKernelGGL(median_recursive_kernel<9>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
+    case 11: hipLaunchKernelGGL(median_recursive_kernel<11>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
+    case 13: hipLaunchKernelGGL(median_recursive_kernel<13>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
+    default: hipLaunchKernelGGL(median_recursive_kernel<15>, dim3(grid), dim3(256), 0, s, d_hist, d_raw, n_out, d_out, count); break;
   }
   EMP_LAUNCH_CHECK();
   return EMP_OK;

@@ -29,7 +29,10 @@ IMG_DTYPES = {torch.float32: 0, torch.uint8: 1, torch.int16: 2, torch.uint16: 2}
 def _require_gpu(device):
     if not torch.cuda.is_available():
         raise RuntimeError('empanada_napari_amd needs a HIP device (MI355X); there is no CPU fallback')
-    return torch.device(device)
+    if device is None:      # the process's current device (a multi-GPU rank selects its GPU once; cuda:0 otherwise)
+        return torch.device('cuda', torch.cuda.current_device())
+    device = torch.device(device)
+    return torch.device('cuda', torch.cuda.current_device()) if device.index is None else device
 
 
 def factor_pad(tensor, factor=16):
@@ -50,7 +53,7 @@ class HipPanopticDeepLab:
     ``weights.fold_state_dict``.
     """
 
-    def __init__(self, state_dict, cfg=None, device='cuda:0', folded=False):
+    def __init__(self, state_dict, cfg=None, device=None, folded=False):
         self.device = _require_gpu(device)
         bifpn = 'BiFPN' in (cfg or {}).get('arch', '')
         self.cfg = dict(weights.MITONET_MINI_CFG if bifpn else weights.MITONET_PDL_CFG, **(cfg or {}))

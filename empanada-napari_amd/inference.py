@@ -10,9 +10,8 @@ import.  Differences, all behind the same results:
     whole chunk of slices; no worker process, no pickled dense maps;
   * ``model_config['model']`` may be a TorchScript file (the reference's export),
     a state dict, or an already built ``HipPanopticDeepLab``.
-Not built yet (raise ``NotImplementedError``):
-label erosion / dilation / hole
-filling, zarr stores when zarr is not installed.
+zarr stores (``store_url``, zarr-backed input volumes) go through ``zstore.open_store``: the zarr package when it
+is installed, otherwise this package's own reader / writer of the zarr v2 directory layout.
 """
 import math
 import os
@@ -21,7 +20,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 
-from . import sparse, weights
+from . import sparse, weights, zstore
 from .engines import (HipPanopticDeepLab, PanopticDeepLabRenderEngine, PanopticDeepLabRenderEngine3d,
                       factor_pad, logits_to_prob)
 from .preprocess import Preprocessor, resize_by_factor
@@ -64,11 +63,17 @@ def _require_scale_one(scale):
 
 
 def _open_zarr(store_url, mode=None):
-    try:
-        import zarr
-    except ImportError as e:
-        raise NotImplementedError('zarr output stores need the zarr package') from e
-    return zarr.open(store_url, mode=mode) if mode else zarr.open(store_url)
+    """``zarr.open(store_url[, mode])`` (inference.py:58,113,404,464)."""
+    return zstore.open_store(store_url, mode)
+
+
+def _device(device=None):
+    """GPU of this engine: the caller's choice, else the process's current device (the reference picks
+    ``cuda:{gpu}`` per rank, multigpu.py:35, and the default device otherwise)."""
+    if device is None:
+        return torch.device('cuda', torch.cuda.current_device())
+    device = torch.device(device)
+    return torch.device('cuda', torch.cuda.current_device()) if device.index is None else device
 
 
 def _class_volume(zarr_store, name, shape, dtype, chunks):
@@ -135,10 +140,10 @@ class Engine2d:
 
     def __init__(self, model_config, inference_scale=1, label_divisor=1000, nms_threshold=0.1, nms_kernel=3,
                  confidence_thr=0.3, semantic_only=False, fine_boundaries=False, tile_size=0, use_gpu=True,
-                 use_quantized=False):
+                 use_quantized=False, device=None):
         if not (torch.cuda.is_available() and use_gpu):
             raise RuntimeError('Engine2d: the MI355X engine has no CPU path (use_gpu=True and a HIP device required)')
-        device = torch.device('cuda:0')
+        device = self.device = _device(device)
         model = load_model(model_config, device)
         self.thing_list = model_config['thing_list']
         self.labels = model_config['labels']
@@ -174,7 +179,7 @@ class Engine2d:
     @torch.no_grad()
     def force_connected(self, pan_seg):
         """:263-279 on the GPU; accepts the device label map and returns an int32 numpy array."""
-        pan = pan_seg if isinstance(pan_seg, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pan_seg)).cuda()
+        pan = pan_seg if isinstance(pan_seg, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pan_seg)).to(self.device)
         pan = pan.to(torch.int32)
         for label in self.engine.thing_list:
             lo = label * self.label_divisor
@@ -231,10 +236,10 @@ class Engine3d:
                  void_label=0, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.3, force_connected=True,
                  min_size=500, min_extent=4, fine_boundaries=False, semantic_only=False, use_gpu=True,
                  use_quantized=False, store_url=None, chunk_size=(256, 256, 256), save_panoptic=False,
-                 label_erosion=0, label_dilation=0, fill_holes_in_segmentation=False, batch_size=None):
+                 label_erosion=0, label_dilation=0, fill_holes_in_segmentation=False, batch_size=None, device=None):
         if not (torch.cuda.is_available() and use_gpu):
             raise RuntimeError('Engine3d: the MI355X engine has no CPU path (use_gpu=True and a HIP device required)')
-        device = torch.device('cuda:0')
+        device = self.device = _device(device)
         model = load_model(model_config, device)
         self.model_config = model_config
         self.labels = model_config['labels']

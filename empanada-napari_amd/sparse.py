@@ -35,7 +35,9 @@ def _lib():
 def _dev(device=None):
     if not torch.cuda.is_available():
         raise RuntimeError('empanada_napari_amd needs a HIP device (MI355X); there is no CPU fallback')
-    return torch.device(device or 'cuda:0')
+    if device is None:      # the process's current device: one rank per GPU sets it once (multigpu.py), cuda:0 otherwise
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device(device)
 
 
 def _hp(a):

@@ -99,7 +99,11 @@ def resnet50_forward(P, x, output_stride=16, taps=None):
             s = stride if b == 0 else 1
             identity = x
             out = _conv(x, P[f'{pre}.conv1'], relu=True, site=True)
+            if taps is not None:
+                taps[pre + '.c1'] = out
             out = _conv(out, P[f'{pre}.conv2'], stride=s, padding=dilation, dilation=dilation, relu=True, site=True)
+            if taps is not None:
+                taps[pre + '.c2'] = out
             out = _conv(out, P[f'{pre}.conv3'])
             if b == 0:
                 identity = _conv(x, P[f'{pre}.downsample.0'], stride=s)
@@ -110,11 +114,13 @@ def resnet50_forward(P, x, output_stride=16, taps=None):
     return pyr  # [p1, p2, p3, p4, p5]
 
 
-def aspp_forward(P, pre, x, rates):
+def aspp_forward(P, pre, x, rates, taps=None):
     """decoders/aspp.py:96-102 (+ ASPPPooling.forward :45-48)."""
     res = [_conv(x, P[f'{pre}.convs.0.0'], relu=True, site=True)]
     for i, r in enumerate(rates, start=1):
         res.append(_conv(x, P[f'{pre}.convs.{i}.0'], padding=r, dilation=r, relu=True, site=True))
+    if taps is not None:
+        taps[f'{pre}.cat'] = torch.cat(res, dim=1)
     size = x.shape[-2:]
     pooled = F.adaptive_avg_pool2d(x, 1)
     pooled = _conv(pooled, P[f'{pre}.convs.4.aspp_pooling.1'], relu=True, w32=True)
@@ -131,13 +137,15 @@ def aspp_forward(P, pre, x, rates):
 
 def decoder_forward(P, pre, pyr, low_level_stages, rates, taps=None):
     """decoders/panoptic_deeplab.py:68-80."""
-    x = aspp_forward(P, f'{pre}.aspp', pyr[-1], rates)
+    x = aspp_forward(P, f'{pre}.aspp', pyr[-1], rates, taps)
     if taps is not None:
         taps[f'{pre}.aspp'] = x
     for i, stage in enumerate(low_level_stages):
         l = _conv(pyr[stage], P[f'{pre}.project.{i}.0'], relu=True, site=True)
         x = _round(f'bilinear:{pre}.{i}', F.interpolate(x, size=l.shape[2:], mode='bilinear', align_corners=True))
         x = torch.cat((x, l), dim=1)
+        if taps is not None:
+            taps[f'{pre}.stage{i}.cat'] = x
         x = _conv(x, (P[f'{pre}.fuse.{i}.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=True)
         x = _conv(x, P[f'{pre}.fuse.{i}.0.sepconv.1'], relu=True, site=True)
     return x
@@ -337,3 +345,85 @@ def model_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None, em
         assert emu is None, 'fp16 emulation is written for the Panoptic-DeepLab forward only'
         return bifpn_forward(P, x, cfg, render_steps, interpolate_ins, taps)
     return pdl_forward(P, x, cfg, render_steps, interpolate_ins, taps, emu)
+
+
+# ----------------------------------------------------------------------------
+# teacher-forced layer check (test infrastructure for the HIP engine's full-size parity)
+# ----------------------------------------------------------------------------
+@torch.no_grad()
+def teacher_forced_layers(P, cfg, x, tap):
+    """Every layer of the Panoptic-DeepLab forward evaluated ON THE ENGINE'S OWN INPUTS.
+
+    Two fp16 pipelines whose fp32 sums are merely ordered differently drift apart layer after layer (one flipped
+    last bit perturbs every output that reads it, which flips more bits: after ~10 layers 40 % of the elements
+    differ by an ulp and the end-to-end distance between the pipelines equals their distance to fp32 --
+    tools/layer_parity.py), so an end-to-end comparison cannot separate kernel error from format error.  Layer by
+    layer it can: ``tap(name)`` returns the engine's map ``name`` as an (N,C,H,W) fp32 tensor; this generator
+    recomputes each layer from the engine's INPUT map(s) in fp32 with the engine's fp16-rounded weights and yields
+    ``(output tap name, expected fp32 value before the output rounding, rounds_to_fp16)``.  A correct kernel equals
+    the expectation rounded to fp16 except where its fp32 sum, accumulated in another order, falls on the other side
+    of a rounding boundary (one ulp, a fraction of a percent of the elements).
+    Covers encoder, ASPP, decoder stage(s) and the three heads (heads.py:12-19); PointRend is checked on identical
+    inputs by ``point_rend_forward`` directly."""
+    r16 = Fp16Emu.r16
+
+    def W(name, fp32=False):
+        w, b = P[name]
+        return (_t(w) if fp32 else r16(_t(w))), _t(b)
+
+    def conv(xin, name, stride=1, padding=0, dilation=1, groups=1):
+        w, b = W(name)
+        return F.conv2d(xin, w, b if groups == 1 else None, stride, padding, dilation, groups)
+
+    w, b = W('encoder.conv1', fp32=True)
+    yield 'p1', F.max_pool2d(F.relu(F.conv2d(x, w, b, 2, 3)), 3, 2, 1), True
+    xname = 'p1'
+    pyr = ['p1']
+    for li, nblocks in enumerate(RESNET50_LAYERS, start=1):
+        stride = 1 if li == 1 else 2
+        dil = 1
+        if li == 4 and cfg['stage4_stride'] == 16:
+            stride, dil = 1, 2
+        for bidx in range(nblocks):
+            pre = f'encoder.layer{li}.{bidx}'
+            s = stride if bidx == 0 else 1
+            xin = tap(xname)
+            yield pre + '.c1', F.relu(conv(xin, pre + '.conv1')), True
+            yield pre + '.c2', F.relu(conv(tap(pre + '.c1'), pre + '.conv2', s, dil, dil)), True
+            idn = conv(xin, pre + '.downsample.0', s) if bidx == 0 else xin
+            yield pre, F.relu(conv(tap(pre + '.c2'), pre + '.conv3') + idn), True
+            xname = pre
+        pyr.append(xname)
+    p5 = tap(pyr[4])
+    rates = cfg['atrous_rates']
+    decs = ['semantic_decoder'] + (['instance_decoder'] if cfg['ins_decoder'] else [])
+    for d in decs:
+        a = f'{d}.aspp'
+        res = [F.relu(conv(p5, f'{a}.convs.0.0'))]
+        for i, r in enumerate(rates, start=1):
+            res.append(F.relu(conv(p5, f'{a}.convs.{i}.0', 1, r, r)))
+        yield f'{a}.cat', torch.cat(res, dim=1), True
+        w, b = W(f'{a}.convs.4.aspp_pooling.1', fp32=True)
+        pooled = F.relu(F.conv2d(F.adaptive_avg_pool2d(p5, 1), w, b))
+        w, b = P[f'{a}.project.0']
+        cat = tap(f'{a}.cat')
+        c4 = cat.shape[1]
+        y = F.conv2d(cat, r16(_t(w))[:, :c4], _t(b)) + F.conv2d(pooled, _t(w)[:, c4:])
+        yield a, F.relu(y), True
+        xn = a
+        for i, stage in enumerate(cfg['low_level_stages']):
+            low = F.relu(conv(tap(pyr[stage]), f'{d}.project.{i}.0'))
+            up = F.interpolate(tap(xn), size=low.shape[2:], mode='bilinear', align_corners=True)
+            yield f'{d}.stage{i}.cat', torch.cat((up, low), dim=1), True
+            cat = tap(f'{d}.stage{i}.cat')
+            dw = r16(conv(cat, f'{d}.fuse.{i}.0.sepconv.0', 1, 2, 1, cat.shape[1]))
+            yield f'{d}.stage{i}.out', F.relu(conv(dw, f'{d}.fuse.{i}.0.sepconv.1')), True
+            xn = f'{d}.stage{i}.out'
+    last = len(cfg['low_level_stages']) - 1
+    semx = tap(f'semantic_decoder.stage{last}.out')
+    insx = tap(f'instance_decoder.stage{last}.out') if cfg['ins_decoder'] else semx
+    for head, xin in (('semantic_head', semx), ('ins_center', insx), ('ins_xy', insx)):
+        dw = r16(conv(xin, f'{head}.head.0.0.sepconv.0', 1, 2, 1, xin.shape[1]))
+        y = F.relu(conv(dw, f'{head}.head.0.0.sepconv.1'))
+        w, b = W(f'{head}.head.1', fp32=True)
+        yield head + '.out', F.conv2d(y, w, b), False

@@ -146,3 +146,96 @@ def test_dense_rle_roundtrip_and_cc():
     for a in seg[1].values():
         ys, xs = np.unravel_index(osp.rle_decode(a['starts'], a['runs']), pan.shape)
         assert a['box'] == (ys.min(), xs.min(), ys.max() + 1, xs.max() + 1)
+
+
+# ---- independent witness for the skimage-backed pieces: scipy.ndimage ----
+def _scipy_label_equal_values(seg):
+    """skimage.measure.label(seg) written with scipy only: full-connectivity components of each distinct non-zero
+    value (ndimage.label on the value's mask), renumbered 1.. in raster order of each component's first element."""
+    from scipy import ndimage as ndi
+    struct = np.ones((3,) * seg.ndim, dtype=bool)
+    firsts, masks = [], []
+    for v in np.unique(seg):
+        if v == 0:
+            continue
+        lab, n = ndi.label(seg == v, structure=struct)
+        for i, sl in enumerate(ndi.find_objects(lab), start=1):
+            m = np.zeros(seg.shape, bool)
+            m[sl] = lab[sl] == i
+            firsts.append(int(np.flatnonzero(m.ravel())[0]))
+            masks.append(m)
+    out = np.zeros(seg.shape, dtype=np.int64)
+    for number, k in enumerate(np.argsort(firsts), start=1):
+        out[masks[k]] = number
+    return out
+
+
+def _random_label_map(rng, shape, nvals, density):
+    seg = rng.integers(1, nvals + 1, size=shape) * (rng.random(shape) < density)
+    return seg.astype(np.int64)
+
+
+@pytest.mark.parametrize('seed,shape,nvals,density', [(0, (37, 53), 1, 0.45), (1, (64, 64), 3, 0.6), (2, (20, 91), 6, 0.9),
+                                                     (3, (48, 48), 2, 0.3), (4, (1, 40), 2, 0.7), (5, (40, 1), 2, 0.7)])
+def test_connected_components_2d_agree_with_scipy_witness(seed, shape, nvals, density):
+    rng = np.random.default_rng(seed)
+    seg = _random_label_map(rng, shape, nvals, density)
+    np.testing.assert_array_equal(osp.connected_components(seg), _scipy_label_equal_values(seg))
+    np.testing.assert_array_equal(osp.label_nd(seg), _scipy_label_equal_values(seg))
+
+
+def test_connected_components_2d_structured_cases():
+    # diagonal touch joins (8-connectivity), equal-value only, U shape whose arms meet late (label merge), empty map
+    seg = np.array([[1, 0, 0, 2], [0, 1, 2, 0], [0, 2, 1, 0], [2, 0, 0, 1]])
+    np.testing.assert_array_equal(osp.connected_components(seg), _scipy_label_equal_values(seg))
+    assert osp.connected_components(seg).max() == 2
+    u = np.zeros((6, 7), int)
+    u[:, 1] = u[:, 5] = u[5, 1:6] = 7
+    assert osp.connected_components(u).max() == 1
+    np.testing.assert_array_equal(osp.connected_components(u), _scipy_label_equal_values(u))
+    assert osp.connected_components(np.zeros((5, 5), int)).max() == 0
+
+
+@pytest.mark.parametrize('seed,shape', [(10, (9, 14, 11)), (11, (4, 30, 30)), (12, (16, 8, 8))])
+def test_label_3d_26_connectivity_agrees_with_scipy_witness(seed, shape):
+    rng = np.random.default_rng(seed)
+    seg = _random_label_map(rng, shape, 3, 0.35)
+    np.testing.assert_array_equal(osp.label_nd(seg), _scipy_label_equal_values(seg))
+    # corner-only contact joins under full connectivity
+    c = np.zeros((3, 3, 3), int)
+    c[0, 0, 0] = c[1, 1, 1] = c[2, 2, 2] = 4
+    assert osp.label_nd(c).max() == 1
+
+
+@pytest.mark.parametrize('seed,shape', [(20, (41, 37)), (21, (6, 17, 13))])
+def test_regionprops_rle_agrees_with_scipy_find_objects(seed, shape):
+    """regionprops' .label / .bbox (half-open) / .coords (row-major) as rle.py:73-81 and filters.py:100-112 consume them:
+    boxes against ndimage.find_objects, runs against a decode of the row-major coordinates."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(seed)
+    seg = _scipy_label_equal_values(_random_label_map(rng, shape, 2, 0.4))
+    attrs = osp.regionprops_rle(seg) if len(shape) == 2 else osp.regionprops_rle_nd(seg)
+    objs = ndi.find_objects(seg)
+    assert sorted(attrs) == list(range(1, len(objs) + 1))
+    for lab, sl in enumerate(objs, start=1):
+        box = tuple(s.start for s in sl) + tuple(s.stop for s in sl)
+        assert tuple(attrs[lab]['box']) == box
+        idx = np.concatenate([np.arange(s, s + r) for s, r in zip(attrs[lab]['starts'], attrs[lab]['runs'])])
+        np.testing.assert_array_equal(idx, np.flatnonzero(seg.ravel() == lab))
+        assert np.all(np.diff(attrs[lab]['starts']) > attrs[lab]['runs'][:-1])          # maximal, ascending runs
+
+
+def test_force_connected_pan_matches_scipy_witness():
+    """Engine2d.force_connected (inference.py:263-279): per thing class, CC-relabel the class's id range, + min id."""
+    rng = np.random.default_rng(30)
+    div = 1000
+    pan = np.zeros((50, 60), np.int64)
+    blobs = _random_label_map(rng, pan.shape, 4, 0.5)
+    pan[blobs > 0] = div + blobs[blobs > 0]                    # class 1 instances
+    pan[10:20, 30:50] = 2 * div                                 # a stuff class, untouched
+    got = osp.force_connected_pan(pan, [1], div)
+    inst = np.where((pan >= div) & (pan < 2 * div), pan, 0)
+    want = pan.copy()
+    cc = _scipy_label_equal_values(inst)
+    want[cc > 0] = cc[cc > 0] + div
+    np.testing.assert_array_equal(got, want)
