@@ -85,6 +85,8 @@ PROTOTYPES = {
     'emp_panoptic_merge_work_bytes': (sz, [c_int, c_int, c_int]),
     'emp_ccl8_work_bytes': (sz, [c_int, c_int, c_int]),
     'emp_ccl8': (c_int, [vp, c_int, c_int, c_int, vp, vp, vp, vp]),
+    'emp_force_connected_work_bytes': (sz, [c_int, c_int, c_int]),
+    'emp_force_connected': (c_int, [vp, c_int, c_int, c_int, C.POINTER(c_i32), c_int, c_i64, vp, vp, vp]),
     'emp_ccl26': (c_int, [vp, c_int, c_int, c_int, vp, vp, vp, vp]),
     'emp_morph_cross3d': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'emp_fill_holes_slices': (c_int, [vp, c_i64, c_i64, c_i64]),

@@ -235,6 +235,26 @@ __global__ void __launch_bounds__(256) ccl_relabel_kernel(const int* __restrict_
   }
 }
 
+// Engine2d.force_connected (empanada_napari/inference.py:263-279) pieces: isolate one class's id range as the CCL
+// input (and, for the first class, narrow the int64 map to int32 on the way), then write cc + min_id back
+template <typename T>
+__global__ void __launch_bounds__(256) fc_select_kernel(const T* __restrict__ pan, int32_t* __restrict__ out,
+                                                        int32_t* __restrict__ sel, int64_t total, int64_t lo,
+                                                        int64_t hi, int write_out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t v = (int64_t)pan[i];
+    if (write_out) out[i] = (int32_t)v;
+    sel[i] = (v >= lo && v < hi) ? (int32_t)v : 0;
+  }
+}
+__global__ void __launch_bounds__(256) fc_apply_kernel(const int32_t* __restrict__ cc, int32_t* __restrict__ out,
+                                                       int64_t total, int32_t lo) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int32_t c = cc[i];
+    if (c > 0) out[i] = c + lo;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // run extraction over the raveled image
 // flags: bit0 = run start (label != 0 and differs from the previous element),
@@ -428,6 +448,42 @@ static int ccl_run(const int32_t* d_in, int N, int depth, int H, int W, int32_t*
 int emp_ccl8(const int32_t* d_in, int N, int H, int W, int32_t* d_out, int32_t* d_num, void* d_work, void* stream) {
   EMP_REQUIRE(d_in && d_out && d_work && N > 0 && H > 0 && W > 0, "ccl8: bad arguments");
   return ccl_run(d_in, N, 0, H, W, d_out, d_num, d_work, (hipStream_t)stream);
+}
+
+size_t emp_force_connected_work_bytes(int N, int H, int W) {
+  return emp_ccl8_work_bytes(N, H, W) + (size_t)N * H * W * 4 + 256;
+}
+
+int emp_force_connected(const int64_t* d_pan, int N, int H, int W, const int32_t* h_thing_list, int n_things,
+                        int64_t label_divisor, int32_t* d_out, void* d_work, void* stream) {
+  EMP_REQUIRE(d_pan && d_out && d_work && N > 0 && H > 0 && W > 0 && n_things >= 0 && label_divisor > 0,
+              "force_connected: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)N * H * W;
+  int32_t* sel = (int32_t*)d_work;
+  void* ccl_work = (char*)d_work + (((size_t)total * 4 + 255) & ~(size_t)255);
+  if (n_things == 0) {   // nothing to relabel: the narrowing alone
+    hipLaunchKernelGGL(fc_select_kernel<int64_t>, dim3(grid_for(total)), dim3(256), 0, s, d_pan, d_out, sel, total,
+                       (int64_t)1, (int64_t)0, 1);
+    EMP_LAUNCH_CHECK();
+    return EMP_OK;
+  }
+  for (int t = 0; t < n_things; ++t) {
+    const int64_t lo = (int64_t)h_thing_list[t] * label_divisor, hi = lo + label_divisor;
+    EMP_REQUIRE(hi < (1ll << 31), "force_connected: class id range beyond int32");
+    // later classes read the map the earlier ones have relabelled (the reference edits pan_seg in place)
+    if (t == 0)
+      hipLaunchKernelGGL(fc_select_kernel<int64_t>, dim3(grid_for(total)), dim3(256), 0, s, d_pan, d_out, sel, total, lo, hi, 1);
+    else
+      hipLaunchKernelGGL(fc_select_kernel<int32_t>, dim3(grid_for(total)), dim3(256), 0, s, (const int32_t*)d_out, d_out, sel,
+                         total, lo, hi, 0);
+    EMP_LAUNCH_CHECK();
+    const int rc = ccl_run(sel, N, 0, H, W, sel, nullptr, ccl_work, s);   // relabel does not read its input: in place
+    if (rc) return rc;
+    hipLaunchKernelGGL(fc_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, sel, d_out, total, (int32_t)lo);
+    EMP_LAUNCH_CHECK();
+  }
+  return EMP_OK;
 }
 
 // work buffer: emp_ccl8_work_bytes(1, D * H, W)

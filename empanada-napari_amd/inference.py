@@ -178,17 +178,16 @@ class Engine2d:
 
     @torch.no_grad()
     def force_connected(self, pan_seg):
-        """:263-279 on the GPU; accepts the device label map and returns an int32 numpy array."""
-        pan = pan_seg if isinstance(pan_seg, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pan_seg)).to(self.device)
-        pan = pan.to(torch.int32)
-        for label in self.engine.thing_list:
-            lo = label * self.label_divisor
-            hi = lo + self.label_divisor
-            inst = torch.where((pan >= lo) & (pan < hi), pan, torch.zeros_like(pan))
-            cc, _ = sparse.ccl8(inst[None])
-            cc = cc[0]
-            pan = torch.where(cc > 0, cc + lo, pan)
-        return pan.cpu().numpy().astype(np.int32, copy=False)
+        """:263-279 on the GPU (one fused call: class-range select, 8-connected components, + min id; int64 -> int32 on
+        the device); accepts a device label map or a numpy array and returns an int32 numpy array."""
+        return self._force_connected_dev(pan_seg).cpu().numpy()
+
+    def _force_connected_dev(self, pan_seg, out=None):
+        pan = pan_seg if isinstance(pan_seg, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(pan_seg))
+        pan = pan.to(self.device, non_blocking=True).to(torch.int64)
+        squeeze = pan.ndim == 2
+        res = sparse.force_connected(pan[None] if squeeze else pan, list(self.engine.thing_list), self.label_divisor, out)
+        return res[0] if squeeze else res
 
     def infer(self, image):
         if self.tile_size > 0 and any(s > self.tile_size for s in image.shape):
@@ -205,6 +204,86 @@ class Engine2d:
         x = self.preprocessor(resize_by_factor(image, self.inference_scale))['image'].unsqueeze(0)
         pan_seg = self.engine(x, size, upsampling=self.inference_scale)
         return self.force_connected(pan_seg.squeeze(0))
+
+    @torch.no_grad()
+    def infer_batch(self, images, batch=32):
+        """``[self.infer(im) for im in images]`` for equally sized 2-D uint8 / uint16 images at native scale, as a
+        pipeline (no reference counterpart: the reference's engine asserts batch 1, engines.py:306, and a caller loops):
+        ``batch`` images per forward; the next batch's upload (pinned staging buffer, copy stream) and the previous
+        batch's int32 label maps going back (second copy stream, straight into one pinned result block) overlap the
+        current batch's forward + voting + merge + force_connected.  Returns a list of int32 (h,w) arrays (views of
+        that block).  Bit-identical to the per-image calls (batch invariance, DESIGN.md finding 13)."""
+        from .preprocess import normalize_params
+        images = list(images)
+        if not images:
+            return []
+        h, w = images[0].shape
+        dt = images[0].dtype
+        assert all(im.ndim == 2 and im.shape == (h, w) and im.dtype == dt for im in images), 'one size and dtype per call'
+        assert dt in (np.uint8, np.uint16) and self.inference_scale == 1 and not (self.tile_size > 0 and max(h, w) > self.tile_size)
+        sub, mul = normalize_params(self.preprocessor.mean, self.preprocessor.std, np.iinfo(dt).max)
+        eng, dev = self.engine, self.device
+        pf = self.padding_factor
+        pad_to = (-(-h // pf) * pf, -(-w // pf) * pf)
+        n = len(images)
+        tdt = torch.uint8 if dt == np.uint8 else torch.uint16
+        result = torch.empty((n, h, w), dtype=torch.int32, pin_memory=True)
+        stage = [torch.empty((batch, 1, h, w), dtype=tdt, pin_memory=True) for _ in range(2)]
+        d_in = [torch.empty((batch, 1, h, w), dtype=tdt, device=dev) for _ in range(2)]
+        d_out = [torch.empty((batch, h, w), dtype=torch.int32, device=dev) for _ in range(2)]
+        main = torch.cuda.current_stream(dev)
+        up, down = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        ev_in = [None, None]       # upload of the buffer finished
+        ev_free = [None, None]     # forward that read the input buffer finished
+        ev_done = [None, None]     # label maps of the buffer complete
+        ev_back = [None, None]     # download of the output buffer finished
+        chunks = [(i0, min(n, i0 + batch)) for i0 in range(0, n, batch)]
+
+        def upload(k):
+            i0, i1 = chunks[k]
+            b = k & 1
+            if ev_in[b] is not None:
+                ev_in[b].synchronize()          # the staging buffer's previous upload has left the host
+            st = stage[b].numpy()
+            for j in range(i1 - i0):
+                st[j, 0] = images[i0 + j]
+            with torch.cuda.stream(up):
+                if ev_free[b] is not None:
+                    up.wait_event(ev_free[b])
+                d_in[b][:i1 - i0].copy_(stage[b][:i1 - i0], non_blocking=True)
+                ev_in[b] = torch.cuda.Event()
+                ev_in[b].record(up)
+
+        upload(0)
+        for k, (i0, i1) in enumerate(chunks):
+            b, m = k & 1, i1 - i0
+            if k + 1 < len(chunks):
+                upload(k + 1)
+            main.wait_event(ev_in[b])
+            mo = eng.model(d_in[b][:m], 2, interpolate_ins=not eng.coarse_boundaries, sub=float(sub), mul=float(mul),
+                           pad_to=pad_to)
+            ev_free[b] = torch.cuda.Event()
+            ev_free[b].record(main)
+            sem = logits_to_prob(mo['sem_logits'])
+            cells, _, _, kmax = eng.instance_cells_int(mo['ctr_hmp'], mo['offsets'], 1)
+            pan = eng.panoptic_merge_int(sem, cells, kmax)[:, :h, :w]
+            if ev_back[b] is not None:
+                main.wait_event(ev_back[b])
+            sparse.force_connected(pan.contiguous(), list(eng.thing_list), self.label_divisor, d_out[b][:m])
+            ev_done[b] = torch.cuda.Event()
+            ev_done[b].record(main)
+            with torch.cuda.stream(down):
+                down.wait_event(ev_done[b])
+                result[i0:i1].copy_(d_out[b][:m], non_blocking=True)
+                ev_back[b] = torch.cuda.Event()
+                ev_back[b].record(down)
+        for e in ev_back:
+            if e is not None:
+                e.synchronize()
+        arr = result.numpy()
+        out = [arr[i] for i in range(n)]
+        self._keepalive = result       # the views borrow the pinned block
+        return out
 
 
     def _infer_tiled(self, image):
@@ -336,6 +415,11 @@ class Engine3d:
         eng = self.engine
         lib = eng.lib
         from . import _abi
+        if not isinstance(volume, np.ndarray) and hasattr(volume, 'dtype') and hasattr(volume, 'shape') and \
+                int(np.prod(volume.shape)) * np.dtype(volume.dtype).itemsize <= (8 << 30):
+            # chunked stores (zarr arrays, zstore.DirArray): one sequential read of the chunks instead of a strided
+            # gather per slice (the reference's VolumeDataset indexes the store per slice, volume_dataset.py:39)
+            volume = np.asarray(volume[...])
         n = volume.shape[axis]
         ks, mid = eng.ks, eng.mid_idx
         ups = self.inference_scale

@@ -136,6 +136,22 @@ def pan_stack_to_rle_segs(pan, labels, label_divisor, thing_list, force_connecte
 
 
 @torch.no_grad()
+def force_connected(pan, thing_list, label_divisor, out=None):
+    """Engine2d.force_connected (empanada_napari/inference.py:263-279) for a batch on the device: pan (N,H,W) int64
+    device tensor -> (N,H,W) int32 device tensor (``out`` if given)."""
+    lib = _lib()
+    pan = pan.contiguous()
+    assert pan.dtype == torch.int64 and pan.ndim == 3
+    N, H, W = pan.shape
+    if out is None:
+        out = torch.empty((N, H, W), dtype=torch.int32, device=pan.device)
+    work = torch.empty((int(lib.emp_force_connected_work_bytes(N, H, W)),), dtype=torch.uint8, device=pan.device)
+    tl = (C.c_int32 * max(1, len(thing_list)))(*thing_list)
+    _abi.check(lib.emp_force_connected(_abi.ptr(pan), N, H, W, tl, len(thing_list), int(label_divisor), _abi.ptr(out),
+                                       _abi.ptr(work), _abi.stream_ptr(pan.device)), 'emp_force_connected')
+    return out
+
+
 def pan_stack_to_runs(pan, labels, label_divisor, thing_list, force_connected=True):
     """The GPU half of pan_stack_to_rle_segs without building Python objects: pan (N,H,W) ->
     {class: (list of N (n_i,3) int64 {start, length, label} arrays in raster order, id offset)} for StackMatcher.push_runs."""

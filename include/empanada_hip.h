@@ -270,6 +270,15 @@ EMP_API size_t emp_ccl8_work_bytes(int N, int H, int W);
 EMP_API int emp_ccl8(const int32_t* d_in, int N, int H, int W, int32_t* d_out, int32_t* d_num,
              void* d_work, void* stream);
 
+/* Engine2d.force_connected, empanada_napari/inference.py:263-279, for a batch of label maps in one call: for each
+ * thing class in list order, the ids in [class*divisor, (class+1)*divisor) are replaced by their 8-connected
+ * components numbered in raster order + class*divisor (later classes see the earlier classes' relabelling, as the
+ * reference edits pan_seg in place).  d_pan (N,H,W) int64 (the Render engine's output); d_out (N,H,W) int32 (what
+ * Engine2d.infer returns after .astype(np.int32), inference.py:325); h_thing_list is a HOST array. */
+EMP_API size_t emp_force_connected_work_bytes(int N, int H, int W);
+EMP_API int emp_force_connected(const int64_t* d_pan, int N, int H, int W, const int32_t* h_thing_list, int n_things,
+                        int64_t label_divisor, int32_t* d_out, void* d_work, void* stream);
+
 /* 26-connected components of EQUAL non-zero label of ONE volume (skimage.measure.label on a 3-D array, default
  * full connectivity), numbered in raster order of first voxels.  replaces filters.connected_components,
  * empanada/inference/filters.py:14-20, as used by filters.pan_seg_to_rle_seg (:58-116) after erode / dilate /

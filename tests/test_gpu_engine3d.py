@@ -322,3 +322,104 @@ def test_config0_bifpn_single_512_tile_through_engine2d():
     cells = oeng.cells(out['ctr_hmp'].cpu().numpy(), out['offsets'].cpu().numpy(), 1)
     pan = oeng.postprocess(sem, cells)[0].astype(np.int32)
     np.testing.assert_array_equal(got, osp.force_connected_pan(pan.copy(), [1], DIV))
+
+
+def test_stack_postprocessing_matches_oracle(model_config):
+    """inference.py:56-109: relabel 1..n (stable sort of runs, inference.py:31-54), size / span filters, dense fill."""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine3d, stack_postprocessing
+    from oracle import sparse as osp
+    vol = synth.blob_volume(18, 40, 48, seed=8, n_blobs=5)
+    eng = Engine3d(model_config, label_divisor=DIV, median_kernel_size=3, nms_kernel=3, confidence_thr=0.5,
+                   min_size=0, min_extent=0, batch_size=5)
+    pans = [p.cpu().numpy() for p in eng.predict_slices(vol, 0)]
+    _, trs = eng.infer_on_axis(vol, 'xy')
+    out = list(stack_postprocessing({'xy': trs}, None, model_config, label_divisor=DIV, min_size=40, min_extent=3,
+                                    dtype=np.uint32))
+    assert len(out) == 1
+    svol, name, inst = out[0]
+    otr = _oracle_axis(pans, vol.shape, 'xy', 0, 0)
+    ost = osp.InstanceTracker(1, DIV, vol.shape, 'xy')
+    ost.instances = osp.instance_relabel(otr)
+    osp.remove_small_objects(ost, 40)
+    osp.remove_pancakes(ost, 3)
+    assert len(ost.instances) > 0
+    _same_instances(inst, ost.instances)
+    np.testing.assert_array_equal(svol, osp.numpy_fill_instances(np.zeros(vol.shape, np.uint32), ost.instances))
+    assert name == 'mito' and svol.dtype == np.uint32
+
+
+def test_zarr_volume_in_zarr_store_out(model_config, tmp_path):
+    """BASELINE configs[2] says 'zarr volume': a zarr v2 directory store as the INPUT volume and ``store_url`` outputs
+    (panoptic stack per axis, consensus / stack volumes; inference.py:100-103,404,474-489) give what the numpy route
+    gives; the store is then read back through the files alone.  Median kernel 11 (the widget's maximum,
+    _volume_inference.py:388) exercises the wide recursive-median instantiation."""
+    import json
+    from empanada_napari_amd import synth, zstore
+    from empanada_napari_amd.inference import Engine3d, tracker_consensus, stack_postprocessing
+    vol = synth.blob_volume(24, 40, 32, seed=12, n_blobs=6)
+    src = zstore.open_store(str(tmp_path / 'in.zarr'), mode='w').create_array('em', shape=vol.shape, dtype=np.uint8,
+                                                                               chunks=(8, 16, 16))
+    src[...] = vol
+    zvol = zstore.open_store(str(tmp_path / 'in.zarr'), mode='r')['em']
+    kw = dict(label_divisor=DIV, median_kernel_size=11, nms_kernel=3, confidence_thr=0.5, min_size=20, min_extent=2,
+              save_panoptic=True, batch_size=6)
+    ref_eng = Engine3d(model_config, **kw)
+    url = str(tmp_path / 'out.zarr')
+    eng = Engine3d(model_config, store_url=url, chunk_size=(8, 16, 16), **kw)
+    trackers, ref_trackers = {}, {}
+    for axis_name in ('xy', 'xz', 'yz'):
+        ref_stack, ref_trackers[axis_name] = ref_eng.infer_on_axis(vol, axis_name)
+        stack, trackers[axis_name] = eng.infer_on_axis(zvol, axis_name)
+        _same_instances(trackers[axis_name][0].instances, ref_trackers[axis_name][0].instances)
+        np.testing.assert_array_equal(np.asarray(stack[...]), ref_stack)
+        assert tuple(stack.chunks) == (8, 16, 16) and stack.dtype == np.int32
+    ref = list(tracker_consensus(ref_trackers, None, model_config, label_divisor=DIV, pixel_vote_thr=2, min_size=20,
+                                 min_extent=2, dtype=np.uint32))
+    out = list(tracker_consensus(trackers, url, model_config, label_divisor=DIV, pixel_vote_thr=2, min_size=20,
+                                 min_extent=2, dtype=np.uint32, chunk_size=(8, 16, 16)))
+    np.testing.assert_array_equal(np.asarray(out[0][0][...]), ref[0][0])
+    _same_instances(out[0][2], ref[0][2])
+    # the files on disk are a zarr v2 store any reader opens
+    meta = json.load(open(tmp_path / 'out.zarr' / 'mito' / '.zarray'))
+    assert meta['zarr_format'] == 2 and meta['shape'] == list(vol.shape) and meta['compressor'] is None
+    back = zstore.open_store(url, mode='r')
+    assert set(back.array_keys()) >= {'mito', 'panoptic_xy', 'panoptic_xz', 'panoptic_yz'}
+    np.testing.assert_array_equal(back['mito'][...], ref[0][0])
+    sp = list(stack_postprocessing({'xy': trackers['xy']}, url, model_config, label_divisor=DIV, min_size=20,
+                                   min_extent=2, dtype=np.uint32, chunk_size=(8, 16, 16)))
+    sr = list(stack_postprocessing({'xy': ref_trackers['xy']}, None, model_config, label_divisor=DIV, min_size=20,
+                                   min_extent=2, dtype=np.uint32))
+    np.testing.assert_array_equal(np.asarray(sp[0][0][...]), sr[0][0])
+
+
+def test_engine2d_infer_batch_equals_per_image_calls(model_config):
+    """the pipelined batch API (uploads / downloads on side streams, fused force_connected) returns exactly what
+    Engine2d.infer returns image by image, incl. a ragged last batch, non-multiple-of-16 sizes and uint16 input"""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine2d
+    from oracle import sparse as osp
+    eng = Engine2d(model_config, label_divisor=DIV, nms_kernel=3, confidence_thr=0.5)
+    imgs = [np.ascontiguousarray(t[:150, :170]) for t in synth.em_tiles(7, 200, seed=40)]
+    want = [eng.infer(im) for im in imgs]
+    got = eng.infer_batch(imgs, batch=3)
+    assert len(got) == 7
+    for a, b in zip(got, want):
+        assert a.dtype == np.int32 and a.shape == (150, 170)
+        np.testing.assert_array_equal(a, b)
+    assert any(len(np.unique(a)) > 2 for a in got)
+    imgs16 = [im.astype(np.uint16) * 257 for im in imgs[:2]]
+    for a, im in zip(eng.infer_batch(imgs16, batch=8), imgs16):
+        np.testing.assert_array_equal(a, eng.infer(im))
+    assert eng.infer_batch([]) == []
+    # multi-class ranges: the fused force_connected against the oracle on a synthetic two-class map
+    from empanada_napari_amd import sparse as ps
+    rng = np.random.default_rng(3)
+    pan = np.zeros((2, 64, 80), np.int64)
+    m = rng.random(pan.shape)
+    pan[m > 0.55] = DIV + rng.integers(1, 4, size=int((m > 0.55).sum()))
+    pan[m < 0.2] = 2 * DIV + rng.integers(1, 3, size=int((m < 0.2).sum()))
+    pan[:, :8, :8] = 3 * DIV                                   # a stuff class stays as it is
+    out = ps.force_connected(torch.from_numpy(pan).cuda(), [1, 2], DIV).cpu().numpy()
+    for i in range(2):
+        np.testing.assert_array_equal(out[i], osp.force_connected_pan(pan[i].copy(), [1, 2], DIV).astype(np.int32))

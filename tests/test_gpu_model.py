@@ -99,7 +99,10 @@ def test_taps_match_oracle(setup):
     assert got.shape == want.shape
     assert ((got - want).abs().max() / (want.abs().mean() + 1e-6)).item() < 5e-3
     sem_c = taps['sem_coarse'].numpy()
-    print('coarse sem max err', np.abs(sem_c - sem_c).max(), 'worst rms', worst)
+    got_c = model.tap_raw('semantic_head.out', tuple(sem_c.shape)).cpu().numpy()
+    e_c = np.abs(_sig(got_c) - _sig(sem_c))
+    print('coarse sem prob max err', e_c.max(), 'worst rms', worst)
+    assert e_c.max() < 1e-2 and np.sqrt((e_c ** 2).mean()) < 1e-3
     for k in ('ctr_hmp', 'offsets'):
         d = (out[k].cpu() - ref[k]).abs().max().item()
         print(k, 'max abs err', d)

@@ -144,3 +144,26 @@ def test_median_is_exact_selection():
         ptrs = (C.c_void_p * ks)(*[a.data_ptr() for a in t])
         _abi.check(lib.emp_median_slices(ptrs, ks, _abi.ptr(out), out.numel(), _abi.stream_ptr()), 'median')
         np.testing.assert_array_equal(out.cpu().numpy(), np.sort(x, axis=0)[(ks - 1) // 2])
+
+
+@pytest.mark.parametrize('i', [0, 5, 8])
+def test_harden_and_get_panoptic_seg_api(golden_dir, i):
+    """engines.py:114-121,277-292: the two-step API (harden, then get_panoptic_seg on the class map) gives the label
+    map of postprocess()."""
+    from empanada_napari_amd.engines import PanopticDeepLabRenderEngine
+    from oracle import postprocess as opp
+    g = np.load(os.path.join(golden_dir, 'postprocess.npz'))
+    H, W, coarse, ncls, k, thr, sem, ctr, off = _case(g, i)
+    tl = [1] if ncls == 1 else [1, 2]
+    eng = PanopticDeepLabRenderEngine(_Fake({}), tl, label_divisor=1000, nms_threshold=thr, nms_kernel=k,
+                                      confidence_thr=0.5, coarse_boundaries=coarse)
+    prob = torch.from_numpy(opp.logits_to_prob(sem)).cuda()
+    hard = eng._harden_seg(prob)
+    assert hard.dtype == torch.int64 and tuple(hard.shape) == (1, 1, H, W)
+    np.testing.assert_array_equal(hard.cpu().numpy(), opp.harden_seg(opp.logits_to_prob(sem), 0.5))
+    cells = eng.get_instance_cells(torch.from_numpy(ctr).cuda(), torch.from_numpy(off).cuda(), 1)
+    a = eng.get_panoptic_seg(hard[0], cells)
+    b = eng.postprocess(prob, cells)
+    assert torch.equal(a, b) and a.dtype == torch.int64
+    want = opp.get_panoptic_seg(opp.harden_seg(opp.logits_to_prob(sem), 0.5)[0], cells.cpu().numpy(), tl, 1000, 64, 0)
+    np.testing.assert_array_equal(a.cpu().numpy(), want)

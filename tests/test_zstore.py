@@ -1,0 +1,112 @@
+"""zarr v2 directory stores without the zarr package (empanada-napari_amd/zstore.py): the on-disk layout is checked
+against the zarr v2 specification by reading the files back with numpy / json only, and the array semantics against
+numpy on random basic selections."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from empanada_napari_amd import zstore
+
+
+def test_layout_follows_the_v2_spec(tmp_path):
+    g = zstore.open_store(str(tmp_path / 'seg.zarr'), mode='w')
+    a = g.create_array('mito', shape=(5, 7, 9), dtype=np.int32, chunks=(2, 4, 9), overwrite=True)
+    ref = np.arange(5 * 7 * 9, dtype=np.int32).reshape(5, 7, 9)
+    a[...] = ref
+    root = tmp_path / 'seg.zarr'
+    assert json.load(open(root / '.zgroup')) == {'zarr_format': 2}
+    meta = json.load(open(root / 'mito' / '.zarray'))
+    assert meta['zarr_format'] == 2 and meta['shape'] == [5, 7, 9] and meta['chunks'] == [2, 4, 9]
+    assert meta['dtype'] == '<i4' and meta['compressor'] is None and meta['order'] == 'C' and meta['fill_value'] == 0
+    # chunk (i,j,k) lives in file "i.j.k", is a FULL chunk in C order, edge chunks padded with the fill value
+    files = sorted(f for f in os.listdir(root / 'mito') if not f.startswith('.'))
+    assert files == sorted(f'{i}.{j}.0' for i in range(3) for j in range(2))
+    c = np.fromfile(root / 'mito' / '2.1.0', dtype='<i4').reshape(2, 4, 9)
+    np.testing.assert_array_equal(c[:1, :3], ref[4:5, 4:7])
+    assert not c[1:].any() and not c[:, 3:].any()
+    assert a.nchunks == 6 and a.cdata_shape == (3, 2, 1)
+
+
+def test_reopen_and_basic_selections_match_numpy(tmp_path):
+    rng = np.random.default_rng(0)
+    url = str(tmp_path / 'v.zarr')
+    g = zstore.open_store(url, mode='w')
+    a = g.create_dataset('x', shape=(11, 13, 6), dtype=np.uint8, chunks=(4, 5, 6))     # zarr-python 2 spelling (multigpu.py:202)
+    ref = np.zeros((11, 13, 6), np.uint8)
+    for _ in range(40):
+        lo = [int(rng.integers(0, n)) for n in ref.shape]
+        hi = [int(rng.integers(l + 1, n + 1)) for l, n in zip(lo, ref.shape)]
+        sl = tuple(slice(l, h) for l, h in zip(lo, hi))
+        blk = rng.integers(0, 255, size=[h - l for l, h in zip(lo, hi)], dtype=np.uint8)
+        a[sl] = blk
+        ref[sl] = blk
+    a[3] = 7
+    ref[3] = 7
+    a[2:4, 5] = np.full((2, 6), 9, np.uint8)
+    ref[2:4, 5] = 9
+    b = zstore.open_store(url, mode='r')['x']
+    np.testing.assert_array_equal(b[...], ref)
+    np.testing.assert_array_equal(b[4], ref[4])
+    np.testing.assert_array_equal(b[2:9, 1:12, 3], ref[2:9, 1:12, 3])
+    np.testing.assert_array_equal(np.asarray(b), ref)
+    assert b.shape == ref.shape and b.dtype == np.uint8 and b.chunks == (4, 5, 6)
+    with pytest.raises(PermissionError):
+        b[0] = 1
+    with pytest.raises(NotImplementedError):
+        b[::2]
+    assert 'x' in zstore.open_store(url) and zstore.open_store(url).array_keys() == ['x']
+
+
+def test_untouched_chunks_read_as_fill_value_and_overwrite(tmp_path):
+    g = zstore.open_store(str(tmp_path / 's.zarr'), mode='w')
+    a = g.create_array('a', shape=(6, 6), dtype=np.int64, chunks=(3, 3))
+    a[0:3, 0:3] = 5
+    assert a[...].sum() == 45 and sorted(f for f in os.listdir(a.path) if not f.startswith('.')) == ['0.0']
+    with pytest.raises(FileExistsError):
+        g.create_array('a', shape=(2, 2), dtype=np.int64, chunks=(2, 2))
+    a2 = g.create_array('a', shape=(2, 2), dtype=np.int64, chunks=(2, 2), overwrite=True)
+    assert a2[...].sum() == 0
+    # mode='w' on an existing store wipes it; on a directory that is not a store it refuses
+    g2 = zstore.open_store(str(tmp_path / 's.zarr'), mode='w')
+    assert g2.array_keys() == []
+    os.makedirs(tmp_path / 'notastore')
+    open(tmp_path / 'notastore' / 'precious.txt', 'w').write('x')
+    with pytest.raises(FileExistsError):
+        zstore.open_store(str(tmp_path / 'notastore'), mode='w')
+
+
+def test_compressed_arrays_are_refused(tmp_path):
+    p = tmp_path / 'c.zarr' / 'a'
+    os.makedirs(p)
+    json.dump({'zarr_format': 2}, open(tmp_path / 'c.zarr' / '.zgroup', 'w'))
+    json.dump({'zarr_format': 2, 'shape': [4], 'chunks': [4], 'dtype': '<i4', 'compressor': {'id': 'blosc'},
+               'fill_value': 0, 'order': 'C', 'filters': None}, open(p / '.zarray', 'w'))
+    with pytest.raises(NotImplementedError, match='compress'):
+        zstore.open_store(str(tmp_path / 'c.zarr'), mode='r')['a']
+
+
+def test_chunk_ranges_cover_the_store_chunks(tmp_path):
+    """the reference's chunked fill splits runs at chunk faces (zarr_utils.py:20-58, pinned by its tests restated in
+    test_oracle_sparse.py); a DirArray filled run by run through those ranges equals the dense fill"""
+    from oracle import sparse as osp
+    d, h, w = 6, 8, 10
+    a = zstore.open_store(str(tmp_path / 'f.zarr'), mode='w').create_array('a', shape=(d, h, w), dtype=np.int32,
+                                                                             chunks=(4, 3, 6))
+    starts, runs = np.array([3, 75, 200, 470]), np.array([40, 20, 133, 10])
+    dense = np.zeros(d * h * w, np.int32)
+    for s, r in zip(starts, runs):
+        dense[s:s + r] = 7
+    ranges = np.stack([starts, starts + runs], axis=1)
+    for modulo, divisor in ((d * h * w, 4 * h * w), (h * w, 3 * w), (w, 6)):
+        ranges = np.array(osp.chunk_ranges(ranges, modulo, divisor))
+    flat = np.zeros(d * h * w, np.int32)
+    for s, e in ranges:
+        z0, y0, x0 = np.unravel_index(s, (d, h, w))
+        z1, y1, x1 = np.unravel_index(e - 1, (d, h, w))
+        assert (z0 // 4, y0 // 3, x0 // 6) == (z1 // 4, y1 // 3, x1 // 6), 'a chunked range stays inside one chunk'
+        flat[s:e] = 7
+    np.testing.assert_array_equal(flat, dense)
+    a[...] = flat.reshape(d, h, w)
+    np.testing.assert_array_equal(a[...].ravel(), dense)
