@@ -1,35 +1,80 @@
 #!/usr/bin/env python
-"""bench.py -- tiles/sec of the MitoNet-class 2D hot path on MI355X.
+"""bench.py -- the two halves of BASELINE.json's metric on MI355X.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus 1 --steps 10 --warmup 3                 # EM tiles/sec (headline, default workload)
+    python bench.py --gpus N ...                                    # starts its own N ranks (torchrun child) when
+                                                                    # RANK is unset; under torchrun it IS a rank
+    python bench.py --workload stack3d --gpus N ...                 # voxels/sec of the 3-D stack path, z-slabs over N GPUs
 
-One "step" = one pass of the hot path over one batch of synthetic EM tiles that
-is already resident in HBM as uint8: fused normalisation + Panoptic-DeepLab/
-PointRend forward (fp16 MFMA, fp32 accumulate) + sigmoid + centre NMS/voting +
-panoptic merge -> int64 label maps on the device (BASELINE.json configs[1]:
-1024x1024 tiles, batch 32).  Tiles are independent, so N GPUs shard tiles with
-no data-path collective ("weak" scaling: 32 tiles per GPU per step).
+workload `tiles` (BASELINE configs[1]): one "step" = one pass of the hot path over one batch of synthetic EM tiles
+already resident in HBM as uint8: fused normalisation + Panoptic-DeepLab/PointRend forward (fp16 MFMA, fp32
+accumulate) + sigmoid + centre NMS/voting + panoptic merge -> int64 label maps on the device, 32 distinct 1024x1024
+tiles per GPU.  Tiles are independent: N GPUs shard tiles with no data-path collective ("weak" scaling).  The same
+JSON line also carries the Engine2d-level rate (host uint8 tile -> int32 numpy label map incl. force_connected and
+both PCIe copies, pipelined), the batch-1 latency, and -- N = 1 only, outside the timed region -- the CPU port beside
+it and the 512^3 ortho-plane job (configs[2]).
+
+workload `stack3d` (configs[3] in small): a procedural (hash-seeded, never stored) uint8 volume of `--depth` slices
+PER GPU of `--size`^2, xy stack inference with the recursive median through MultiGPUEngine3d's slab pipeline
+(RCCL neighbour halo + filtered carry) + matching / tracking on rank 0; value = voxels/s of the whole job.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import __graft_entry__ as graft  # noqa: E402
 
-PEAK_F16_TFLOPS = 2500.0  # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F16_TFLOPS = 2500.0   # dense fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0      # HBM3E, same guide
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', choices=['tiles', 'stack3d'], default='tiles')
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--micro-batch', type=int, default=0, help='forward in chunks of this many tiles (0 = whole batch)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-tiles', type=int, default=8)
+    ap.add_argument('--stack3d', type=int, default=512, help='tiles workload: side of the 3-D cube of the second metric (0 = skip)')
+    ap.add_argument('--engine2d', type=int, default=1, help='tiles workload: also measure the Engine2d-level rate (0 = skip)')
+    ap.add_argument('--depth', type=int, default=128, help='stack3d workload: slices per GPU')
+    ap.add_argument('--ks', type=int, default=3, help='stack3d workload: median kernel size')
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: start the N ranks as a torchrun child BEFORE anything touches the GPU (this
+    process never initialises HIP; torch.cuda.device_count() does not) and relay its output and exit code."""
+    import socket
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f'bench.py: --gpus {args.gpus} requested but {have} GPU(s) visible; refusing to report a smaller job',
+              file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(cfg, P, tile_size, n_tiles, seed):
     """Oracle (CPU restatement of the reference engine) on a bounded sample of the same workload."""
+    import torch
     from empanada_napari_amd import synth
     from empanada_napari_amd.preprocess import normalize
     from oracle import pdl_model, postprocess as opp
@@ -51,60 +96,125 @@ def cpu_baseline(cfg, P, tile_size, n_tiles, seed):
                       f'({dt:.1f} s)'}
 
 
-def stack3d_line(model, size):
+def cpu_stack_baseline(cfg, P, vol, n_slices=12):
+    """The oracle's restatement of the reference's per-axis control flow (3-D engine with the recursive median, dense ->
+    RLE, matcher, tracker) on the first ``n_slices`` xy slices of the same volume."""
+    import numpy as np
+    import torch
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model, postprocess as opp, sparse as osp
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+
+    def model(x, rs, interp):
+        o = pdl_model.pdl_forward(P, torch.from_numpy(x), cfg, rs, interp)
+        return {k: v.numpy() for k, v in o.items()}
+
+    eng = opp.RenderEngine3d(model, [1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                             padding_factor=16, coarse_boundaries=True, median_kernel_size=3)
+    sub = np.ascontiguousarray(vol[:n_slices])
+    t0 = time.perf_counter()
+    pans = []
+    for z in range(sub.shape[0]):
+        r = eng(normalize(sub[z], 0.57571, 0.12765)[None, None], sub[z].shape, 1)
+        if r is not None:
+            pans.append(r[0])
+    pans += [s[0] for s in eng.end(1)]
+    m = osp.RLEMatcher(1, 10000, 0.25, 0.25)
+    stack = [osp.apply_matchers(osp.pan_seg_to_rle_seg(p, [1], 10000, [1], force_connected=True), [m]) for p in pans]
+    m.target_rle, m.assign_new = None, False
+    tr = osp.InstanceTracker(1, 10000, sub.shape, 'xy')
+    for idx in range(len(pans) - 1, -1, -1):
+        tr.update(osp.apply_matchers(stack[idx], [m])[1], idx)
+    tr.finish()
+    dt = time.perf_counter() - t0
+    return {'value': round(sub.size / dt, 1), 'unit': 'voxels/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n_slices} xy slices of the same volume, ONE axis pass (3-D engine + median + dense->RLE + matcher '
+                      f'+ tracker), fp32 ({dt:.1f} s); the three-axis job + consensus is >= 3x this work per voxel'}
+
+
+def stack_roofline(flops_fwd, voxels_per_axis, axes, ks, seconds):
+    """MFMA work of the forward + mandatory HBM traffic of the per-voxel stages, against the time of the whole job."""
+    hbm = axes * voxels_per_axis * ((ks + 1) * 4 + 12 + 8.75)     # median (ks+1)*4 B, CCL+RLE ~12 B, voting/merge 8.75 B per voxel
+    tf = flops_fwd / seconds / 1e12
+    return {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(tf / PEAK_F16_TFLOPS, 4), 'traffic': None,
+            'note': 'whole-job rate: forward FLOPs of every slice / wall time (host matching and consensus included in the time)',
+            'forward_flops': flops_fwd, 'post_hbm_bytes_algorithmic': hbm,
+            'post_hbm_gbs_if_alone': round(hbm / seconds / 1e9, 1)}
+
+
+def stack3d_line(model, size, cfg=None, P=None, with_cpu=True):
     """Second half of BASELINE's metric (configs[2]): ortho-plane 3-D inference + consensus on a synthetic size^3 uint8
-    cube, one GPU -- Engine3d.infer_on_axis x 3 + tracker_consensus as a user runs it (tools/bench_stack3d.py has the
-    stage breakdown and the CPU port beside it)."""
-    from empanada_napari_amd import synth
+    cube held in a zarr v2 directory store, one GPU -- Engine3d.infer_on_axis x 3 + tracker_consensus as a user runs it
+    (tools/bench_stack3d.py has the stage breakdown)."""
+    import tempfile
+    import numpy as np
+    import torch
+    from empanada_napari_amd import synth, zstore
     from empanada_napari_amd.inference import Engine3d, tracker_consensus
     mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
           'norms': {'mean': 0.57571, 'std': 0.12765}}
     vol = synth.blob_volume(size, size, size, seed=0, n_blobs=max(8, (size // 32) ** 2), fast=True)
+    tmp = tempfile.mkdtemp(prefix='emp_bench_')
+    src = zstore.open_store(os.path.join(tmp, 'em.zarr'), mode='w').create_array(
+        'em', shape=vol.shape, dtype=np.uint8, chunks=(min(256, size),) * 3)
+    src[...] = vol
+    zvol = zstore.open_store(os.path.join(tmp, 'em.zarr'), mode='r')['em']
     eng = Engine3d(mc, label_divisor=10000, median_kernel_size=3, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5,
                    min_size=500, min_extent=5)
-    def job():
-        trackers = {name: eng.infer_on_axis(vol, name)[1] for name in ('xy', 'xz', 'yz')}
+    flops = [0.0]
+
+    def job(count=False):
+        trackers = {}
+        v = np.asarray(zvol[...])                # the store is read ONCE per job (counted in the time)
+        for name in ('xy', 'xz', 'yz'):
+            trackers[name] = eng.infer_on_axis(v, name)[1]
+            if count:
+                flops[0] += model.last_flops() / max(1, eng.slice_batch((size, size))) * size
         return list(tracker_consensus(trackers, None, mc, label_divisor=10000, pixel_vote_thr=2, cluster_iou_thr=0.75,
                                       allow_one_view=False, min_size=500, min_extent=5, dtype=np.uint32))
 
     job()                    # one untimed pass, like the W warm-up steps of the tile metric: first launches, and the
     torch.cuda.synchronize()  # caching allocator's first hipMallocs for each axis' block sizes (~50 ms on the xz axis)
     t0 = time.perf_counter()
-    out = job()
+    out = job(count=True)
     dt = time.perf_counter() - t0
-    return {'metric': 'voxels/sec, 3-D ortho-plane stack + consensus', 'value': round(vol.size / dt, 1), 'unit': 'voxels/s',
-            'volume': [size] * 3, 'seconds': round(dt, 3), 'consensus_objects': len(out[0][2]), 'n_gpus': 1}
+    res = {'metric': 'voxels/sec, 3-D ortho-plane stack + consensus', 'value': round(vol.size / dt, 1), 'unit': 'voxels/s',
+           'volume': [size] * 3, 'source': 'zarr v2 directory store (uncompressed, 256^3 chunks), read inside the timed job',
+           'seconds': round(dt, 3), 'consensus_objects': len(out[0][2]), 'n_gpus': 1,
+           'roofline': stack_roofline(flops[0], vol.size, 3, 3, dt)}
+    if with_cpu and cfg is not None:
+        try:
+            res['cpu_baseline'] = cpu_stack_baseline(cfg, P, vol, 12)
+        except Exception as e:
+            res['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'}
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--size', type=int, default=1024)
-    ap.add_argument('--micro-batch', type=int, default=0, help='forward in chunks of this many tiles (0 = whole batch)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-tiles', type=int, default=8)
-    ap.add_argument('--stack3d', type=int, default=512, help='side of the 3-D cube of the second metric line (0 = skip)')
-    args = ap.parse_args()
+def traffic_from_profiles():
+    """HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes (tools/hbm_traffic.py): NOT measured in
+    this run -- the JSON names the file and the commit it was taken at."""
+    for name in ('r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+        p = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(p):
+            try:
+                tj = json.load(open(p))
+                k = tj['per_kernel']['conv_igemm256_kernel']
+                return ((k['fetch_corrected'] + k['write']) / k['launches_per_step'], tj['hbm_bytes_per_step'],
+                        f'profiles/{name}' + (f" @ {tj['commit']}" if 'commit' in tj else ''))
+            except Exception:
+                continue
+    return None, None, None
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    dist_on = world > 1 or os.environ.get('EMP_BENCH_FORCE_DIST') == '1'   # the env switch runs the RCCL path on one GPU
-    if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
 
-    graft.load_package()
+def run_tiles(args, rank, local_rank, world, dist_on, dev):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     from empanada_napari_amd import synth, weights
-    from empanada_napari_amd.engines import HipPanopticDeepLab, PanopticDeepLabRenderEngine
+    from empanada_napari_amd.engines import HipPanopticDeepLab, PanopticDeepLabRenderEngine, logits_to_prob
     from empanada_napari_amd.preprocess import normalize_params
 
     cfg = dict(weights.MITONET_PDL_CFG)
@@ -114,12 +224,10 @@ def main():
                                       confidence_thr=0.5, padding_factor=16, coarse_boundaries=True)
     B, S = args.batch, args.size
     mb = args.micro_batch or B
-    # synthetic tiles: a few distinct ones tiled to the batch (generation cost only), different per rank
-    base = synth.em_tiles(min(B, 4), S, seed=1234 + rank)
-    tiles = torch.from_numpy(np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B])[:, None].to(dev)
+    host_tiles = synth.em_tiles(B, S, seed=1234 + 1000 * rank)       # B DISTINCT tiles, different per rank
+    tiles = torch.from_numpy(host_tiles)[:, None].to(dev)
     sub, mul = normalize_params(0.57571, 0.12765, 255)
     model.reserve(mb, S, S)
-
     fwd_ms = []
 
     def step(timed):
@@ -133,7 +241,6 @@ def main():
             if timed:
                 e1.record()
                 fwd_ms.append((e0, e1))
-            from empanada_napari_amd.engines import logits_to_prob
             sem = logits_to_prob(o['sem_logits'])
             cells, _, _, kmax = eng.instance_cells_int(o['ctr_hmp'], o['offsets'], 1)
             outs.append(eng.panoptic_merge_int(sem, cells, kmax))
@@ -148,7 +255,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step(True)
+        step(True)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -165,57 +272,188 @@ def main():
     flops_fwd = model.last_flops() * (B / mb)  # per step (last_flops is per forward call of mb tiles)
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * args.steps / dt
+    if rank != 0:
+        return None
 
+    fwd_ms_per_step = fwd_total_ms / args.steps
+    traffic, step_traffic, traffic_src = (None, None, None)
+    if B == 32 and S == 1024 and mb == 32:
+        traffic, step_traffic, traffic_src = traffic_from_profiles()
+    fwd_tflops = flops_fwd / (fwd_ms_per_step * 1e-3) / 1e12
+    # dominant kernel: conv_igemm256_kernel, every launch of the timed region bracketed by HIP events on its stream
+    achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    res = {
+        'metric': 'EM tiles/sec (1024^2 fp16)', 'value': round(value, 2), 'unit': 'tiles/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16',
+        'data': 'synthetic',
+        'config': {'workload': f'MitoNet-class PanopticDeepLabPR/resnet50 2D inference, {S}x{S} uint8 tiles ({B} distinct per '
+                               f'GPU, resident in HBM when the timed region starts), batch {B} per GPU, forward + instance '
+                               f'post-processing to int64 label maps on the device',
+                   'tile': S, 'batch_per_gpu': B, 'micro_batch': mb, 'weights': 'seeded random init (seed 0)',
+                   'parallelism': f'tile-sharded x{world}, no data-path collective; RCCL ranks: {world if dist_on else 0}'},
+        'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(achieved / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
+                     'traffic_note': 'average HBM bytes per launch of this kernel (2*FETCH_SIZE + WRITE_SIZE, separate '
+                                     'rocprofv3 PMC passes); NOT measured in this run, taken from ' + str(traffic_src),
+                     'step_traffic_all_kernels': step_traffic,
+                     'kernel': 'conv_igemm256_kernel (256x256 implicit-GEMM tile: ASPP 3x3, layer3/4 convs)',
+                     'launches_per_step': dom_launches / max(args.steps, 1),
+                     'kernel_ms_per_step': round(dom_ms / max(args.steps, 1), 3),
+                     'kernel_share_of_step': round(dom_ms / max(args.steps, 1) / ms_per_step, 3),
+                     'kernel_flops_per_step': dom_flops / max(args.steps, 1),
+                     'forward_tflops': round(fwd_tflops, 2), 'forward_frac': round(fwd_tflops / PEAK_F16_TFLOPS, 4),
+                     'flops_per_tile': round(flops_fwd / B / 1e9, 2), 'forward_ms_per_step': round(fwd_ms_per_step, 3)},
+        'arena_gib': round(model.arena_bytes() / 2 ** 30, 2),
+    }
+    # ---- batch-1 latency (the reference API's contract, engines.py:300-325: one tile per call) ----
+    try:
+        one = tiles[:1]
+        for _ in range(3):
+            eng.call_raw(one, sub, mul)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.call_raw(one, sub, mul)
+        torch.cuda.synchronize()
+        res['latency_ms_batch1'] = round((time.perf_counter() - t0) / 20 * 1e3, 3)
+    except Exception as e:
+        res['latency_ms_batch1'] = {'error': f'{type(e).__name__}: {e}'}
+    # ---- Engine2d level: host uint8 tile -> int32 numpy label map (force_connected + both PCIe copies), pipelined ----
+    if args.engine2d and world == 1:
+        try:
+            from empanada_napari_amd.inference import Engine2d
+            mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+                  'norms': {'mean': 0.57571, 'std': 0.12765}}
+            e2 = Engine2d(mc, label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5, device=dev)
+            imgs = [host_tiles[i % B] for i in range(B * max(2, min(args.steps, 6)))]
+            e2.infer_batch(imgs[:2 * B], batch=B)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            outs = e2.infer_batch(imgs, batch=B)
+            d2 = time.perf_counter() - t0
+            res['engine2d_tiles_per_s'] = round(len(imgs) / d2, 2)
+            res['engine2d_note'] = (f'Engine2d.infer_batch over {len(imgs)} host uint8 tiles -> int32 numpy label maps: '
+                                    'H2D + forward + voting + merge + force_connected (8-connected components per class) '
+                                    '+ D2H, uploads/downloads on side streams')
+            assert outs[0].dtype == np.int32 and outs[0].shape == (S, S)
+        except Exception as e:
+            res['engine2d_tiles_per_s'] = {'error': f'{type(e).__name__}: {e}'}
+    if world == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(cfg, P, S, args.cpu_tiles, 1234)
+    else:
+        res['cpu_baseline'] = None
+    # the 3-D half of the headline metric, outside the timed region of `value` (rank 0, one GPU)
+    res['stack3d'] = None
+    if world == 1 and args.stack3d > 0:
+        try:
+            res['stack3d'] = stack3d_line(model, args.stack3d, cfg, P, with_cpu=not args.no_cpu_baseline)
+        except Exception as e:      # the headline line must not depend on the extra measurement
+            res['stack3d'] = {'error': f'{type(e).__name__}: {e}'}
+    return res
+
+
+def run_stack3d(args, rank, local_rank, world, dist_on, dev):
+    """z-slab stack inference over `world` GPUs on a procedural volume (weak scaling: --depth slices per GPU)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from empanada_napari_amd import multigpu, synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.inference import Engine3d
+
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    model = HipPanopticDeepLab(P, cfg, device=dev, folded=True)
+    mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.57571, 'std': 0.12765}}
+    S, D = args.size, args.depth * world
+    vol = synth.ProceduralVolume((D, S, S), seed=7, cell=48)
+    kw = dict(label_divisor=10000, median_kernel_size=args.ks, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5,
+              min_size=500, min_extent=5)
+    if dist_on:
+        multigpu.MultiGPUEngine3d.MIN_WORLD = 1
+        eng = multigpu.MultiGPUEngine3d(mc, **kw)
+        job = lambda: eng.infer_on_axis(vol, 'xy')
+    else:
+        e3 = Engine3d(mc, device=dev, **kw)
+        host = [None]
+
+        def job():
+            if host[0] is None:     # one GPU: the volume is synthesised once on the device and handed over as numpy
+                host[0] = vol.block(0, 0, D, dev).cpu().numpy()
+            st, tr = e3.infer_on_axis(host[0], 'xy')
+            for t in tr:
+                t.instances        # joins the deferred backward pass
+            return st, tr
+    for _ in range(max(1, min(args.warmup, 1))):
+        job()
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    t0 = time.perf_counter()
+    nobj = 0
+    for _ in range(args.steps):
+        st, tr = job()
+        if tr is not None:
+            nobj = len(tr[0].instances)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return None
+    vox = float(D) * S * S
+    sec = dt / args.steps
+    flops = model.last_flops()      # last forward call of this rank
+    return {'metric': 'voxels/sec, 3-D stack (xy) z-slab inference', 'value': round(vox / sec, 1), 'unit': 'voxels/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': 1, 'ms_per_step': round(sec * 1e3, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': f'procedural uint8 volume {D}x{S}x{S} ({args.depth} slices per GPU), xy stack inference, '
+                                   f'recursive median ks={args.ks}, z-slabs over {world} GPU(s), neighbour halo + filtered '
+                                   f'carry over RCCL, run lists to rank 0, C++ matcher + tracker',
+                       'rccl_ranks': world if dist_on else 0, 'tracked_objects': nobj,
+                       'parallelism': f'z-slab x{world}'},
+            'roofline': {'bound': 'mfma', 'achieved': None, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
+                         'traffic': None, 'note': 'see the tiles workload for the kernel roofline; this line is the job rate',
+                         'last_forward_flops_rank0': flops},
+            'cpu_baseline': None}
+
+
+def main():
+    args = parse_args()
+    if 'RANK' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    import torch
+    import __graft_entry__ as graft
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if rank == 0:
+            print(f'bench.py: --gpus {args.gpus} does not match the launcher\'s WORLD_SIZE {world}', file=sys.stderr)
+        sys.exit(2)
+    dist_on = world > 1 or os.environ.get('EMP_BENCH_FORCE_DIST') == '1'   # the env switch runs the RCCL path on one GPU
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    graft.load_package()
+    run = run_tiles if args.workload == 'tiles' else run_stack3d
+    res = run(args, rank, local_rank, world, dist_on, dev)
     if rank == 0:
-        fwd_ms_per_step = fwd_total_ms / args.steps
-        traffic = step_traffic = None
-        try:  # HBM bytes from the committed PMC passes (only valid for the default workload)
-            if B == 32 and S == 1024 and mb == 32:
-                tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))
-                step_traffic = tj['hbm_bytes_per_step']
-                k = tj['per_kernel']['conv_igemm256_kernel']
-                traffic = (k['fetch_corrected'] + k['write']) / k['launches_per_step']     # per launch, like `achieved`
-        except Exception:
-            traffic = step_traffic = None
-        fwd_tflops = flops_fwd / (fwd_ms_per_step * 1e-3) / 1e12
-        # dominant kernel: conv_igemm256_kernel, every launch of the timed region bracketed by HIP events on its stream
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        res = {
-            'metric': 'EM tiles/sec (1024^2 fp16)', 'value': round(value, 2), 'unit': 'tiles/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16',
-            'data': 'synthetic',
-            'config': {'workload': f'MitoNet-class PanopticDeepLabPR/resnet50 2D inference, {S}x{S} uint8 tiles, '
-                                   f'batch {B} per GPU, forward + instance post-processing to int64 label maps',
-                       'tile': S, 'batch_per_gpu': B, 'micro_batch': mb, 'weights': 'seeded random init (seed 0)',
-                       'parallelism': f'tile-sharded x{world}, no collective'},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
-                         'traffic_note': 'average HBM bytes per launch of this kernel (2*FETCH_SIZE + WRITE_SIZE, separate '
-                                         'rocprofv3 PMC passes, profiles/r01_hbm_traffic.json)',
-                         'step_traffic_all_kernels': step_traffic,
-                         'kernel': 'conv_igemm256_kernel (256x256 implicit-GEMM tile: ASPP 3x3, layer3/4 convs)',
-                         'launches_per_step': dom_launches / max(args.steps, 1),
-                         'kernel_ms_per_step': round(dom_ms / max(args.steps, 1), 3),
-                         'kernel_share_of_step': round(dom_ms / max(args.steps, 1) / ms_per_step, 3),
-                         'kernel_flops_per_step': dom_flops / max(args.steps, 1),
-                         'forward_tflops': round(fwd_tflops, 2), 'forward_frac': round(fwd_tflops / PEAK_F16_TFLOPS, 4),
-                         'flops_per_tile': round(flops_fwd / B / 1e9, 2), 'forward_ms_per_step': round(fwd_ms_per_step, 3)},
-            'arena_gib': round(model.arena_bytes() / 2 ** 30, 2),
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(cfg, P, S, args.cpu_tiles, 1234)
-        else:
-            res['cpu_baseline'] = None
-        # the 3-D half of the headline metric, outside the timed region of `value` (rank 0, one GPU)
-        res['stack3d'] = None
-        if world == 1 and args.stack3d > 0:
-            try:
-                res['stack3d'] = stack3d_line(model, args.stack3d)
-            except Exception as e:      # the headline line must not depend on the extra measurement
-                res['stack3d'] = {'error': f'{type(e).__name__}: {e}'}
         print(json.dumps(res), flush=True)
     if dist_on:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

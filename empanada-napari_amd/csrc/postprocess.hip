@@ -97,10 +97,12 @@ __global__ void __launch_bounds__(256) median_kernel(MedianPtrs ptrs, int ks, fl
 // a thread walks its pixel through the slices, carrying the filtered history in registers):
 //   hist: (mid, count) filtered maps preceding the run (only if n_hist == mid), raw: (n_raw, count) raw maps
 //   out[j] = median(hist/out[j-mid..j-1], raw[j..j+mid]) for j in [0, n_out); needs n_raw >= n_out + mid
+// out MAY BE raw (in place: map j is in registers before out[j] is stored, maps beyond j + mid are read later), so
+// neither pointer is __restrict__: a whole slab is filtered without a second slab-sized buffer (multigpu.py)
 template <int KS>
 __global__ void __launch_bounds__(256) median_recursive_kernel(const float* __restrict__ hist,
-                                                               const float* __restrict__ raw, int n_out,
-                                                               float* __restrict__ out, size_t count) {
+                                                               const float* raw, int n_out,
+                                                               float* out, size_t count) {
   constexpr int MID = (KS - 1) / 2;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
     float h[MID > 0 ? MID : 1];

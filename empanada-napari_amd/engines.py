@@ -188,11 +188,13 @@ class HipPanopticDeepLab:
 
 
 @torch.no_grad()
-def logits_to_prob(logits):
-    """engines.py:22-30 on the device."""
+def logits_to_prob(logits, out=None):
+    """engines.py:22-30 on the device (``out``: optional contiguous destination of the same shape)."""
     lib = _abi.load()
     logits = logits.contiguous()
-    out = torch.empty_like(logits)
+    if out is None:
+        out = torch.empty_like(logits)
+    assert out.shape == logits.shape and out.is_contiguous() and out.dtype == torch.float32
     N, Cc, H, W = logits.shape
     _abi.check(lib.emp_logits_to_prob(_abi.ptr(logits), _abi.ptr(out), N, Cc, H, W, _abi.stream_ptr(logits.device)),
                'emp_logits_to_prob')

@@ -130,3 +130,70 @@ def head_outputs(H, W, n_inst, seed=0, coarse=True, num_classes=1, plateau=False
     return (np.ascontiguousarray(sem[None].astype(np.float32)),
             np.ascontiguousarray(ctr[None, None].astype(np.float32)),
             np.ascontiguousarray(off[None].astype(np.float32)))
+
+
+class ProceduralVolume:
+    """A (D,H,W) uint8 EM-like volume that is never stored: every voxel is a pure function of (seed, z, y, x), so any
+    rank synthesises any block of it (the 4096^3 volume of BASELINE configs[3] would be
+    64 GiB).  Content: one Gaussian blob per cell of a ``cell``-sized lattice (centre, width and amplitude hashed
+    from the cell index; a voxel sums the blobs of its 27 neighbouring cells) plus hashed per-voxel noise -- the
+    reference's blob fixtures (tests/test_button_widgets.py:119-140) at any size.
+
+    ``block(axis, lo, hi, device)`` -> uint8 torch tensor (hi-lo, A, B): slices lo..hi-1 along ``axis`` in the layout
+    ``np.moveaxis(volume, axis, 0)`` gives, computed with torch on ``device`` (integer hashing is exact everywhere; the
+    float blob sum is evaluated the same way on every rank of one device type).  ``numpy()`` materialises it whole
+    (small shapes: tests)."""
+
+    def __init__(self, shape, seed=0, cell=48, dtype=np.uint8):
+        self.shape = tuple(int(s) for s in shape)
+        assert len(self.shape) == 3
+        self.seed, self.cell = int(seed), int(cell)
+        self.dtype = np.dtype(dtype)
+        self.ndim = 3
+
+    @staticmethod
+    def _mix(x):
+        """splitmix64 finaliser on int64 tensors (wrapping arithmetic)."""
+        import torch
+        x = (x ^ (x >> 30) & 0x3FFFFFFFF) * -4658895280553007687          # 0xBF58476D1CE4E5B9
+        x = (x ^ (x >> 27) & 0x1FFFFFFFFF) * -7723592293110705685         # 0x94D049BB133111EB
+        return x ^ ((x >> 31) & 0x1FFFFFFFF)
+
+    def _u01(self, key, salt):
+        """uniform [0,1) floats from int64 keys."""
+        h = self._mix(key * 6364136223846793005 + (self.seed * 1442695040888963407 + salt * 1013904223))
+        return ((h >> 11) & 0xFFFFFF).to(__import__('torch').float32) * (1.0 / 16777216.0)
+
+    def block(self, axis, lo, hi, device='cpu'):
+        import torch
+        D, H, W = self.shape
+        dev = torch.device(device)
+        rng_ax = [torch.arange(n, device=dev, dtype=torch.int64) for n in (D, H, W)]
+        rng_ax[axis] = rng_ax[axis][lo:hi]
+        z, y, x = torch.meshgrid(*rng_ax, indexing='ij')
+        c = self.cell
+        cz, cy, cx = z // c, y // c, x // c
+        val = torch.zeros(z.shape, dtype=torch.float32, device=dev)
+        zf, yf, xf = z.float(), y.float(), x.float()
+        for dz in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    kz, ky, kx = cz + dz, cy + dy, cx + dx
+                    key = (kz * 1000003 + ky) * 1000003 + kx
+                    bz = (kz.float() + self._u01(key, 1)) * c
+                    by = (ky.float() + self._u01(key, 2)) * c
+                    bx = (kx.float() + self._u01(key, 3)) * c
+                    sig = (0.18 + 0.14 * self._u01(key, 4)) * c
+                    amp = 120.0 + 135.0 * self._u01(key, 5)
+                    d2 = (zf - bz) ** 2 + (yf - by) ** 2 + (xf - bx) ** 2
+                    val += amp * torch.exp(-d2 / (2.0 * sig * sig))
+        lin = (z * H + y) * W + x
+        noise = (self._u01(lin, 7) + self._u01(lin, 8) + self._u01(lin, 9) + self._u01(lin, 10) - 2.0) * 17.3   # ~N(0, 10)
+        out = torch.clamp(val + noise, 0, 255).to(torch.uint8)
+        return out.movedim(axis, 0).contiguous()
+
+    def numpy(self):
+        return self.block(0, 0, self.shape[0], 'cpu').numpy()
+
+    def __getitem__(self, key):
+        return self.numpy()[key]

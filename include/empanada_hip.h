@@ -224,7 +224,8 @@ EMP_API int emp_median_slices(const float* const* h_slice_ptrs, int ks, float* d
 /* The same filter over a run of consecutive slices in one launch (batched 3-D path): the recursion of
  * _MedianQueue.get_next (engines.py:76-84) is per pixel, so one thread carries the filtered history.
  *   d_hist (mid,count) filtered maps preceding the run; d_raw (n_raw,count) raw maps of the run plus
- *   mid look-ahead maps; d_out (n_out,count): out[j] = median(filtered[j-mid..j-1], raw[j..j+mid]). */
+ *   mid look-ahead maps; d_out (n_out,count): out[j] = median(filtered[j-mid..j-1], raw[j..j+mid]).
+ *   ks odd, 3..15 (the widget offers up to 11, _volume_inference.py:388).  d_out may be d_raw (in place). */
 EMP_API int emp_median_recursive(const float* d_hist, const float* d_raw, int n_raw, int ks, int n_out,
                          float* d_out, size_t count, void* stream);
 

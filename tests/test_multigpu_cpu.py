@@ -84,3 +84,74 @@ def test_slab_bounds_and_single_process_filter():
     a = multigpu.filtered_stack(vals[:4], 3, med, None, vals[4:5], first=True, last=False)
     b = multigpu.filtered_stack(vals[4:], 3, med, a[-1:], None, first=False, last=True)
     assert a + b == [5, 5, 5, 5, 5, 2]
+
+
+def _oracle_tracker(pans, shape, min_size, min_extent):
+    from oracle import sparse as osp
+    m = osp.RLEMatcher(1, 1000, 0.25, 0.25)
+    stack = [osp.apply_matchers(osp.pan_seg_to_rle_seg(p, [1], 1000, [1], force_connected=True), [m]) for p in pans]
+    m.target_rle = None
+    m.assign_new = False
+    tr = osp.InstanceTracker(1, 1000, shape, 'xy')
+    for idx in range(len(pans) - 1, -1, -1):
+        tr.update(osp.apply_matchers(stack[idx], [m])[1], idx)
+    tr.finish()
+    osp.remove_small_objects(tr, min_size)
+    osp.remove_pancakes(tr, min_extent)
+    return tr
+
+
+@pytest.mark.parametrize('world,ks', [(2, 3), (3, 5)])
+def test_public_multigpu_engine_spawns_its_ranks(golden_dir, world, ks):
+    """The PUBLIC API as the widget calls it (empanada_napari/multigpu.py:121-260): construct in one process, call
+    infer_on_axis, get (stack, trackers).  The engine spawns ``world`` rank processes itself (gloo here, RCCL on GPUs),
+    each runs the slab pipeline -- halo send, filtered carry, in-place median, run lists gathered on the host group --
+    with the oracle's arithmetic plugged in, and the calling process matches + tracks in C++.  Result: the trackers the
+    single-process reference trace gives (golden median3d.npz -> oracle matcher / tracker)."""
+    import mg_oracle_backend as mgb
+    from empanada_napari_amd import multigpu
+    g = np.load(os.path.join(golden_dir, 'median3d.npz'))
+    n = g['sem_logits'].shape[0]
+    mc = {'golden': os.path.join(golden_dir, 'median3d.npz'), 'thing_list': [1], 'labels': [1],
+          'class_names': {1: 'mito'}, 'padding_factor': 16, 'norms': {'mean': 0.5, 'std': 0.1}}
+    eng = multigpu.MultiGPUEngine3d(mc, label_divisor=1000, median_kernel_size=ks, nms_kernel=3, confidence_thr=0.5,
+                                    min_size=10, min_extent=2, world_size=world, dist_backend='gloo',
+                                    backend_factory=mgb.oracle_backend_factory)
+    try:
+        vol = np.zeros((n, 64, 64), np.uint8)            # the stand-in backend reads the golden head tensors instead
+        for _ in range(2):                                # the rank processes persist across calls
+            stack, trackers = eng.infer_on_axis(vol, 'xy')
+            assert stack is None and len(trackers) == 1 and trackers[0].class_id == 1
+            want = _oracle_tracker(list(g[f'pan_ks{ks}'][:, 0].astype(np.int64)), vol.shape, 10, 2)
+            got = trackers[0].instances
+            assert len(want.instances) > 0 and [int(k) for k in got] == [int(k) for k in want.instances]
+            for k in got:
+                assert tuple(int(v) for v in got[k]['box']) == tuple(int(v) for v in want.instances[k]['box'])
+                np.testing.assert_array_equal(got[k]['starts'], want.instances[k]['starts'])
+                np.testing.assert_array_equal(got[k]['runs'], want.instances[k]['runs'])
+        assert eng.dtype == np.int32 and all(p.is_alive() for p in eng._procs)
+    finally:
+        eng.close()
+    assert eng._procs is None
+
+
+def test_public_multigpu_engine_errors():
+    from empanada_napari_amd import multigpu
+    mc = {'model': 'nowhere.pth', 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.5, 'std': 0.1}}
+    with pytest.raises(Exception, match='2 or more GPUs'):          # multigpu.py:143-144 (no GPU in this container)
+        multigpu.MultiGPUEngine3d(mc)
+    assert multigpu.active_ranks(10, 8, 5) == 5 and multigpu.active_ranks(3, 4, 1) == 3 and multigpu.active_ranks(1, 4, 7) == 1
+
+
+def test_rank_failure_is_reported(golden_dir):
+    """a rank that dies (here: the backend factory raises) surfaces as an exception in the caller, not as a hang"""
+    import mg_oracle_backend as mgb
+    from empanada_napari_amd import multigpu
+    mc = {'golden': '/nonexistent/golden.npz', 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'},
+          'padding_factor': 16, 'norms': {'mean': 0.5, 'std': 0.1}}
+    eng = multigpu.MultiGPUEngine3d(mc, median_kernel_size=3, world_size=2, dist_backend='gloo',
+                                    backend_factory=mgb.oracle_backend_factory)
+    with pytest.raises(RuntimeError, match='rank'):
+        eng.infer_on_axis(np.zeros((8, 64, 64), np.uint8), 'xy')
+    assert eng._procs is None
