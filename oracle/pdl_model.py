@@ -415,7 +415,7 @@ def teacher_forced_layers(P, cfg, x, tap):
             low = F.relu(conv(tap(pyr[stage]), f'{d}.project.{i}.0'))
             up = F.interpolate(tap(xn), size=low.shape[2:], mode='bilinear', align_corners=True)
             yield f'{d}.stage{i}.cat', torch.cat((up, low), dim=1), True
-            cat = tap(f'{d}.stage{i}.cat')
+            cat = tap(f'{d}.stage{i}.cat')[:, :up.shape[1] + low.shape[1]]     # the engine pads the concat to 64 channels
             dw = r16(conv(cat, f'{d}.fuse.{i}.0.sepconv.0', 1, 2, 1, cat.shape[1]))
             yield f'{d}.stage{i}.out', F.relu(conv(dw, f'{d}.fuse.{i}.0.sepconv.1')), True
             xn = f'{d}.stage{i}.out'
