@@ -459,7 +459,7 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   //  results but 5-15 % SLOWER than the two-stage kernel on every layer shape (e.g. 512->2048 1x1: 0.547 vs 0.502 ms,
   //  128->512: 0.316 vs 0.278) -- with two workgroups per CU the global-load latency is already covered and the
   //  second barrier per 64 channels costs more than the deeper prefetch saves)
-  int v = variant & 15, tile = (variant >> 4) & 15, kg = variant >> 8;
+  int v = variant & 15, tile = (variant >> 4) & 15, kg = (variant >> 8) & 255, mode256 = (variant >> 16) & 15;
   EMP_REQUIRE(v <= 3 && tile <= 6, "conv: bad variant %d", variant);
   if (tile == 6) return launch_conv3x3_c64(p, stream);
   {
@@ -471,7 +471,7 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   }
   if (tile == 4) {
     EMP_REQUIRE(p.out2 == nullptr, "conv: the 256x256 tile has no second destination");
-    return launch_conv_igemm256(p, stream);
+    return launch_conv_igemm256(p, stream, kg, mode256);      // here kg counts 32-channel slabs
   }
   // K walk (variant bits 8+: 0 auto | g = channel slabs per group): with many input channels and several taps a
   // tap-major walk streams the whole input once per tap through an L2 that holds only ~4 MB per XCD; groups of

@@ -52,6 +52,9 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// DMA_EARLY: how many of the 4 LDS-DMA pieces of K-tile t+3 a wave issues in its LOAD slot (before the wait), the
+// rest go out in the shadow of its MFMAs
+template <int DMA_EARLY>
 __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
 
@@ -205,8 +208,13 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
     // ---- LOAD slot: fragments of K-tile t, addresses of K-tile t+3 ----
     load_frags(t);
     stage_prep();
-    // my pieces of K-tile t+1 have landed (the 4 pieces of t+2 may be in flight; t+3 is issued in the MFMA slot)
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < DMA_EARLY; ++i) dma(i);
+    // my pieces of K-tile t+1 have landed (the 4 pieces of t+2 may be in flight, and the DMA_EARLY pieces of t+3
+    // just issued; the rest of t+3 is issued in the MFMA slot)
+    if (DMA_EARLY == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    if (DMA_EARLY == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    if (DMA_EARLY == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
     // ---- COMPUTE slot: 32 MFMAs with the 4 DMA pieces of K-tile t+3 issued in their shadow ----
@@ -215,7 +223,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
     for (int q = 0; q < 8; ++q) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[q], acc[c][q], 0, 0, 0);
-      if (q & 1) {
+      if ((q & 1) && (q >> 1) >= DMA_EARLY) {
         __builtin_amdgcn_sched_barrier(0);
         dma(q >> 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -291,26 +299,39 @@ bool conv_igemm256_supported(const ConvParams& p) {
   return p.Cout % 256 == 0 && p.ps_cout == 0 && p.Cin % KS == 0 && p.KH * p.KW * (p.Cin / KS) + (p.in2 ? p.Cin2 / KS : 0) >= 4;
 }
 
-int launch_conv_igemm256(ConvParams p, hipStream_t stream) {
+template <int DMA_EARLY>
+static int launch256(const ConvParams& p, int grid, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm256_kernel<DMA_EARLY>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_igemm256_kernel<DMA_EARLY>, dim3(grid), dim3(512), NSLOT * SLOT_BYTES, stream, p);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+// kg: channel slabs (32 ch) per K-walk group, 0 = default; mode: 0 = default, 1 / 2 = 2 / 4 DMA pieces issued early
+int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode) {
   EMP_REQUIRE(conv_igemm256_supported(p), "conv256: unsupported shape (Cout=%d)", p.Cout);
   {
     const int CB = p.Cin / KS, KT = p.KH * p.KW;
-    int kg = (KT > 1 && CB > 8 && CB % 8 == 0) ? 8 : CB;      // 256-channel groups, see conv_igemm.hip
+    static const int env_kg = [] { const char* e = getenv("EMP_CONV256_KGROUP"); return e ? atoi(e) : 0; }();   // A/B runs
+    if (kg == 0) kg = env_kg;
+    if (kg == 0) kg = 8;                                       // 256-channel groups, see conv_igemm.hip
+    if (KT == 1 || kg > CB || CB % kg != 0) kg = CB;
     p.kgroup = kg;
   }
+  static const int env_mode = [] { const char* e = getenv("EMP_CONV256_MODE"); return e ? atoi(e) : 0; }();
+  if (mode == 0) mode = env_mode;
   p.mt = cdiv(p.M, 256);
   p.nt = p.Cout / 256;
   p.mt_per_xcd = cdiv(p.mt, 8);
   const int grid = 8 * p.mt_per_xcd * p.nt;
-  static bool attr_set = false;
-  if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm256_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(conv_igemm256_kernel, dim3(grid), dim3(512), NSLOT * SLOT_BYTES, stream, p);
-  EMP_LAUNCH_CHECK();
-  return EMP_OK;
+  if (mode == 1) return launch256<2>(p, grid, stream);
+  if (mode == 2) return launch256<4>(p, grid, stream);
+  return launch256<0>(p, grid, stream);
 }
 
 }  // namespace emp

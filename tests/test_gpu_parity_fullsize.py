@@ -52,7 +52,7 @@ def case():
     from empanada_napari_amd.engines import HipPanopticDeepLab
     from empanada_napari_amd.preprocess import normalize
     from oracle import pdl_model
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))      # oneDNN convs stop scaling (and oversubscribe) beyond ~32 threads
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
     # the seeded network's centre head stays below the NMS threshold on most of a tile: lift the two head biases so

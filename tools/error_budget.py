@@ -53,7 +53,7 @@ def main():
     ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r02_error_budget.csv'))
     ap.add_argument('--sites', type=int, default=1, help='0: groups and mitigations only')
     args = ap.parse_args()
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))      # oneDNN convs stop scaling (and oversubscribe) beyond ~32 threads
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
     img = synth.em_tiles(1, args.size, seed=5)

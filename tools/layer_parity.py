@@ -22,7 +22,7 @@ from oracle import pdl_model  # noqa: E402
 
 def main():
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))      # oneDNN convs stop scaling (and oversubscribe) beyond ~32 threads
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
     model = HipPanopticDeepLab(P, cfg, folded=True)
