@@ -87,6 +87,31 @@ __global__ void __launch_bounds__(256) ccl_init_kernel(const int32_t* __restrict
     parent[i] = in[i] != 0 ? (int)(i % hw) : -1;
 }
 
+// 2-D initialisation: a pixel starts under the FIRST pixel of its horizontal run (consecutive equal labels in a row),
+// as far as the run lies inside the pixel's wave -- one ballot instead of one union per pixel.  A run that continues
+// from the previous wave is linked by ccl_merge_kernel (lane 0).  Same indexing as the merge kernel: 64 consecutive
+// image-local pixels per wave.
+__global__ void __launch_bounds__(256) ccl_init_rows_kernel(const int32_t* __restrict__ in, int* __restrict__ parent_all,
+                                                            int hw, int w) {
+  const int n = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int32_t* im = in + (size_t)n * hw;
+  const bool live = p < hw;
+  const int32_t v = live ? im[p] : 0;
+  const int x = live ? p % w : 0;
+  const bool same = v != 0 && x > 0 && im[p - 1] == v;
+  const unsigned long long starts = __ballot(!same);
+  const unsigned long long upto = starts & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  const int s = upto ? 63 - __clzll(upto) : 0;        // no start bit at or below me: the run came in from the previous wave
+  if (live) parent_all[(size_t)n * hw + p] = v != 0 ? p - (lane - s) : -1;
+}
+
+// Unions across rows, only where they are not implied (runs are already joined):
+//   up            unless the left neighbour and the up-left neighbour are equal too (the left pixel's `up` union covers it)
+//   up-left       only if `up` differs and `left` differs (else the left pixel's `up` union is this one)
+//   up-right      only if `up` differs and `right` differs (else the right pixel's `up` union is this one)
+// In the interior of a blob no pixel issues a union: the atomics are left to run ends and corners.
 __global__ void __launch_bounds__(256) ccl_merge_kernel(const int32_t* __restrict__ in, int* __restrict__ parent_all,
                                                         int h, int w) {
   const int n = blockIdx.y;
@@ -98,11 +123,18 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(const int32_t* __restric
   const int32_t v = im[p];
   if (v == 0) return;
   const int y = p / w, x = p - y * w;
-  if (x > 0 && im[p - 1] == v) uf_union(parent, p, p - 1);
+  const bool left = x > 0 && im[p - 1] == v;
+  if ((threadIdx.x & 63) == 0 && left) uf_union(parent, p, p - 1);      // run continuing across the wave boundary
   if (y > 0) {
-    if (im[p - w] == v) uf_union(parent, p, p - w);
-    if (x > 0 && im[p - w - 1] == v) uf_union(parent, p, p - w - 1);
-    if (x + 1 < w && im[p - w + 1] == v) uf_union(parent, p, p - w + 1);
+    const bool up = im[p - w] == v;
+    const bool ul = x > 0 && im[p - w - 1] == v;
+    if (up) {
+      if (!(left && ul)) uf_union(parent, p, p - w);
+    } else {
+      if (ul && !left) uf_union(parent, p, p - w - 1);
+      const bool right = x + 1 < w && im[p + 1] == v;
+      if (x + 1 < w && im[p - w + 1] == v && !right) uf_union(parent, p, p - w + 1);
+    }
   }
 }
 
@@ -425,7 +457,10 @@ static int ccl_run(const int32_t* d_in, int N, int depth, int H, int W, int32_t*
   uint32_t* blockcnt = (uint32_t*)(rank + (size_t)N * hw);
   uint32_t* blockoff = blockcnt + (size_t)N * nb;
   const int64_t total = (int64_t)N * hw;
-  hipLaunchKernelGGL(ccl_init_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_in, parent, total, hw);
+  if (depth > 0)
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_in, parent, total, hw);
+  else
+    hipLaunchKernelGGL(ccl_init_rows_kernel, dim3(cdiv(hw, 256), N), dim3(256), 0, s, d_in, parent, hw, W);
   EMP_LAUNCH_CHECK();
   if (depth > 0)
     hipLaunchKernelGGL(ccl_merge3d_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, s, d_in, parent, depth, H, W);

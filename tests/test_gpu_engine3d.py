@@ -423,3 +423,49 @@ def test_engine2d_infer_batch_equals_per_image_calls(model_config):
     out = ps.force_connected(torch.from_numpy(pan).cuda(), [1, 2], DIV).cpu().numpy()
     for i in range(2):
         np.testing.assert_array_equal(out[i], osp.force_connected_pan(pan[i].copy(), [1, 2], DIV).astype(np.int32))
+
+
+def _picklable_model_config():
+    """model_config whose 'model' is a state dict (the spawned rank processes rebuild the engine from it)"""
+    from empanada_napari_amd import weights
+    cfg = dict(weights.MITONET_PDL_CFG)
+    sd = weights.seeded_state_dict(cfg, seed=0)
+    for name, shift in (('ins_center.head.1', 0.75), ('semantic_head.head.1', 2.5), ('semantic_pr.point_head.predictor', 2.5)):
+        sd[name + '.bias'] = sd[name + '.bias'] + np.float32(shift)
+    return {'model': sd, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+            'norms': {'mean': 0.57571, 'std': 0.12765}}
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_multigpu_engine_spawns_rccl_ranks(monkeypatch, world):
+    """The public MultiGPUEngine3d API in its own launch mode (multigpu.py:214-238): the engine starts ``world`` rank
+    processes (one per GPU, RCCL process group + gloo host group), each builds its engine from the pickled
+    model_config; same trackers and panoptic stack as Engine3d in this process.  world = 2 needs two GPUs; world = 1
+    runs the same machinery (spawn, RCCL init, shared-memory volume, procedural volume, persistent ranks) on one."""
+    from empanada_napari_amd import multigpu, synth
+    from empanada_napari_amd.inference import Engine3d
+    if torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs')
+    mc = _picklable_model_config()
+    monkeypatch.setattr(multigpu.MultiGPUEngine3d, 'MIN_WORLD', 1)
+    kw = dict(label_divisor=DIV, median_kernel_size=5, nms_kernel=3, confidence_thr=0.5, min_size=20, min_extent=2)
+    pv = synth.ProceduralVolume((14, 40, 56), seed=5, cell=16)
+    vol = pv.block(0, 0, 14, 'cuda').cpu().numpy()           # the ranks synthesise their blocks on the GPU as well
+    mg = multigpu.MultiGPUEngine3d(mc, world_size=world, save_panoptic=True, **kw)
+    try:
+        e3 = Engine3d(mc, stuff_area=32, save_panoptic=True, **kw)      # the multi-GPU flavour's stuff_area (Q11)
+        for axis, v in (('xy', vol), ('xz', vol), ('xy', pv)):
+            sa, ta = mg.infer_on_axis(v, axis)
+            sb, tb = e3.infer_on_axis(vol, axis)
+            assert len(tb[0].instances) > 0
+            _same_instances(ta[0].instances, tb[0].instances)
+            np.testing.assert_array_equal(sa, sb)
+        assert all(p.is_alive() for p in mg._procs) and len(mg._procs) == world
+    finally:
+        mg.close()
+    with pytest.raises(Exception, match='inference_scale'):
+        bad = multigpu.MultiGPUEngine3d(mc, world_size=1, inference_scale=2, **kw)
+        try:
+            bad.infer_on_axis(vol, 'xy')
+        finally:
+            bad.close()
