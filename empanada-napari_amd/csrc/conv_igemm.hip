@@ -490,7 +490,7 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
     tile = (p.Cout <= 64) ? 2 : 1;
     // a single image leaves the deep layers with a handful of 128x128 tiles for 256 CUs (batch-1 latency, the
     // reference's own calling convention): 64x64 tiles walk K in the same order (bit-identical results) on 4x the CUs
-    static const int small_below = [] { const char* e = getenv("EMP_CONV_SMALL_TILES_BELOW"); return e ? atoi(e) : 0; }();
+    static const int small_below = [] { const char* e = getenv("EMP_CONV_SMALL_TILES_BELOW"); return e ? atoi(e) : 256; }();
     if (tile == 1 && (int64_t)cdiv(p.M, 128) * cdiv(p.Cout, 128) < small_below && !p.out2) tile = 3;
   }
   if (v == 0) v = 3;

@@ -227,16 +227,28 @@ class Engine2d:
         pad_to = (-(-h // pf) * pf, -(-w // pf) * pf)
         n = len(images)
         tdt = torch.uint8 if dt == np.uint8 else torch.uint16
-        result = torch.empty((n, h, w), dtype=torch.int32, pin_memory=True)
-        stage = [torch.empty((batch, 1, h, w), dtype=tdt, pin_memory=True) for _ in range(2)]
-        d_in = [torch.empty((batch, 1, h, w), dtype=tdt, device=dev) for _ in range(2)]
-        d_out = [torch.empty((batch, h, w), dtype=torch.int32, device=dev) for _ in range(2)]
+        # staging: two pinned input and two pinned output blocks + their device twins, kept on the engine (pinning
+        # hundreds of MB per call costs more than a batch's forward); results are ordinary numpy arrays filled from
+        # the pinned blocks by a copier thread (the copies release the GIL) while the GPU runs the next batch
+        key = (batch, h, w, str(dt))
+        if self.__dict__.get('_stage_key') != key:
+            self._stage_key = key
+            self._stage = dict(
+                hin=[torch.empty((batch, 1, h, w), dtype=tdt, pin_memory=True) for _ in range(2)],
+                hout=[torch.empty((batch, h, w), dtype=torch.int32, pin_memory=True) for _ in range(2)],
+                din=[torch.empty((batch, 1, h, w), dtype=tdt, device=dev) for _ in range(2)],
+                dout=[torch.empty((batch, h, w), dtype=torch.int32, device=dev) for _ in range(2)])
+        st_ = self._stage
+        stage, hout, d_in, d_out = st_['hin'], st_['hout'], st_['din'], st_['dout']
+        result = np.empty((n, h, w), dtype=np.int32)
+        copier = self._host_copier()
         main = torch.cuda.current_stream(dev)
         up, down = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         ev_in = [None, None]       # upload of the buffer finished
         ev_free = [None, None]     # forward that read the input buffer finished
         ev_done = [None, None]     # label maps of the buffer complete
         ev_back = [None, None]     # download of the output buffer finished
+        host_free = [None, None]   # copier has emptied the pinned output block
         chunks = [(i0, min(n, i0 + batch)) for i0 in range(0, n, batch)]
 
         def upload(k):
@@ -253,6 +265,10 @@ class Engine2d:
                 d_in[b][:i1 - i0].copy_(stage[b][:i1 - i0], non_blocking=True)
                 ev_in[b] = torch.cuda.Event()
                 ev_in[b].record(up)
+
+        def drain(b, i0, i1, ev):
+            ev.synchronize()
+            result[i0:i1] = hout[b][:i1 - i0].numpy()
 
         upload(0)
         for k, (i0, i1) in enumerate(chunks):
@@ -272,18 +288,24 @@ class Engine2d:
             sparse.force_connected(pan.contiguous(), list(eng.thing_list), self.label_divisor, d_out[b][:m])
             ev_done[b] = torch.cuda.Event()
             ev_done[b].record(main)
+            if host_free[b] is not None:
+                host_free[b].result()           # the copier has emptied this pinned block (two batches ago)
             with torch.cuda.stream(down):
                 down.wait_event(ev_done[b])
-                result[i0:i1].copy_(d_out[b][:m], non_blocking=True)
+                hout[b][:m].copy_(d_out[b][:m], non_blocking=True)
                 ev_back[b] = torch.cuda.Event()
                 ev_back[b].record(down)
-        for e in ev_back:
-            if e is not None:
-                e.synchronize()
-        arr = result.numpy()
-        out = [arr[i] for i in range(n)]
-        self._keepalive = result       # the views borrow the pinned block
-        return out
+            host_free[b] = copier.submit(drain, b, i0, i1, ev_back[b])
+        for f in host_free:
+            if f is not None:
+                f.result()
+        return [result[i] for i in range(n)]
+
+    def _host_copier(self):
+        c = self.__dict__.get('_copier')
+        if c is None:
+            c = self.__dict__['_copier'] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='emp-d2h')
+        return c
 
 
     def _infer_tiled(self, image):

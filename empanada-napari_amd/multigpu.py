@@ -483,30 +483,52 @@ class MultiGPUEngine3d:
         shape = tuple(int(s) for s in volume.shape)
         assert len(segs) == shape[self.axes[axis_name]]
         trackers = self.create_trackers(shape, axis_name)
+        priv = self.create_trackers(shape, axis_name)
         width = [s for i, s in enumerate(shape) if i != self.axes[axis_name]][1]
-        # forward matching (patterns.py:279-350), backward matching and tracking (multigpu.py:240-252) of the gathered
-        # run lists, per class, in C++ (sparse.StackMatcher)
-        for tr in trackers:
-            sm = sparse.StackMatcher(tr.class_id, self.label_divisor, self.merge_iou_thr, self.merge_ioa_thr,
-                                     match=tr.class_id in self.thing_list)
-            for s in segs:
-                v = s[tr.class_id]
-                if isinstance(v, tuple):
-                    sm.push_runs(v[0], width, v[1])
-                else:
-                    sm.push_objects(v)
-            sm.forward()
-            tr.instances = sm.backward_and_track(axis_name, shape)
-            tr.finished = True
-        for tr in trackers:
-            sparse.remove_small_objects(tr, min_size=self.min_size)
-            sparse.remove_pancakes(tr, min_span=self.min_extent)
+        min_size, min_extent = self.min_size, self.min_extent
         stack = self.create_panoptic_stack(axis_name, shape)
-        if stack is not None:
-            if isinstance(stack, np.ndarray):
-                sparse.fill_panoptic_volume(stack, trackers)
-            else:       # chunked store: compose every class in memory, one pass over the store's chunks
-                tmp = np.zeros(shape, dtype=self.dtype)
-                sparse.fill_panoptic_volume(tmp, trackers)
-                stack[...] = tmp
+
+        def tail():
+            # forward matching (patterns.py:279-350), backward matching and tracking (multigpu.py:240-252) of the
+            # gathered run lists, per class, in C++ (sparse.StackMatcher)
+            for tr in priv:
+                sm = sparse.StackMatcher(tr.class_id, self.label_divisor, self.merge_iou_thr, self.merge_ioa_thr,
+                                         match=tr.class_id in self.thing_list)
+                for s in segs:
+                    v = s[tr.class_id]
+                    if isinstance(v, tuple):
+                        sm.push_runs(v[0], width, v[1])
+                    else:
+                        sm.push_objects(v)
+                sm.forward()
+                tr.instances = sm.backward_and_track(axis_name, shape)
+                tr.finished = True
+            for tr in priv:
+                sparse.remove_small_objects(tr, min_size=min_size)
+                sparse.remove_pancakes(tr, min_span=min_extent)
+            for tr, pv in zip(trackers, priv):
+                tr.__dict__['_instances'] = pv.instances
+                tr.finished = True
+
+        if stack is None:
+            # host-only work: runs behind the caller (the next axis' GPU work, typically); reading ``tracker.instances``
+            # joins it, as with Engine3d.infer_on_axis
+            fut = self._host_worker().submit(tail)
+            for tr in trackers:
+                tr.__dict__['_pending'] = fut
+            return None, trackers
+        tail()
+        if isinstance(stack, np.ndarray):
+            sparse.fill_panoptic_volume(stack, trackers)
+        else:       # chunked store: compose every class in memory, one pass over the store's chunks
+            tmp = np.zeros(shape, dtype=self.dtype)
+            sparse.fill_panoptic_volume(tmp, trackers)
+            stack[...] = tmp
         return stack, trackers
+
+    def _host_worker(self):
+        w = self.__dict__.get('_worker')
+        if w is None:
+            from concurrent.futures import ThreadPoolExecutor
+            w = self.__dict__['_worker'] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='emp-mg-match')
+        return w

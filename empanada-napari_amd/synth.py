@@ -144,12 +144,21 @@ class ProceduralVolume:
     float blob sum is evaluated the same way on every rank of one device type).  ``numpy()`` materialises it whole
     (small shapes: tests)."""
 
-    def __init__(self, shape, seed=0, cell=48, dtype=np.uint8):
+    def __init__(self, shape, seed=0, cell=48, dtype=np.uint8, cache=False):
         self.shape = tuple(int(s) for s in shape)
         assert len(self.shape) == 3
         self.seed, self.cell = int(seed), int(cell)
         self.dtype = np.dtype(dtype)
         self.ndim = 3
+        # cache=True keeps every block it has synthesised (per process, on the block's device): a benchmark pays for
+        # the synthesis once, in its warm-up pass, not inside the timed region (the real volume would already exist)
+        self.cache = {} if cache else None
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        if d.get('cache') is not None:
+            d['cache'] = {}
+        return d
 
     @staticmethod
     def _mix(x):
@@ -166,8 +175,17 @@ class ProceduralVolume:
 
     def block(self, axis, lo, hi, device='cpu'):
         import torch
-        D, H, W = self.shape
         dev = torch.device(device)
+        if self.cache is None:
+            return self._block(axis, lo, hi, dev)
+        key = (axis, lo, hi, str(dev))
+        if key not in self.cache:
+            self.cache[key] = self._block(axis, lo, hi, dev)
+        return self.cache[key]
+
+    def _block(self, axis, lo, hi, dev):
+        import torch
+        D, H, W = self.shape
         rng_ax = [torch.arange(n, device=dev, dtype=torch.int64) for n in (D, H, W)]
         rng_ax[axis] = rng_ax[axis][lo:hi]
         z, y, x = torch.meshgrid(*rng_ax, indexing='ij')
