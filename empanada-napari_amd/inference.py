@@ -252,6 +252,7 @@ class Engine2d:
         chunks = [(i0, min(n, i0 + batch)) for i0 in range(0, n, batch)]
 
         def upload(k):
+            """host staging copy + H2D of batch k, on the uploader thread (numpy copies and the enqueue release the GIL)"""
             i0, i1 = chunks[k]
             b = k & 1
             if ev_in[b] is not None:
@@ -263,23 +264,26 @@ class Engine2d:
                 if ev_free[b] is not None:
                     up.wait_event(ev_free[b])
                 d_in[b][:i1 - i0].copy_(stage[b][:i1 - i0], non_blocking=True)
-                ev_in[b] = torch.cuda.Event()
-                ev_in[b].record(up)
+                e = torch.cuda.Event()
+                e.record(up)
+            ev_in[b] = e
 
         def drain(b, i0, i1, ev):
             ev.synchronize()
             result[i0:i1] = hout[b][:i1 - i0].numpy()
 
-        upload(0)
+        uploader = self._host_copier('_uploader')
+        pending_up = uploader.submit(upload, 0)
         for k, (i0, i1) in enumerate(chunks):
             b, m = k & 1, i1 - i0
-            if k + 1 < len(chunks):
-                upload(k + 1)
+            pending_up.result()
             main.wait_event(ev_in[b])
             mo = eng.model(d_in[b][:m], 2, interpolate_ins=not eng.coarse_boundaries, sub=float(sub), mul=float(mul),
                            pad_to=pad_to)
             ev_free[b] = torch.cuda.Event()
             ev_free[b].record(main)
+            if k + 1 < len(chunks):      # the other input buffer's last reader (forward k-1) is already recorded
+                pending_up = uploader.submit(upload, k + 1)
             sem = logits_to_prob(mo['sem_logits'])
             cells, _, _, kmax = eng.instance_cells_int(mo['ctr_hmp'], mo['offsets'], 1)
             pan = eng.panoptic_merge_int(sem, cells, kmax)[:, :h, :w]
@@ -301,10 +305,10 @@ class Engine2d:
                 f.result()
         return [result[i] for i in range(n)]
 
-    def _host_copier(self):
-        c = self.__dict__.get('_copier')
+    def _host_copier(self, name='_copier'):
+        c = self.__dict__.get(name)
         if c is None:
-            c = self.__dict__['_copier'] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='emp-d2h')
+            c = self.__dict__[name] = ThreadPoolExecutor(max_workers=1, thread_name_prefix='emp' + name)
         return c
 
 
