@@ -23,6 +23,17 @@
 //   90 barrier = two slots of ~680 cycles against 512 cycles of MFMA issue; the chip holds ~1.45 GHz under this
 //   load, so 1.24-1.29 PFLOP/s here is ~80 % of the clock-adjusted matrix peak (128 x 128 tile: 0.96-1.0).
 //   Ablations: no DMA 0.73 ms, no MFMA 0.75 ms, no fragment reads 0.80 ms vs 0.99 ms complete.
+//   Tried in round 2 and removed (tools/conv256_ab.py, same process, random data, bit-identical results):
+//   (a) K-walk groups of 128 / 64 channels instead of 256 (less L2 spill of the dilated taps): 0.960 -> 0.969 / 0.991 ms;
+//   (b) 2 or all 4 LDS-DMA pieces issued in the LOAD slot instead of in the MFMAs' shadow (template DMA_EARLY, kept):
+//       0.960 vs 0.965 / 0.963 ms;
+//   (c) a "pair" schedule -- a slot covers TWO K-tiles, ring of five slots (all 160 KiB), the second tile's fragments
+//       read in the shadow of the first tile's MFMAs, COMPUTE slots of 64 back-to-back MFMAs, two barriers per 64
+//       channels instead of four (238 VGPRs): 0.998 vs 1.012 ms (ASPP), 0.517 vs 0.521 (layer4 3x3), 0.282 vs 0.289
+//       (2048 -> 512 1x1).  Halving the barriers and removing the per-slot pipe bubbles buys nothing: with the effective
+//       clock at 1.35-1.7 GHz under this load (profiles/r02_conv256_pmc.txt, GRBM_GUI_ACTIVE) the kernel sits at what the
+//       chip sustains, not at an issue-slot limit -- MI355X_MICROARCH.md "DVFS give-back" (3), and the guide's own best
+//       256^2 template measures the same 1.32 PFLOP/s on random operands.
 //   * LDS rows are 64 B; 16-byte chunk c of row r is stored at chunk c ^ ((-(r >> 2)) & 3): conflict-free for the
 //     ds_read_b128 lane groups of gfx950; the swizzle is applied to the DMA source address (lane-linear dest).
 #include "common.h"
@@ -292,6 +303,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
     }
   }
 }
+
 
 }  // namespace
 

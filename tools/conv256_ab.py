@@ -38,8 +38,9 @@ def main():
         b = torch.randn((Cout,), device=dev)
         out = torch.empty((B, H, W, Cout), device=dev, dtype=torch.float16)
         flops = 2.0 * B * H * W * Cout * Cin * k_ * k_
-        kgs = [8, 4, 2] if k_ > 1 else [0]
-        VARS = [(f'kg{kg} m{m}', 3 + 16 * 4 + 256 * kg + 65536 * m) for kg in kgs for m in (0, 1, 2)]
+        kgs = [8] if k_ > 1 else [0]
+        modes = [int(m) for m in os.environ.get('MODES', '0,3').split(',')]
+        VARS = [(f'kg{kg} m{m}', 3 + 16 * 4 + 256 * kg + 65536 * m) for kg in kgs for m in modes]
         times = {k: [] for k, _ in VARS}
         ref = {}
         for rnd in range(6):
@@ -55,12 +56,12 @@ def main():
                 torch.cuda.synchronize()
                 if rnd > 0:
                     times[k].append(e0.elapsed_time(e1) / reps)
-                elif rnd == 0:
-                    kgname = k.split()[0]
-                    if kgname not in ref:
-                        ref[kgname] = out.clone()
-                    else:
-                        assert torch.equal(ref[kgname], out), f'{name} {k}: not bit-identical to mode 0'
+                kgname = k.split()[0]
+                if kgname not in ref:
+                    ref[kgname] = out.clone()
+                elif not torch.equal(ref[kgname], out):      # every round: a race shows up as a rare wrong tile
+                    bad = (ref[kgname] != out).float().mean().item()
+                    print(f'!! {name} {k} round {rnd}: differs from mode 0 in {bad:.2e} of the elements', flush=True)
         print(f'{name:24s} {flops/1e9:8.1f} GF | ' +
               ' | '.join(f'{k} {np.median(t)*1e3:6.0f}us {flops/np.median(t)/1e9:5.0f}TF' for k, t in times.items()), flush=True)
 
