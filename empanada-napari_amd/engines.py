@@ -304,40 +304,6 @@ class PanopticDeepLabRenderEngine(_Engine):
             max_c = 1 << (kmax - 1).bit_length()  # rare: more centres than the default bound, redo exactly
 
     @torch.no_grad()
-    def instance_cells_launch(self, ctr_hmp, offsets, upsampling=1):
-        """``instance_cells_int`` without the host sync: enqueues the voting with the default centre bound and an
-        asynchronous read-back of the largest centre count; ``instance_cells_finish`` returns (cells, kmax) later, so a
-        pipeline can enqueue the NEXT batch's forward before it has to wait for this one."""
-        ctr_hmp = ctr_hmp.contiguous().float()
-        offsets = offsets.contiguous().float()
-        N, _, h, w = ctr_hmp.shape
-        step = 4 if self.coarse_boundaries else 1
-        up = int(upsampling * step)
-        dev = ctr_hmp.device
-        cells = torch.empty((N, h * up, w * up), dtype=torch.int32, device=dev)
-        centers = torch.empty((N, self.MAX_CENTERS, 2), dtype=torch.int32, device=dev)
-        num = torch.empty((N,), dtype=torch.int32, device=dev)
-        work = torch.empty((int(self.lib.emp_instance_cells_work_bytes(N, h, w)),), dtype=torch.uint8, device=dev)
-        _abi.check(self.lib.emp_instance_cells(_abi.ptr(ctr_hmp), _abi.ptr(offsets), N, h, w, float(self.nms_threshold),
-                                               int(self.nms_kernel), step, up, _abi.ptr(cells), _abi.ptr(centers),
-                                               _abi.ptr(num), self.MAX_CENTERS, _abi.ptr(work), _abi.stream_ptr(dev)),
-                   'emp_instance_cells')
-        host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
-        host.copy_(num.max().reshape(1), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        return dict(cells=cells, host=host, ev=ev, args=(ctr_hmp, offsets, upsampling), keep=(centers, num, work))
-
-    @torch.no_grad()
-    def instance_cells_finish(self, h):
-        h['ev'].synchronize()
-        kmax = int(h['host'][0])
-        if kmax > self.MAX_CENTERS:      # rare: more centres than the default bound, redo exactly
-            cells, _, _, kmax = self.instance_cells_int(*h['args'])
-            return cells, kmax
-        return h['cells'], kmax
-
-    @torch.no_grad()
     def panoptic_merge_int(self, sem, cells, max_ids):
         """sem (N,C,H,W) probabilities, cells (N,H,W) int32 -> pan (N,H,W) int64."""
         sem = sem.contiguous().float()

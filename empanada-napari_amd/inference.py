@@ -272,11 +272,20 @@ class Engine2d:
             ev.synchronize()
             result[i0:i1] = hout[b][:i1 - i0].numpy()
 
-        def post(k, sem, hc):
-            """voting read-back, merge, force_connected and the download of batch k (enqueued behind forward k+1)"""
-            i0, i1 = chunks[k]
+        uploader = self._host_copier('_uploader')
+        pending_up = uploader.submit(upload, 0)
+        for k, (i0, i1) in enumerate(chunks):
             b, m = k & 1, i1 - i0
-            cells, kmax = eng.instance_cells_finish(hc)
+            pending_up.result()
+            main.wait_event(ev_in[b])
+            mo = eng.model(d_in[b][:m], 2, interpolate_ins=not eng.coarse_boundaries, sub=float(sub), mul=float(mul),
+                           pad_to=pad_to)
+            ev_free[b] = torch.cuda.Event()
+            ev_free[b].record(main)
+            if k + 1 < len(chunks):      # the other input buffer's last reader (forward k-1) is already recorded
+                pending_up = uploader.submit(upload, k + 1)
+            sem = logits_to_prob(mo['sem_logits'])
+            cells, _, _, kmax = eng.instance_cells_int(mo['ctr_hmp'], mo['offsets'], 1)
             pan = eng.panoptic_merge_int(sem, cells, kmax)[:, :h, :w]
             if ev_back[b] is not None:
                 main.wait_event(ev_back[b])
@@ -291,27 +300,6 @@ class Engine2d:
                 ev_back[b] = torch.cuda.Event()
                 ev_back[b].record(down)
             host_free[b] = copier.submit(drain, b, i0, i1, ev_back[b])
-
-        uploader = self._host_copier('_uploader')
-        pending_up = uploader.submit(upload, 0)
-        prev = None
-        for k, (i0, i1) in enumerate(chunks):
-            b, m = k & 1, i1 - i0
-            pending_up.result()
-            main.wait_event(ev_in[b])
-            mo = eng.model(d_in[b][:m], 2, interpolate_ins=not eng.coarse_boundaries, sub=float(sub), mul=float(mul),
-                           pad_to=pad_to)
-            ev_free[b] = torch.cuda.Event()
-            ev_free[b].record(main)
-            if k + 1 < len(chunks):      # the other input buffer's last reader (forward k-1) is already recorded
-                pending_up = uploader.submit(upload, k + 1)
-            sem = logits_to_prob(mo['sem_logits'])
-            hc = eng.instance_cells_launch(mo['ctr_hmp'], mo['offsets'], 1)
-            # the GPU queue now holds forward k: only then wait for batch k-1's centre count and enqueue its tail
-            if prev is not None:
-                post(*prev)
-            prev = (k, sem, hc)
-        post(*prev)
         for f in host_free:
             if f is not None:
                 f.result()
