@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument('--cpu-tiles', type=int, default=8)
     ap.add_argument('--stack3d', type=int, default=512, help='tiles workload: side of the 3-D cube of the second metric (0 = skip)')
     ap.add_argument('--engine2d', type=int, default=1, help='tiles workload: also measure the Engine2d-level rate (0 = skip)')
+    ap.add_argument('--latency', type=int, default=1, help='tiles workload: also measure the batch-1 latency (0 = skip)')
     ap.add_argument('--depth', type=int, default=128, help='stack3d workload: slices per GPU')
     ap.add_argument('--ks', type=int, default=3, help='stack3d workload: median kernel size')
     return ap.parse_args()
@@ -308,6 +309,8 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
     }
     # ---- batch-1 latency (the reference API's contract, engines.py:300-325: one tile per call) ----
     try:
+        if not args.latency:
+            raise RuntimeError('skipped (--latency 0)')
         one = tiles[:1]
         for _ in range(3):
             eng.call_raw(one, sub, mul)
