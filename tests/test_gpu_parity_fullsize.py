@@ -216,3 +216,36 @@ def test_end_to_end_label_flips_vs_fp32_pipeline(case):
     assert n_ref > 0 and n_hip > 0
     assert fg_flip < 2e-3 * pan.size, f'{fg_flip} foreground flips'
     assert abs(n_hip - n_ref) <= max(2, 0.02 * n_ref)
+
+
+@pytest.mark.parametrize('ncls', [1, 4])
+def test_bifpn_512_tile_vs_fp32_forward(ncls):
+    """PanopticBiFPNPR (MitoNet_v1_mini class; 4 outputs = BASELINE configs[4]) on one 512^2 tile against the fp32 oracle
+    forward (pinned by tests/golden/bifpn_forward.npz): the same statement as (B) for the second network family -- rms inside
+    1e-3 of the head's scale, max reported.  Its encoder and heads are the kernels that (A) checks layer by layer."""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg = dict(weights.MITONET_MINI_CFG, num_classes=ncls)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    x = torch.from_numpy(normalize(synth.em_tiles(1, 512, seed=77), 0.57571, 0.12765))[:, None]
+    out = {k: v.cpu() for k, v in model(x.cuda(), 2, False).items()}
+    taps = {}
+    ref = pdl_model.bifpn_forward(P, x, cfg, 2, False, taps)
+    rep = {}
+    for k in ('ctr_hmp', 'offsets'):
+        d = (out[k] - ref[k]).abs()
+        scale = float(ref[k].pow(2).mean().sqrt())
+        rep[k] = dict(max=float(d.max()), rms=float(d.pow(2).mean().sqrt()), scale_rms=scale)
+        assert rep[k]['rms'] < 2e-3 * max(1.0, scale), (k, rep[k])
+    if ncls == 1:
+        pe = (torch.sigmoid(out['sem_logits']) - torch.sigmoid(ref['sem_logits'])).abs()
+    else:
+        pe = (torch.softmax(out['sem_logits'], 1) - torch.softmax(ref['sem_logits'], 1)).abs()
+    rep['prob'] = dict(max=float(pe.max()), rms=float(pe.pow(2).mean().sqrt()), frac_over_1e2=float((pe > 1e-2).float().mean()))
+    print(f'BiFPN ({ncls} class) 512^2 vs fp32 oracle:', rep)
+    _report(f'bifpn_512_ncls{ncls}', rep)
+    assert rep['prob']['frac_over_1e2'] < 2e-2          # PointRend selection flips only
