@@ -71,10 +71,23 @@ struct emp_stack_matcher {
   int64_t next_label = 0;
   Slice target;
   std::vector<Slice> stack;
-  // pending step
+  // pending step: the overlap matrix is kept SPARSE (an object overlaps a handful of targets, not thousands):
+  // col_ent[c] = (target index, intersection) of every target that intersects match object c, ascending target index
   int pending = -1, nt = 0, nm = 0;
+  struct Ent { int t; int64_t inter; };
+  std::vector<std::vector<Ent>> col_ent;
+  std::vector<int64_t> ta, ma;                 // areas
+  // the part of the assignment problem that needs a solver: rows / columns (ascending original indices) of the connected
+  // components of the overlap graph that are not a single pair; `iou` is its dense block; the single pairs are applied
+  // directly (an optimal assignment contains them: every other entry of their row and column is 0)
+  std::vector<int> blk_rows, blk_cols;
+  std::vector<int64_t> pair_rows, pair_cols;
   std::vector<double> iou;
-  std::vector<float> ioa;
+  double iou_of(int r, int c) const {
+    for (const Ent& e : col_ent[(size_t)c])
+      if (e.t == r) return (double)e.inter / (double)(ta[(size_t)r] + ma[(size_t)c] - e.inter);
+    return 0.0;
+  }
   // tracker
   int axis = 0;
   int64_t D = 0, H = 0, W = 0;
@@ -187,28 +200,98 @@ int emp_sm_step_begin(emp_stack_matcher* h, int64_t idx, int* nt, int* nm) {
   *nt = h->nt;
   *nm = h->nm;
   if (h->nt == 0 || h->nm == 0) return EMP_OK;
-  h->iou.assign((size_t)h->nt * h->nm, 0.0);
-  h->ioa.assign((size_t)h->nt * h->nm, 0.f);
-  std::vector<int64_t> ta((size_t)h->nt), ma((size_t)h->nm);
-  for (int i = 0; i < h->nt; ++i) { int64_t a = 0; for (int64_t r : h->target[(size_t)i].runs) a += r; ta[(size_t)i] = a; }
-  for (int j = 0; j < h->nm; ++j) { int64_t a = 0; for (int64_t r : cur[(size_t)j].runs) a += r; ma[(size_t)j] = a; }
-  for (int i = 0; i < h->nt; ++i) {
-    const Obj& t = h->target[(size_t)i];
-    for (int j = 0; j < h->nm; ++j) {
-      const Obj& m = cur[(size_t)j];
-      // box screen (array_utils.py:148-211): non-empty intersection of the half-open boxes
-      if (std::min(t.box[2], m.box[2]) <= std::max(t.box[0], m.box[0]) ||
-          std::min(t.box[3], m.box[3]) <= std::max(t.box[1], m.box[1]))
-        continue;
-      const int64_t inter = intersection_sorted(t.starts, t.runs, m.starts, m.runs);
-      h->iou[(size_t)i * h->nm + j] = (double)inter / (double)(ta[(size_t)i] + ma[(size_t)j] - inter);
-      h->ioa[(size_t)i * h->nm + j] = (float)((double)inter / (double)ma[(size_t)j]);
+  const int nt_ = h->nt, nm_ = h->nm;
+  h->ta.assign((size_t)nt_, 0);
+  h->ma.assign((size_t)nm_, 0);
+  for (int i = 0; i < nt_; ++i) { int64_t a = 0; for (int64_t r : h->target[(size_t)i].runs) a += r; h->ta[(size_t)i] = a; }
+  for (int j = 0; j < nm_; ++j) { int64_t a = 0; for (int64_t r : cur[(size_t)j].runs) a += r; h->ma[(size_t)j] = a; }
+  // candidate pairs through a uniform grid over the target boxes (64-pixel cells) instead of all nt x nm box tests
+  constexpr int CS = 6;
+  int64_t my = 1, mx = 1;
+  for (const Obj& o : h->target) { my = std::max(my, o.box[2]); mx = std::max(mx, o.box[3]); }
+  for (const Obj& o : cur) { my = std::max(my, o.box[2]); mx = std::max(mx, o.box[3]); }
+  const int64_t gy = ((my - 1) >> CS) + 1, gx = ((mx - 1) >> CS) + 1;
+  std::vector<int> cell_off((size_t)(gy * gx) + 1, 0);
+  auto cells_of = [&](const Obj& o, int64_t& y0, int64_t& y1, int64_t& x0, int64_t& x1) {
+    y0 = std::max<int64_t>(0, o.box[0]) >> CS; x0 = std::max<int64_t>(0, o.box[1]) >> CS;
+    y1 = std::max<int64_t>(o.box[0], o.box[2] - 1) >> CS; x1 = std::max<int64_t>(o.box[1], o.box[3] - 1) >> CS;
+    y1 = std::min(y1, gy - 1); x1 = std::min(x1, gx - 1);
+  };
+  for (const Obj& o : h->target) {
+    int64_t y0, y1, x0, x1;
+    cells_of(o, y0, y1, x0, x1);
+    for (int64_t y = y0; y <= y1; ++y) for (int64_t x = x0; x <= x1; ++x) ++cell_off[(size_t)(y * gx + x) + 1];
+  }
+  for (size_t i = 1; i < cell_off.size(); ++i) cell_off[i] += cell_off[i - 1];
+  std::vector<int> cell_items((size_t)cell_off.back());
+  {
+    std::vector<int> fill(cell_off.begin(), cell_off.end() - 1);
+    for (int i = 0; i < nt_; ++i) {
+      int64_t y0, y1, x0, x1;
+      cells_of(h->target[(size_t)i], y0, y1, x0, x1);
+      for (int64_t y = y0; y <= y1; ++y) for (int64_t x = x0; x <= x1; ++x) cell_items[(size_t)fill[(size_t)(y * gx + x)]++] = i;
+    }
+  }
+  h->col_ent.assign((size_t)nm_, {});
+  std::vector<int> seen((size_t)nt_, -1);
+  std::vector<int> deg_r((size_t)nt_, 0);
+  for (int j = 0; j < nm_; ++j) {
+    const Obj& m = cur[(size_t)j];
+    int64_t y0, y1, x0, x1;
+    cells_of(m, y0, y1, x0, x1);
+    auto& ents = h->col_ent[(size_t)j];
+    for (int64_t y = y0; y <= y1; ++y)
+      for (int64_t x = x0; x <= x1; ++x)
+        for (int k = cell_off[(size_t)(y * gx + x)]; k < cell_off[(size_t)(y * gx + x) + 1]; ++k) {
+          const int i = cell_items[(size_t)k];
+          if (seen[(size_t)i] == j) continue;
+          seen[(size_t)i] = j;
+          const Obj& t = h->target[(size_t)i];
+          // box screen (array_utils.py:148-211): non-empty intersection of the half-open boxes
+          if (std::min(t.box[2], m.box[2]) <= std::max(t.box[0], m.box[0]) ||
+              std::min(t.box[3], m.box[3]) <= std::max(t.box[1], m.box[1]))
+            continue;
+          const int64_t inter = intersection_sorted(t.starts, t.runs, m.starts, m.runs);
+          if (inter > 0) ents.push_back({i, inter});
+        }
+    std::sort(ents.begin(), ents.end(), [](const emp_stack_matcher::Ent& a, const emp_stack_matcher::Ent& b) { return a.t < b.t; });
+    for (const auto& e : ents) ++deg_r[(size_t)e.t];
+  }
+  // connected components of the overlap graph: single pairs are assigned here, the rest forms the solver's block
+  h->blk_rows.clear(); h->blk_cols.clear(); h->pair_rows.clear(); h->pair_cols.clear(); h->iou.clear();
+  std::vector<int> parent((size_t)(nt_ + nm_));
+  for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int)i;
+  auto find = [&](int a) { while (parent[(size_t)a] != a) { parent[(size_t)a] = parent[(size_t)parent[(size_t)a]]; a = parent[(size_t)a]; } return a; };
+  for (int j = 0; j < nm_; ++j)
+    for (const auto& e : h->col_ent[(size_t)j]) {
+      const int a = find(e.t), b2 = find(nt_ + j);
+      if (a != b2) parent[(size_t)std::max(a, b2)] = std::min(a, b2);
+    }
+  std::vector<char> root_conflict((size_t)(nt_ + nm_), 0);
+  for (int i = 0; i < nt_; ++i) if (deg_r[(size_t)i] > 1) root_conflict[(size_t)find(i)] = 1;
+  for (int j = 0; j < nm_; ++j) if (h->col_ent[(size_t)j].size() > 1) root_conflict[(size_t)find(nt_ + j)] = 1;
+  for (int i = 0; i < nt_; ++i) if (deg_r[(size_t)i] > 0 && root_conflict[(size_t)find(i)]) h->blk_rows.push_back(i);
+  for (int j = 0; j < nm_; ++j) {
+    if (h->col_ent[(size_t)j].empty()) continue;
+    if (root_conflict[(size_t)find(nt_ + j)]) h->blk_cols.push_back(j);
+    else { h->pair_rows.push_back(h->col_ent[(size_t)j][0].t); h->pair_cols.push_back(j); }
+  }
+  if (!h->blk_rows.empty()) {
+    const size_t bt = h->blk_rows.size(), bm = h->blk_cols.size();
+    std::vector<int> row_pos((size_t)nt_, -1);
+    for (size_t i = 0; i < bt; ++i) row_pos[(size_t)h->blk_rows[i]] = (int)i;
+    h->iou.assign(bt * bm, 0.0);
+    for (size_t c = 0; c < bm; ++c) {
+      const int j = h->blk_cols[c];
+      for (const auto& e : h->col_ent[(size_t)j])
+        h->iou[(size_t)row_pos[(size_t)e.t] * bm + c] = (double)e.inter / (double)(h->ta[(size_t)e.t] + h->ma[(size_t)j] - e.inter);
     }
   }
   return EMP_OK;
 }
 
-// dense (nt x nm) float64 IoU matrix of the pending step (valid until the next step_begin)
+// dense float64 IoU matrix of the pending step's SOLVER BLOCK, emp_sm_pending_shape rows x columns (valid until the next
+// step_begin): the rows / columns of the overlap graph's components that are not single pairs, in ascending order
 const double* emp_sm_iou(const emp_stack_matcher* h) { return (h && !h->iou.empty()) ? h->iou.data() : nullptr; }
 
 // Second half: `rows` / `cols` is the assignment on the IoU matrix (all pairs; pairs below the IoU threshold are
@@ -219,12 +302,19 @@ int emp_sm_step_apply(emp_stack_matcher* h, const int64_t* rows, const int64_t* 
   const int nt = h->nt, nm = h->nm;
   const bool have = nt > 0 && nm > 0;
   std::vector<int64_t> matched_t((size_t)nm, -1);     // per match object: index of the matched target, or -1
-  if (have)
+  if (have) {
+    // `rows` / `cols` index the solver block (emp_sm_pending_shape); the single pairs found by step_begin join them
+    const int64_t bt = (int64_t)h->blk_rows.size(), bm = (int64_t)h->blk_cols.size();
     for (int64_t k = 0; k < n; ++k) {
-      const int64_t r = rows[k], c = cols[k];
-      EMP_REQUIRE(r >= 0 && r < nt && c >= 0 && c < nm, "sm_step_apply: assignment out of range");
-      if (h->iou[(size_t)r * nm + c] >= h->iou_thr) matched_t[(size_t)c] = r;
+      EMP_REQUIRE(rows[k] >= 0 && rows[k] < bt && cols[k] >= 0 && cols[k] < bm, "sm_step_apply: assignment out of range");
+      const int r = h->blk_rows[(size_t)rows[k]], c = h->blk_cols[(size_t)cols[k]];
+      if (h->iou[(size_t)rows[k] * (size_t)bm + (size_t)cols[k]] >= h->iou_thr) matched_t[(size_t)c] = r;
     }
+    for (size_t k = 0; k < h->pair_rows.size(); ++k) {
+      const int r = (int)h->pair_rows[k], c = (int)h->pair_cols[k];
+      if (h->iou_of(r, c) >= h->iou_thr) matched_t[(size_t)c] = r;
+    }
+  }
   // new label per object, groups in first-occurrence order
   std::vector<int64_t> group_label;
   std::vector<std::vector<int>> members;
@@ -234,13 +324,14 @@ int emp_sm_step_apply(emp_stack_matcher* h, const int64_t* rows, const int64_t* 
     if (matched_t[(size_t)c] >= 0) {
       nl = h->target[(size_t)matched_t[(size_t)c]].label;
     } else {
+      // argmax over the column of the float32 IoA matrix (first maximum; rows without overlap hold 0)
       float best = 0.f;
       int arg = 0;
-      if (have) {
-        best = h->ioa[(size_t)c];
-        for (int r = 1; r < nt; ++r)
-          if (h->ioa[(size_t)r * nm + c] > best) { best = h->ioa[(size_t)r * nm + c]; arg = r; }
-      }
+      if (have)
+        for (const auto& e : h->col_ent[(size_t)c]) {
+          const float v = (float)((double)e.inter / (double)h->ma[(size_t)c]);
+          if (v > best) { best = v; arg = e.t; }
+        }
       // numpy >= 2 compares the float32 matrix entry with the Python float threshold in float32 (NEP 50)
       if (have && best >= (float)h->ioa_thr) nl = h->target[(size_t)arg].label;
       else if (h->assign_new) nl = h->next_label++;
@@ -316,21 +407,9 @@ int emp_sm_run(emp_stack_matcher* h, int64_t idx, int dir, int64_t count, int tr
       if (nt == 0 || nm == 0) {
         rc = emp_sm_step_apply(h, nullptr, nullptr, 0);
       } else {
+        if (!h->blk_rows.empty()) { *stopped_at = i; return EMP_OK; }      // a real assignment problem: the caller solves it
         rows.clear();
         cols.clear();
-        std::vector<char> col_used((size_t)nm, 0);
-        bool simple = true;
-        for (int r = 0; r < nt && simple; ++r) {
-          int found = -1;
-          for (int c = 0; c < nm; ++c)
-            if (h->iou[(size_t)r * nm + c] > 0.0) {
-              if (found >= 0 || col_used[(size_t)c]) { simple = false; break; }
-              found = c;
-              col_used[(size_t)c] = 1;
-            }
-          if (found >= 0) { rows.push_back(r); cols.push_back(found); }
-        }
-        if (!simple) { *stopped_at = i; return EMP_OK; }
         rc = emp_sm_step_apply(h, rows.data(), cols.data(), (int64_t)rows.size());
       }
       if (rc) return rc;
@@ -345,8 +424,8 @@ int emp_sm_run(emp_stack_matcher* h, int64_t idx, int dir, int64_t count, int tr
 
 int emp_sm_pending_shape(const emp_stack_matcher* h, int* nt, int* nm) {
   EMP_REQUIRE(h && nt && nm && h->pending >= 0, "sm_pending_shape: no pending step");
-  *nt = h->nt;
-  *nm = h->nm;
+  *nt = (int)h->blk_rows.size();      // the solver block (0 x 0: nothing to solve, call emp_sm_step_apply with n = 0)
+  *nm = (int)h->blk_cols.size();
   return EMP_OK;
 }
 

@@ -442,20 +442,15 @@ class StackMatcher:
         _abi.check(self.lib.emp_sm_step_begin(self._h, int(idx), C.byref(nt), C.byref(nm)), 'emp_sm_step_begin')
         if nt.value < 0:
             return
-        if nt.value == 0 or nm.value == 0:
-            _abi.check(self.lib.emp_sm_step_apply(self._h, None, None, 0), 'emp_sm_step_apply')
-            return
-        ptr = self.lib.emp_sm_iou(self._h)
-        iou = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(nt.value, nm.value))
-        rows, cols = linear_sum_assignment(iou, maximize=True)
-        rows = np.ascontiguousarray(rows, dtype=i64)
-        cols = np.ascontiguousarray(cols, dtype=i64)
-        _abi.check(self.lib.emp_sm_step_apply(self._h, _hp(rows), _hp(cols), len(rows)), 'emp_sm_step_apply')
+        self._solve_pending()
 
     def _solve_pending(self):
         cnt, cnm = C.c_int(0), C.c_int(0)
         _abi.check(self.lib.emp_sm_pending_shape(self._h, C.byref(cnt), C.byref(cnm)), 'emp_sm_pending_shape')
-        nt, nm = cnt.value, cnm.value
+        nt, nm = cnt.value, cnm.value          # the solver block: components of the overlap graph that are not single pairs
+        if nt == 0 or nm == 0:
+            _abi.check(self.lib.emp_sm_step_apply(self._h, None, None, 0), 'emp_sm_step_apply')
+            return
         iou = np.ctypeslib.as_array(C.cast(self.lib.emp_sm_iou(self._h), C.POINTER(C.c_double)), shape=(nt, nm))
         rows, cols = linear_sum_assignment(iou, maximize=True)
         rows = np.ascontiguousarray(rows, dtype=i64)

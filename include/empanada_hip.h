@@ -344,17 +344,24 @@ EMP_API int emp_sm_push_slice_objects(emp_stack_matcher_t* h, int64_t n, const i
                               const int64_t* off, const int64_t* starts, const int64_t* runs);
 EMP_API int64_t emp_sm_num_slices(const emp_stack_matcher_t* h);
 EMP_API int emp_sm_begin_backward(emp_stack_matcher_t* h);
-/* nt < 0: nothing to assign (target initialised / class not matched); nt == 0 or nm == 0: call step_apply with n = 0 */
+/* First half of RLEMatcher.__call__ (matcher.py:280-326) for slice idx.  nt / nm: number of target / slice objects;
+ * nt < 0: nothing to assign (target initialised / class not matched).  The overlap matrix is held sparse (candidates by a
+ * 64-pixel grid over the boxes, exact run intersections); the connected components of its graph that are a single
+ * (target, object) pair are assigned by the library -- any optimal assignment contains them, every other entry of their
+ * row and column is 0 and zero-IoU pairs never pass the threshold (matcher.py:226-229) -- and the rest forms the SOLVER
+ * BLOCK: emp_sm_pending_shape gives its shape (0 x 0: nothing to solve), emp_sm_iou its dense float64 IoU matrix (rows /
+ * columns in ascending original order).  The caller runs scipy.optimize.linear_sum_assignment(maximize=True) on the block,
+ * as the reference does on the whole matrix (matcher.py:218), and passes the result, in BLOCK coordinates, to
+ * emp_sm_step_apply (n = 0 when the block is empty). */
 EMP_API int emp_sm_step_begin(emp_stack_matcher_t* h, int64_t idx, int* nt, int* nm);
-EMP_API const double* emp_sm_iou(const emp_stack_matcher_t* h);          /* (nt,nm) float64, valid until the next step */
+EMP_API const double* emp_sm_iou(const emp_stack_matcher_t* h);          /* solver block, valid until the next step */
 EMP_API int emp_sm_step_apply(emp_stack_matcher_t* h, const int64_t* rows, const int64_t* cols, int64_t n);
 /* Runs `count` steps from slice idx in direction dir (+1 / -1), feeding the tracker after each when `track`, and stops
- * before the first slice whose IoU matrix has a row or column with more than one non-zero entry (*stopped_at = its
- * index, step pending: solve emp_sm_iou with linear_sum_assignment, emp_sm_step_apply, emp_sm_track, resume), or runs to
- * the end (*stopped_at = -1).  Matrices without such conflicts need no solver: every non-zero pair is in any optimal
- * assignment.  Replaces the per-slice Python loop of forward_matching / backward_matching, patterns.py:68-121. */
+ * before the first slice with a non-empty solver block (*stopped_at = its index, step pending: solve emp_sm_iou with
+ * linear_sum_assignment, emp_sm_step_apply, emp_sm_track, resume), or runs to the end (*stopped_at = -1).
+ * Replaces the per-slice Python loop of forward_matching / backward_matching, patterns.py:68-121. */
 EMP_API int emp_sm_run(emp_stack_matcher_t* h, int64_t idx, int dir, int64_t count, int track, int64_t* stopped_at);
-/* shape (targets x objects) of the pending step's IoU matrix */
+/* shape of the pending step's solver block */
 EMP_API int emp_sm_pending_shape(const emp_stack_matcher_t* h, int* nt, int* nm);
 EMP_API int emp_sm_tracker_init(emp_stack_matcher_t* h, int axis /* 0 xy, 1 xz, 2 yz */, int64_t D, int64_t H, int64_t W);
 EMP_API int emp_sm_track(emp_stack_matcher_t* h, int64_t idx, int64_t index2d);
