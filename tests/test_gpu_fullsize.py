@@ -122,3 +122,72 @@ def test_bifpn_batch_of_1024_tiles_is_repeatable_and_image_independent():
         # a batch of one takes the small-problem kernels for the deepest maps (fewer tiles than workgroups): same
         # arithmetic and K order, so still identical
         assert torch.equal(one[k][0], a[k][2]), k
+
+
+def test_config2_batch_of_32_tiles_properties(engine):
+    """BASELINE configs[1] at its own batch size (32 x 1024^2): repeatable bit for bit, three scattered tiles equal the
+    reference-style single calls, ids of the class are 1..K without gaps on every tile, and the Engine2d pipeline
+    (host tiles in, int32 maps out, force_connected) agrees with per-image Engine2d.infer on them."""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine2d
+    from empanada_napari_amd.preprocess import normalize_params
+    host = synth.em_tiles(32, 1024, seed=99)
+    tiles = torch.from_numpy(host)[:, None].cuda()
+    sub, mul = normalize_params(0.57571, 0.12765, 255)
+    a = engine.infer_batch(tiles, sub=float(sub), mul=float(mul)).clone()
+    b = engine.infer_batch(tiles, sub=float(sub), mul=float(mul))
+    assert torch.equal(a, b) and a.shape == (32, 1024, 1024)
+    for i in (0, 13, 31):
+        assert torch.equal(engine.call_raw(tiles[i:i + 1], sub, mul)[0], a[i]), f'tile {i}'
+    for i in range(32):
+        ids = torch.unique(a[i])
+        ids = ids[ids > 0]
+        assert len(ids) > 0 and int(ids.min()) == DIV + 1 and int(ids.max()) == DIV + len(ids)
+    mc = {'model': engine.model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.57571, 'std': 0.12765}}
+    e2 = Engine2d(mc, label_divisor=DIV, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5)
+    outs = e2.infer_batch(list(host), batch=32)
+    for i in (0, 13, 31):
+        np.testing.assert_array_equal(outs[i], e2.infer(host[i]))
+        # force_connected only renumbers: same foreground as the engine-level map
+        np.testing.assert_array_equal(outs[i] > 0, a[i].cpu().numpy() > 0)
+
+
+def test_config3_512_cube_orthoplane_job_properties(engine, tmp_path):
+    """BASELINE configs[2] at its own size (512^3, three axes + consensus), where no oracle can follow: the job is
+    repeatable, the zarr-store route equals the numpy route, the consensus volume is exactly the fill of its instances,
+    ids are 1..n, every instance passes the size / span filters and its runs are sorted, disjoint and inside its box."""
+    from empanada_napari_amd import synth, zstore
+    from empanada_napari_amd.inference import Engine3d, tracker_consensus
+    mc = {'model': engine.model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.57571, 'std': 0.12765}}
+    vol = synth.blob_volume(512, 512, 512, seed=0, n_blobs=256, fast=True)
+    kw = dict(label_divisor=DIV, median_kernel_size=3, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5, min_size=500,
+              min_extent=5)
+    e3 = Engine3d(mc, **kw)
+
+    def job(v, url=None):
+        trs = {name: e3.infer_on_axis(v, name)[1] for name in ('xy', 'xz', 'yz')}
+        return list(tracker_consensus(trs, url, mc, label_divisor=DIV, pixel_vote_thr=2, cluster_iou_thr=0.75,
+                                      allow_one_view=False, min_size=500, min_extent=5, dtype=np.uint32,
+                                      chunk_size=(256, 256, 256)))[0]
+    cvol, name, inst = job(vol)
+    cvol2, _, inst2 = job(vol)
+    np.testing.assert_array_equal(cvol, cvol2)
+    assert list(inst) == list(inst2) == list(range(1, len(inst) + 1)) and len(inst) > 0
+    src = zstore.open_store(str(tmp_path / 'em.zarr'), mode='w').create_array('em', shape=vol.shape, dtype=np.uint8,
+                                                                               chunks=(256, 256, 256))
+    src[...] = vol
+    zvol, _, zinst = job(zstore.open_store(str(tmp_path / 'em.zarr'), mode='r')['em'], str(tmp_path / 'out.zarr'))
+    np.testing.assert_array_equal(np.asarray(zvol[...]), cvol)
+    want = np.zeros(vol.size, np.uint32)
+    for k, a in inst.items():
+        st, rn = np.asarray(a['starts']), np.asarray(a['runs'])
+        assert int(rn.sum()) >= 500 and np.all(np.diff(st) > 0) and np.all(st[1:] >= (st + rn)[:-1])
+        z, y, x = np.unravel_index(np.concatenate([st, st + rn - 1]), vol.shape)
+        box = a['box']
+        assert z.min() >= box[0] and y.min() >= box[1] and x.min() >= box[2] and z.max() < box[3] and y.max() < box[4] and x.max() < box[5]
+        assert min(box[3] - box[0], box[4] - box[1], box[5] - box[2]) >= 5
+        for s, r in zip(st, rn):
+            want[s:s + r] = k
+    np.testing.assert_array_equal(cvol.ravel(), want)
