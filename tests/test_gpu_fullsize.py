@@ -156,7 +156,7 @@ def test_config2_batch_of_32_tiles_properties(engine):
 def test_config3_512_cube_orthoplane_job_properties(engine, tmp_path):
     """BASELINE configs[2] at its own size (512^3, three axes + consensus), where no oracle can follow: the job is
     repeatable, the zarr-store route equals the numpy route, the consensus volume is exactly the fill of its instances,
-    ids are 1..n, every instance passes the size / span filters and its runs are sorted, disjoint and inside its box."""
+    ids ascend, every instance passes the size / span filters and its runs are sorted, disjoint and inside its box."""
     from empanada_napari_amd import synth, zstore
     from empanada_napari_amd.inference import Engine3d, tracker_consensus
     mc = {'model': engine.model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
@@ -174,7 +174,8 @@ def test_config3_512_cube_orthoplane_job_properties(engine, tmp_path):
     cvol, name, inst = job(vol)
     cvol2, _, inst2 = job(vol)
     np.testing.assert_array_equal(cvol, cvol2)
-    assert list(inst) == list(inst2) == list(range(1, len(inst) + 1)) and len(inst) > 0
+    # consensus ids count the clusters from 1 in component order; the size / span filters then drop some (inference.py:139-147)
+    assert list(inst) == list(inst2) and len(inst) > 0 and list(inst) == sorted(inst) and min(inst) >= 1
     src = zstore.open_store(str(tmp_path / 'em.zarr'), mode='w').create_array('em', shape=vol.shape, dtype=np.uint8,
                                                                                chunks=(256, 256, 256))
     src[...] = vol
