@@ -2,16 +2,26 @@
 // (reference: empanada/inference/matcher.py:136-326, patterns.py:55-121, tracker.py:61-123).
 //
 // The reference walks a stack of slices twice (forward, then backward with assign_new = False) and keeps every
-// slice as a Python dict of {label: {'box','starts','runs'}}; with the network at ~1 ms per slice that bookkeeping
-// was 85 % of the wall time of a 512^3 ortho-plane job.  Here a stack of one class lives in one C++ object: slices
-// arrive as the GPU run extractor's (start, length, label) triples, objects are CSR-free small vectors, and a step is
-//   emp_sm_step_begin  -> dense IoU (float64) / IoA (float32) matrices of target x match objects,
-//   [caller]           -> the assignment on the IoU matrix (scipy.optimize.linear_sum_assignment, as the reference),
-//   emp_sm_step_apply  -> label propagation, IoA merge, new labels, union of the objects that share a label.
+// slice as a Python dict of {label: {'box','starts','runs'}}; objects that end up with one label are merged
+// (merge_attrs: box union, join_ranges of the runs) and become the next target.
+//
+// Data model here (round 2): a slice is a set of COMPONENTS -- what the GPU run extractor delivers: the 8-connected
+// components of one class, or the objects handed over by emp_sm_push_slice_objects -- stored once, as CSR run lists with
+// area and box; an OBJECT is a label plus a list of member components.  Matching never touches runs twice:
+//   * the run intersections between the components of two neighbouring slices are computed ONCE (grid-screened boxes,
+//     two-pointer sweep over the sorted runs) into a sparse pair table that the forward AND the backward pass read;
+//   * an object's area is the sum of its members' areas, its overlap with another object the sum over member pairs
+//     (components of one slice are disjoint pixel sets: they come from one label map), its box the union;
+//   * a step regroups member lists; runs are merged (sorted, touching runs joined: array_utils.py:658-699) only when an
+//     object is read out -- by the tracker or by emp_sm_slice_object_runs.
+// A step is
+//   emp_sm_step_begin  -> sparse IoU (float64) / IoA (float32) of target x match objects; single-pair components of the
+//                         overlap graph are assigned here, the rest is the dense SOLVER BLOCK,
+//   [caller]           -> scipy.optimize.linear_sum_assignment on that block (the reference solves the whole matrix,
+//                         matcher.py:218; zero entries never pass the threshold :226-229),
+//   emp_sm_step_apply  -> label propagation, IoA merge, new labels, regrouping in first-occurrence order.
 // Exactness notes: IoU = inter / (a + b - inter) in float64, IoA = float32(inter / area_match) as numpy stores it;
-// objects are visited in dict order (ascending component label after extraction, first-occurrence order after a
-// step); an object that keeps a label alone keeps its run list untouched, objects that share one are joined with the
-// reference's join_ranges rule (ranges that touch are merged).
+// objects are visited in dict order (ascending component label after extraction, first-occurrence order after a step).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -22,12 +32,24 @@
 
 namespace {
 
-struct Obj {
+struct Pair { int a; int64_t inter; };        // overlap of a component with component `a` of the neighbouring slice
+
+struct FObj {
   int64_t label;
   int64_t box[4];
-  std::vector<int64_t> starts, runs;
+  std::vector<int> members;                    // component indices of this slice
 };
-using Slice = std::vector<Obj>;
+
+struct FSlice {
+  int K = 0;                                   // components 0..K-1
+  std::vector<int64_t> area, box;              // (K), (4K)
+  std::vector<int64_t> run_off, starts, lens;  // CSR by component, runs ascending by start
+  std::vector<FObj> objs;                      // current objects, in dict order
+  // overlaps with the PREVIOUS pushed slice: by own component (fwd) and by the previous slice's component (rev)
+  bool pairs_ready = false;
+  std::vector<int64_t> fwd_off, rev_off;
+  std::vector<Pair> fwd, rev;
+};
 
 struct Track {
   int64_t label;
@@ -36,11 +58,10 @@ struct Track {
   std::vector<int64_t> yz;   // yz stacks before finish(): (start in the (D,H) plane, length, x) triples
 };
 
-int64_t intersection_sorted(const std::vector<int64_t>& s1, const std::vector<int64_t>& r1,
-                            const std::vector<int64_t>& s2, const std::vector<int64_t>& r2) {
+int64_t intersection_sorted(const int64_t* s1, const int64_t* r1, size_t n1, const int64_t* s2, const int64_t* r2, size_t n2) {
   size_t i = 0, j = 0;
   int64_t acc = 0;
-  while (i < s1.size() && j < s2.size()) {
+  while (i < n1 && j < n2) {
     const int64_t a0 = s1[i], a1 = a0 + r1[i], b0 = s2[j], b1 = b0 + r2[j];
     const int64_t lo = a0 > b0 ? a0 : b0, hi = a1 < b1 ? a1 : b1;
     if (hi > lo) acc += hi - lo;
@@ -49,17 +70,116 @@ int64_t intersection_sorted(const std::vector<int64_t>& s1, const std::vector<in
   return acc;
 }
 
-void sort_runs(Obj& o) {   // runs of a merged object are produced sorted; extraction output is sorted by construction
-  bool sorted = true;
-  for (size_t i = 1; i < o.starts.size(); ++i) if (o.starts[i] < o.starts[i - 1]) { sorted = false; break; }
-  if (sorted) return;
-  std::vector<size_t> idx(o.starts.size());
-  for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
-  std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return o.starts[a] < o.starts[b]; });
-  std::vector<int64_t> s(idx.size()), r(idx.size());
-  for (size_t i = 0; i < idx.size(); ++i) { s[i] = o.starts[idx[i]]; r[i] = o.runs[idx[i]]; }
-  o.starts.swap(s);
-  o.runs.swap(r);
+// component runs of a freshly built slice: sorted by start (extraction output is; pushed objects may not be)
+void sort_component_runs(FSlice& sl) {
+  for (int c = 0; c < sl.K; ++c) {
+    const int64_t o0 = sl.run_off[(size_t)c], o1 = sl.run_off[(size_t)c + 1];
+    bool sorted = true;
+    for (int64_t i = o0 + 1; i < o1; ++i) if (sl.starts[(size_t)i] < sl.starts[(size_t)i - 1]) { sorted = false; break; }
+    if (sorted) continue;
+    std::vector<int64_t> idx((size_t)(o1 - o0));
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = o0 + (int64_t)i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return sl.starts[(size_t)a] < sl.starts[(size_t)b]; });
+    std::vector<int64_t> s(idx.size()), r(idx.size());
+    for (size_t i = 0; i < idx.size(); ++i) { s[i] = sl.starts[(size_t)idx[i]]; r[i] = sl.lens[(size_t)idx[i]]; }
+    std::copy(s.begin(), s.end(), sl.starts.begin() + o0);
+    std::copy(r.begin(), r.end(), sl.lens.begin() + o0);
+  }
+}
+
+// runs of an object: a single member's list as it is, several members' lists sorted and joined where they touch
+void object_runs(const FSlice& sl, const FObj& o, std::vector<int64_t>& st, std::vector<int64_t>& rn) {
+  st.clear();
+  rn.clear();
+  if (o.members.size() == 1) {
+    const int c = o.members[0];
+    st.assign(sl.starts.begin() + sl.run_off[(size_t)c], sl.starts.begin() + sl.run_off[(size_t)c + 1]);
+    rn.assign(sl.lens.begin() + sl.run_off[(size_t)c], sl.lens.begin() + sl.run_off[(size_t)c + 1]);
+    return;
+  }
+  std::vector<std::pair<int64_t, int64_t>> rg;
+  for (int c : o.members)
+    for (int64_t i = sl.run_off[(size_t)c]; i < sl.run_off[(size_t)c + 1]; ++i)
+      rg.emplace_back(sl.starts[(size_t)i], sl.starts[(size_t)i] + sl.lens[(size_t)i]);
+  std::stable_sort(rg.begin(), rg.end(), [](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) {
+    return a.first < b.first;
+  });
+  for (const auto& r : rg) {
+    if (!st.empty() && st.back() + rn.back() >= r.first) {
+      const int64_t end = std::max(st.back() + rn.back(), r.second);
+      rn.back() = end - st.back();
+    } else {
+      st.push_back(r.first);
+      rn.push_back(r.second - r.first);
+    }
+  }
+}
+
+// sparse overlap table between the components of `prev` and `cur` (both directions)
+void build_pairs(const FSlice& prev, FSlice& cur) {
+  constexpr int CS = 6;                        // 64-pixel grid cells over the boxes
+  int64_t my = 1, mx = 1;
+  for (int c = 0; c < prev.K; ++c) { my = std::max(my, prev.box[4 * (size_t)c + 2]); mx = std::max(mx, prev.box[4 * (size_t)c + 3]); }
+  for (int c = 0; c < cur.K; ++c) { my = std::max(my, cur.box[4 * (size_t)c + 2]); mx = std::max(mx, cur.box[4 * (size_t)c + 3]); }
+  const int64_t gy = ((my - 1) >> CS) + 1, gx = ((mx - 1) >> CS) + 1;
+  auto cells_of = [&](const int64_t* b, int64_t& y0, int64_t& y1, int64_t& x0, int64_t& x1) {
+    y0 = std::max<int64_t>(0, b[0]) >> CS; x0 = std::max<int64_t>(0, b[1]) >> CS;
+    y1 = std::min(std::max<int64_t>(b[0], b[2] - 1) >> CS, gy - 1);
+    x1 = std::min(std::max<int64_t>(b[1], b[3] - 1) >> CS, gx - 1);
+  };
+  std::vector<int> cell_off((size_t)(gy * gx) + 1, 0);
+  for (int c = 0; c < prev.K; ++c) {
+    int64_t y0, y1, x0, x1;
+    cells_of(&prev.box[4 * (size_t)c], y0, y1, x0, x1);
+    for (int64_t y = y0; y <= y1; ++y) for (int64_t x = x0; x <= x1; ++x) ++cell_off[(size_t)(y * gx + x) + 1];
+  }
+  for (size_t i = 1; i < cell_off.size(); ++i) cell_off[i] += cell_off[i - 1];
+  std::vector<int> items((size_t)cell_off.back());
+  {
+    std::vector<int> fill(cell_off.begin(), cell_off.end() - 1);
+    for (int c = 0; c < prev.K; ++c) {
+      int64_t y0, y1, x0, x1;
+      cells_of(&prev.box[4 * (size_t)c], y0, y1, x0, x1);
+      for (int64_t y = y0; y <= y1; ++y) for (int64_t x = x0; x <= x1; ++x) items[(size_t)fill[(size_t)(y * gx + x)]++] = c;
+    }
+  }
+  cur.fwd_off.assign((size_t)cur.K + 1, 0);
+  cur.fwd.clear();
+  std::vector<int> seen((size_t)prev.K, -1);
+  std::vector<int64_t> rev_cnt((size_t)prev.K + 1, 0);
+  std::vector<Pair> tmp;
+  for (int b = 0; b < cur.K; ++b) {
+    const int64_t* bb = &cur.box[4 * (size_t)b];
+    int64_t y0, y1, x0, x1;
+    cells_of(bb, y0, y1, x0, x1);
+    tmp.clear();
+    const int64_t bo = cur.run_off[(size_t)b], bn = cur.run_off[(size_t)b + 1] - bo;
+    for (int64_t y = y0; y <= y1; ++y)
+      for (int64_t x = x0; x <= x1; ++x)
+        for (int k = cell_off[(size_t)(y * gx + x)]; k < cell_off[(size_t)(y * gx + x) + 1]; ++k) {
+          const int a = items[(size_t)k];
+          if (seen[(size_t)a] == b) continue;
+          seen[(size_t)a] = b;
+          const int64_t* ab = &prev.box[4 * (size_t)a];
+          // box screen (array_utils.py:148-211): non-empty intersection of the half-open boxes
+          if (std::min(ab[2], bb[2]) <= std::max(ab[0], bb[0]) || std::min(ab[3], bb[3]) <= std::max(ab[1], bb[1])) continue;
+          const int64_t ao = prev.run_off[(size_t)a], an = prev.run_off[(size_t)a + 1] - ao;
+          const int64_t inter = intersection_sorted(&prev.starts[(size_t)ao], &prev.lens[(size_t)ao], (size_t)an,
+                                                    &cur.starts[(size_t)bo], &cur.lens[(size_t)bo], (size_t)bn);
+          if (inter > 0) tmp.push_back({a, inter});
+        }
+    std::sort(tmp.begin(), tmp.end(), [](const Pair& p, const Pair& q) { return p.a < q.a; });
+    for (const Pair& pr : tmp) { cur.fwd.push_back(pr); ++rev_cnt[(size_t)pr.a + 1]; }
+    cur.fwd_off[(size_t)b + 1] = (int64_t)cur.fwd.size();
+  }
+  cur.rev_off.assign((size_t)prev.K + 1, 0);
+  for (int a = 0; a < prev.K; ++a) cur.rev_off[(size_t)a + 1] = cur.rev_off[(size_t)a] + rev_cnt[(size_t)a + 1];
+  cur.rev.assign(cur.fwd.size(), Pair{0, 0});
+  std::vector<int64_t> fill(cur.rev_off.begin(), cur.rev_off.end() - 1);
+  for (int b = 0; b < cur.K; ++b)           // ascending b: every rev list comes out sorted by b
+    for (int64_t k = cur.fwd_off[(size_t)b]; k < cur.fwd_off[(size_t)b + 1]; ++k)
+      cur.rev[(size_t)fill[(size_t)cur.fwd[(size_t)k].a]++] = Pair{b, cur.fwd[(size_t)k].inter};
+  cur.pairs_ready = true;
 }
 
 }  // namespace
@@ -67,10 +187,10 @@ void sort_runs(Obj& o) {   // runs of a merged object are produced sorted; extra
 struct emp_stack_matcher {
   int64_t class_id, divisor;
   double iou_thr, ioa_thr;
-  bool do_match = true, assign_new = true, has_target = false;
+  bool do_match = true, assign_new = true;
   int64_t next_label = 0;
-  Slice target;
-  std::vector<Slice> stack;
+  int target_idx = -1;                         // slice whose objects are the current target (update_target)
+  std::vector<FSlice> stack;
   // pending step: the overlap matrix is kept SPARSE (an object overlaps a handful of targets, not thousands):
   // col_ent[c] = (target index, intersection) of every target that intersects match object c, ascending target index
   int pending = -1, nt = 0, nm = 0;
@@ -88,6 +208,8 @@ struct emp_stack_matcher {
       if (e.t == r) return (double)e.inter / (double)(ta[(size_t)r] + ma[(size_t)c] - e.inter);
     return 0.0;
   }
+  // scratch pair table for a target that is not the neighbouring slice (never on the pipeline's path)
+  FSlice scratch;
   // tracker
   int axis = 0;
   int64_t D = 0, H = 0, W = 0;
@@ -97,6 +219,28 @@ struct emp_stack_matcher {
 };
 
 using namespace emp;
+
+namespace {
+
+void finish_slice(emp_stack_matcher* h, FSlice& sl, const std::vector<int64_t>& labels) {
+  sort_component_runs(sl);
+  sl.area.assign((size_t)sl.K, 0);
+  for (int c = 0; c < sl.K; ++c) {
+    int64_t a = 0;
+    for (int64_t i = sl.run_off[(size_t)c]; i < sl.run_off[(size_t)c + 1]; ++i) a += sl.lens[(size_t)i];
+    sl.area[(size_t)c] = a;
+  }
+  sl.objs.resize((size_t)sl.K);
+  for (int c = 0; c < sl.K; ++c) {
+    FObj& o = sl.objs[(size_t)c];
+    o.label = labels[(size_t)c];
+    std::memcpy(o.box, &sl.box[4 * (size_t)c], sizeof(o.box));
+    o.members.assign(1, c);
+  }
+  (void)h;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -114,50 +258,83 @@ emp_stack_matcher* emp_sm_create(int64_t class_id, int64_t label_divisor, double
 void emp_sm_destroy(emp_stack_matcher* h) { delete h; }
 
 // Append a slice from the run extractor: `runs` is (n,3) {start, length, label} in raster order, labels > 0; the slice
-// plane is `width` pixels wide.  Objects are created in ascending label order (regionprops order) with half-open boxes,
-// exactly like rle.pan_seg_to_rle_seg; `id_offset` is added to every label (component index -> class id range).
+// plane is `width` pixels wide.  Components are created in ascending label order (regionprops order) with half-open
+// boxes, exactly like rle.pan_seg_to_rle_seg; `id_offset` is added to every label (component index -> class id range).
 int emp_sm_push_slice_runs(emp_stack_matcher* h, const int64_t* runs, int64_t n, int64_t width, int64_t id_offset) {
   EMP_REQUIRE(h && (runs || n == 0) && n >= 0 && width > 0, "sm_push_slice_runs: bad arguments");
-  std::vector<int64_t> order((size_t)n);
-  for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return runs[3 * a + 2] < runs[3 * b + 2]; });
-  Slice sl;
-  for (int64_t k = 0; k < n; ++k) {
-    const int64_t* r = runs + 3 * order[(size_t)k];
-    const int64_t s = r[0], ln = r[1], lab = r[2] + id_offset;
+  h->stack.emplace_back();
+  FSlice& sl = h->stack.back();
+  // distinct labels, ascending: a counting pass when they are dense (component ids 1..K), a sort otherwise
+  int64_t maxlab = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    EMP_REQUIRE(runs[3 * i + 2] > 0, "sm_push_slice_runs: labels must be positive");
+    maxlab = std::max(maxlab, runs[3 * i + 2]);
+  }
+  std::vector<int64_t> labels;
+  std::vector<int> comp_of_run((size_t)n);
+  if (maxlab <= 4 * n + 1024) {
+    std::vector<int> idx((size_t)maxlab + 1, 0);
+    for (int64_t i = 0; i < n; ++i) idx[(size_t)runs[3 * i + 2]] = 1;
+    int k = 0;
+    for (int64_t v = 1; v <= maxlab; ++v)
+      if (idx[(size_t)v]) { idx[(size_t)v] = k++; labels.push_back(v + id_offset); }
+    for (int64_t i = 0; i < n; ++i) comp_of_run[(size_t)i] = idx[(size_t)runs[3 * i + 2]];
+  } else {
+    std::vector<int64_t> u((size_t)n);
+    for (int64_t i = 0; i < n; ++i) u[(size_t)i] = runs[3 * i + 2];
+    std::sort(u.begin(), u.end());
+    u.erase(std::unique(u.begin(), u.end()), u.end());
+    for (int64_t v : u) labels.push_back(v + id_offset);
+    for (int64_t i = 0; i < n; ++i)
+      comp_of_run[(size_t)i] = (int)(std::lower_bound(u.begin(), u.end(), runs[3 * i + 2]) - u.begin());
+  }
+  const int K = (int)labels.size();
+  sl.K = K;
+  sl.run_off.assign((size_t)K + 1, 0);
+  for (int64_t i = 0; i < n; ++i) ++sl.run_off[(size_t)comp_of_run[(size_t)i] + 1];
+  for (int c = 0; c < K; ++c) sl.run_off[(size_t)c + 1] += sl.run_off[(size_t)c];
+  sl.starts.resize((size_t)n);
+  sl.lens.resize((size_t)n);
+  sl.box.resize(4 * (size_t)K);
+  for (int c = 0; c < K; ++c) {
+    sl.box[4 * (size_t)c] = sl.box[4 * (size_t)c + 1] = INT64_MAX;
+    sl.box[4 * (size_t)c + 2] = sl.box[4 * (size_t)c + 3] = INT64_MIN;
+  }
+  std::vector<int64_t> fill(sl.run_off.begin(), sl.run_off.end() - 1);
+  for (int64_t i = 0; i < n; ++i) {          // raster order in, so every component's runs come out ascending
+    const int c = comp_of_run[(size_t)i];
+    const int64_t s = runs[3 * i], ln = runs[3 * i + 1];
     const int64_t e = s + ln - 1;
     const int64_t y0 = s / width, y1 = e / width;
     const int64_t x0 = y0 == y1 ? s % width : 0, x1 = y0 == y1 ? e % width : width - 1;
-    if (sl.empty() || sl.back().label != lab) {
-      Obj o;
-      o.label = lab;
-      o.box[0] = y0; o.box[1] = x0; o.box[2] = y1 + 1; o.box[3] = x1 + 1;
-      sl.push_back(std::move(o));
-    } else {
-      Obj& o = sl.back();
-      o.box[0] = std::min(o.box[0], y0); o.box[1] = std::min(o.box[1], x0);
-      o.box[2] = std::max(o.box[2], y1 + 1); o.box[3] = std::max(o.box[3], x1 + 1);
-    }
-    sl.back().starts.push_back(s);
-    sl.back().runs.push_back(ln);
+    int64_t* b = &sl.box[4 * (size_t)c];
+    b[0] = std::min(b[0], y0); b[1] = std::min(b[1], x0);
+    b[2] = std::max(b[2], y1 + 1); b[3] = std::max(b[3], x1 + 1);
+    const int64_t pos = fill[(size_t)c]++;
+    sl.starts[(size_t)pos] = s;
+    sl.lens[(size_t)pos] = ln;
   }
-  h->stack.push_back(std::move(sl));
+  finish_slice(h, sl, labels);
   return EMP_OK;
 }
 
-// Append a slice given as objects (labels, (n,4) boxes, CSR runs): the generic form of the above.
+// Append a slice given as objects (labels, (n,4) boxes, CSR runs): the generic form of the above; every object is one
+// component (objects of a slice must be disjoint pixel sets, as anything read from a label map is).
 int emp_sm_push_slice_objects(emp_stack_matcher* h, int64_t n, const int64_t* labels, const int64_t* boxes,
                               const int64_t* off, const int64_t* starts, const int64_t* runs) {
   EMP_REQUIRE(h && n >= 0, "sm_push_slice_objects: bad arguments");
-  Slice sl((size_t)n);
-  for (int64_t i = 0; i < n; ++i) {
-    Obj& o = sl[(size_t)i];
-    o.label = labels[i];
-    std::memcpy(o.box, boxes + 4 * i, sizeof(o.box));
-    o.starts.assign(starts + off[i], starts + off[i + 1]);
-    o.runs.assign(runs + off[i], runs + off[i + 1]);
-  }
-  h->stack.push_back(std::move(sl));
+  h->stack.emplace_back();
+  FSlice& sl = h->stack.back();
+  sl.K = (int)n;
+  sl.run_off.assign(off, off + n + 1);
+  const int64_t base = n ? off[0] : 0;
+  for (auto& v : sl.run_off) v -= base;
+  const int64_t total = n ? off[n] - base : 0;
+  sl.starts.assign(starts + base, starts + base + total);
+  sl.lens.assign(runs + base, runs + base + total);
+  sl.box.assign(boxes, boxes + 4 * n);
+  std::vector<int64_t> labs(labels, labels + n);
+  finish_slice(h, sl, labs);
   return EMP_OK;
 }
 
@@ -166,99 +343,81 @@ int64_t emp_sm_num_slices(const emp_stack_matcher* h) { return h ? (int64_t)h->s
 // patterns.py:102-109: the backward pass starts from a fresh target and never creates labels
 int emp_sm_begin_backward(emp_stack_matcher* h) {
   EMP_REQUIRE(h != nullptr, "sm_begin_backward: null handle");
-  h->has_target = false;
-  h->target.clear();
+  h->target_idx = -1;
   h->assign_new = false;
   return EMP_OK;
 }
 
-// First half of RLEMatcher.__call__ / apply_matchers for slice `idx`.  Returns through nt / nm the matrix shape; nt < 0
-// means "no assignment needed" (the slice initialised the target, the class is not matched, or one side is empty:
-// call emp_sm_step_apply with n = 0 in the last case -- reported as nt = 0 or nm = 0).
+// First half of RLEMatcher.__call__ / apply_matchers for slice `idx` (see the header for the solver-block contract).
 int emp_sm_step_begin(emp_stack_matcher* h, int64_t idx, int* nt, int* nm) {
   EMP_REQUIRE(h && nt && nm && idx >= 0 && idx < (int64_t)h->stack.size(), "sm_step_begin: bad arguments");
   *nt = -1;
   *nm = 0;
   h->pending = -1;
   if (!h->do_match) return EMP_OK;
-  Slice& cur = h->stack[(size_t)idx];
-  if (!h->has_target) {   // initialize_target (matcher.py:262-268)
-    h->target = cur;
-    h->has_target = true;
-    if (!cur.empty()) {
-      int64_t mx = cur[0].label;
-      for (const Obj& o : cur) mx = std::max(mx, o.label);
+  FSlice& cur = h->stack[(size_t)idx];
+  if (h->target_idx < 0) {   // initialize_target (matcher.py:262-268)
+    h->target_idx = (int)idx;
+    if (!cur.objs.empty()) {
+      int64_t mx = cur.objs[0].label;
+      for (const FObj& o : cur.objs) mx = std::max(mx, o.label);
       h->next_label = mx + 1;
     }
     return EMP_OK;
   }
-  for (Obj& o : h->target) sort_runs(o);
-  for (Obj& o : cur) sort_runs(o);
+  EMP_REQUIRE(h->target_idx != (int)idx, "sm_step_begin: slice %lld is the current target", (long long)idx);
+  FSlice& tgt = h->stack[(size_t)h->target_idx];
   h->pending = (int)idx;
-  h->nt = (int)h->target.size();
-  h->nm = (int)cur.size();
+  h->nt = (int)tgt.objs.size();
+  h->nm = (int)cur.objs.size();
   *nt = h->nt;
   *nm = h->nm;
+  h->blk_rows.clear(); h->blk_cols.clear(); h->pair_rows.clear(); h->pair_cols.clear(); h->iou.clear();
+  h->col_ent.assign((size_t)h->nm, {});
   if (h->nt == 0 || h->nm == 0) return EMP_OK;
   const int nt_ = h->nt, nm_ = h->nm;
+  // component-level overlaps between the two slices: stored with the LATER slice when they are neighbours (both passes
+  // read the same table), computed into a scratch table otherwise
+  const int ti = h->target_idx, ci = (int)idx;
+  const FSlice* tab;        // table owner: pairs of (owner's previous slice, owner)
+  bool target_is_prev;      // the target slice is the "previous" side of the table
+  if (ci == ti + 1) {
+    if (!cur.pairs_ready) build_pairs(tgt, cur);
+    tab = &cur; target_is_prev = true;
+  } else if (ci == ti - 1) {
+    if (!tgt.pairs_ready) build_pairs(cur, tgt);
+    tab = &tgt; target_is_prev = false;
+  } else {
+    h->scratch = FSlice();
+    h->scratch.K = cur.K; h->scratch.box = cur.box; h->scratch.run_off = cur.run_off;
+    h->scratch.starts = cur.starts; h->scratch.lens = cur.lens;
+    build_pairs(tgt, h->scratch);
+    tab = &h->scratch; target_is_prev = true;
+  }
   h->ta.assign((size_t)nt_, 0);
   h->ma.assign((size_t)nm_, 0);
-  for (int i = 0; i < nt_; ++i) { int64_t a = 0; for (int64_t r : h->target[(size_t)i].runs) a += r; h->ta[(size_t)i] = a; }
-  for (int j = 0; j < nm_; ++j) { int64_t a = 0; for (int64_t r : cur[(size_t)j].runs) a += r; h->ma[(size_t)j] = a; }
-  // candidate pairs through a uniform grid over the target boxes (64-pixel cells) instead of all nt x nm box tests
-  constexpr int CS = 6;
-  int64_t my = 1, mx = 1;
-  for (const Obj& o : h->target) { my = std::max(my, o.box[2]); mx = std::max(mx, o.box[3]); }
-  for (const Obj& o : cur) { my = std::max(my, o.box[2]); mx = std::max(mx, o.box[3]); }
-  const int64_t gy = ((my - 1) >> CS) + 1, gx = ((mx - 1) >> CS) + 1;
-  std::vector<int> cell_off((size_t)(gy * gx) + 1, 0);
-  auto cells_of = [&](const Obj& o, int64_t& y0, int64_t& y1, int64_t& x0, int64_t& x1) {
-    y0 = std::max<int64_t>(0, o.box[0]) >> CS; x0 = std::max<int64_t>(0, o.box[1]) >> CS;
-    y1 = std::max<int64_t>(o.box[0], o.box[2] - 1) >> CS; x1 = std::max<int64_t>(o.box[1], o.box[3] - 1) >> CS;
-    y1 = std::min(y1, gy - 1); x1 = std::min(x1, gx - 1);
-  };
-  for (const Obj& o : h->target) {
-    int64_t y0, y1, x0, x1;
-    cells_of(o, y0, y1, x0, x1);
-    for (int64_t y = y0; y <= y1; ++y) for (int64_t x = x0; x <= x1; ++x) ++cell_off[(size_t)(y * gx + x) + 1];
-  }
-  for (size_t i = 1; i < cell_off.size(); ++i) cell_off[i] += cell_off[i - 1];
-  std::vector<int> cell_items((size_t)cell_off.back());
-  {
-    std::vector<int> fill(cell_off.begin(), cell_off.end() - 1);
-    for (int i = 0; i < nt_; ++i) {
-      int64_t y0, y1, x0, x1;
-      cells_of(h->target[(size_t)i], y0, y1, x0, x1);
-      for (int64_t y = y0; y <= y1; ++y) for (int64_t x = x0; x <= x1; ++x) cell_items[(size_t)fill[(size_t)(y * gx + x)]++] = i;
-    }
-  }
-  h->col_ent.assign((size_t)nm_, {});
-  std::vector<int> seen((size_t)nt_, -1);
+  std::vector<int> tobj((size_t)tgt.K, -1);
+  for (int i = 0; i < nt_; ++i)
+    for (int c : tgt.objs[(size_t)i].members) { tobj[(size_t)c] = i; h->ta[(size_t)i] += tgt.area[(size_t)c]; }
   std::vector<int> deg_r((size_t)nt_, 0);
   for (int j = 0; j < nm_; ++j) {
-    const Obj& m = cur[(size_t)j];
-    int64_t y0, y1, x0, x1;
-    cells_of(m, y0, y1, x0, x1);
     auto& ents = h->col_ent[(size_t)j];
-    for (int64_t y = y0; y <= y1; ++y)
-      for (int64_t x = x0; x <= x1; ++x)
-        for (int k = cell_off[(size_t)(y * gx + x)]; k < cell_off[(size_t)(y * gx + x) + 1]; ++k) {
-          const int i = cell_items[(size_t)k];
-          if (seen[(size_t)i] == j) continue;
-          seen[(size_t)i] = j;
-          const Obj& t = h->target[(size_t)i];
-          // box screen (array_utils.py:148-211): non-empty intersection of the half-open boxes
-          if (std::min(t.box[2], m.box[2]) <= std::max(t.box[0], m.box[0]) ||
-              std::min(t.box[3], m.box[3]) <= std::max(t.box[1], m.box[1]))
-            continue;
-          const int64_t inter = intersection_sorted(t.starts, t.runs, m.starts, m.runs);
-          if (inter > 0) ents.push_back({i, inter});
-        }
+    for (int b : cur.objs[(size_t)j].members) {
+      h->ma[(size_t)j] += cur.area[(size_t)b];
+      const std::vector<int64_t>& off = target_is_prev ? tab->fwd_off : tab->rev_off;
+      const std::vector<Pair>& lst = target_is_prev ? tab->fwd : tab->rev;
+      for (int64_t k = off[(size_t)b]; k < off[(size_t)b + 1]; ++k) {
+        const int t = tobj[(size_t)lst[(size_t)k].a];
+        if (t < 0) continue;
+        bool found = false;
+        for (auto& e : ents) if (e.t == t) { e.inter += lst[(size_t)k].inter; found = true; break; }
+        if (!found) ents.push_back({t, lst[(size_t)k].inter});
+      }
+    }
     std::sort(ents.begin(), ents.end(), [](const emp_stack_matcher::Ent& a, const emp_stack_matcher::Ent& b) { return a.t < b.t; });
     for (const auto& e : ents) ++deg_r[(size_t)e.t];
   }
   // connected components of the overlap graph: single pairs are assigned here, the rest forms the solver's block
-  h->blk_rows.clear(); h->blk_cols.clear(); h->pair_rows.clear(); h->pair_cols.clear(); h->iou.clear();
   std::vector<int> parent((size_t)(nt_ + nm_));
   for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int)i;
   auto find = [&](int a) { while (parent[(size_t)a] != a) { parent[(size_t)a] = parent[(size_t)parent[(size_t)a]]; a = parent[(size_t)a]; } return a; };
@@ -294,16 +453,16 @@ int emp_sm_step_begin(emp_stack_matcher* h, int64_t idx, int* nt, int* nm) {
 // step_begin): the rows / columns of the overlap graph's components that are not single pairs, in ascending order
 const double* emp_sm_iou(const emp_stack_matcher* h) { return (h && !h->iou.empty()) ? h->iou.data() : nullptr; }
 
-// Second half: `rows` / `cols` is the assignment on the IoU matrix (all pairs; pairs below the IoU threshold are
+// Second half: `rows` / `cols` is the assignment on the solver block (all pairs; pairs below the IoU threshold are
 // dropped here, matcher.py:226-229).
 int emp_sm_step_apply(emp_stack_matcher* h, const int64_t* rows, const int64_t* cols, int64_t n) {
   EMP_REQUIRE(h && h->pending >= 0 && n >= 0, "sm_step_apply: no pending step");
-  Slice& cur = h->stack[(size_t)h->pending];
+  FSlice& cur = h->stack[(size_t)h->pending];
+  const FSlice& tgt = h->stack[(size_t)h->target_idx];
   const int nt = h->nt, nm = h->nm;
   const bool have = nt > 0 && nm > 0;
   std::vector<int64_t> matched_t((size_t)nm, -1);     // per match object: index of the matched target, or -1
   if (have) {
-    // `rows` / `cols` index the solver block (emp_sm_pending_shape); the single pairs found by step_begin join them
     const int64_t bt = (int64_t)h->blk_rows.size(), bm = (int64_t)h->blk_cols.size();
     for (int64_t k = 0; k < n; ++k) {
       EMP_REQUIRE(rows[k] >= 0 && rows[k] < bt && cols[k] >= 0 && cols[k] < bm, "sm_step_apply: assignment out of range");
@@ -322,7 +481,7 @@ int emp_sm_step_apply(emp_stack_matcher* h, const int64_t* rows, const int64_t* 
   for (int c = 0; c < nm; ++c) {
     int64_t nl;
     if (matched_t[(size_t)c] >= 0) {
-      nl = h->target[(size_t)matched_t[(size_t)c]].label;
+      nl = tgt.objs[(size_t)matched_t[(size_t)c]].label;
     } else {
       // argmax over the column of the float32 IoA matrix (first maximum; rows without overlap hold 0)
       float best = 0.f;
@@ -333,9 +492,9 @@ int emp_sm_step_apply(emp_stack_matcher* h, const int64_t* rows, const int64_t* 
           if (v > best) { best = v; arg = e.t; }
         }
       // numpy >= 2 compares the float32 matrix entry with the Python float threshold in float32 (NEP 50)
-      if (have && best >= (float)h->ioa_thr) nl = h->target[(size_t)arg].label;
+      if (have && best >= (float)h->ioa_thr) nl = tgt.objs[(size_t)arg].label;
       else if (h->assign_new) nl = h->next_label++;
-      else nl = cur[(size_t)c].label;
+      else nl = cur.objs[(size_t)c].label;
     }
     auto it = gi.find(nl);
     if (it == gi.end()) {
@@ -346,72 +505,42 @@ int emp_sm_step_apply(emp_stack_matcher* h, const int64_t* rows, const int64_t* 
       members[it->second].push_back(c);
     }
   }
-  Slice out(members.size());
+  std::vector<FObj> out(members.size());
   for (size_t g = 0; g < members.size(); ++g) {
-    Obj& o = out[g];
+    FObj& o = out[g];
     o.label = group_label[g];
     const std::vector<int>& mem = members[g];
-    if (mem.size() == 1) {
-      Obj& src = cur[(size_t)mem[0]];
-      std::memcpy(o.box, src.box, sizeof(o.box));
-      o.starts.swap(src.starts);
-      o.runs.swap(src.runs);
-      continue;
-    }
-    // merge_attrs folded over the group: box union, join_ranges of all runs (array_utils.py:658-699)
-    std::memcpy(o.box, cur[(size_t)mem[0]].box, sizeof(o.box));
-    std::vector<std::pair<int64_t, int64_t>> rg;
+    // merge_attrs folded over the group: box union; the runs are joined when the object is read out
+    std::memcpy(o.box, cur.objs[(size_t)mem[0]].box, sizeof(o.box));
     for (int c : mem) {
-      const Obj& s = cur[(size_t)c];
-      o.box[0] = std::min(o.box[0], s.box[0]); o.box[1] = std::min(o.box[1], s.box[1]);
-      o.box[2] = std::max(o.box[2], s.box[2]); o.box[3] = std::max(o.box[3], s.box[3]);
-      for (size_t i = 0; i < s.starts.size(); ++i) rg.emplace_back(s.starts[i], s.starts[i] + s.runs[i]);
-    }
-    std::stable_sort(rg.begin(), rg.end(), [](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) {
-      return a.first < b.first;
-    });
-    for (const auto& r : rg) {
-      if (!o.starts.empty() && o.starts.back() + o.runs.back() >= r.first) {
-        const int64_t end = std::max(o.starts.back() + o.runs.back(), r.second);
-        o.runs.back() = end - o.starts.back();
-      } else {
-        o.starts.push_back(r.first);
-        o.runs.push_back(r.second - r.first);
-      }
+      const FObj& sobj = cur.objs[(size_t)c];
+      o.box[0] = std::min(o.box[0], sobj.box[0]); o.box[1] = std::min(o.box[1], sobj.box[1]);
+      o.box[2] = std::max(o.box[2], sobj.box[2]); o.box[3] = std::max(o.box[3], sobj.box[3]);
+      o.members.insert(o.members.end(), sobj.members.begin(), sobj.members.end());
     }
   }
-  cur.swap(out);
-  h->target = cur;      // update_target
+  cur.objs.swap(out);
+  h->target_idx = h->pending;      // update_target
   h->pending = -1;
   return EMP_OK;
 }
 
 // Runs `count` consecutive steps from slice idx in direction dir (+1 forward pass, -1 backward pass; `track`: feed the
-// tracker after every step, as backward_matching does) and stops BEFORE the assignment of the first slice whose IoU
-// matrix needs a real linear_sum_assignment: *stopped_at = that slice (its step is pending: the caller fetches
-// emp_sm_iou, solves, calls emp_sm_step_apply [+ emp_sm_track] and resumes behind it), or -1 when all steps ran.
-// A step needs no solver when every row and every column of the matrix holds at most one non-zero entry: an optimal
-// assignment then contains all of those pairs (any other entry adds 0), and pairs with IoU 0 never pass the
-// threshold (matcher.py:226-229), so the kept matches equal scipy's.
+// tracker after every step, as backward_matching does) and stops BEFORE the assignment of the first slice with a
+// non-empty solver block: *stopped_at = that slice (its step is pending: the caller fetches emp_sm_iou, solves, calls
+// emp_sm_step_apply [+ emp_sm_track] and resumes behind it), or -1 when all steps ran.
 int emp_sm_track(emp_stack_matcher* h, int64_t idx, int64_t index2d);
 int emp_sm_run(emp_stack_matcher* h, int64_t idx, int dir, int64_t count, int track, int64_t* stopped_at) {
   EMP_REQUIRE(h && stopped_at && (dir == 1 || dir == -1) && count >= 0, "sm_run: bad arguments");
   *stopped_at = -1;
-  std::vector<int64_t> rows, cols;
   for (int64_t k = 0; k < count; ++k) {
     const int64_t i = idx + k * dir;
     int nt = 0, nm = 0;
     int rc = emp_sm_step_begin(h, i, &nt, &nm);
     if (rc) return rc;
     if (nt >= 0) {
-      if (nt == 0 || nm == 0) {
-        rc = emp_sm_step_apply(h, nullptr, nullptr, 0);
-      } else {
-        if (!h->blk_rows.empty()) { *stopped_at = i; return EMP_OK; }      // a real assignment problem: the caller solves it
-        rows.clear();
-        cols.clear();
-        rc = emp_sm_step_apply(h, rows.data(), cols.data(), (int64_t)rows.size());
-      }
+      if (!h->blk_rows.empty()) { *stopped_at = i; return EMP_OK; }      // a real assignment problem: the caller solves it
+      rc = emp_sm_step_apply(h, nullptr, nullptr, 0);
       if (rc) return rc;
     }
     if (track) {
@@ -443,7 +572,9 @@ int emp_sm_tracker_init(emp_stack_matcher* h, int axis, int64_t D, int64_t H, in
 int emp_sm_track(emp_stack_matcher* h, int64_t idx, int64_t index2d) {
   EMP_REQUIRE(h && !h->finished && idx >= 0 && idx < (int64_t)h->stack.size(), "sm_track: bad arguments");
   const int64_t H = h->H, W = h->W;
-  for (const Obj& o : h->stack[(size_t)idx]) {
+  const FSlice& sl = h->stack[(size_t)idx];
+  std::vector<int64_t> ost, orn;
+  for (const FObj& o : sl.objs) {
     int64_t box[6];
     const int64_t y1 = o.box[0], x1 = o.box[1], y2 = o.box[2], x2 = o.box[3];
     if (h->axis == 0) { box[0] = index2d; box[1] = y1; box[2] = x1; box[3] = index2d + 1; box[4] = y2; box[5] = x2; }
@@ -461,8 +592,9 @@ int emp_sm_track(emp_stack_matcher* h, int64_t idx, int64_t index2d) {
       t = &h->tracks[it->second];
       for (int k = 0; k < 3; ++k) { t->box[k] = std::min(t->box[k], box[k]); t->box[3 + k] = std::max(t->box[3 + k], box[3 + k]); }
     }
-    for (size_t i = 0; i < o.starts.size(); ++i) {
-      const int64_t st = o.starts[i], rn = o.runs[i];
+    object_runs(sl, o, ost, orn);
+    for (size_t i = 0; i < ost.size(); ++i) {
+      const int64_t st = ost[i], rn = orn[i];
       if (h->axis == 0) {                     // plane (H,W) at depth index2d
         t->starts.push_back(st + index2d * (H * W));
         t->runs.push_back(rn);
@@ -588,26 +720,31 @@ int emp_sm_track_runs(const emp_stack_matcher* h, int64_t k, int64_t* starts, in
 
 // ---- slice read-back (parity tests, save_panoptic) ----------------------------------------------------------------
 int64_t emp_sm_slice_num_objects(const emp_stack_matcher* h, int64_t idx) {
-  return (h && idx >= 0 && idx < (int64_t)h->stack.size()) ? (int64_t)h->stack[(size_t)idx].size() : -1;
+  return (h && idx >= 0 && idx < (int64_t)h->stack.size()) ? (int64_t)h->stack[(size_t)idx].objs.size() : -1;
 }
 
 int emp_sm_slice_object_info(const emp_stack_matcher* h, int64_t idx, int64_t k, int64_t* label, int64_t* box4,
                              int64_t* n_runs) {
-  EMP_REQUIRE(h && idx >= 0 && idx < (int64_t)h->stack.size() && k >= 0 && k < (int64_t)h->stack[(size_t)idx].size(),
+  EMP_REQUIRE(h && idx >= 0 && idx < (int64_t)h->stack.size() && k >= 0 && k < (int64_t)h->stack[(size_t)idx].objs.size(),
               "sm_slice_object_info: bad arguments");
-  const Obj& o = h->stack[(size_t)idx][(size_t)k];
+  const FSlice& sl = h->stack[(size_t)idx];
+  const FObj& o = sl.objs[(size_t)k];
   *label = o.label;
   std::memcpy(box4, o.box, sizeof(o.box));
-  *n_runs = (int64_t)o.starts.size();
+  std::vector<int64_t> st, rn;
+  object_runs(sl, o, st, rn);
+  *n_runs = (int64_t)st.size();
   return EMP_OK;
 }
 
 int emp_sm_slice_object_runs(const emp_stack_matcher* h, int64_t idx, int64_t k, int64_t* starts, int64_t* runs) {
-  EMP_REQUIRE(h && idx >= 0 && idx < (int64_t)h->stack.size() && k >= 0 && k < (int64_t)h->stack[(size_t)idx].size(),
+  EMP_REQUIRE(h && idx >= 0 && idx < (int64_t)h->stack.size() && k >= 0 && k < (int64_t)h->stack[(size_t)idx].objs.size(),
               "sm_slice_object_runs: bad arguments");
-  const Obj& o = h->stack[(size_t)idx][(size_t)k];
-  std::memcpy(starts, o.starts.data(), o.starts.size() * sizeof(int64_t));
-  std::memcpy(runs, o.runs.data(), o.runs.size() * sizeof(int64_t));
+  const FSlice& sl = h->stack[(size_t)idx];
+  std::vector<int64_t> st, rn;
+  object_runs(sl, sl.objs[(size_t)k], st, rn);
+  std::memcpy(starts, st.data(), st.size() * sizeof(int64_t));
+  std::memcpy(runs, rn.data(), rn.size() * sizeof(int64_t));
   return EMP_OK;
 }
 
