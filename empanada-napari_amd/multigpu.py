@@ -142,6 +142,39 @@ def active_ranks(n_slices, world, ks):
     return max(1, min(world, n_slices // max(1, mid)))
 
 
+def _via_host(t, group):
+    """gloo moves host tensors only: device maps are staged through the host on that backend (the CPU tests, and the
+    GPU test that runs two ranks on ONE device); RCCL sends them as they are."""
+    return t.is_cuda and dist.get_backend(group) == 'gloo'
+
+
+class _Sent:
+    """an isend in flight together with the buffer it reads"""
+
+    def __init__(self, work, buf):
+        self.work, self.buf = work, buf
+
+    def wait(self):
+        self.work.wait()
+        self.buf = None
+
+
+def _isend(t, dst, group):
+    buf = t.contiguous()
+    if _via_host(buf, group):
+        buf = buf.cpu()
+    return _Sent(dist.isend(buf, dst=dst, group=group), buf)
+
+
+def _recv(t, src, group):
+    if _via_host(t, group):
+        buf = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(buf, src=src, group=group)
+        t.copy_(buf)
+    else:
+        dist.recv(t, src=src, group=group)
+
+
 def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None):
     """SPMD body of one axis on one rank.
 
@@ -168,16 +201,16 @@ def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None):
         sem, stash = backend.forward(lo, hi, n_ahead)
         reqs = []
         if mid and has_prev:          # my first raw maps are the look-ahead of the previous rank
-            reqs.append(dist.isend(sem[:mid].contiguous(), dst=rank - 1, group=group))
+            reqs.append(_isend(sem[:mid], rank - 1, group))
         if mid and has_next:          # straight into the tail of the slab buffer
-            dist.recv(sem[n_own:], src=rank + 1, group=group)
+            _recv(sem[n_own:], rank + 1, group)
         hist = None
         if mid and has_prev:          # carry: filtered tail of the previous slab (ripples down the ranks)
             hist = torch.empty_like(sem[:mid])
-            dist.recv(hist, src=rank - 1, group=group)
+            _recv(hist, rank - 1, group)
         backend.median_inplace(sem, n_own, hist, n_ahead, rank == 0, rank == aw - 1, ks)
         if mid and has_next:
-            reqs.append(dist.isend(sem[n_own - mid:n_own].contiguous(), dst=rank + 1, group=group))
+            reqs.append(_isend(sem[n_own - mid:n_own], rank + 1, group))
         per_slice = backend.runs(sem[:n_own], stash)
         for r in reqs:
             r.wait()
@@ -288,9 +321,11 @@ def _free_port():
 
 
 def _default_backend_factory(model_config, engine_kwargs, rank):
-    """-> callable (volume, axis) -> backend, on this rank's GPU"""
+    """-> callable (volume, axis) -> backend, on this rank's GPU (``engine_kwargs['devices']``: rank -> device index)"""
     from .inference import Engine3d
-    dev = torch.device('cuda', rank)
+    engine_kwargs = dict(engine_kwargs)
+    devices = engine_kwargs.pop('devices', None)
+    dev = torch.device('cuda', devices[rank] if devices else rank)
     torch.cuda.set_device(dev)
     e3 = Engine3d(model_config, device=dev, **engine_kwargs)
     return lambda volume, axis: HipSlabBackend(e3, volume, axis)
@@ -302,8 +337,10 @@ def _rank_main(rank, world, port, dist_backend, model_config, engine_kwargs, bac
         os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if dist_backend == 'nccl':
-            torch.cuda.set_device(rank)
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+            devices = engine_kwargs.get('devices')
+            dev = torch.device('cuda', devices[rank] if devices else rank)
+            torch.cuda.set_device(dev)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
             host_group = dist.new_group(backend='gloo')
         else:
             dist.init_process_group(dist_backend, rank=rank, world_size=world)
@@ -342,8 +379,9 @@ class MultiGPUEngine3d:
     constructs the engine and calls ``infer_on_axis``; rank 0 returns ``(stack, trackers)``, the others ``(None, None)``.
 
     Extra keyword arguments (not in the reference): ``world_size`` (default ``torch.cuda.device_count()``),
-    ``dist_backend`` ('nccl' = RCCL; 'gloo' for the CPU tests), ``backend_factory`` (the per-rank arithmetic; tests plug
-    the oracle in), ``batch_size``, ``group``."""
+    ``dist_backend`` ('nccl' = RCCL; 'gloo' for the CPU tests -- device maps are then staged through the host),
+    ``backend_factory`` (the per-rank arithmetic; tests plug the oracle in), ``devices`` (rank -> device index; default
+    rank r on cuda:r), ``batch_size``, ``group``."""
     MIN_WORLD = 2
     MULTIGPU_STUFF_AREA = 32      # patterns.py:258,289
 
@@ -351,7 +389,7 @@ class MultiGPUEngine3d:
                  void_label=0, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.3, force_connected=True,
                  min_size=500, min_extent=4, fine_boundaries=False, semantic_only=False, store_url=None,
                  chunk_size=(256, 256, 256), save_panoptic=False, batch_size=None, group=None, world_size=None,
-                 dist_backend='nccl', backend_factory=None):
+                 dist_backend='nccl', backend_factory=None, devices=None):
         self.spmd = dist.is_initialized()
         if self.spmd:
             world = dist.get_world_size(group)
@@ -375,6 +413,8 @@ class MultiGPUEngine3d:
             stuff_area=self.MULTIGPU_STUFF_AREA, void_label=void_label, nms_threshold=nms_threshold, nms_kernel=nms_kernel,
             confidence_thr=confidence_thr, force_connected=force_connected, min_size=min_size, min_extent=min_extent,
             fine_boundaries=fine_boundaries, semantic_only=semantic_only, batch_size=batch_size)
+        if devices is not None:       # rank -> device index (default: rank r on cuda:r)
+            self.engine_kwargs['devices'] = list(devices)
         from .inference import _open_zarr
         self.zarr_store = _open_zarr(store_url, mode='w') if store_url is not None else None
         self._procs = None

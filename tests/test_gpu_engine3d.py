@@ -469,3 +469,27 @@ def test_multigpu_engine_spawns_rccl_ranks(monkeypatch, world):
             bad.infer_on_axis(vol, 'xy')
         finally:
             bad.close()
+
+
+@pytest.mark.parametrize('ks', [3, 7])
+def test_multigpu_two_ranks_on_one_gpu(monkeypatch, ks):
+    """Two REAL ranks of the HIP slab pipeline (each its own process, engine and arena) sharing the one GPU of this box,
+    gloo as the transport (device maps staged through the host): raw look-ahead to the previous rank, filtered carry to
+    the next, in-place recursive median per slab, run lists gathered to the caller -- against Engine3d on the whole
+    stack.  Everything of the N > 1 path except the RCCL transport itself (covered at world 1 above and on gloo in
+    tests/test_multigpu_cpu.py)."""
+    from empanada_napari_amd import multigpu, synth
+    from empanada_napari_amd.inference import Engine3d
+    mc = _picklable_model_config()
+    kw = dict(label_divisor=DIV, median_kernel_size=ks, nms_kernel=3, confidence_thr=0.5, min_size=20, min_extent=2)
+    vol = synth.ProceduralVolume((13, 40, 56), seed=9, cell=16).numpy()
+    mg = multigpu.MultiGPUEngine3d(mc, world_size=2, dist_backend='gloo', devices=[0, 0], **kw)
+    try:
+        e3 = Engine3d(mc, stuff_area=32, **kw)
+        for axis in ('xy', 'yz'):
+            _, ta = mg.infer_on_axis(vol, axis)
+            _, tb = e3.infer_on_axis(vol, axis)
+            assert len(tb[0].instances) > 0
+            _same_instances(ta[0].instances, tb[0].instances)
+    finally:
+        mg.close()
