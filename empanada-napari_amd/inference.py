@@ -312,19 +312,41 @@ class Engine2d:
         return c
 
 
-    def _infer_tiled(self, image):
+    def _infer_tiled(self, image, batched=True):
         """inference.py:283-318: per tile engine call -> RLE on the GPU -> image frame -> tile consensus -> dense.
-        The tile rectangles come from ``tile.Tiler`` (cztile stand-in, parity unpinned)."""
+        The tile rectangles come from ``tile.Tiler`` (cztile stand-in, parity unpinned).  The tiles have one size, so for
+        raw integer images at native scale they go through the engine in batches (``batched``; same label maps as the
+        per-tile calls -- batch invariance) and the dense -> RLE step runs on a whole batch."""
         from .tile import Tiler
         tiler = Tiler(image.shape, tile_size=self.tile_size, overlap_width=min(128, int(self.tile_size * 0.1)))
         self.last_tiler = tiler
         rle_segs = []
-        for i in range(len(tiler)):
-            tile = tiler(image, i)
-            x = self.preprocessor(resize_by_factor(tile, self.inference_scale))['image'].unsqueeze(0)
-            pan = self.engine(x, tile.shape, upsampling=self.inference_scale).squeeze(0).to(torch.int32)
-            seg = sparse.pan_seg_to_rle_seg(pan, self.labels, self.label_divisor, self.engine.thing_list)
-            rle_segs.append(tiler.translate_rle_seg(seg, i))
+        raw = (batched and isinstance(image, np.ndarray) and image.dtype in (np.uint8, np.uint16) and
+               self.inference_scale == 1)
+        if raw:
+            from .preprocess import normalize_params
+            eng = self.engine
+            sub, mul = normalize_params(self.preprocessor.mean, self.preprocessor.std, np.iinfo(image.dtype).max)
+            th, tw = tiler(image, 0).shape
+            pf = self.padding_factor
+            pad_to = (-(-th // pf) * pf, -(-tw // pf) * pf)
+            bs = int(max(1, min(64, (1 << 25) // max(1, pad_to[0] * pad_to[1]))))       # about 32 Mpixel per batch
+            for i0 in range(0, len(tiler), bs):
+                idx = range(i0, min(len(tiler), i0 + bs))
+                x = torch.from_numpy(np.stack([tiler(image, i) for i in idx]))[:, None].to(self.device, non_blocking=True)
+                mo = eng.model(x, 2, interpolate_ins=not eng.coarse_boundaries, sub=float(sub), mul=float(mul), pad_to=pad_to)
+                sem = logits_to_prob(mo['sem_logits'])
+                cells, _, _, kmax = eng.instance_cells_int(mo['ctr_hmp'], mo['offsets'], 1)
+                pan = eng.panoptic_merge_int(sem, cells, kmax)[:, :th, :tw].to(torch.int32)
+                segs = sparse.pan_stack_to_rle_segs(pan.contiguous(), self.labels, self.label_divisor, eng.thing_list)
+                rle_segs += [tiler.translate_rle_seg(seg, i) for seg, i in zip(segs, idx)]
+        else:
+            for i in range(len(tiler)):
+                tile = tiler(image, i)
+                x = self.preprocessor(resize_by_factor(tile, self.inference_scale))['image'].unsqueeze(0)
+                pan = self.engine(x, tile.shape, upsampling=self.inference_scale).squeeze(0).to(torch.int32)
+                seg = sparse.pan_seg_to_rle_seg(pan, self.labels, self.label_divisor, self.engine.thing_list)
+                rle_segs.append(tiler.translate_rle_seg(seg, i))
         rle_seg = {}
         for label in self.labels:
             if label in self.engine.thing_list:

@@ -178,6 +178,8 @@ def test_engine2d_tiled_inference_equals_oracle_pipeline(model_config):
     want = osp.rle_seg_to_pan_seg(ref, img.shape)
     assert np.array_equal(out, want)
     assert len(np.unique(out)) > 2, 'degenerate test image: no instances'
+    # the batched tile route (raw integers, one forward per group of tiles) == the per-tile route
+    assert np.array_equal(eng._infer_tiled(img, batched=False), out)
 
 
 @pytest.mark.parametrize('dtype', [np.uint8, np.int16])
