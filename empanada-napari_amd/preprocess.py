@@ -43,8 +43,14 @@ def resize_by_factor(image, scale_factor=1):
     """data/utils/transforms.py:9-21: cv2.resize(image, (ceil(w/s), ceil(h/s))) with cv2's default
     INTER_LINEAR (half-pixel centres, edge replicate, no anti-aliasing) == bilinear, align_corners=False.
     Pinned by the reference's three float cases (tests/test_transforms.py:6-28, restated in
-    tests/test_host_misc.py); for integer images cv2 rounds in fixed point -- parity unpinned there
-    (cv2 is absent from this image), the float result is rounded half away from zero and clipped."""
+    tests/test_host_misc.py).  Integer images: cv2 (opencv-python >= 4.11, absent from this image) works in fixed
+    point.  Its published arithmetic (imgproc/resize.cpp) for the cases this path allows -- power-of-two factors,
+    volume_dataset.py:26-27 -- on sides divisible by the factor: factor 2 is re-routed to the fast area path,
+    dst = (a + b + c + d + 2) >> 2 over the 2x2 block; factors 4, 8 sample at 4k + 1.5 (weights exactly 1/2, 11-bit
+    coefficients 1024 + 1024), and the 8-bit vertical pass ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2 reduces
+    to the same (a + b + c + d + 2) >> 2 over the four centre pixels.  floor(mean + 0.5) below is that value, so uint8
+    images with sides divisible by the factor agree by arithmetic; odd sides (fractional weights rounded to 11 bits)
+    and uint16 at factors > 2 (cv2 rounds a float result half to even) remain PARITY UNPINNED."""
     if scale_factor == 1:
         return image
     import math
