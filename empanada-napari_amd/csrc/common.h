@@ -133,6 +133,12 @@ int launch_point_features(const half_t* feat, int N, int fh, int fw, int C, int 
                           int ncls, const int32_t* idx, int P, int H2, int W2, half_t* x0, half_t* x1, int ld,
                           hipStream_t s);
 
+// fused point head: sampling + fc layers + predictor + scatter in one launch (pointrend.hip)
+bool pr_mlp_supported(int C, int ld, int ncls, int num_fc);
+int launch_pr_mlp(const half_t* feat, int N, int fh, int fw, int C, int feat_ld, const float* coarse, int ncls,
+                  const int32_t* idx, int P, int H2, int W2, const half_t* const* fc_w, const float* const* fc_b,
+                  int num_fc, int ld, const float* pred_w, const float* pred_b, float* out, int64_t plane, hipStream_t s);
+
 // ---------------------------------------------------------------------------
 // post-processing (postprocess.hip)
 // ---------------------------------------------------------------------------

@@ -62,6 +62,7 @@ struct emp_pdl {
   bool fuse_stem = [] { const char* e = getenv("EMP_FUSE_STEM"); return !(e && e[0] == '0'); }();   // stem.hip
   bool fuse_ds = [] { const char* e = getenv("EMP_FUSE_DS"); return !(e && e[0] == '0'); }();       // conv3 + downsample in one GEMM
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
+  bool fuse_pr = [] { const char* e = getenv("EMP_FUSE_PR"); return !(e && e[0] == '0'); }();             // pointrend.hip
 
   // device parameters
   std::map<std::string, DevConv> convs;
@@ -839,6 +840,21 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
     const int64_t plane = (int64_t)hh * ww;
     const int k = (int)(plane < P ? plane : P);
     RC(launch_topk_smallest(keys, N, plane, k, rawp<char>(n, "pr.topk"), n->raw.at("pr.topk").second, idx, s));
+    if (n->fuse_pr && pr_mlp_supported(n->dec_ch, ldp, n->ncls, c.num_fc)) {
+      // sampling + fc layers + predictor + scatter in one launch: the (points x ldp) rows stay in LDS
+      const half_t* fw_[4];
+      const float* fb_[4];
+      for (int f = 0; f < c.num_fc; ++f) {
+        const DevConv& dc = n->convs.at("semantic_pr.point_head.fc_layers." + std::to_string(f) + ".0");
+        fw_[f] = dc.w; fb_[f] = dc.b;
+        n->flops += 2.0 * (double)N * k * dc.cout * (double)dc.cin;
+      }
+      RC(launch_pr_mlp(semx.p, N, hq, wq, n->dec_ch, semx.ld, coarse, n->ncls, idx, k, hh, ww, fw_, fb_, c.num_fc, ldp,
+                       n->f32w.at("pr.predictor.w"), n->f32w.at("pr.predictor.b"), nxt, plane, s));
+      n->flops += 2.0 * (double)N * k * ldp * n->ncls;
+      cur = nxt;
+      continue;
+    }
     RC(launch_point_features(semx.p, N, hq, wq, n->dec_ch, semx.ld, coarse, n->ncls, idx, k, hh, ww, X[0], X[1], ldp, s));
     Act xa[2];
     for (int j = 0; j < 2; ++j) {

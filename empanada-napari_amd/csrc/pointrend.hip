@@ -273,6 +273,189 @@ __global__ void __launch_bounds__(256) point_features_kernel(const half_t* __res
   }
 }
 
+// ---------------------------------------------------------------------------
+// Fused point head (point_rend.py:181-188,241-269, eval): point sampling -> num_fc x (Conv1d k=1 + ReLU, coarse logits
+// concatenated at every layer) -> predictor -> scatter, for a tile of 128 points per workgroup.  Replaces
+// point_features_kernel + num_fc implicit-GEMM launches + head1x1_kernel: the (points x 320) rows never reach HBM.
+//   LDS: X[128 points][LD channels] fp16, rows of LD*2 bytes, 16-byte chunk c of each 128-byte segment stored at
+//        c ^ (row & 7) (conflict-free ds_read_b128 fragment reads, as in conv_igemm.hip).
+//   gather    : half a wave per point, lane = 8 channels; arithmetic of point_features_kernel (fmaf chain per tap).
+//   layer     : wave w owns couts [MT*16*w, +MT*16) x all 128 points; K walked in ascending 32-channel steps from a zero
+//               accumulator (the order of conv_igemm_kernel: results are bit-identical to the unfused launches); weight
+//               fragments straight from L2; bias + ReLU + ONE fp16 rounding, written back over X[:, 0:C) after a barrier.
+//   predictor : half a wave per point on the fp16 row, fp32 weights, the reduction order of head1x1_kernel.
+// Two workgroups per CU (80 KiB of LDS each at LD = 320): one gathers while the other multiplies.
+template <int C>
+struct PrCfg {
+  static constexpr int MT = C / 128;          // 16-cout tiles per wave (8 waves cover C couts)
+};
+
+struct PrParams {
+  const half_t* feat; int N, fh, fw, feat_ld;
+  const float* coarse; int ncls;
+  const int32_t* idx; int P, H2, W2;
+  const half_t* w[4]; const float* b[4]; int num_fc;    // fc layers: [C][LD] fp16, bias fp32
+  const float* pw; const float* pb;                     // predictor [ncls][LD] fp32
+  float* out; int64_t plane;
+  int64_t npts; int tiles;
+};
+
+template <int C, int LD>
+__global__ void __launch_bounds__(512, 2) pr_mlp_kernel(const PrParams p) {
+  constexpr int MT = PrCfg<C>::MT;
+  constexpr int LDB = LD * 2;                 // bytes per row
+  constexpr int KSTEPS = LD / 32;
+  constexpr int KC = LD / 8;                  // 16-byte chunks per row
+  extern __shared__ __attribute__((aligned(1024))) char X[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hl = lane & 31, hw = tid >> 5;    // half-wave index 0..15
+  const int fr = lane & 15, fq = lane >> 4;
+  auto xoff = [](int row, int chunk) { return row * LDB + (chunk >> 3) * 128 + (((chunk & 7) ^ (row & 7)) << 4); };
+
+  for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+    const int64_t g0 = (int64_t)tile * 128;
+    // ---------------- gather ----------------
+    for (int j = 0; j < 8; ++j) {
+      const int row = hw + 16 * j;
+      const int64_t pt = g0 + row;
+      const bool live = pt < p.npts;
+      const int n = live ? (int)(pt / p.P) : 0;
+      const int id = live ? p.idx[pt] : 0;
+      const int iy = id / p.W2, ix = id - iy * p.W2;
+      const float w_step = 1.0f / (float)p.W2, h_step = 1.0f / (float)p.H2;
+      const float cx = 0.5f * w_step + w_step * (float)ix;
+      const float cy = 0.5f * h_step + h_step * (float)iy;
+      const float gx = 2.0f * cx - 1.0f, gy = 2.0f * cy - 1.0f;
+      const float sx = ((gx + 1.f) * (float)p.fw - 1.f) * 0.5f;
+      const float sy = ((gy + 1.f) * (float)p.fh - 1.f) * 0.5f;
+      const float fx0 = floorf(sx), fy0 = floorf(sy);
+      const int xa = (int)fx0, ya = (int)fy0, xb = xa + 1, yb = ya + 1;
+      const float lx = sx - fx0, ly = sy - fy0;
+      const float w00 = (1.f - lx) * (1.f - ly), w01 = lx * (1.f - ly), w10 = (1.f - lx) * ly, w11 = lx * ly;
+      const bool ok00 = live && xa >= 0 && xa < p.fw && ya >= 0 && ya < p.fh;
+      const bool ok01 = live && xb >= 0 && xb < p.fw && ya >= 0 && ya < p.fh;
+      const bool ok10 = live && xa >= 0 && xa < p.fw && yb >= 0 && yb < p.fh;
+      const bool ok11 = live && xb >= 0 && xb < p.fw && yb >= 0 && yb < p.fh;
+      const half_t* fb = p.feat + (size_t)n * p.fh * p.fw * p.feat_ld;
+      if (hl < C / 8) {
+        const int cg = hl;
+        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto accum = [&](bool ok, int yy, int xx, float wt) {
+          if (ok) {
+            f16x8 v = *reinterpret_cast<const f16x8*>(fb + ((size_t)yy * p.fw + xx) * p.feat_ld + cg * 8);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[c] = fmaf((float)v[c], wt, a[c]);
+          }
+        };
+        accum(ok00, ya, xa, w00);
+        accum(ok01, ya, xb, w01);
+        accum(ok10, yb, xa, w10);
+        accum(ok11, yb, xb, w11);
+        f16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (half_t)a[c];
+        *reinterpret_cast<f16x8*>(X + xoff(row, cg)) = o;
+      }
+      // tail chunks [C, LD): coarse logits in the first ncls slots, zeros elsewhere (lanes 0 .. (LD-C)/8 - 1 of the
+      // half-wave; C/8 <= 32 - 8 is not guaranteed, so the tail is written in a second step by the same lanes)
+      if (hl < (LD - C) / 8) {
+        f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hl == 0) {
+          for (int c = 0; c < p.ncls && c < 8; ++c) {
+            const float* cb = p.coarse + ((size_t)n * p.ncls + c) * p.fh * p.fw;
+            float v = 0.f;
+            if (ok00) v = fmaf(cb[ya * p.fw + xa], w00, v);
+            if (ok01) v = fmaf(cb[ya * p.fw + xb], w01, v);
+            if (ok10) v = fmaf(cb[yb * p.fw + xa], w10, v);
+            if (ok11) v = fmaf(cb[yb * p.fw + xb], w11, v);
+            o[c] = (half_t)v;
+          }
+        }
+        *reinterpret_cast<f16x8*>(X + xoff(row, C / 8 + hl)) = o;
+      }
+    }
+    __syncthreads();
+    // ---------------- fc layers ----------------
+    for (int f = 0; f < p.num_fc; ++f) {
+      f32x4 acc[MT][8];
+#pragma unroll
+      for (int c = 0; c < MT; ++c)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const half_t* wb = p.w[f] + (size_t)(wave * MT * 16 + fr) * LD + fq * 8;
+#pragma unroll 2
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        f16x8 wf[MT];
+#pragma unroll
+        for (int c = 0; c < MT; ++c) wf[c] = *reinterpret_cast<const f16x8*>(wb + (size_t)c * 16 * LD + ks * 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f16x8 pf = *reinterpret_cast<const f16x8*>(X + xoff(q * 16 + fr, ks * 4 + fq));
+#pragma unroll
+          for (int c = 0; c < MT; ++c) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf, acc[c][q], 0, 0, 0);
+        }
+      }
+      __syncthreads();      // every wave is done reading this layer's input
+#pragma unroll
+      for (int c = 0; c < MT; ++c) {
+        const int co = wave * MT * 16 + c * 16 + fq * 4;       // 4 consecutive couts of this lane
+        const float4 bv = *reinterpret_cast<const float4*>(p.b[f] + co);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int row = q * 16 + fr;
+          f16x4 o;
+          o[0] = (half_t)fmaxf(acc[c][q][0] + bv.x, 0.f);
+          o[1] = (half_t)fmaxf(acc[c][q][1] + bv.y, 0.f);
+          o[2] = (half_t)fmaxf(acc[c][q][2] + bv.z, 0.f);
+          o[3] = (half_t)fmaxf(acc[c][q][3] + bv.w, 0.f);
+          *reinterpret_cast<f16x4*>(X + xoff(row, co >> 3) + (co & 7) * 2) = o;
+        }
+      }
+      __syncthreads();
+    }
+    // ---------------- predictor + scatter ----------------
+    for (int j = 0; j < 8; ++j) {
+      const int row = hw + 16 * j;
+      const int64_t pt = g0 + row;
+      const bool live = pt < p.npts;
+      float xv[2][8];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int kc = hl + 32 * jj;
+        if (kc < KC) {
+          const f16x8 v = *reinterpret_cast<const f16x8*>(X + xoff(row, kc));
+#pragma unroll
+          for (int c = 0; c < 8; ++c) xv[jj][c] = (float)v[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) xv[jj][c] = 0.f;
+        }
+      }
+      const int n = live ? (int)(pt / p.P) : 0;
+      const int64_t pix = live ? (int64_t)p.idx[pt] : 0;
+      for (int c = 0; c < p.ncls; ++c) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int kc = hl + 32 * jj;
+          if (kc < KC) {
+            const float4* wp = reinterpret_cast<const float4*>(p.pw + (size_t)c * LD + kc * 8);
+            const float4 w0 = wp[0], w1 = wp[1];
+            sacc = fmaf(xv[jj][0], w0.x, sacc); sacc = fmaf(xv[jj][1], w0.y, sacc);
+            sacc = fmaf(xv[jj][2], w0.z, sacc); sacc = fmaf(xv[jj][3], w0.w, sacc);
+            sacc = fmaf(xv[jj][4], w1.x, sacc); sacc = fmaf(xv[jj][5], w1.y, sacc);
+            sacc = fmaf(xv[jj][6], w1.z, sacc); sacc = fmaf(xv[jj][7], w1.w, sacc);
+          }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+        if (hl == 0 && live) p.out[((size_t)n * p.ncls + c) * p.plane + pix] = sacc + p.pb[c];
+      }
+    }
+    __syncthreads();        // X is rewritten by the next tile's gather
+  }
+}
+
 inline int grid_for(int64_t total, int per_block = 256, int cap = 256 * 16) {
   int64_t g = (total + per_block - 1) / per_block;
   if (g > cap) g = cap;
@@ -336,6 +519,45 @@ int launch_point_features(const half_t* feat, int N, int fh, int fw, int C, int 
   int64_t pts = (int64_t)N * P;
   hipLaunchKernelGGL(point_features_kernel, dim3((unsigned)cdiv64(pts, 8)), dim3(256), 0, s, feat, N, fh, fw, C, feat_ld,
                      coarse, ncls, idx, P, H2, W2, x0, x1, ld);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+bool pr_mlp_supported(int C, int ld, int ncls, int num_fc) {
+  return ((C == 256 && ld == 320) || (C == 128 && ld == 192)) && ncls >= 1 && ncls <= 8 && num_fc >= 1 && num_fc <= 4;
+}
+
+int launch_pr_mlp(const half_t* feat, int N, int fh, int fw, int C, int feat_ld, const float* coarse, int ncls,
+                  const int32_t* idx, int P, int H2, int W2, const half_t* const* fc_w, const float* const* fc_b,
+                  int num_fc, int ld, const float* pred_w, const float* pred_b, float* out, int64_t plane,
+                  hipStream_t s) {
+  EMP_REQUIRE(pr_mlp_supported(C, ld, ncls, num_fc), "pr_mlp: unsupported shape C=%d ld=%d", C, ld);
+  PrParams p{};
+  p.feat = feat; p.N = N; p.fh = fh; p.fw = fw; p.feat_ld = feat_ld;
+  p.coarse = coarse; p.ncls = ncls; p.idx = idx; p.P = P; p.H2 = H2; p.W2 = W2;
+  for (int i = 0; i < num_fc; ++i) { p.w[i] = fc_w[i]; p.b[i] = fc_b[i]; }
+  p.num_fc = num_fc; p.pw = pred_w; p.pb = pred_b; p.out = out; p.plane = plane;
+  p.npts = (int64_t)N * P;
+  p.tiles = (int)cdiv64(p.npts, 128);
+  const int grid = p.tiles < 512 ? p.tiles : 512;       // two workgroups per CU
+  const size_t lds = (size_t)128 * ld * 2;
+  if (C == 256) {
+    static bool attr = false;
+    if (!attr) {
+      EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pr_mlp_kernel<256, 320>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr = true;
+    }
+    hipLaunchKernelGGL((pr_mlp_kernel<256, 320>), dim3(grid), dim3(512), lds, s, p);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pr_mlp_kernel<128, 192>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr = true;
+    }
+    hipLaunchKernelGGL((pr_mlp_kernel<128, 192>), dim3(grid), dim3(512), lds, s, p);
+  }
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }

@@ -208,3 +208,33 @@ def test_fused_launches_equal_unfused_bit_exact(setup):
     # PointRend refines the most uncertain cells: a cell picked by one side only differs by (refined - interpolated)
     d = (fused['sem_logits'] - plain['sem_logits']).abs()
     assert (d > 5e-2).float().mean().item() < 5e-3 and d.median().item() < 5e-3
+
+
+@pytest.mark.parametrize('arch', ['pdl', 'bifpn4'])
+def test_fused_point_head_equals_unfused_launches_bit_exact(arch):
+    """pointrend.hip's fused point head (sampling + fc layers + predictor + scatter in one launch, rows in LDS) keeps the
+    arithmetic and the K order of point_features + conv_igemm + head1x1: identical sem_logits, both networks."""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    if arch == 'pdl':
+        cfg = dict(weights.MITONET_PDL_CFG)
+        P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    else:
+        cfg = dict(weights.MITONET_MINI_CFG, num_classes=4)
+        P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
+    x = _norm(synth.em_tiles(3, 256, seed=41)).cuda()
+    fused_model = HipPanopticDeepLab(P, cfg, folded=True)
+    old = os.environ.get('EMP_FUSE_PR')
+    try:
+        os.environ['EMP_FUSE_PR'] = '0'
+        plain_model = HipPanopticDeepLab(P, cfg, folded=True)
+    finally:
+        if old is None:
+            os.environ.pop('EMP_FUSE_PR', None)
+        else:
+            os.environ['EMP_FUSE_PR'] = old
+    for rs in (1, 2, 3):
+        a = {k: v.clone() for k, v in fused_model(x, rs, False).items()}
+        b = plain_model(x, rs, False)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (arch, rs, k, float((a[k] - b[k]).abs().max()))
