@@ -275,16 +275,22 @@ __global__ void __launch_bounds__(256) point_features_kernel(const half_t* __res
 
 // ---------------------------------------------------------------------------
 // Fused point head (point_rend.py:181-188,241-269, eval): point sampling -> num_fc x (Conv1d k=1 + ReLU, coarse logits
-// concatenated at every layer) -> predictor -> scatter, for a tile of 128 points per workgroup.  Replaces
+// concatenated at every layer) -> predictor -> scatter, for a tile of 256 points per workgroup.  Replaces
 // point_features_kernel + num_fc implicit-GEMM launches + head1x1_kernel: the (points x 320) rows never reach HBM.
-//   LDS: X[128 points][LD channels] fp16, rows of LD*2 bytes, 16-byte chunk c of each 128-byte segment stored at
+//   LDS: X[256 points][LD channels] fp16 (all 160 KiB at LD = 320), rows of LD*2 bytes, 16-byte chunk c of each 128-byte segment stored at
 //        c ^ (row & 7) (conflict-free ds_read_b128 fragment reads, as in conv_igemm.hip).
 //   gather    : half a wave per point, lane = 8 channels; arithmetic of point_features_kernel (fmaf chain per tap).
-//   layer     : wave w owns couts [MT*16*w, +MT*16) x all 128 points; K walked in ascending 32-channel steps from a zero
-//               accumulator (the order of conv_igemm_kernel: results are bit-identical to the unfused launches); weight
-//               fragments straight from L2; bias + ReLU + ONE fp16 rounding, written back over X[:, 0:C) after a barrier.
+//   layer     : wave w owns couts [MT*16*w, +MT*16) x all 256 points; K walked in ascending 32-channel steps from a zero
+//               accumulator (the order of conv_igemm_kernel: results are bit-identical to the unfused launches); the
+//               wave's weight fragments of the WHOLE layer (MT x LD/32 x 4 VGPRs) are loaded from L2 in one burst,
+//               the next layer's during this layer's epilogue, so the K loop waits for LDS only [first version:
+//               fragments fetched per K-step at two workgroups per CU -- 302 us per launch, 8x its MFMA time, every
+//               K-step exposed an L2 round trip]; bias + ReLU + ONE fp16 rounding, written back over X[:, 0:C) after
+//               a barrier.  Two passes of 128 points per layer (64 accumulator VGPRs beside 72 weight VGPRs).
+//   Measured (32 x 8192 points, MI355X): 257 us per launch = gather 88 (0.54 GB of scattered 512-byte pixel rows: at the
+//   memory system's rate) + layers ~115 (MFMA time 60) + predictor ~40, against 120 + 330 + 55 us for the launches it
+//   replaces; bit-identical sem_logits (tests/test_gpu_model.py).
 //   predictor : half a wave per point on the fp16 row, fp32 weights, the reduction order of head1x1_kernel.
-// Two workgroups per CU (80 KiB of LDS each at LD = 320): one gathers while the other multiplies.
 template <int C>
 struct PrCfg {
   static constexpr int MT = C / 128;          // 16-cout tiles per wave (8 waves cover C couts)
@@ -301,11 +307,14 @@ struct PrParams {
 };
 
 template <int C, int LD>
-__global__ void __launch_bounds__(512, 2) pr_mlp_kernel(const PrParams p) {
+__global__ void __launch_bounds__(512, 1) pr_mlp_kernel(const PrParams p) {
   constexpr int MT = PrCfg<C>::MT;
   constexpr int LDB = LD * 2;                 // bytes per row
-  constexpr int KSTEPS = LD / 32;
+  // K-steps: channels [C + 8, LD) of a row are zeros (ncls <= 8) and so are the weights' pad columns, so the steps beyond
+  // C/32 + 1 add exact zeros: skipping them leaves every sum bit-identical
+  constexpr int KSTEPS = C / 32 + 1;
   constexpr int KC = LD / 8;                  // 16-byte chunks per row
+  constexpr int PT = 256, QT = PT / 16;       // points per tile, 16-point MFMA tiles
   extern __shared__ __attribute__((aligned(1024))) char X[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hl = lane & 31, hw = tid >> 5;    // half-wave index 0..15
@@ -313,15 +322,19 @@ __global__ void __launch_bounds__(512, 2) pr_mlp_kernel(const PrParams p) {
   auto xoff = [](int row, int chunk) { return row * LDB + (chunk >> 3) * 128 + (((chunk & 7) ^ (row & 7)) << 4); };
 
   for (int tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
-    const int64_t g0 = (int64_t)tile * 128;
+    const int64_t g0 = (int64_t)tile * PT;
     // ---------------- gather ----------------
-    for (int j = 0; j < 8; ++j) {
-      const int row = hw + 16 * j;
+    // 16 points per half-wave, four at a time: the sixteen 16-byte feature taps of a group (and lane 0's coarse-logit
+    // taps) are in flight before the first is used.  [measured: this phase moves 0.54 GB of scattered 512-byte pixel
+    // rows per launch in ~105 us = 5 TB/s -- it is at the memory system's rate, deeper batching (8 points) was slower]
+    auto sample_geometry = [&](int row, int& n, int& xa, int& ya, float* wt, bool* ok) {
       const int64_t pt = g0 + row;
       const bool live = pt < p.npts;
-      const int n = live ? (int)(pt / p.P) : 0;
       const int id = live ? p.idx[pt] : 0;
+      n = live ? (int)(pt / p.P) : 0;
       const int iy = id / p.W2, ix = id - iy * p.W2;
+      // point_rend.py:131-135 (fp32): coord = 0.5*step + step*index, step = 1/size; point_sample: grid = 2*coord - 1;
+      // grid_sample(align_corners=False): ((g+1)*size - 1)/2
       const float w_step = 1.0f / (float)p.W2, h_step = 1.0f / (float)p.H2;
       const float cx = 0.5f * w_step + w_step * (float)ix;
       const float cy = 0.5f * h_step + h_step * (float)iy;
@@ -329,127 +342,172 @@ __global__ void __launch_bounds__(512, 2) pr_mlp_kernel(const PrParams p) {
       const float sx = ((gx + 1.f) * (float)p.fw - 1.f) * 0.5f;
       const float sy = ((gy + 1.f) * (float)p.fh - 1.f) * 0.5f;
       const float fx0 = floorf(sx), fy0 = floorf(sy);
-      const int xa = (int)fx0, ya = (int)fy0, xb = xa + 1, yb = ya + 1;
+      xa = (int)fx0; ya = (int)fy0;
+      const int xb = xa + 1, yb = ya + 1;
       const float lx = sx - fx0, ly = sy - fy0;
-      const float w00 = (1.f - lx) * (1.f - ly), w01 = lx * (1.f - ly), w10 = (1.f - lx) * ly, w11 = lx * ly;
-      const bool ok00 = live && xa >= 0 && xa < p.fw && ya >= 0 && ya < p.fh;
-      const bool ok01 = live && xb >= 0 && xb < p.fw && ya >= 0 && ya < p.fh;
-      const bool ok10 = live && xa >= 0 && xa < p.fw && yb >= 0 && yb < p.fh;
-      const bool ok11 = live && xb >= 0 && xb < p.fw && yb >= 0 && yb < p.fh;
-      const half_t* fb = p.feat + (size_t)n * p.fh * p.fw * p.feat_ld;
-      if (hl < C / 8) {
-        const int cg = hl;
-        float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        auto accum = [&](bool ok, int yy, int xx, float wt) {
-          if (ok) {
-            f16x8 v = *reinterpret_cast<const f16x8*>(fb + ((size_t)yy * p.fw + xx) * p.feat_ld + cg * 8);
+      wt[0] = (1.f - lx) * (1.f - ly); wt[1] = lx * (1.f - ly); wt[2] = (1.f - lx) * ly; wt[3] = lx * ly;
+      ok[0] = live && xa >= 0 && xa < p.fw && ya >= 0 && ya < p.fh;
+      ok[1] = live && xb >= 0 && xb < p.fw && ya >= 0 && ya < p.fh;
+      ok[2] = live && xa >= 0 && xa < p.fw && yb >= 0 && yb < p.fh;
+      ok[3] = live && xb >= 0 && xb < p.fw && yb >= 0 && yb < p.fh;
+    };
+    {
+      constexpr int GB = 4;
+#pragma unroll 1
+      for (int j0 = 0; j0 < PT / 16; j0 += GB) {
+        int nn[GB], xa[GB], ya[GB];
+        float wt[GB][4];
+        bool ok[GB][4];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[c] = fmaf((float)v[c], wt, a[c]);
+        for (int u = 0; u < GB; ++u) sample_geometry(hw + 16 * (j0 + u), nn[u], xa[u], ya[u], wt[u], ok[u]);
+        if (hl < C / 8) {
+          f16x8 v[GB][4];
+#pragma unroll
+          for (int u = 0; u < GB; ++u) {
+            const half_t* fb = p.feat + (size_t)nn[u] * p.fh * p.fw * p.feat_ld + hl * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int yy = ya[u] + (t >> 1), xx = xa[u] + (t & 1);
+              const half_t* src = ok[u][t] ? fb + ((size_t)yy * p.fw + xx) * p.feat_ld : p.feat;
+              v[u][t] = *reinterpret_cast<const f16x8*>(src);
+            }
           }
-        };
-        accum(ok00, ya, xa, w00);
-        accum(ok01, ya, xb, w01);
-        accum(ok10, yb, xa, w10);
-        accum(ok11, yb, xb, w11);
-        f16x8 o;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o[c] = (half_t)a[c];
-        *reinterpret_cast<f16x8*>(X + xoff(row, cg)) = o;
-      }
-      // tail chunks [C, LD): coarse logits in the first ncls slots, zeros elsewhere (lanes 0 .. (LD-C)/8 - 1 of the
-      // half-wave; C/8 <= 32 - 8 is not guaranteed, so the tail is written in a second step by the same lanes)
-      if (hl < (LD - C) / 8) {
-        f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (hl == 0) {
-          for (int c = 0; c < p.ncls && c < 8; ++c) {
-            const float* cb = p.coarse + ((size_t)n * p.ncls + c) * p.fh * p.fw;
-            float v = 0.f;
-            if (ok00) v = fmaf(cb[ya * p.fw + xa], w00, v);
-            if (ok01) v = fmaf(cb[ya * p.fw + xb], w01, v);
-            if (ok10) v = fmaf(cb[yb * p.fw + xa], w10, v);
-            if (ok11) v = fmaf(cb[yb * p.fw + xb], w11, v);
-            o[c] = (half_t)v;
+          for (int u = 0; u < GB; ++u) {
+            float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (ok[u][t]) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a[c] = fmaf((float)v[u][t][c], wt[u][t], a[c]);
+              }
+            f16x8 o;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o[c] = (half_t)a[c];
+            *reinterpret_cast<f16x8*>(X + xoff(hw + 16 * (j0 + u), hl)) = o;
           }
         }
-        *reinterpret_cast<f16x8*>(X + xoff(row, C / 8 + hl)) = o;
+        // tail chunks [C, LD): coarse logits in the first ncls slots, zeros elsewhere
+        if (hl < (LD - C) / 8) {
+          f16x8 o[GB];
+#pragma unroll
+          for (int u = 0; u < GB; ++u) o[u] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          if (hl == 0) {
+            for (int c = 0; c < p.ncls && c < 8; ++c) {
+              float cv[GB][4];
+#pragma unroll
+              for (int u = 0; u < GB; ++u) {
+                const float* cb = p.coarse + ((size_t)nn[u] * p.ncls + c) * p.fh * p.fw;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  cv[u][t] = ok[u][t] ? cb[(ya[u] + (t >> 1)) * p.fw + xa[u] + (t & 1)] : 0.f;
+              }
+#pragma unroll
+              for (int u = 0; u < GB; ++u) {
+                float vv = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  if (ok[u][t]) vv = fmaf(cv[u][t], wt[u][t], vv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[u][e] = (e == c) ? (half_t)vv : o[u][e];     // runtime c: select, no dynamic index
+              }
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < GB; ++u) *reinterpret_cast<f16x8*>(X + xoff(hw + 16 * (j0 + u), C / 8 + hl)) = o[u];
+        }
       }
     }
     __syncthreads();
     // ---------------- fc layers ----------------
-    for (int f = 0; f < p.num_fc; ++f) {
-      f32x4 acc[MT][8];
-#pragma unroll
-      for (int c = 0; c < MT; ++c)
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 wf[KSTEPS][MT];
+    auto load_weights = [&](int f) {
       const half_t* wb = p.w[f] + (size_t)(wave * MT * 16 + fr) * LD + fq * 8;
-#pragma unroll 2
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        f16x8 wf[MT];
 #pragma unroll
-        for (int c = 0; c < MT; ++c) wf[c] = *reinterpret_cast<const f16x8*>(wb + (size_t)c * 16 * LD + ks * 32);
+      for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const f16x8 pf = *reinterpret_cast<const f16x8*>(X + xoff(q * 16 + fr, ks * 4 + fq));
+        for (int c = 0; c < MT; ++c) wf[ks][c] = *reinterpret_cast<const f16x8*>(wb + (size_t)c * 16 * LD + ks * 32);
+    };
+    load_weights(0);
+    for (int f = 0; f < p.num_fc; ++f) {
+      // two passes of 128 points (64 accumulator VGPRs beside the layer's 80 weight VGPRs): a pass's rows are rewritten
+      // with the layer's output as soon as every wave has finished reading them
+#pragma unroll 1
+      for (int hf = 0; hf < PT / 128; ++hf) {
+        f32x4 acc[MT][8];
 #pragma unroll
-          for (int c = 0; c < MT; ++c) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf, acc[c][q], 0, 0, 0);
+        for (int c = 0; c < MT; ++c)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const f16x8 pf = *reinterpret_cast<const f16x8*>(X + xoff(hf * 128 + q * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int c = 0; c < MT; ++c) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][c], pf, acc[c][q], 0, 0, 0);
+          }
         }
-      }
-      __syncthreads();      // every wave is done reading this layer's input
+        if (hf + 1 == PT / 128 && f + 1 < p.num_fc) load_weights(f + 1);      // in flight during the barrier and the epilogue
+        __syncthreads();      // every wave is done reading these rows
 #pragma unroll
-      for (int c = 0; c < MT; ++c) {
-        const int co = wave * MT * 16 + c * 16 + fq * 4;       // 4 consecutive couts of this lane
-        const float4 bv = *reinterpret_cast<const float4*>(p.b[f] + co);
+        for (int c = 0; c < MT; ++c) {
+          const int co = wave * MT * 16 + c * 16 + fq * 4;       // 4 consecutive couts of this lane
+          const float4 bv = *reinterpret_cast<const float4*>(p.b[f] + co);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int row = q * 16 + fr;
-          f16x4 o;
-          o[0] = (half_t)fmaxf(acc[c][q][0] + bv.x, 0.f);
-          o[1] = (half_t)fmaxf(acc[c][q][1] + bv.y, 0.f);
-          o[2] = (half_t)fmaxf(acc[c][q][2] + bv.z, 0.f);
-          o[3] = (half_t)fmaxf(acc[c][q][3] + bv.w, 0.f);
-          *reinterpret_cast<f16x4*>(X + xoff(row, co >> 3) + (co & 7) * 2) = o;
+          for (int q = 0; q < 8; ++q) {
+            const int row = hf * 128 + q * 16 + fr;
+            f16x4 o;
+            o[0] = (half_t)fmaxf(acc[c][q][0] + bv.x, 0.f);
+            o[1] = (half_t)fmaxf(acc[c][q][1] + bv.y, 0.f);
+            o[2] = (half_t)fmaxf(acc[c][q][2] + bv.z, 0.f);
+            o[3] = (half_t)fmaxf(acc[c][q][3] + bv.w, 0.f);
+            *reinterpret_cast<f16x4*>(X + xoff(row, co >> 3) + (co & 7) * 2) = o;
+          }
         }
       }
       __syncthreads();
     }
     // ---------------- predictor + scatter ----------------
-    for (int j = 0; j < 8; ++j) {
-      const int row = hw + 16 * j;
-      const int64_t pt = g0 + row;
-      const bool live = pt < p.npts;
-      float xv[2][8];
+    // class by class: the class's fp32 weights (two 8-channel chunks per lane) are loaded once, then the half-wave walks
+    // its 16 rows; per row the arithmetic and the reduction order of head1x1_kernel
+    for (int c = 0; c < p.ncls; ++c) {
+      float wv[2][8];
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int kc = hl + 32 * jj;
         if (kc < KC) {
-          const f16x8 v = *reinterpret_cast<const f16x8*>(X + xoff(row, kc));
-#pragma unroll
-          for (int c = 0; c < 8; ++c) xv[jj][c] = (float)v[c];
+          const float4* wp = reinterpret_cast<const float4*>(p.pw + (size_t)c * LD + kc * 8);
+          const float4 w0 = wp[0], w1 = wp[1];
+          wv[jj][0] = w0.x; wv[jj][1] = w0.y; wv[jj][2] = w0.z; wv[jj][3] = w0.w;
+          wv[jj][4] = w1.x; wv[jj][5] = w1.y; wv[jj][6] = w1.z; wv[jj][7] = w1.w;
         } else {
 #pragma unroll
-          for (int c = 0; c < 8; ++c) xv[jj][c] = 0.f;
+          for (int e = 0; e < 8; ++e) wv[jj][e] = 0.f;
         }
       }
-      const int n = live ? (int)(pt / p.P) : 0;
-      const int64_t pix = live ? (int64_t)p.idx[pt] : 0;
-      for (int c = 0; c < p.ncls; ++c) {
+      const float bias = p.pb[c];
+#pragma unroll 4
+      for (int j = 0; j < PT / 16; ++j) {
+        const int row = hw + 16 * j;
+        const int64_t pt = g0 + row;
+        const bool live = pt < p.npts;
         float sacc = 0.f;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           const int kc = hl + 32 * jj;
           if (kc < KC) {
-            const float4* wp = reinterpret_cast<const float4*>(p.pw + (size_t)c * LD + kc * 8);
-            const float4 w0 = wp[0], w1 = wp[1];
-            sacc = fmaf(xv[jj][0], w0.x, sacc); sacc = fmaf(xv[jj][1], w0.y, sacc);
-            sacc = fmaf(xv[jj][2], w0.z, sacc); sacc = fmaf(xv[jj][3], w0.w, sacc);
-            sacc = fmaf(xv[jj][4], w1.x, sacc); sacc = fmaf(xv[jj][5], w1.y, sacc);
-            sacc = fmaf(xv[jj][6], w1.z, sacc); sacc = fmaf(xv[jj][7], w1.w, sacc);
+            const f16x8 v = *reinterpret_cast<const f16x8*>(X + xoff(row, kc));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sacc = fmaf((float)v[e], wv[jj][e], sacc);
           }
         }
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
-        if (hl == 0 && live) p.out[((size_t)n * p.ncls + c) * p.plane + pix] = sacc + p.pb[c];
+        if (hl == 0 && live) {
+          const int n = (int)(pt / p.P);
+          p.out[((size_t)n * p.ncls + c) * p.plane + (int64_t)p.idx[pt]] = sacc + bias;
+        }
       }
     }
     __syncthreads();        // X is rewritten by the next tile's gather
@@ -538,9 +596,9 @@ int launch_pr_mlp(const half_t* feat, int N, int fh, int fw, int C, int feat_ld,
   for (int i = 0; i < num_fc; ++i) { p.w[i] = fc_w[i]; p.b[i] = fc_b[i]; }
   p.num_fc = num_fc; p.pw = pred_w; p.pb = pred_b; p.out = out; p.plane = plane;
   p.npts = (int64_t)N * P;
-  p.tiles = (int)cdiv64(p.npts, 128);
-  const int grid = p.tiles < 512 ? p.tiles : 512;       // two workgroups per CU
-  const size_t lds = (size_t)128 * ld * 2;
+  p.tiles = (int)cdiv64(p.npts, 256);
+  const int grid = p.tiles < 256 ? p.tiles : 256;       // one workgroup per CU
+  const size_t lds = (size_t)256 * ld * 2;
   if (C == 256) {
     static bool attr = false;
     if (!attr) {
