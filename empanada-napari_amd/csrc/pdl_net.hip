@@ -411,6 +411,7 @@ int plan(emp_pdl* n, int N, int H, int W, int RS, hipStream_t stream) {
           std::string q = L + ".P" + std::to_string(3 + lv);
           if (li == 0 && lv < 3) { add_act(n, pl, q + ".rtd", N, lh[lv], lw[lv], F); add_act(n, pl, q + ".rbu", N, lh[lv], lw[lv], F); }
           add_act(n, pl, q + ".fuse", N, lh[lv], lw[lv], F);
+          if (lv > 0) add_act(n, pl, q + ".fuseb", N, lh[lv], lw[lv], F);   // bottom-up node's fused input (kept for taps)
           add_act(n, pl, q + ".dw", N, lh[lv], lw[lv], F);
           add_act(n, pl, q + ".td", N, lh[lv], lw[lv], F);
           add_act(n, pl, q + ".bu", N, lh[lv], lw[lv], F);
@@ -619,7 +620,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
         const std::string pre = fp + ".bifpns." + std::to_string(li);
         auto node = [&](const std::string& dirpre, const std::string& q, const half_t* a, const half_t* b2,
                         const half_t* c3, float ca, float cb, float cc, int mode, const std::string& outname) -> int {
-          const Act& fz = A(q + ".fuse");
+          const Act& fz = A(q + (mode ? ".fuseb" : ".fuse"));
           RC(launch_fuse_combine(a, b2, c3, ca, cb, cc, mode, N, fz.H, fz.W, F, fz.p, s));
           n->flops += 2.0 * 9.0 * (double)N * fz.H * fz.W * F;
           const std::string pwn = dirpre + ".after_combines.0.0.sepconv.1";

@@ -375,25 +375,7 @@ def teacher_forced_layers(P, cfg, x, tap):
         w, b = W(name)
         return F.conv2d(xin, w, b if groups == 1 else None, stride, padding, dilation, groups)
 
-    w, b = W('encoder.conv1', fp32=True)
-    yield 'p1', F.max_pool2d(F.relu(F.conv2d(x, w, b, 2, 3)), 3, 2, 1), True
-    xname = 'p1'
-    pyr = ['p1']
-    for li, nblocks in enumerate(RESNET50_LAYERS, start=1):
-        stride = 1 if li == 1 else 2
-        dil = 1
-        if li == 4 and cfg['stage4_stride'] == 16:
-            stride, dil = 1, 2
-        for bidx in range(nblocks):
-            pre = f'encoder.layer{li}.{bidx}'
-            s = stride if bidx == 0 else 1
-            xin = tap(xname)
-            yield pre + '.c1', F.relu(conv(xin, pre + '.conv1')), True
-            yield pre + '.c2', F.relu(conv(tap(pre + '.c1'), pre + '.conv2', s, dil, dil)), True
-            idn = conv(xin, pre + '.downsample.0', s) if bidx == 0 else xin
-            yield pre, F.relu(conv(tap(pre + '.c2'), pre + '.conv3') + idn), True
-            xname = pre
-        pyr.append(xname)
+    pyr = yield from _tf_encoder(P, cfg, x, tap)
     p5 = tap(pyr[4])
     rates = cfg['atrous_rates']
     decs = ['semantic_decoder'] + (['instance_decoder'] if cfg['ins_decoder'] else [])
@@ -422,8 +404,136 @@ def teacher_forced_layers(P, cfg, x, tap):
     last = len(cfg['low_level_stages']) - 1
     semx = tap(f'semantic_decoder.stage{last}.out')
     insx = tap(f'instance_decoder.stage{last}.out') if cfg['ins_decoder'] else semx
+    yield from _tf_heads(P, semx, insx, tap)
+
+
+def _tf_weights(P, name, fp32=False):
+    w, b = P[name]
+    return (_t(w) if fp32 else Fp16Emu.r16(_t(w))), _t(b)
+
+
+def _tf_conv(P, xin, name, stride=1, padding=0, dilation=1, groups=1):
+    w, b = _tf_weights(P, name)
+    return F.conv2d(xin, w, b if groups == 1 else None, stride, padding, dilation, groups)
+
+
+def _tf_encoder(P, cfg, x, tap):
+    """ResNet-50 part of the teacher-forced check (both network families); returns the pyramid's tap names."""
+    def conv(xin, name, stride=1, padding=0, dilation=1, groups=1):
+        return _tf_conv(P, xin, name, stride, padding, dilation, groups)
+
+    w, b = _tf_weights(P, 'encoder.conv1', fp32=True)
+    yield 'p1', F.max_pool2d(F.relu(F.conv2d(x, w, b, 2, 3)), 3, 2, 1), True
+    xname = 'p1'
+    pyr = ['p1']
+    for li, nblocks in enumerate(RESNET50_LAYERS, start=1):
+        stride = 1 if li == 1 else 2
+        dil = 1
+        if li == 4 and cfg.get('stage4_stride', 32) == 16:
+            stride, dil = 1, 2
+        for bidx in range(nblocks):
+            pre = f'encoder.layer{li}.{bidx}'
+            s = stride if bidx == 0 else 1
+            xin = tap(xname)
+            yield pre + '.c1', F.relu(conv(xin, pre + '.conv1')), True
+            yield pre + '.c2', F.relu(conv(tap(pre + '.c1'), pre + '.conv2', s, dil, dil)), True
+            idn = conv(xin, pre + '.downsample.0', s) if bidx == 0 else xin
+            yield pre, F.relu(conv(tap(pre + '.c2'), pre + '.conv3') + idn), True
+            xname = pre
+        pyr.append(xname)
+    return pyr
+
+
+def _tf_heads(P, semx, insx, tap):
+    """heads.py:12-19 on the engine's decoder outputs: 5x5 separable conv + ReLU + fp32 1x1.  The engine fuses the
+    whole head into one launch when it has at most two output planes (the 256-channel map then never leaves the CU,
+    fp32); a wider head (multi-class semantic) stores that map in fp16 as ``<head>.pw`` and runs the 1x1 from it."""
     for head, xin in (('semantic_head', semx), ('ins_center', insx), ('ins_xy', insx)):
-        dw = r16(conv(xin, f'{head}.head.0.0.sepconv.0', 1, 2, 1, xin.shape[1]))
-        y = F.relu(conv(dw, f'{head}.head.0.0.sepconv.1'))
-        w, b = W(f'{head}.head.1', fp32=True)
+        dw = Fp16Emu.r16(_tf_conv(P, xin, f'{head}.head.0.0.sepconv.0', 1, 2, 1, xin.shape[1]))
+        y = F.relu(_tf_conv(P, dw, f'{head}.head.0.0.sepconv.1'))
+        w, b = _tf_weights(P, f'{head}.head.1', fp32=True)
+        if w.shape[0] > 2:
+            yield head + '.pw', y, True
+            y = tap(head + '.pw')
         yield head + '.out', F.conv2d(y, w, b), False
+
+
+@torch.no_grad()
+def teacher_forced_layers_bifpn(P, cfg, x, tap):
+    """The PanopticBiFPN forward (bifpn.py:185-236, panoptic_bifpn.py:70-82) layer by layer ON THE ENGINE'S OWN INPUTS,
+    same contract as ``teacher_forced_layers``.  Engine tap names (pdl_net.hip): ``p2f``; per decoder ``{d}_fpn.p6pre``,
+    ``.in.P6``, ``.in.P7`` (max-pools: exact), per BiFPN layer ``li`` and level ``P{3..7}`` the resampled inputs ``.rtd`` /
+    ``.rbu`` (layer 0, P3..P5), the fused maps ``.fuse`` (top-down node) / ``.fuseb`` (bottom-up node) and the node
+    outputs ``.td`` / ``.bu``; ``{d}_decoder.cat{i}`` and ``.out``; then the three heads."""
+    r16 = Fp16Emu.r16
+
+    def conv(xin, name, stride=1, padding=0, dilation=1, groups=1):
+        return _tf_conv(P, xin, name, stride, padding, dilation, groups)
+
+    def sep3(pre, fused_name):
+        fz = tap(fused_name)
+        dw = r16(conv(fz, f'{pre}.after_combines.0.0.sepconv.0', 1, 1, 1, fz.shape[1]))
+        return _silu(conv(dw, f'{pre}.after_combines.0.0.sepconv.1'))
+
+    pyr = yield from _tf_encoder(P, cfg, x, tap)
+    yield 'p2f', conv(tap(pyr[1]), 'p2_resample.conv.0'), True
+    eps = 1e-4
+    decs = ['semantic'] + (['instance'] if cfg['ins_decoder'] else [])
+    for d in decs:
+        fp = f'{d}_fpn'
+        yield f'{fp}.p6pre', conv(tap(pyr[4]), f'{fp}.p6_resample.conv.0'), True
+        yield f'{fp}.in.P6', F.max_pool2d(tap(f'{fp}.p6pre'), 3, 2, 1), True
+        yield f'{fp}.in.P7', F.max_pool2d(tap(f'{fp}.in.P6'), 3, 2, 1), True
+        feat = [pyr[2], pyr[3], pyr[4], f'{fp}.in.P6', f'{fp}.in.P7']              # P3..P7
+        for li in range(cfg['fpn_layers']):
+            L, pre = f'{fp}.l{li}', f'{fp}.bifpns.{li}'
+            dp = f'{pre}.top_down_fpn'
+            w = _fusion_weights(P, f'{dp}.weights')
+            td_prev = feat[4]
+            for i in range(4):
+                lv = 3 - i
+                q = f'{L}.P{3 + lv}'
+                hi = feat[lv]
+                if f'{dp}.resamplings.{i}.conv.0' in P:
+                    yield q + '.rtd', conv(tap(feat[lv]), f'{dp}.resamplings.{i}.conv.0'), True
+                    hi = q + '.rtd'
+                up = F.interpolate(tap(td_prev), scale_factor=2.0, mode='nearest')
+                fused = (w[i] * up + w[i + 1] * tap(hi)) / (w[i] + w[i + 1] + eps)
+                yield q + '.fuse', fused, True
+                yield q + '.td', sep3(dp, q + '.fuse'), True
+                td_prev = q + '.td'
+            dp = f'{pre}.bottom_up_fpn'
+            w = _fusion_weights(P, f'{dp}.weights')
+            bu_prev = f'{L}.P3.td'
+            new = [bu_prev]
+            for i in range(4):
+                lv = i + 1
+                q = f'{L}.P{3 + lv}'
+                lo = feat[lv]
+                if f'{dp}.resamplings.{i}.conv.0' in P:
+                    yield q + '.rbu', conv(tap(feat[lv]), f'{dp}.resamplings.{i}.conv.0'), True
+                    lo = q + '.rbu'
+                down = F.max_pool2d(tap(bu_prev), 3, 2, 1)
+                if i < 3:
+                    fused = (w[i] * down + w[i + 1] * tap(lo) + w[i + 2] * tap(q + '.td')) / (w[i] + w[i + 1] + w[i + 2] + eps)
+                else:
+                    fused = (w[i] * down + w[i + 1] * tap(lo)) / (w[i] + w[i + 1] + eps)
+                yield q + '.fuseb', fused, True
+                yield q + '.bu', sep3(dp, q + '.fuseb'), True
+                bu_prev = q + '.bu'
+                new.append(bu_prev)
+            feat = new
+        dp = f'{d}_decoder'
+        skips = [feat[3], feat[2], feat[1], feat[0], 'p2f']
+        xn = feat[4]
+        for i in range(5):
+            w, b = _tf_weights(P, f'{dp}.upsamplings.{i}.0')
+            up = F.relu(F.conv_transpose2d(tap(xn), w, b, stride=2))     # cat{i-1} carries 2F channels, all of them inputs
+            yield f'{dp}.cat{i}', torch.cat([up, tap(skips[i])], dim=1), True
+            xn = f'{dp}.cat{i}'
+        cat = tap(xn)
+        dw = r16(conv(cat, f'{dp}.fusion.0.sepconv.0', 1, 2, 1, cat.shape[1]))
+        yield f'{dp}.out', F.relu(conv(dw, f'{dp}.fusion.0.sepconv.1')), True
+    semx = tap('semantic_decoder.out')
+    insx = tap('instance_decoder.out') if cfg['ins_decoder'] else semx
+    yield from _tf_heads(P, semx, insx, tap)

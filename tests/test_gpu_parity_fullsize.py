@@ -87,29 +87,11 @@ def test_every_layer_is_the_correctly_rounded_fp32_result_at_full_size(case):
     def tap(name):
         return model.tap(name).float().cpu().permute(0, 3, 1, 2).contiguous()
 
-    rows, worst_flip, worst_ulp = [], 0.0, 0.0
-    for name, want, rounds in pdl_model.teacher_forced_layers(case['P'], case['cfg'], case['x'], tap):
-        rms = float(want.pow(2).mean().sqrt())
-        if rounds:
-            got = tap(name)[:, :want.shape[1]]
-            w16 = pdl_model.Fp16Emu.r16(want)
-            d = (got - w16).abs()
-            ulp = torch.maximum(want.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
-            excess = float((d - ulp - 1e-4 * max(1.0, rms)).max())
-            flips = float((got != w16).float().mean())
-            rows.append((name, rms, float(d.max()), flips))
-            worst_flip = max(worst_flip, flips)
-            worst_ulp = max(worst_ulp, float((d / ulp).max()))
-            assert excess <= 0, f'{name}: off by more than one fp16 ulp (max |d| {float(d.max()):.3e}, rms {rms:.3f})'
-            assert flips < 0.05, f'{name}: {flips:.3%} of the elements differ from the correctly rounded result'
-        else:
-            got = fp32_heads[name]
-            d = float((got - want).abs().max())
-            rows.append((name, rms, d, 0.0))
-            assert d < 1e-4 * max(1.0, rms), f'{name}: fp32 head off by {d:.3e} (rms {rms:.3f})'
+    rows = _teacher_forced_rows(pdl_model.teacher_forced_layers(case['P'], case['cfg'], case['x'], tap), tap, fp32_heads)
+    worst_flip, worst_ulp = max(r[3] for r in rows), max(r[4] for r in rows)
     for r in rows:
-        print('%-36s rms %8.4f  max|d| %.3e  differing %.4f' % r)
-    _report('teacher_forced', dict(layers=len(rows), worst_differing_fraction=worst_flip, worst_error_in_ulps=worst_ulp,
+        print('%-36s rms %8.4f  max|d| %.3e  differing %.4f  d/tol %.2f' % r)
+    _report('teacher_forced', dict(layers=len(rows), worst_differing_fraction=worst_flip, worst_error_over_tolerance=worst_ulp,
                                    heads={r[0]: r[2] for r in rows if r[0].endswith('.out') and 'stage' not in r[0]}))
     assert len(rows) >= 60
 
@@ -249,3 +231,59 @@ def test_bifpn_512_tile_vs_fp32_forward(ncls):
     print(f'BiFPN ({ncls} class) 512^2 vs fp32 oracle:', rep)
     _report(f'bifpn_512_ncls{ncls}', rep)
     assert rep['prob']['frac_over_1e2'] < 2e-2          # PointRend selection flips only
+
+
+def _teacher_forced_rows(gen, tap, fp32_heads):
+    """Shared assertion loop of the teacher-forced checks: one fp16 ulp (+1e-4 of the map's scale for the rounded
+    depthwise intermediate) where the engine stores fp16, 1e-4 of the scale on the fp32 heads."""
+    from oracle import pdl_model
+    rows = []
+    for name, want, rounds in gen:
+        rms = float(want.pow(2).mean().sqrt())
+        if rounds:
+            got = tap(name)[:, :want.shape[1]]
+            w16 = pdl_model.Fp16Emu.r16(want)
+            d = (got - w16).abs()
+            ulp = torch.maximum(want.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
+            excess = float((d - ulp - 1e-4 * max(1.0, rms)).max())
+            flips = float((got != w16).float().mean())
+            rows.append((name, rms, float(d.max()), flips, float((d / (ulp + 1e-4 * max(1.0, rms))).max())))
+            assert excess <= 0, f'{name}: off by more than one fp16 ulp (max |d| {float(d.max()):.3e}, rms {rms:.3f})'
+            assert flips < 0.05, f'{name}: {flips:.3%} of the elements differ from the correctly rounded result'
+        else:
+            got = fp32_heads[name]
+            d = float((got - want).abs().max())
+            rows.append((name, rms, d, 0.0, 0.0))
+            assert d < 1e-4 * max(1.0, rms), f'{name}: fp32 head off by {d:.3e} (rms {rms:.3f})'
+    return rows
+
+
+@pytest.mark.parametrize('ncls', [1, 4])
+def test_bifpn_every_layer_is_the_correctly_rounded_fp32_result(ncls):
+    """(A) for the second network family: every map of the PanopticBiFPNPR forward at 512^2 -- encoder at
+    output stride 32, P2 / P6 resampling, the 3 x (top-down + bottom-up) fast-normalised fusion nodes with their 3x3
+    separable convs, the five transposed-conv decoder steps, the 5x5 fusion and the three heads -- recomputed by
+    oracle.pdl_model.teacher_forced_layers_bifpn from the engine's own input maps."""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg = dict(weights.MITONET_MINI_CFG, num_classes=ncls)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    x = torch.from_numpy(normalize(synth.em_tiles(1, 512, seed=77), 0.57571, 0.12765))[:, None]
+    out = {k: v.cpu() for k, v in model(x.cuda(), 2, False).items()}
+    heads = {'semantic_head.out': model.tap_raw('semantic_head.out', (1, ncls, 128, 128)).cpu(),
+             'ins_center.out': out['ctr_hmp'], 'ins_xy.out': out['offsets']}
+
+    def tap(name):
+        return model.tap(name).float().cpu().permute(0, 3, 1, 2).contiguous()
+
+    rows = _teacher_forced_rows(pdl_model.teacher_forced_layers_bifpn(P, cfg, x, tap), tap, heads)
+    for r in rows:
+        print('%-44s rms %9.4f  max|d| %.3e  differing %.4f  d/tol %.2f' % r)
+    _report(f'teacher_forced_bifpn_ncls{ncls}',
+            dict(layers=len(rows), worst_differing_fraction=max(r[3] for r in rows), worst_error_over_tolerance=max(r[4] for r in rows),
+                 heads={r[0]: r[2] for r in rows if r[0] in heads}))
+    assert len(rows) >= 170
