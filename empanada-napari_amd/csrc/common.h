@@ -79,6 +79,9 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream);
 bool conv_igemm256_supported(const ConvParams& p);
 bool conv_uses_256(const ConvParams& p);      // launch_conv_igemm's auto choice
 int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg = 0, int mode = 0);
+// half tile, two workgroups per CU, for the short-K layers (conv_igemm256.hip)
+bool conv_igemm_h256_supported(const ConvParams& p);
+int launch_conv_igemm_h256(ConvParams p, hipStream_t stream, int kg = 0);
 // 64 -> 64 channel 3x3 with register-resident weights and an LDS halo tile (conv3x3c64.hip)
 bool conv3x3_c64_supported(const ConvParams& p);
 int launch_conv3x3_c64(const ConvParams& p, hipStream_t stream);

@@ -34,6 +34,8 @@
 // the cout tiles of one pixel tile run back to back on the same XCD.
 #include "common.h"
 
+#include <type_traits>
+
 namespace emp {
 
 namespace {
@@ -49,10 +51,20 @@ __device__ __forceinline__ int perm32(int x) {
 }
 
 // epilogue activation: 0 none | 1 ReLU | 2 SiLU (x * sigmoid(x), bifpn.py:35,91)
-__device__ __forceinline__ float apply_act(float x, int act) {
-  if (act == 1) return fmaxf(x, 0.f);
-  if (act == 2) return x / (1.f + __expf(-x));
+// compile-time ACT: a run-time switch inside the unrolled epilogue costs ~6 scalar branches PER ELEMENT
+// [measured: 470-850 s_cbranch per kernel, the epilogue of a 256 x 256 tile took ~10 us]
+template <int ACT>
+__device__ __forceinline__ float apply_act(float x) {
+  if (ACT == 1) return fmaxf(x, 0.f);
+  if (ACT == 2) return x / (1.f + __expf(-x));
   return x;
+}
+// calls f(integral_constant<int, act>) with act in {0, 1, 2}
+template <typename F>
+__device__ __forceinline__ void dispatch_act(int act, F&& f) {
+  if (act == 1) f(std::integral_constant<int, 1>{});
+  else if (act == 2) f(std::integral_constant<int, 2>{});
+  else f(std::integral_constant<int, 0>{});
 }
 // output element offset of pixel m / cout co.  ps_cout > 0: the GEMM computes a k=2,s=2 transposed
 // convolution as 4 sub-pixel 1x1 convs (cout blocks q = dy*2+dx of ps_cout channels each) and the
@@ -326,6 +338,8 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave reads back only its own writes
+    dispatch_act(p.act, [&](auto act_tag) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int i = 0; i < TM / RPI; ++i) {
       const int row = i * RPI + l / CPR;
@@ -349,13 +363,16 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
       }
       f16x8 o;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = (half_t)apply_act(v[r], p.act);
+      for (int r = 0; r < 8; ++r) o[r] = (half_t)apply_act<ACT>(v[r]);
       *reinterpret_cast<f16x8*>(out_ptr(p, m, co_l, HoWo)) = o;
     }
+    });
     return;
   } else {
     compute((S - 1) & 1);
     // ---- direct epilogue: lane (fq, fr) owns couts P*32 + fq*8 + [0,8) of pixel fr of each pixel tile ----
+    dispatch_act(p.act, [&](auto act_tag) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
       const int m = m0 + wm * TM + t * 16 + fr;
@@ -391,10 +408,11 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
         }
         f16x8 o;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) o[r] = (half_t)apply_act(v[r], p.act);
+        for (int r = 0; r < 8; ++r) o[r] = (half_t)apply_act<ACT>(v[r]);
         *reinterpret_cast<f16x8*>(out_ptr(p, m, co, HoWo)) = o;
       }
     }
+    });
   }
 }
 
@@ -451,7 +469,8 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   }
   // variant = staging + 16 * tile
   //   staging: 0 auto | 1 register staging | 2 LDS-DMA | 3 LDS-DMA + LDS-transposed epilogue
-  //   tile   : 0 auto | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x256 (conv_igemm256.hip; Cout % 256 == 0)
+  //   tile   : 0 auto | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x256 (conv_igemm256.hip; Cout % 256 == 0) |
+  //            5 half tile 128x256 / 256x128, two workgroups per CU (conv_igemm256.hip; Cout % 128 == 0) | 6 conv3x3_c64
   // (tried and removed, slower on MI355X: a persistent cross-tile pipeline, and a 256x128 8-wave tile with
   //  three LDS stages + counted vmcnt / raw barriers: 865 vs 990 TF/s on the ASPP shape -- DESIGN.md section 4;
   //  a 128x128 4-wave tile with the 256x256 kernel's four-slot ring of 32-channel K-tiles, LDS-DMA three tiles ahead,
@@ -462,6 +481,7 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   int v = variant & 15, tile = (variant >> 4) & 15, kg = (variant >> 8) & 255, mode256 = (variant >> 16) & 15;
   EMP_REQUIRE(v <= 3 && tile <= 6, "conv: bad variant %d", variant);
   if (tile == 6) return launch_conv3x3_c64(p, stream);
+  if (tile == 5) return launch_conv_igemm_h256(p, stream, kg);      // kg counts 32-channel slabs
   {
     // 64 -> 64 channel 3x3 (ResNet layer1 conv2): weights in registers, halo tile in LDS (conv3x3c64.hip), once there
     // are enough 8 x 16 tiles for its 256 persistent workgroups

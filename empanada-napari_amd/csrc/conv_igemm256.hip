@@ -51,16 +51,85 @@ __device__ __forceinline__ int perm32b(int x) {
   const int t = x >> 4, i = x & 15;
   return ((i >> 2) << 3) + (t << 2) + (i & 3);
 }
-__device__ __forceinline__ float act_fn(float x, int act) {
-  if (act == 1) return fmaxf(x, 0.f);
-  if (act == 2) return x / (1.f + __expf(-x));
-  return x;
-}
 __device__ __forceinline__ void lds_barrier() {
   // Raw barrier that orders LDS traffic only.  A fence (or __syncthreads) would also drain vmcnt: an in-flight
   // LDS-DMA is a pending LDS write on the VM counter.  The "memory" clobber keeps the compiler from moving
   // memory accesses across it; DMA completion is handled by the counted vmcnt waits of the issuing waves.
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Epilogue of a 128-pixel x 64-cout wave tile straight from the accumulators: lane (fq, fr) owns couts
+// co0 + pair*32 + fq*8 + [0,8) of pixel mrow0 + q*16 + fr.  ACT is a compile-time constant (a run-time switch inside
+// the unrolled loops costs ~6 scalar branches per ELEMENT: 850 s_cbranch, ~10 us per 256 x 256 tile [measured]); the
+// bias is read once and the 16 residual fragments are requested up front (the K-loop's fragment registers are free).
+template <int ACT>
+__device__ __forceinline__ float act_c(float x) {
+  if (ACT == 1) return fmaxf(x, 0.f);
+  if (ACT == 2) return x / (1.f + __expf(-x));
+  return x;
+}
+template <int ACT>
+__device__ __forceinline__ void wave_epilogue(const ConvParams& p, f32x4 (&acc)[4][8], int mrow0, int co0, int fr, int fq,
+                                              int HoWo) {
+  float bv[2][8];
+#pragma unroll
+  for (int P = 0; P < 2; ++P) {
+    const int co = co0 + P * 32 + fq * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bv[P][r] = 0.f;
+    if (p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+      bv[P][0] = b0.x; bv[P][1] = b0.y; bv[P][2] = b0.z; bv[P][3] = b0.w;
+      bv[P][4] = b1.x; bv[P][5] = b1.y; bv[P][6] = b1.z; bv[P][7] = b1.w;
+    }
+  }
+  f16x8 rv[8][2];
+  if (p.res) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int m = mrow0 + q * 16 + fr;
+      const half_t* rp = m < p.M ? p.res + (size_t)m * p.res_ld + co0 + fq * 8 : p.zero;
+      rv[q][0] = *reinterpret_cast<const f16x8*>(rp);
+      rv[q][1] = *reinterpret_cast<const f16x8*>(m < p.M ? rp + 32 : p.zero);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int m = mrow0 + q * 16 + fr;
+    if (m >= p.M) continue;
+    half_t* orow = p.out + (size_t)m * p.out_ld + co0 + fq * 8;
+    const float* bn = p.bias_n ? p.bias_n + (size_t)(m / HoWo) * p.Cout + co0 + fq * 8 : nullptr;
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[2 * P][q][r] + bv[P][r];
+        v[4 + r] = acc[2 * P + 1][q][r] + bv[P][4 + r];
+      }
+      if (bn) {
+        const float4 b0 = *reinterpret_cast<const float4*>(bn + P * 32);
+        const float4 b1 = *reinterpret_cast<const float4*>(bn + P * 32 + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[q][P][r];
+      }
+      f16x8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = (half_t)act_c<ACT>(v[r]);
+      *reinterpret_cast<f16x8*>(orow + P * 32) = o;
+    }
+  }
+}
+__device__ __forceinline__ void wave_epilogue_any(const ConvParams& p, f32x4 (&acc)[4][8], int mrow0, int co0, int fr,
+                                                  int fq, int HoWo) {
+  if (p.act == 1) wave_epilogue<1>(p, acc, mrow0, co0, fr, fq, HoWo);
+  else if (p.act == 2) wave_epilogue<2>(p, acc, mrow0, co0, fr, fq, HoWo);
+  else wave_epilogue<0>(p, acc, mrow0, co0, fr, fq, HoWo);
 }
 
 // DMA_EARLY: how many of the 4 LDS-DMA pieces of K-tile t+3 a wave issues in its LOAD slot (before the wait), the
@@ -263,47 +332,188 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
   }
   if (grp == 0) lds_barrier();      // equal barrier count for both groups
 
-  // ---- epilogue: lane (fq, fr) owns couts pair*32 + fq*8 + [0,8) of pixel fr of each pixel tile ----
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int m = m0 + grp * 128 + q * 16 + fr;
-    if (m >= p.M) continue;
-    const int n_img = (p.bias_n != nullptr) ? m / HoWo : 0;
-#pragma unroll
-    for (int P = 0; P < 2; ++P) {
-      const int co = n0 + wc * 64 + P * 32 + fq * 8;
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[2 * P][q][r];
-        v[4 + r] = acc[2 * P + 1][q][r];
-      }
-      if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      }
-      if (p.bias_n) {
-        const float* bn = p.bias_n + (size_t)n_img * p.Cout + co;
-        const float4 b0 = *reinterpret_cast<const float4*>(bn);
-        const float4 b1 = *reinterpret_cast<const float4*>(bn + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      }
-      if (p.res) {
-        const f16x8 rv = *reinterpret_cast<const f16x8*>(p.res + (size_t)m * p.res_ld + co);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
-      }
-      f16x8 o;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] = (half_t)act_fn(v[r], p.act);
-      *reinterpret_cast<f16x8*>(p.out + (size_t)m * p.out_ld + co) = o;
-    }
-  }
+  wave_epilogue_any(p, acc, m0 + grp * 128, n0 + wc * 64, fr, fq, HoWo);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Half tile: one "group" of the kernel above as its own workgroup -- 4 waves, PXR pixels x COR couts with
+// PXR + COR = 384 (128 x 256 or 256 x 128), the same 128 x 64 wave tile (12 fragment reads per 32 MFMAs), K-tiles of
+// 32 channels through a ring of THREE 24 KiB slots filled two K-tiles ahead, ONE LDS-only barrier per K-tile, and TWO
+// workgroups per CU (72 KiB LDS, <= 256 VGPRs each).  For the layers whose K is too short for the full tile (ResNet
+// conv3 / projection shortcuts / stride-2 3x3s: 4-24 K-tiles): there the 256 x 256 tile spends as long in its
+// prologue + epilogue (256 KiB of residual + output per tile, nothing to overlap them with on a one-workgroup CU) as
+// in its main loop, and the 128 x 128 tile is LDS-read bound (64 x 64 wave tile: 128 B/clk at the MFMA peak).  Two
+// independent workgroups overlap one's epilogue with the other's main loop.  K order = the other kernels' order.
+template <int PXR, int COR>
+__global__ void __launch_bounds__(256, 2) conv_igemm_h256_kernel(const ConvParams p) {
+  constexpr int PPW = PXR / 64, CPW = COR / 64;        // 16-row pieces per wave and K-tile: pixels / couts (2+4 or 4+2)
+  constexpr int HSLOT = (PXR + COR) * 64;              // 24576
+  constexpr int HW_OFF = PXR * 64;
+  constexpr int NWC = COR / 64;                        // waves along the couts (4 or 2)
+  constexpr int NP = PPW + CPW;                        // 6 DMA pieces per wave and K-tile
+  static_assert(PXR + COR == 384 && NP == 6, "half tile: 128 x 256 or 256 x 128");
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, j = bid >> 3;
+  const int mtile = xcd * p.mt_per_xcd + j / p.nt;
+  const int ntile = j % p.nt;
+  if (mtile >= p.mt) return;
+  const int m0 = mtile * PXR, n0 = ntile * COR;
+
+  const int tid = threadIdx.x, l = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wp = wave / NWC, wc = wave % NWC;
+  const int HoWo = p.Ho * p.Wo;
+  const int KT = p.KH * p.KW;
+  const int CB = p.Cin / KS;
+  const int KG = p.kgroup;
+  const int KT1 = KT * CB;
+  const int KTOT = KT1 + (p.in2 ? p.Cin2 / KS : 0);
+  const bool pointwise = (KT == 1) && p.stride == 1 && p.pad == 0;
+
+  const int srow = l >> 2;
+  const int schunk = (l & 3) ^ ((-(l >> 4)) & 3);
+  const half_t* a_img[PPW];
+  int a_iy0[PPW], a_ix0[PPW];
+  const half_t* a_cur[PPW];
+  int a_inc[PPW];
+  const half_t* a_two[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int m = m0 + (wave + 4 * i) * 16 + srow;
+    a_img[i] = p.in;
+    a_iy0[i] = a_ix0[i] = -(1 << 28);
+    a_cur[i] = p.zero;
+    a_inc[i] = 0;
+    a_two[i] = p.zero;
+    if (m < p.M) {
+      if (p.in2) {
+        const int n = m / HoWo;
+        const int r = m - n * HoWo;
+        const int oy = r / p.Wo;
+        const int ox = r - oy * p.Wo;
+        a_two[i] = p.in2 + (((size_t)n * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.in2_ld + schunk * 8;
+      }
+      if (pointwise) {
+        a_cur[i] = p.in + (size_t)m * p.in_ld + schunk * 8;
+        a_inc[i] = KS;
+      } else {
+        const int n = m / HoWo;
+        const int r = m - n * HoWo;
+        const int oy = r / p.Wo;
+        const int ox = r - oy * p.Wo;
+        a_iy0[i] = oy * p.stride - p.pad;
+        a_ix0[i] = ox * p.stride - p.pad;
+        a_img[i] = p.in + (size_t)n * p.H * p.W * p.in_ld + schunk * 8;
+      }
+    }
+  }
+  const half_t* b_base[CPW];
+  const half_t* b_cur[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int row = (wave + 4 * i) * 16 + srow;
+    const int co = n0 + (row & ~31) + perm32b(row & 31);
+    b_base[i] = b_cur[i] = p.wgt + (size_t)co * (KT * p.Cin + (p.in2 ? p.Cin2 : 0)) + schunk * 8;
+  }
+  int st_ky = 0, st_kx = 0, st_cb = 0, st_grp = 0, st_u = 0;
+  auto stage = [&]() {        // address work + the 6 LDS-DMA pieces of K-tile st_u into ring slot st_u % 3
+    if (st_u == KT1 && p.in2) {
+#pragma unroll
+      for (int i = 0; i < PPW; ++i) {
+        a_cur[i] = a_two[i];
+        a_inc[i] = (a_two[i] != p.zero) ? KS : 0;
+      }
+    }
+    if (st_cb == 0 && st_u < KT1) {
+      const int c0 = st_grp * KG * KS;
+      if (!pointwise) {
+        const int dy = st_ky * p.dil, dx = st_kx * p.dil;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+          const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+          const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          a_cur[i] = ok ? a_img[i] + ((size_t)iy * p.W + ix) * p.in_ld + c0 : p.zero;
+          a_inc[i] = ok ? KS : 0;
+        }
+      }
+      if (KG != CB) {
+        const int koff = (st_ky * p.KW + st_kx) * p.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) b_cur[i] = b_base[i] + koff;
+      }
+    }
+    char* slot = lds + (st_u % 3) * HSLOT;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_cur[i],
+                                       (__attribute__((address_space(3))) void*)(slot + (wave + 4 * i) * 1024), 16, 0, 0);
+      a_cur[i] += a_inc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_cur[i],
+                                       (__attribute__((address_space(3))) void*)(slot + HW_OFF + (wave + 4 * i) * 1024), 16, 0, 0);
+      b_cur[i] += KS;
+    }
+    if (++st_cb == KG) {
+      st_cb = 0;
+      if (++st_kx == p.KW) {
+        st_kx = 0;
+        if (++st_ky == p.KH) { st_ky = 0; ++st_grp; }
+      }
+    }
+    ++st_u;
+  };
+
+  const int fr = l & 15, fq = l >> 4;
+  const int foff = fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
+  const int p_off = wp * 128 * 64 + foff;
+  const int w_off = HW_OFF + wc * 64 * 64 + foff;
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: two K-tiles in flight, the first one landed
+  stage();
+  if (KTOT > 1) {
+    stage();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  lds_barrier();
+
+  f16x8 pf[8], wf[4];
+  for (int t = 0; t < KTOT; ++t) {
+    const char* base = lds + (t % 3) * HSLOT;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wf[c] = *reinterpret_cast<const f16x8*>(base + w_off + c * 1024);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pf[q] = *reinterpret_cast<const f16x8*>(base + p_off + q * 1024);
+    // K-tile t+2 goes into the slot of K-tile t-1, which every wave finished reading before the previous barrier
+    if (t + 2 < KTOT) {
+      stage();
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");     // my pieces of t+1 landed, t+2 in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[q], acc[c][q], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  wave_epilogue_any(p, acc, m0 + wp * 128, n0 + wc * 64, fr, fq, HoWo);
+}
 
 }  // namespace
 
@@ -344,6 +554,39 @@ int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode) {
   if (mode == 1) return launch256<2>(p, grid, stream);
   if (mode == 2) return launch256<4>(p, grid, stream);
   return launch256<0>(p, grid, stream);
+}
+
+// half tile (conv_igemm_h256_kernel): 128 pixels x 256 couts when Cout % 256 == 0, else 256 pixels x 128 couts
+bool conv_igemm_h256_supported(const ConvParams& p) {
+  return p.Cout % 128 == 0 && p.ps_cout == 0 && p.out2 == nullptr && p.Cin % KS == 0 && (!p.in2 || p.Cin2 % KS == 0);
+}
+
+template <int PXR, int COR>
+static int launch_h256(ConvParams p, hipStream_t stream) {
+  static bool attr_set = false;
+  constexpr int LDS_BYTES = 3 * (PXR + COR) * 64;
+  if (!attr_set) {
+    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_h256_kernel<PXR, COR>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    attr_set = true;
+  }
+  p.mt = cdiv(p.M, PXR);
+  p.nt = p.Cout / COR;
+  p.mt_per_xcd = cdiv(p.mt, 8);
+  const int grid = 8 * p.mt_per_xcd * p.nt;
+  hipLaunchKernelGGL((conv_igemm_h256_kernel<PXR, COR>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_conv_igemm_h256(ConvParams p, hipStream_t stream, int kg) {
+  EMP_REQUIRE(conv_igemm_h256_supported(p), "conv h256: unsupported shape (Cout=%d)", p.Cout);
+  const int CB = p.Cin / KS, KT = p.KH * p.KW;
+  if (kg == 0) kg = 8;
+  if (KT == 1 || kg > CB || CB % kg != 0) kg = CB;
+  p.kgroup = kg;
+  if (p.Cout % 256 == 0) return launch_h256<128, 256>(p, stream);
+  return launch_h256<256, 128>(p, stream);
 }
 
 }  // namespace emp
