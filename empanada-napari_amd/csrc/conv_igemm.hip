@@ -430,15 +430,25 @@ int launch_tpl(ConvParams p, hipStream_t stream) {
 }  // namespace
 
 // auto dispatch rule: 256x256 tile (conv_igemm256.hip) when it fills the chip -- one workgroup per CU, so it needs
-// >= ~1 tile per CU -- and K is long enough to amortise its prologue / epilogue.
+// >= ~1 tile per CU -- and K is long enough to amortise its prologue / epilogue: K >= 512, or K >= 128 when the
+// reduction continues over a second source (projection shortcuts: 128 x 128 tiles would re-read both sources per cout
+// tile).  [profiles/r02_rule_sweep.txt: layer1.0 conv3+ds 508 -> 402 us, layer2.0 conv3+ds 419 -> 313, layer4 conv3
+// 490 -> 450; K = 128 / 256 with a residual (layer2 / layer3 conv3) stay on 128 x 128: 263 vs 294, 165 vs 180.]
 bool conv_uses_256(const ConvParams& p) {
   static const bool no256 = [] { const char* e = getenv("EMP_CONV_NO256"); return e && e[0] == '1'; }();   // A/B runs
   static const int min_k = [] { const char* e = getenv("EMP_CONV_256_MINK"); return e ? atoi(e) : 512; }();
   const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * (p.Cout / 256);
-  // one workgroup per CU cannot overlap its epilogue with another tile's main loop: with a residual to read the
-  // epilogue moves 256 KB per tile, as long as a K = 512 main loop (layer4 conv3: 0.57 ms vs 0.51 on 128x128)
   const int k256 = p.KH * p.KW * p.Cin + (p.in2 ? p.Cin2 : 0);
-  return !no256 && !p.out2 && conv_igemm256_supported(p) && tiles256 >= 192 && k256 >= (p.res ? 2 * min_k : min_k);
+  return !no256 && !p.out2 && conv_igemm256_supported(p) && tiles256 >= 192 && k256 >= (p.in2 ? min_k / 4 : min_k);
+}
+// half tile 256 pixels x 128 couts, two workgroups per CU (conv_igemm256.hip): the 128-cout layers with K >= 256
+// (layer2 conv1 / stride-2 conv2: 350 -> 325 us, 244 -> 230) -- the 128 x 128 tile is LDS-read bound there
+bool conv_uses_h256(const ConvParams& p) {
+  static const int h256 = [] { const char* e = getenv("EMP_CONV_H256"); return e ? atoi(e) : 1; }();   // A/B runs: 0 off, 2 all
+  if (!h256 || !conv_igemm_h256_supported(p)) return false;
+  const int64_t tiles = (int64_t)cdiv(p.M, 128) * (p.Cout / 128) / 2;
+  if (tiles < 1024) return false;
+  return h256 == 2 || (p.Cout == 128 && p.KH * p.KW * p.Cin >= 256);
 }
 
 int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
@@ -507,6 +517,7 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   }
   if (tile == 0) {
     if (conv_uses_256(p)) return launch_conv_igemm256(p, stream);
+    if (conv_uses_h256(p)) return launch_conv_igemm_h256(p, stream);
     tile = (p.Cout <= 64) ? 2 : 1;
     // a single image leaves the deep layers with a handful of 128x128 tiles for 256 CUs (batch-1 latency, the
     // reference's own calling convention): 64x64 tiles walk K in the same order (bit-identical results) on 4x the CUs
