@@ -71,6 +71,14 @@ struct ConvParams {
   // Two convolutions of the same input (the two decoders' low-level projections) share one pass over it.
   half_t* out2;
   int out2_ld, split;
+  // optional back-to-back 1x1 convolution of the finished tile (256x256 tile only, Cout == 256 so that a workgroup owns
+  // all channels of its pixels): next_out[m][0..next_cout) = relu(next_w . out[m][0..Cout) + next_b) -- the conv1 of the
+  // NEXT bottleneck block computed from the tile while it is still in LDS, so that launch and its read of the widest
+  // map go away.  next_w (next_cout, Cout) fp16 row-major, next_cout == 64 (ResNet layer1).
+  const half_t* next_w;
+  const float* next_b;
+  half_t* next_out;
+  int next_cout, next_ld;
 };
 
 // variant: 0 = auto, 1 = register-staged, 2 = LDS-DMA staged
@@ -79,6 +87,7 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream);
 bool conv_igemm256_supported(const ConvParams& p);
 bool conv_uses_256(const ConvParams& p);      // launch_conv_igemm's auto choice
 int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg = 0, int mode = 0);
+bool conv_b2b_supported(const ConvParams& p);   // can the 256x256 tile run p with its next_* convolution fused in
 // half tile, two workgroups per CU, for the short-K layers (conv_igemm256.hip)
 bool conv_igemm_h256_supported(const ConvParams& p);
 int launch_conv_igemm_h256(ConvParams p, hipStream_t stream, int kg = 0);

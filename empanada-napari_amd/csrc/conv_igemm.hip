@@ -489,6 +489,10 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   //  128->512: 0.316 vs 0.278) -- with two workgroups per CU the global-load latency is already covered and the
   //  second barrier per 64 channels costs more than the deeper prefetch saves)
   int v = variant & 15, tile = (variant >> 4) & 15, kg = (variant >> 8) & 255, mode256 = (variant >> 16) & 15;
+  if (p.next_w) {
+    EMP_REQUIRE(conv_b2b_supported(p), "conv: a fused next convolution needs the 256x256 tile (Cout == 256, >= 192 tiles)");
+    return launch_conv_igemm256(p, stream, kg, mode256);
+  }
   EMP_REQUIRE(v <= 3 && tile <= 6, "conv: bad variant %d", variant);
   if (tile == 6) return launch_conv3x3_c64(p, stream);
   if (tile == 5) return launch_conv_igemm_h256(p, stream, kg);      // kg counts 32-channel slabs

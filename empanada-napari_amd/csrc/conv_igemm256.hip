@@ -125,6 +125,104 @@ __device__ __forceinline__ void wave_epilogue(const ConvParams& p, f32x4 (&acc)[
     }
   }
 }
+// Fused epilogue + back-to-back 1x1 conv (ConvParams::next_*): the finished fp16 tile (256 pixels x 256 channels =
+// 128 KiB) goes to HBM as usual AND into the (now idle) LDS ring as rows of 512 B -- 16-byte chunk c of pixel row r at
+// chunk c ^ (r & 15) -- from where wave w multiplies pixel rows [32w, 32w+32) with the next conv's weights (A fragments
+// straight from L2, rows permuted like the main kernel's so that a lane ends up with 8 consecutive couts): K ascends in
+// 32-channel steps from a zero accumulator, i.e. the result is bit-identical to the separate launch.
+template <int ACT>
+__device__ __forceinline__ void wave_epilogue_b2b(const ConvParams& p, f32x4 (&acc)[4][8], char* lds, int m0, int grp, int wc,
+                                                  int wave, int fr, int fq, int HoWo) {
+  const int mrow0 = m0 + grp * 128, co0 = wc * 64;
+  float bv[2][8];
+#pragma unroll
+  for (int P = 0; P < 2; ++P) {
+    const int co = co0 + P * 32 + fq * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bv[P][r] = 0.f;
+    if (p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
+      bv[P][0] = b0.x; bv[P][1] = b0.y; bv[P][2] = b0.z; bv[P][3] = b0.w;
+      bv[P][4] = b1.x; bv[P][5] = b1.y; bv[P][6] = b1.z; bv[P][7] = b1.w;
+    }
+  }
+  f16x8 rv[8][2];
+  if (p.res) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int m = mrow0 + q * 16 + fr;
+      const half_t* rp = m < p.M ? p.res + (size_t)m * p.res_ld + co0 + fq * 8 : p.zero;
+      rv[q][0] = *reinterpret_cast<const f16x8*>(rp);
+      rv[q][1] = *reinterpret_cast<const f16x8*>(m < p.M ? rp + 32 : p.zero);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = grp * 128 + q * 16 + fr;
+    const int m = m0 + row;
+    half_t* orow = p.out + (size_t)m * p.out_ld + co0 + fq * 8;
+#pragma unroll
+    for (int P = 0; P < 2; ++P) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[2 * P][q][r] + bv[P][r];
+        v[4 + r] = acc[2 * P + 1][q][r] + bv[P][4 + r];
+      }
+      if (p.res) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[q][P][r];
+      }
+      f16x8 o;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = (half_t)act_c<ACT>(v[r]);
+      if (m < p.M) *reinterpret_cast<f16x8*>(orow + P * 32) = o;
+      const int chunk = wc * 8 + P * 4 + fq;
+      *reinterpret_cast<f16x8*>(lds + row * 512 + ((chunk ^ (row & 15)) << 4)) = o;
+    }
+  }
+  lds_barrier();
+  // ---- second GEMM: next_out[32 pixels of this wave][64 couts]; both operands from LDS (the next conv's weights were
+  // LDS-DMA'd behind the ring at kernel entry: a global load here would sit behind the tile's 16 stores on the in-order
+  // vector-memory counter, and holding 32 fragments in registers next to the accumulators spills) ----
+  const char* w2 = lds + NSLOT * SLOT_BYTES;
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    f32x4 a2[2][2];
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) a2[tp][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r0 = pp * 32 + perm32b(fr), r1 = pp * 32 + perm32b(16 + fr);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const f16x8 wa = *reinterpret_cast<const f16x8*>(w2 + r0 * 512 + (((ks * 4 + fq) ^ (r0 & 15)) << 4));
+      const f16x8 wb = *reinterpret_cast<const f16x8*>(w2 + r1 * 512 + (((ks * 4 + fq) ^ (r1 & 15)) << 4));
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = wave * 32 + t * 16 + fr;
+        const f16x8 yb = *reinterpret_cast<const f16x8*>(lds + row * 512 + (((ks * 4 + fq) ^ (row & 15)) << 4));
+        a2[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, yb, a2[0][t], 0, 0, 0);
+        a2[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb, yb, a2[1][t], 0, 0, 0);
+      }
+    }
+    const int co2 = pp * 32 + fq * 8;
+    const float4 b0 = *reinterpret_cast<const float4*>(p.next_b + co2);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.next_b + co2 + 4);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int m = m0 + wave * 32 + t * 16 + fr;
+      if (m >= p.M) continue;
+      f16x8 o;
+      o[0] = (half_t)fmaxf(a2[0][t][0] + b0.x, 0.f); o[1] = (half_t)fmaxf(a2[0][t][1] + b0.y, 0.f);
+      o[2] = (half_t)fmaxf(a2[0][t][2] + b0.z, 0.f); o[3] = (half_t)fmaxf(a2[0][t][3] + b0.w, 0.f);
+      o[4] = (half_t)fmaxf(a2[1][t][0] + b1.x, 0.f); o[5] = (half_t)fmaxf(a2[1][t][1] + b1.y, 0.f);
+      o[6] = (half_t)fmaxf(a2[1][t][2] + b1.z, 0.f); o[7] = (half_t)fmaxf(a2[1][t][3] + b1.w, 0.f);
+      *reinterpret_cast<f16x8*>(p.next_out + (size_t)m * p.next_ld + co2) = o;
+    }
+  }
+}
 __device__ __forceinline__ void wave_epilogue_any(const ConvParams& p, f32x4 (&acc)[4][8], int mrow0, int co0, int fr,
                                                   int fq, int HoWo) {
   if (p.act == 1) wave_epilogue<1>(p, acc, mrow0, co0, fr, fq, HoWo);
@@ -134,7 +232,7 @@ __device__ __forceinline__ void wave_epilogue_any(const ConvParams& p, f32x4 (&a
 
 // DMA_EARLY: how many of the 4 LDS-DMA pieces of K-tile t+3 a wave issues in its LOAD slot (before the wait), the
 // rest go out in the shadow of its MFMAs
-template <int DMA_EARLY>
+template <int DMA_EARLY, bool B2B>
 __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
 
@@ -263,6 +361,45 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (B2B) {
+    // the next conv's weights (64 couts x 256 channels = 32 KiB) behind the ring: 4 LDS-DMA pieces per wave, rows of
+    // 512 B, 16-byte chunk c of row r at chunk c ^ (r & 15); oldest on the vector-memory counter, so every later
+    // counted wait covers them
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = wave * 4 + i;                    // 1 KiB = rows 2*piece, 2*piece + 1
+      const int r = piece * 2 + (l >> 5), cdst = l & 31;
+      const half_t* srcw = p.next_w + (size_t)r * 256 + ((cdst ^ (r & 15)) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcw,
+                                       (__attribute__((address_space(3))) void*)(lds + NSLOT * SLOT_BYTES + piece * 1024), 16, 0, 0);
+    }
+  }
+  f16x8 pf[8], wf[4];
+  if (KTOT < 4) {
+    // short reduction (ResNet layer1's 64 -> 256 conv3 with a fused next conv): everything staged at once, no pipeline
+#pragma unroll 1
+    for (int u = 0; u < KTOT; ++u) {
+      stage_prep();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma(i);
+      ++st_u;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+#pragma unroll 1
+    for (int t = 0; t < KTOT; ++t) {
+      const char* base = lds + t * SLOT_BYTES;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wf[c] = *reinterpret_cast<const f16x8*>(base + w_off + c * 1024);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pf[q] = *reinterpret_cast<const f16x8*>(base + p_off + q * 1024);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[q], acc[c][q], 0, 0, 0);
+    }
+    lds_barrier();      // every wave is done reading the ring
+  } else {
   // ---- prologue: three K-tiles in flight, the first one landed ----
 #pragma unroll 1
   for (int u = 0; u < 3; ++u) {
@@ -275,7 +412,6 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
   lds_barrier();
   if (grp == 1) lds_barrier();      // group 1 runs one slot behind group 0
 
-  f16x8 pf[8], wf[4];
   auto load_frags = [&](int t) {
     const char* base = lds + (t & (NSLOT - 1)) * SLOT_BYTES;
 #pragma unroll
@@ -331,8 +467,14 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
     lds_barrier();
   }
   if (grp == 0) lds_barrier();      // equal barrier count for both groups
+  }
 
-  wave_epilogue_any(p, acc, m0 + grp * 128, n0 + wc * 64, fr, fq, HoWo);
+  if constexpr (B2B) {      // n0 == 0: the launcher guarantees Cout == 256
+    if (p.act == 1) wave_epilogue_b2b<1>(p, acc, lds, m0, grp, wc, wave, fr, fq, HoWo);
+    else wave_epilogue_b2b<0>(p, acc, lds, m0, grp, wc, wave, fr, fq, HoWo);
+  } else {
+    wave_epilogue_any(p, acc, m0 + grp * 128, n0 + wc * 64, fr, fq, HoWo);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -517,19 +659,26 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_h256_kernel(const ConvParam
 
 }  // namespace
 
-bool conv_igemm256_supported(const ConvParams& p) {
-  return p.Cout % 256 == 0 && p.ps_cout == 0 && p.Cin % KS == 0 && p.KH * p.KW * (p.Cin / KS) + (p.in2 ? p.Cin2 / KS : 0) >= 4;
+bool conv_b2b_supported(const ConvParams& p) {
+  return p.next_w != nullptr && p.Cout == 256 && p.next_cout == 64 &&
+         p.next_ld % 8 == 0 && p.ps_cout == 0 && p.out2 == nullptr && p.bias_n == nullptr && p.act <= 1 &&
+         (int64_t)cdiv(p.M, 256) >= 192 && p.Cin % KS == 0 && (!p.in2 || p.Cin2 % KS == 0);
 }
 
-template <int DMA_EARLY>
+bool conv_igemm256_supported(const ConvParams& p) {
+  return p.Cout % 256 == 0 && p.ps_cout == 0 && p.Cin % KS == 0 && p.KH * p.KW * (p.Cin / KS) + (p.in2 ? p.Cin2 / KS : 0) >= 1;
+}
+
+template <int DMA_EARLY, bool B2B = false>
 static int launch256(const ConvParams& p, int grid, hipStream_t stream) {
   static bool attr_set = false;
+  constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + (B2B ? 64 * 256 * 2 : 0);
   if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm256_kernel<DMA_EARLY>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, NSLOT * SLOT_BYTES));
+    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm256_kernel<DMA_EARLY, B2B>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_igemm256_kernel<DMA_EARLY>, dim3(grid), dim3(512), NSLOT * SLOT_BYTES, stream, p);
+  hipLaunchKernelGGL((conv_igemm256_kernel<DMA_EARLY, B2B>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
@@ -537,6 +686,7 @@ static int launch256(const ConvParams& p, int grid, hipStream_t stream) {
 // kg: channel slabs (32 ch) per K-walk group, 0 = default; mode: 0 = default, 1 / 2 = 2 / 4 DMA pieces issued early
 int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode) {
   EMP_REQUIRE(conv_igemm256_supported(p), "conv256: unsupported shape (Cout=%d)", p.Cout);
+  EMP_REQUIRE(p.next_w == nullptr || conv_b2b_supported(p), "conv256: the fused next convolution needs Cout == 256 (got %d)", p.Cout);
   {
     const int CB = p.Cin / KS, KT = p.KH * p.KW;
     static const int env_kg = [] { const char* e = getenv("EMP_CONV256_KGROUP"); return e ? atoi(e) : 0; }();   // A/B runs
@@ -551,6 +701,7 @@ int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode) {
   p.nt = p.Cout / 256;
   p.mt_per_xcd = cdiv(p.mt, 8);
   const int grid = 8 * p.mt_per_xcd * p.nt;
+  if (p.next_w) return launch256<0, true>(p, grid, stream);
   if (mode == 1) return launch256<2>(p, grid, stream);
   if (mode == 2) return launch256<4>(p, grid, stream);
   return launch256<0>(p, grid, stream);

@@ -61,6 +61,7 @@ struct emp_pdl {
   // fused separable convs (sepconv.hip); EMP_FUSE_SEPCONV=0 keeps the dwconv + 1x1 conv + head1x1 launches (A/B runs)
   bool fuse_stem = [] { const char* e = getenv("EMP_FUSE_STEM"); return !(e && e[0] == '0'); }();   // stem.hip
   bool fuse_ds = [] { const char* e = getenv("EMP_FUSE_DS"); return !(e && e[0] == '0'); }();       // conv3 + downsample in one GEMM
+  bool fuse_b2b = [] { const char* e = getenv("EMP_FUSE_B2B"); return !(e && e[0] == '0'); }();     // conv3 + the next block's conv1
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
   bool fuse_pr = [] { const char* e = getenv("EMP_FUSE_PR"); return !(e && e[0] == '0'); }();             // pointrend.hip
 
@@ -491,7 +492,8 @@ T* rawp(emp_pdl* n, const std::string& name) {
 // conv helper: in (channels [0,Cin_pad) of `in`), out channels [coff, coff+Cout) of `out`
 int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const Act& out, int out_coff, int stride,
          int pad, int dil, int act, const Act* res, const float* bias_n, hipStream_t s, int ps_cout = 0,
-         const Act* in2 = nullptr, int stride2 = 1, const Act* out2 = nullptr, int out2_coff = 0, int split = 0) {
+         const Act* in2 = nullptr, int stride2 = 1, const Act* out2 = nullptr, int out2_coff = 0, int split = 0,
+         const std::string* next_name = nullptr, const Act* next_out = nullptr, bool* fused_next = nullptr) {
   const DevConv& dc = n->convs.at(wname);
   ConvParams p{};
   if (out2) {     // couts [split, Cout) go to a second tensor (ConvParams::out2)
@@ -526,12 +528,27 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
   p.act = act;
   p.ps_cout = ps_cout;
   p.M = p.N * p.Ho * p.Wo;
+  double next_flops = 0.0;
+  if (fused_next) *fused_next = false;
+  if (next_name && n->fuse_b2b) {
+    // the next bottleneck's conv1 (1x1, stride 1, ReLU) computed from this launch's tile while it is in LDS
+    const DevConv& nd = n->convs.at(*next_name);
+    p.next_w = nd.w; p.next_b = nd.b; p.next_out = next_out->p; p.next_cout = nd.cout; p.next_ld = next_out->ld;
+    if (nd.kh == 1 && nd.kw == 1 && nd.cin_pad == dc.cout && nd.cin2_pad == 0 && next_out->N == out.N && next_out->H == out.H &&
+        next_out->W == out.W && nd.cout <= next_out->ld && out_coff == 0 && conv_b2b_supported(p)) {
+      *fused_next = true;
+      next_flops = 2.0 * (double)p.M * nd.cout * (double)nd.cin;
+      n->flops += next_flops;
+    } else {
+      p.next_w = nullptr; p.next_b = nullptr; p.next_out = nullptr; p.next_cout = 0; p.next_ld = 0;
+    }
+  }
   const double kflop = (double)(dc.cin * dc.kh * dc.kw + dc.cin2);
   n->flops += 2.0 * (double)p.M * dc.cout * kflop;
   if (n->layer_log)   // EMP_LAYER_LOG=<file>: one line per MFMA launch, in launch order (tools/layer_roofline.py)
     fprintf(n->layer_log, "conv,%s,%d,%d,%d,%d,%d,%d,%d,%d\n", wname.c_str(), p.M, dc.cin_pad + dc.cin2_pad, dc.cout, dc.kh,
             stride, dil, res ? 1 : 0, in.N * in.H * in.W);
-  if (n->profile && conv_uses_256(p)) {
+  if (n->profile && !p.next_w && conv_uses_256(p)) {     // the fused back-to-back launches are another kernel symbol
     if (n->prof_used == n->prof_events.size()) {
       hipEvent_t a, b;
       EMP_CHECK_HIP(hipEventCreate(&a));
@@ -572,19 +589,29 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
   std::string xname = "p1";
   std::string pyr[5];
   pyr[0] = "p1";
+  bool c1_done = false;      // the coming block's conv1 was computed by the previous block's last launch
   for (int li = 1; li <= 4; ++li) {
     int stride = li == 1 ? 1 : 2, dil = 1;
     if (li == 4 && c.stage4_stride == 16) { stride = 1; dil = 2; }
     for (int b = 0; b < kLayers[li - 1]; ++b) {
       const int sb = b == 0 ? stride : 1;
       std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
-      RC(conv(n, p + ".conv1", A(xname), 0, A(p + ".c1"), 0, 1, 0, 1, true, nullptr, nullptr, s));
+      if (!c1_done) RC(conv(n, p + ".conv1", A(xname), 0, A(p + ".c1"), 0, 1, 0, 1, true, nullptr, nullptr, s));
+      c1_done = false;
       RC(conv(n, p + ".conv2", A(p + ".c1"), 0, A(p + ".c2"), 0, sb, dil, dil, true, nullptr, nullptr, s));
+      // the conv1 of the block that follows (same layer, or the first block of the next one): a candidate for the
+      // back-to-back fusion into this block's last launch (ConvParams::next_*; conv() decides)
+      std::string nxt;
+      if (b + 1 < kLayers[li - 1]) nxt = "encoder.layer" + std::to_string(li) + "." + std::to_string(b + 1);
+      else if (li < 4) nxt = "encoder.layer" + std::to_string(li + 1) + ".0";
+      const std::string nxt_w = nxt + ".conv1";
+      const bool has_next = !nxt.empty() && n->convs.count(nxt_w);
       const Act* idn = &A(xname);
       if (b == 0 && n->fuse_ds) {
         // relu(bn3(conv3(c2)) + bn(downsample(x))) as ONE GEMM whose K runs over c2's channels and then over x's
         // (sampled with the block's stride): the shortcut map is neither written nor read back
-        RC(conv(n, p + ".conv3+ds", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, true, nullptr, nullptr, s, 0, &A(xname), sb));
+        RC(conv(n, p + ".conv3+ds", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, true, nullptr, nullptr, s, 0, &A(xname), sb, nullptr, 0, 0,
+                has_next ? &nxt_w : nullptr, has_next ? &A(nxt + ".c1") : nullptr, &c1_done));
         xname = p;
         continue;
       }
@@ -592,7 +619,8 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
         RC(conv(n, p + ".downsample.0", A(xname), 0, A(p + ".ds"), 0, sb, 0, 1, false, nullptr, nullptr, s));
         idn = &A(p + ".ds");
       }
-      RC(conv(n, p + ".conv3", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, true, idn, nullptr, s));
+      RC(conv(n, p + ".conv3", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, true, idn, nullptr, s, 0, nullptr, 1, nullptr, 0, 0,
+              has_next ? &nxt_w : nullptr, has_next ? &A(nxt + ".c1") : nullptr, &c1_done));
       xname = p;
     }
     pyr[li] = xname;

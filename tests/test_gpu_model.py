@@ -238,3 +238,46 @@ def test_fused_point_head_equals_unfused_launches_bit_exact(arch):
         b = plain_model(x, rs, False)
         for k in a:
             assert torch.equal(a[k], b[k]), (arch, rs, k, float((a[k] - b[k]).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('family', ['pdl', 'bifpn'])
+def test_back_to_back_conv_fusion_is_bit_identical_and_active(family, tmp_path, monkeypatch):
+    """ResNet layer1: the conv3 launch of a block also computes the next block's conv1 from its tile in LDS
+    (ConvParams::next_*, conv_igemm256.hip).  Same K order, same epilogue: heads and the intermediate maps must equal
+    the unfused engine bit for bit; the layer log shows that the two conv1 launches are gone at a size where the 256x256
+    tile runs (one 1024^2 tile) and still there at a small one."""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    cfg = dict(weights.MITONET_PDL_CFG if family == 'pdl' else weights.MITONET_MINI_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=11), cfg)
+    taps = ('encoder.layer1.1.c1', 'encoder.layer1.2.c1', 'encoder.layer1.1', 'encoder.layer1.2', 'encoder.layer2.0.c1')
+    res, logs = {}, {}
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('EMP_FUSE_B2B', fuse)
+        log = tmp_path / f'layers_{fuse}.log'
+        monkeypatch.setenv('EMP_LAYER_LOG', str(log))
+        model = HipPanopticDeepLab(P, cfg, folded=True)
+        monkeypatch.delenv('EMP_LAYER_LOG')
+        for B, S in ((1, 1024), (2, 256)):
+            x = torch.from_numpy(normalize(synth.em_tiles(B, S, seed=5), 0.57571, 0.12765))[:, None].cuda()
+            out = model(x, 2, False)
+            res[fuse, S] = [out[k].clone() for k in ('sem_logits', 'ctr_hmp', 'offsets')] + [model.tap(t).clone() for t in taps]
+        torch.cuda.synchronize()
+        del model
+        fw, cur = [], []
+        for line in open(log):
+            if line.strip() == 'end':
+                fw.append(cur)
+                cur = []
+            else:
+                cur.append(line.split(',')[1])
+        logs[fuse] = fw
+    for S in (1024, 256):
+        for a, b in zip(res['0', S], res['1', S]):
+            assert torch.equal(a, b)
+    gone = {'encoder.layer1.1.conv1', 'encoder.layer1.2.conv1'}
+    assert gone <= set(logs['0'][0]) and gone <= set(logs['0'][1])
+    assert not (gone & set(logs['1'][0])), 'the fused launches did not replace conv1 at 1024^2'
+    assert gone <= set(logs['1'][1]), 'a 256^2 tile has too few 256x256 tiles: the separate launches must run'
