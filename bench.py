@@ -298,7 +298,7 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
                      'traffic_note': 'average HBM bytes per launch of this kernel (2*FETCH_SIZE + WRITE_SIZE, separate '
                                      'rocprofv3 PMC passes); NOT measured in this run, taken from ' + str(traffic_src),
                      'step_traffic_all_kernels': step_traffic,
-                     'kernel': 'conv_igemm256_kernel (256x256 implicit-GEMM tile: ASPP 3x3, layer3/4 convs)',
+                     'kernel': 'conv_igemm256_kernel<0, false> (256x256 implicit-GEMM tile: ASPP 3x3, layer3/4 convs, projection shortcuts; the <0, true> instantiation with the fused next conv is not counted)',
                      'launches_per_step': dom_launches / max(args.steps, 1),
                      'kernel_ms_per_step': round(dom_ms / max(args.steps, 1), 3),
                      'kernel_share_of_step': round(dom_ms / max(args.steps, 1) / ms_per_step, 3),

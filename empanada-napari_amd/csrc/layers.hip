@@ -302,11 +302,20 @@ __global__ void __launch_bounds__(256) fuse_combine_kernel(const half_t* __restr
 // ---------------------------------------------------------------------------
 // bilinear resize, align_corners=True, NHWC fp16 (decoders/panoptic_deeplab.py:75)
 // ---------------------------------------------------------------------------
+// one bilinear sample, explicit fma order (shared by both kernels below so that they agree bit for bit whatever the
+// compiler's contraction choices): hy * (hx*v00 + lx*v01) + ly * (hx*v10 + lx*v11)
+__device__ __forceinline__ float bilerp(float v00, float v01, float v10, float v11, float hx, float lx, float hy, float ly) {
+  const float t0 = __builtin_fmaf(lx, v01, hx * v00);
+  const float t1 = __builtin_fmaf(lx, v11, hx * v10);
+  return __builtin_fmaf(ly, t1, hy * t0);
+}
+
 // One block iteration = one output row segment: 256 threads = (256 / CG) pixels x CG 8-channel groups, so the
 // index arithmetic is 32-bit and mostly wave-uniform and every pixel's channels are one contiguous store.
 __global__ void __launch_bounds__(256) bilinear_ac_kernel(const half_t* __restrict__ in, int N, int h, int w, int C,
                                                           int in_ld, half_t* __restrict__ out, int H, int W,
                                                           int out_ld, float sy, float sx, int segs_per_row, int ppb) {
+#pragma clang fp contract(off)      // coordinates and weights round like the oracle's; the sample itself is bilerp's explicit fmas
   const int CG = C >> 3;
   const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;      // channel group, pixel within the segment
   const int total = N * H * segs_per_row;
@@ -343,11 +352,75 @@ __global__ void __launch_bounds__(256) bilinear_ac_kernel(const half_t* __restri
       f16x8 o;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        float r = hy * (hx * (float)v00[u][c] + lx[u] * (float)v01[u][c]) +
-                  ly[u] * (hx * (float)v10[u][c] + lx[u] * (float)v11[u][c]);
-        o[c] = (half_t)r;
+        o[c] = (half_t)bilerp((float)v00[u][c], (float)v01[u][c], (float)v10[u][c], (float)v11[u][c], hx, lx[u], hy, ly[u]);
       }
       if (ok[u]) *reinterpret_cast<f16x8*>(out + oidx[u]) = o;
+    }
+  }
+}
+
+// Up-scaling by >= 3 (the decoder's 64^2 -> 256^2): a thread owns FOUR consecutive output pixels of a row.  Their
+// source columns are x0a .. x0a + 2 (3 * sx < 1), so 6 loads feed 4 stores instead of 16 -- the one-pixel kernel moved
+// 5x the output bytes through the CU's 64 B/clk vector-memory path [0.74 ms for 2.1 GB written].  Per output the
+// arithmetic is the expression of bilinear_ac_kernel on the same source values: bit-identical results.
+__global__ void __launch_bounds__(256) bilinear_ac_up4_kernel(const half_t* __restrict__ in, int N, int h, int w, int C,
+                                                              int in_ld, half_t* __restrict__ out, int H, int W,
+                                                              int out_ld, float sy, float sx, int segs_per_row, int ppb) {
+#pragma clang fp contract(off)      // coordinates and weights round like the oracle's; the sample itself is bilerp's explicit fmas
+  const int CG = C >> 3;
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;      // channel group, 4-pixel group within the segment
+  const int total = N * H * segs_per_row;
+  constexpr int U = 2;                               // output rows in flight per thread (12 loads before any store)
+  for (int b0 = blockIdx.x * U; b0 < total; b0 += gridDim.x * U) {
+    f16x8 s0[U][3], s1[U][3];
+    float ly[U];
+    int oxs[U], xa[U];
+    size_t obase[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int b = b0 + u;
+      const int seg = b % segs_per_row;
+      const int row = b / segs_per_row;
+      const int oy = row % H, n = row / H;
+      const int ox = (seg * ppb + pl) * 4;
+      ok[u] = b < total && pl < ppb && ox < W;
+      const float fy = sy * (float)oy;
+      int y0 = (int)fy, x0 = (int)(sx * (float)ox);
+      if (!ok[u]) { y0 = 0; x0 = 0; }
+      const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+      ly[u] = fy - (float)y0;
+      oxs[u] = ox;
+      xa[u] = x0;
+      const half_t* base = in + (size_t)(ok[u] ? n : 0) * h * w * in_ld + cg * 8;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int xc = x0 + k < w - 1 ? x0 + k : w - 1;
+        s0[u][k] = *reinterpret_cast<const f16x8*>(base + ((size_t)y0 * w + xc) * in_ld);
+        s1[u][k] = *reinterpret_cast<const f16x8*>(base + ((size_t)y1 * w + xc) * in_ld);
+      }
+      obase[u] = (((size_t)n * H + oy) * W + ox) * out_ld + cg * 8;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float hy = 1.f - ly[u];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ox = oxs[u] + j;
+        const float fx = sx * (float)ox;
+        const int x0 = (int)fx;
+        const float lx = fx - (float)x0, hx = 1.f - lx;
+        const bool d = x0 != xa[u];                   // x0 - xa in {0, 1}
+        const bool edge = !(x0 < w - 1);              // x1 == x0
+        const f16x8 a0 = d ? s0[u][1] : s0[u][0], a1 = edge ? a0 : (d ? s0[u][2] : s0[u][1]);
+        const f16x8 c0 = d ? s1[u][1] : s1[u][0], c1 = edge ? c0 : (d ? s1[u][2] : s1[u][1]);
+        f16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          o[c] = (half_t)bilerp((float)a0[c], (float)a1[c], (float)c0[c], (float)c1[c], hx, lx, hy, ly[u]);
+        }
+        if (ok[u] && ox < W) *reinterpret_cast<f16x8*>(out + obase[u] + (size_t)j * out_ld) = o;
+      }
     }
   }
 }
@@ -576,7 +649,18 @@ int launch_bilinear_ac(const half_t* in, int N, int h, int w, int C, int in_ld, 
   float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   const int CG = C / 8;
   EMP_REQUIRE(CG >= 1 && CG <= 256, "bilinear: at most 2048 channels");
-  const int ppb = 256 / CG;                         // pixels per block iteration
+  const int ppb = 256 / CG;                         // pixels (up4: 4-pixel groups) per block iteration
+  static const bool no_up4 = [] { const char* e = getenv("EMP_BILINEAR_NO_UP4"); return e && e[0] == '1'; }();   // A/B runs
+  if (!no_up4 && W % 4 == 0 && 3.f * sx < 1.f && W >= 4 * ppb) {
+    const int segs = cdiv(W / 4, ppb);
+    const int64_t total = (int64_t)N * H * segs;
+    EMP_REQUIRE(total < (1ll << 31), "bilinear: too many row segments");
+    const int grid = (int)(total < 256 * 16 ? total : 256 * 16);
+    hipLaunchKernelGGL(bilinear_ac_up4_kernel, dim3(grid), dim3(256), 0, s, in, N, h, w, C, in_ld, out, H, W, out_ld, sy, sx,
+                       segs, ppb);
+    EMP_LAUNCH_CHECK();
+    return EMP_OK;
+  }
   const int segs = cdiv(W, ppb);
   const int64_t total = (int64_t)N * H * segs;
   EMP_REQUIRE(total < (1ll << 31), "bilinear: too many row segments");

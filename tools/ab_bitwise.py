@@ -1,10 +1,11 @@
 import os, sys, subprocess, json
 import numpy as np
 mode = sys.argv[1] if len(sys.argv) > 1 else 'driver'
+VAR = os.environ.get('AB_VAR', 'EMP_FUSE_B2B')      # the A/B switch: AB_VAR=EMP_BILINEAR_NO_UP4 python tools/ab_bitwise.py
 if mode == 'driver':
     outs = {}
     for v in ('0', '1'):
-        env = dict(os.environ, EMP_FUSE_B2B=v)
+        env = dict(os.environ, **{VAR: v})
         subprocess.check_call([sys.executable, __file__, 'run', f'/tmp/b2b_{v}.npz'], env=env)
         outs[v] = np.load(f'/tmp/b2b_{v}.npz')
     bad = 0
@@ -32,12 +33,12 @@ else:
             out = model(x, 2, False)
             for k, v in out.items():
                 res[f'{name}.{B}x{S}.{k}'] = v.float().cpu().numpy()
-            for t in ('encoder.layer1.1.c1', 'encoder.layer1.2.c1', 'encoder.layer2.0.c1', 'encoder.layer1.2'):
+            for t in ('encoder.layer1.1.c1', 'encoder.layer1.2.c1', 'encoder.layer2.0.c1', 'encoder.layer1.2') + (('semantic_decoder.stage0.cat', 'instance_decoder.stage0.cat') if name == 'pdl' else ()):
                 res[f'{name}.{B}x{S}.{t}'] = model.tap(t).float().cpu().numpy()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3): model(x, 2, False)
             e1.record(); torch.cuda.synchronize()
-            print(name, B, S, 'EMP_FUSE_B2B', os.environ.get('EMP_FUSE_B2B'), 'ms/forward', e0.elapsed_time(e1) / 3)
+            print(name, B, S, VAR, os.environ.get(VAR), 'ms/forward', e0.elapsed_time(e1) / 3)
     np.savez(sys.argv[2], **res)
