@@ -58,7 +58,7 @@ int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_l
                         void* stream) {
   EMP_REQUIRE(d_in && d_w && d_out, "conv2d: null pointer");
   EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d: bad geometry");
-  EMP_REQUIRE(variant >= 0 && (variant & 15) <= 3 && ((variant >> 4) & 15) <= 6 && ((variant >> 8) & 255) <= 64 && (variant >> 16) <= 15, "conv2d: bad variant %d", variant);
+  EMP_REQUIRE(variant >= 0 && (variant & 15) <= 3 && ((variant >> 4) & 15) <= 7 && ((variant >> 8) & 255) <= 64 && (variant >> 16) <= 15, "conv2d: bad variant %d", variant);
   ConvParams p{};
   p.in = (const half_t*)d_in;
   p.wgt = (const half_t*)d_w;
@@ -86,7 +86,7 @@ int emp_conv1x1_dual_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, in
                               int out_ld, int Cout, int relu, int variant, void* stream) {
   EMP_REQUIRE(d_in && d_in2 && d_w && d_out, "conv1x1_dual: null pointer");
   EMP_REQUIRE(N > 0 && H > 0 && W > 0 && H2 > 0 && W2 > 0, "conv1x1_dual: bad geometry");
-  EMP_REQUIRE(variant >= 0 && (variant & 15) <= 3 && ((variant >> 4) & 15) <= 4, "conv1x1_dual: bad variant %d", variant);
+  EMP_REQUIRE(variant >= 0 && (variant & 15) <= 3 && ((variant >> 4) & 15) <= 7, "conv1x1_dual: bad variant %d", variant);
   ConvParams p{};
   p.in = (const half_t*)d_in;
   p.in2 = (const half_t*)d_in2;

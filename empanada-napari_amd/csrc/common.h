@@ -91,6 +91,9 @@ bool conv_b2b_supported(const ConvParams& p);   // can the 256x256 tile run p wi
 // half tile, two workgroups per CU, for the short-K layers (conv_igemm256.hip)
 bool conv_igemm_h256_supported(const ConvParams& p);
 int launch_conv_igemm_h256(ConvParams p, hipStream_t stream, int kg = 0);
+// 64 x 64 tile with a deep LDS-DMA ring for launches with few tiles (batch-1 latency; conv_igemm_s64.hip)
+bool conv_igemm_s64_supported(const ConvParams& p);
+int launch_conv_igemm_s64(ConvParams p, hipStream_t stream, int kg = 0);
 // 64 -> 64 channel 3x3 with register-resident weights and an LDS halo tile (conv3x3c64.hip)
 bool conv3x3_c64_supported(const ConvParams& p);
 int launch_conv3x3_c64(const ConvParams& p, hipStream_t stream);

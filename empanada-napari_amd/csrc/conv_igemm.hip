@@ -480,7 +480,8 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   // variant = staging + 16 * tile
   //   staging: 0 auto | 1 register staging | 2 LDS-DMA | 3 LDS-DMA + LDS-transposed epilogue
   //   tile   : 0 auto | 1 128x128 | 2 128x64 | 3 64x64 | 4 256x256 (conv_igemm256.hip; Cout % 256 == 0) |
-  //            5 half tile 128x256 / 256x128, two workgroups per CU (conv_igemm256.hip; Cout % 128 == 0) | 6 conv3x3_c64
+  //            5 half tile 128x256 / 256x128, two workgroups per CU (conv_igemm256.hip; Cout % 128 == 0) | 6 conv3x3_c64 |
+  //            7 64x64 with a deep LDS-DMA ring (conv_igemm_s64.hip): what 'auto' takes instead of 3 for few-tile launches
   // (tried and removed, slower on MI355X: a persistent cross-tile pipeline, and a 256x128 8-wave tile with
   //  three LDS stages + counted vmcnt / raw barriers: 865 vs 990 TF/s on the ASPP shape -- DESIGN.md section 4;
   //  a 128x128 4-wave tile with the 256x256 kernel's four-slot ring of 32-channel K-tiles, LDS-DMA three tiles ahead,
@@ -493,7 +494,8 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
     EMP_REQUIRE(conv_b2b_supported(p), "conv: a fused next convolution needs the 256x256 tile (Cout == 256, >= 192 tiles)");
     return launch_conv_igemm256(p, stream, kg, mode256);
   }
-  EMP_REQUIRE(v <= 3 && tile <= 6, "conv: bad variant %d", variant);
+  EMP_REQUIRE(v <= 3 && tile <= 7, "conv: bad variant %d", variant);
+  if (tile == 7) return launch_conv_igemm_s64(p, stream, kg);
   if (tile == 6) return launch_conv3x3_c64(p, stream);
   if (tile == 5) return launch_conv_igemm_h256(p, stream, kg);      // kg counts 32-channel slabs
   {
@@ -526,7 +528,12 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
     // a single image leaves the deep layers with a handful of 128x128 tiles for 256 CUs (batch-1 latency, the
     // reference's own calling convention): 64x64 tiles walk K in the same order (bit-identical results) on 4x the CUs
     static const int small_below = [] { const char* e = getenv("EMP_CONV_SMALL_TILES_BELOW"); return e ? atoi(e) : 256; }();
-    if (tile == 1 && (int64_t)cdiv(p.M, 128) * cdiv(p.Cout, 128) < small_below && !p.out2) tile = 3;
+    if (tile == 1 && (int64_t)cdiv(p.M, 128) * cdiv(p.Cout, 128) < small_below && !p.out2) {
+      // one workgroup per CU: only the workgroup's own prefetch hides the memory latency -> deep-ring variant
+      static const bool no_s64 = [] { const char* e = getenv("EMP_CONV_NO_S64"); return e && e[0] == '1'; }();   // A/B runs
+      if (!no_s64 && conv_igemm_s64_supported(p)) return launch_conv_igemm_s64(p, stream);
+      tile = 3;
+    }
   }
   if (v == 0) v = 3;
   if (tile == 1) {

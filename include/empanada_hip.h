@@ -158,7 +158,11 @@ EMP_API const char* emp_pdl_tap_name(const emp_pdl_t* net, int i);
  *   d_w   : (Cout, KH*KW, Cin) fp16
  *   d_bias: (Cout) fp32 or NULL;  d_bias_n: (N,Cout) fp32 or NULL
  *   d_res : (N,Ho,Wo,res_ld) fp16 or NULL
- *   d_out : (N,Ho,Wo,out_ld) fp16; writes channels [0,Cout); Cout % 8 == 0 */
+ *   d_out : (N,Ho,Wo,out_ld) fp16; writes channels [0,Cout); Cout % 8 == 0
+ *   variant: 0 = automatic.  Otherwise staging (bits 0-3: 1 registers | 2 LDS-DMA | 3 LDS-DMA + LDS-transposed epilogue)
+ *     + 16 * tile (1 128x128 | 2 128x64 | 3 64x64 | 4 256x256 | 5 half tile 128x256 / 256x128 | 6 64->64 3x3 with
+ *     register weights | 7 64x64 with a deep LDS-DMA ring, the batch-1 path) + 256 * K-walk group; every tile gives
+ *     bit-identical results (same K order), the parity tests force each one. */
 EMP_API int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_ld,
                         const void* d_w, const float* d_bias, const float* d_bias_n,
                         const void* d_res, int res_ld,

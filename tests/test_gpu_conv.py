@@ -26,8 +26,8 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 16 + 3, 32 + 1, 32 + 2, 32 + 3, 48 + 1, 48 + 2, 48 + 3,
-                                     (1 << 8) + 3, (2 << 8) + 19, (4 << 8) + 35])   # bits 8+: K-walk group size
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 16 + 3, 32 + 1, 32 + 2, 32 + 3, 48 + 1, 48 + 2, 48 + 3, 112,
+                                     (1 << 8) + 3, (2 << 8) + 19, (4 << 8) + 35])   # bits 8+: K-walk group size; 112: deep-ring 64x64
 @pytest.mark.parametrize('case', CASES)
 def test_conv_matches_fp32_reference(case, variant):
     from gpu_common import conv_hip, conv_ref, dev
@@ -183,3 +183,29 @@ def test_conv3x3_c64_register_weights_equals_implicit_gemm(shape, relu, C):
         err = (y.float().cpu() - ref).abs()
         assert torch.all(err <= 2e-3 + 2e-3 * ref.abs()), f'rep {rep}: max err {err.max():.4e}'
         assert torch.equal(y, base), f'rep {rep}: differs from the implicit-GEMM kernel ({(y != base).sum().item()} values)'
+
+
+@pytest.mark.parametrize('case', CASES_256 + [CASES[4], CASES[5], CASES[6], CASES[10]])
+def test_conv_tile_variants_are_bit_identical(case):
+    """Every tile walks K in the same order (256-channel groups, tap-major, ascending 32-channel MFMA steps from a zero
+    accumulator) and applies the same fp32 epilogue: 128x128 (16), 64x64 (48), 256x256 (64), the half tile (80) and the
+    deep-ring 64x64 tile of the batch-1 path (112) must agree bit for bit -- which tile runs depends on the batch, and a
+    batch of N has to equal N batch-1 calls."""
+    from gpu_common import conv_hip, dev
+    N, H, W, Cin, Cout, k, stride, pad, dil, relu, use_res, use_bn = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = (torch.randn((N, H, W, Cin), generator=g)).to(torch.float16).to(dev())
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (1.0 / np.sqrt(Cin * k * k))
+    b = torch.randn((Cout,), generator=g) * 0.1
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = torch.randn((N, Ho, Wo, Cout), generator=g).to(torch.float16).to(dev()) if use_res else None
+    bn = torch.randn((N, Cout), generator=g) * 0.2 if use_bn else None
+    tiles = [16, 48, 112] + ([64] if Cout % 256 == 0 else []) + ([80] if Cout % 128 == 0 else [])
+    ref = None
+    for rep in range(2):
+        for t in tiles:
+            y = conv_hip(x, w, b, bn, res, stride, pad, dil, relu, t + 3)
+            if ref is None:
+                ref = y.clone()
+            assert torch.equal(ref, y), f'tile code {t} (rep {rep}) differs in {(ref != y).float().mean().item():.2e} of the elements'
