@@ -4,8 +4,8 @@
 // workgroup per CU, and nothing but the workgroup's own prefetch hides the L2 / HBM latency.  The two-stage 64 x 64
 // variant of conv_igemm.hip waits a full memory latency per 64-channel K-step (~1 us: an ASPP 3x3 with K = 18432 took
 // 0.3 ms per launch, 73 % of the batch-1 forward).  Here K moves in 32-channel K-tiles (64 pixel rows + 64 cout rows of
-// 64 B = 8 KiB, two 1-KiB LDS-DMA pieces per wave) through a ring of NS = 8 slots filled NS - 1 K-tiles ahead (56 KiB
-// in flight per workgroup), one LDS-only barrier per K-tile, counted vmcnt.  4 waves, wave tile 32 pixels x 32 couts
+// 64 B = 8 KiB, two 1-KiB LDS-DMA pieces per wave), taken in PAIRS through a ring of NS = 5 slots filled NS - 1 pairs
+// ahead (64 KiB in flight per workgroup), one LDS-only barrier per pair (64 channels), counted vmcnt.  4 waves, wave tile 32 pixels x 32 couts
 // (4 MFMAs and 4 fragment reads per K-tile).  K order, operands and epilogue arithmetic are those of the other conv
 // kernels: bit-identical results (tests/test_gpu_conv.py), so a batch of N still equals N batch-1 calls.
 #include "common.h"
@@ -89,7 +89,17 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_s64_kernel(const ConvParams
     b_inc = ok ? SKS : 0;
   }
   int st_ky = 0, st_kx = 0, st_cb = 0, st_grp = 0, st_u = 0;
-  auto stage = [&]() {        // address work + the 2 LDS-DMA pieces of K-tile st_u into ring slot st_u % NS
+  // address work + the 2 LDS-DMA pieces of K-tile st_u into half `h` of ring slot `slot`; K-tiles past the end of K
+  // (the second half of the last pair when the tile count is odd) copy the zero page: 0 x 0 leaves the sums untouched
+  auto stage = [&](char* dst) {
+    if (st_u >= KTOT) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p.zero,
+                                       (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p.zero,
+                                       (__attribute__((address_space(3))) void*)(dst + S_WOFF + wave * 1024), 16, 0, 0);
+      ++st_u;
+      return;
+    }
     if (st_u == KT1 && p.in2) {
       a_cur = a_two;
       a_inc = (a_two != p.zero) ? SKS : 0;
@@ -104,11 +114,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_s64_kernel(const ConvParams
       }
       if (KG != CB) b_cur = b_inc ? b_base + (st_ky * p.KW + st_kx) * p.Cin + c0 : b_base;
     }
-    char* slot = lds + (st_u % NS) * S_SLOT;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_cur,
-                                     (__attribute__((address_space(3))) void*)(slot + wave * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(dst + wave * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_cur,
-                                     (__attribute__((address_space(3))) void*)(slot + S_WOFF + wave * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(dst + S_WOFF + wave * 1024), 16, 0, 0);
     a_cur += a_inc;
     b_cur += b_inc;
     if (++st_cb == KG) {
@@ -119,6 +128,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_s64_kernel(const ConvParams
       }
     }
     ++st_u;
+  };
+  int st_pair = 0;
+  auto stage_pair = [&]() {      // K-tiles 2*st_pair, 2*st_pair + 1 into ring slot st_pair % NS (two 8 KiB halves)
+    char* slot = lds + (st_pair % NS) * (2 * S_SLOT);
+    stage(slot);
+    stage(slot + S_SLOT);
+    ++st_pair;
   };
 
   const int fr = l & 15, fq = l >> 4;
@@ -132,24 +148,30 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_s64_kernel(const ConvParams
 #pragma unroll
     for (int q = 0; q < 2; ++q) acc[c][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // prologue: up to NS - 1 K-tiles in flight, the first one landed
-  const int npro = KTOT < NS - 1 ? KTOT : NS - 1;
+  // K-tiles move in PAIRS (64 channels per barrier: the loop is bound by the LDS-read latency + barrier per iteration,
+  // not by its 4 MFMAs per K-tile); prologue: up to NS - 1 pairs in flight, the first one landed
+  const int NPAIR = (KTOT + 1) >> 1;
+  const int npro = NPAIR < NS - 1 ? NPAIR : NS - 1;
 #pragma unroll 1
-  for (int u = 0; u < npro; ++u) stage();
-  if (npro == NS - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NS - 2)) : "memory");
+  for (int u = 0; u < npro; ++u) stage_pair();
+  if (npro == NS - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (NS - 2)) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-  for (int t = 0; t < KTOT; ++t) {
-    const char* base = lds + (t % NS) * S_SLOT;
+  for (int t = 0; t < NPAIR; ++t) {
+    const char* base = lds + (t % NS) * (2 * S_SLOT);
     const f16x8 w0 = *reinterpret_cast<const f16x8*>(base + w_off);
     const f16x8 w1 = *reinterpret_cast<const f16x8*>(base + w_off + 1024);
     const f16x8 x0 = *reinterpret_cast<const f16x8*>(base + p_off);
     const f16x8 x1 = *reinterpret_cast<const f16x8*>(base + p_off + 1024);
-    // K-tile t + NS - 1 goes into the slot of K-tile t - 1, which every wave finished reading before the previous barrier
-    if (t + NS - 1 < KTOT) {
-      stage();
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * (NS - 2)) : "memory");     // my pieces of t + 1 landed
+    const f16x8 w2 = *reinterpret_cast<const f16x8*>(base + S_SLOT + w_off);
+    const f16x8 w3 = *reinterpret_cast<const f16x8*>(base + S_SLOT + w_off + 1024);
+    const f16x8 x2 = *reinterpret_cast<const f16x8*>(base + S_SLOT + p_off);
+    const f16x8 x3 = *reinterpret_cast<const f16x8*>(base + S_SLOT + p_off + 1024);
+    // pair t + NS - 1 goes into the slot of pair t - 1, which every wave finished reading before the previous barrier
+    if (t + NS - 1 < NPAIR) {
+      stage_pair();
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 * (NS - 2)) : "memory");     // my pieces of pair t + 1 landed
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
@@ -159,6 +181,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_s64_kernel(const ConvParams
     acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x0, acc[1][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x1, acc[0][1], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x1, acc[1][1], 0, 0, 0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, x2, acc[0][0], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3, x2, acc[1][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, x3, acc[0][1], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3, x3, acc[1][1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -217,7 +243,7 @@ bool conv_igemm_s64_supported(const ConvParams& p) {
 // kg: channel slabs (32 ch) per K-walk group, 0 = default (256-channel groups, as the other kernels)
 int launch_conv_igemm_s64(ConvParams p, hipStream_t stream, int kg) {
   EMP_REQUIRE(conv_igemm_s64_supported(p), "conv s64: unsupported shape (Cin=%d Cout=%d)", p.Cin, p.Cout);
-  constexpr int NS = 8;
+  constexpr int NS = 5;      // ring of 5 pairs of K-tiles = 80 KiB: 4 pairs (64 KiB) in flight, two workgroups per CU
   const int CB = p.Cin / SKS, KT = p.KH * p.KW;
   if (kg == 0) kg = 8;
   if (KT == 1 || kg > CB || CB % kg != 0) kg = CB;
@@ -225,14 +251,14 @@ int launch_conv_igemm_s64(ConvParams p, hipStream_t stream, int kg) {
   static bool attr_set = false;
   if (!attr_set) {
     EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_s64_kernel<NS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, NS * S_SLOT));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, NS * 2 * S_SLOT));
     attr_set = true;
   }
   p.mt = cdiv(p.M, 64);
   p.nt = cdiv(p.Cout, 64);
   p.mt_per_xcd = cdiv(p.mt, 8);
   const int grid = 8 * p.mt_per_xcd * p.nt;
-  hipLaunchKernelGGL(conv_igemm_s64_kernel<NS>, dim3(grid), dim3(256), NS * S_SLOT, stream, p);
+  hipLaunchKernelGGL(conv_igemm_s64_kernel<NS>, dim3(grid), dim3(256), NS * 2 * S_SLOT, stream, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
