@@ -71,6 +71,11 @@ struct ConvParams {
   // Two convolutions of the same input (the two decoders' low-level projections) share one pass over it.
   half_t* out2;
   int out2_ld, split;
+  // optional third destination: couts [split3, Cout) go to out3 (then out2 gets [split, split3)); split3 % 8 == 0.
+  // Three convolutions of one map -- the next bottleneck's conv1 and the two decoders' low-level projections of a
+  // ResNet stage output -- share one pass over it.
+  half_t* out3;
+  int out3_ld, split3;
   // optional back-to-back 1x1 convolution of the finished tile (256x256 tile only, Cout == 256 so that a workgroup owns
   // all channels of its pixels): next_out[m][0..next_cout) = relu(next_w . out[m][0..Cout) + next_b) -- the conv1 of the
   // NEXT bottleneck block computed from the tile while it is still in LDS, so that launch and its read of the widest

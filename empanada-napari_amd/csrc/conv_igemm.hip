@@ -72,7 +72,10 @@ __device__ __forceinline__ void dispatch_act(int act, F&& f) {
 __device__ __forceinline__ size_t out_offset(const ConvParams& p, int m, int co, int HoWo);
 // destination of the 8 couts starting at `co` of output pixel m (second destination: ConvParams::out2)
 __device__ __forceinline__ half_t* out_ptr(const ConvParams& p, int m, int co, int HoWo) {
-  if (p.out2 && co >= p.split) return p.out2 + (size_t)m * p.out2_ld + (co - p.split);
+  if (p.out2 && co >= p.split) {
+    if (p.out3 && co >= p.split3) return p.out3 + (size_t)m * p.out3_ld + (co - p.split3);
+    return p.out2 + (size_t)m * p.out2_ld + (co - p.split);
+  }
   return p.out + out_offset(p, m, co, HoWo);
 }
 __device__ __forceinline__ size_t out_offset(const ConvParams& p, int m, int co, int HoWo) {
@@ -465,9 +468,15 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
               "conv: pointers must be 16-byte aligned (zero page 256)");
   EMP_REQUIRE((int64_t)p.N * p.Ho * p.Wo < (1ll << 31), "conv: too many output pixels");
   if (p.out2) {
-    EMP_REQUIRE(p.split > 0 && p.split < p.Cout && p.split % 8 == 0 && p.out2_ld % 8 == 0 && p.out2_ld >= p.Cout - p.split &&
+    EMP_REQUIRE(p.split > 0 && p.split < p.Cout && p.split % 8 == 0 && p.out2_ld % 8 == 0 &&
+                    p.out2_ld >= (p.out3 ? p.split3 : p.Cout) - p.split &&
                     p.out_ld >= p.split && ((uintptr_t)p.out2 % 16) == 0 && p.ps_cout == 0 && p.res == nullptr,
                 "conv: second destination: split=%d must be a multiple of 8 inside (0, Cout=%d)", p.split, p.Cout);
+  }
+  if (p.out3) {
+    EMP_REQUIRE(p.out2 != nullptr && p.split3 > p.split && p.split3 < p.Cout && p.split3 % 8 == 0 && p.out3_ld % 8 == 0 &&
+                    p.out3_ld >= p.Cout - p.split3 && ((uintptr_t)p.out3 % 16) == 0,
+                "conv: third destination: split3=%d must be a multiple of 8 inside (split=%d, Cout=%d)", p.split3, p.split, p.Cout);
   }
   if (p.in2) {
     EMP_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.ps_cout == 0,

@@ -62,6 +62,7 @@ struct emp_pdl {
   bool fuse_stem = [] { const char* e = getenv("EMP_FUSE_STEM"); return !(e && e[0] == '0'); }();   // stem.hip
   bool fuse_ds = [] { const char* e = getenv("EMP_FUSE_DS"); return !(e && e[0] == '0'); }();       // conv3 + downsample in one GEMM
   bool fuse_b2b = [] { const char* e = getenv("EMP_FUSE_B2B"); return !(e && e[0] == '0'); }();     // conv3 + the next block's conv1
+  bool fuse_proj = [] { const char* e = getenv("EMP_FUSE_PROJ"); return !(e && e[0] == '0'); }();   // low-level projections + the next stage's conv1
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
   bool fuse_pr = [] { const char* e = getenv("EMP_FUSE_PR"); return !(e && e[0] == '0'); }();             // pointrend.hip
 
@@ -493,11 +494,18 @@ T* rawp(emp_pdl* n, const std::string& name) {
 int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const Act& out, int out_coff, int stride,
          int pad, int dil, int act, const Act* res, const float* bias_n, hipStream_t s, int ps_cout = 0,
          const Act* in2 = nullptr, int stride2 = 1, const Act* out2 = nullptr, int out2_coff = 0, int split = 0,
-         const std::string* next_name = nullptr, const Act* next_out = nullptr, bool* fused_next = nullptr) {
+         const std::string* next_name = nullptr, const Act* next_out = nullptr, bool* fused_next = nullptr,
+         const Act* out3 = nullptr, int out3_coff = 0, int split3 = 0) {
   const DevConv& dc = n->convs.at(wname);
   ConvParams p{};
+  if (out3) {     // couts [split3, Cout) go to a third tensor (ConvParams::out3)
+    EMP_REQUIRE(out2 && out3->N == out.N && out3->H == out.H && out3->W == out.W && out3_coff + dc.cout - split3 <= out3->ld,
+                "%s: third destination mismatch", wname.c_str());
+    p.out3 = out3->p + out3_coff; p.out3_ld = out3->ld; p.split3 = split3;
+  }
   if (out2) {     // couts [split, Cout) go to a second tensor (ConvParams::out2)
-    EMP_REQUIRE(out2->N == out.N && out2->H == out.H && out2->W == out.W && out2_coff + dc.cout - split <= out2->ld,
+    EMP_REQUIRE(out2->N == out.N && out2->H == out.H && out2->W == out.W &&
+                    out2_coff + (out3 ? split3 : dc.cout) - split <= out2->ld,
                 "%s: second destination mismatch", wname.c_str());
     p.out2 = out2->p + out2_coff; p.out2_ld = out2->ld; p.split = split;
   }
@@ -590,13 +598,31 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
   std::string pyr[5];
   pyr[0] = "p1";
   bool c1_done = false;      // the coming block's conv1 was computed by the previous block's last launch
+  bool proj_done[8] = {false, false, false, false, false, false, false, false};   // decoder projections written by the encoder
   for (int li = 1; li <= 4; ++li) {
     int stride = li == 1 ? 1 : 2, dil = 1;
     if (li == 4 && c.stage4_stride == 16) { stride = 1; dil = 2; }
     for (int b = 0; b < kLayers[li - 1]; ++b) {
       const int sb = b == 0 ? stride : 1;
       std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
-      if (!c1_done) RC(conv(n, p + ".conv1", A(xname), 0, A(p + ".c1"), 0, 1, 0, 1, true, nullptr, nullptr, s));
+      if (!c1_done) {
+        // first block of a stage whose input the decoders project too: one conv, three destinations (see create)
+        int pi = -1;
+        if (b == 0 && c.arch == 0)
+          for (int i = 0; i < c.n_stages; ++i)
+            if (c.low_level_stages[i] == li - 1 && n->convs.count(p + ".conv1+project." + std::to_string(i))) pi = i;
+        if (pi >= 0) {
+          const int xch = pi == 0 ? n->aspp_ch : n->dec_ch;      // where the projected channels sit in the concat buffers
+          const Act& cb1 = A("semantic_decoder.stage" + std::to_string(pi) + ".cat");
+          const Act& cb2 = A("instance_decoder.stage" + std::to_string(pi) + ".cat");
+          const int c1 = n->convs.at(p + ".conv1").cout;
+          RC(conv(n, p + ".conv1+project." + std::to_string(pi), A(xname), 0, A(p + ".c1"), 0, 1, 0, 1, true, nullptr, nullptr, s,
+                  0, nullptr, 1, &cb1, xch, c1, nullptr, nullptr, nullptr, &cb2, xch, c1 + c.low_level_proj_sem[pi]));
+          proj_done[pi] = true;
+        } else {
+          RC(conv(n, p + ".conv1", A(xname), 0, A(p + ".c1"), 0, 1, 0, 1, true, nullptr, nullptr, s));
+        }
+      }
       c1_done = false;
       RC(conv(n, p + ".conv2", A(p + ".c1"), 0, A(p + ".c2"), 0, sb, dil, dil, true, nullptr, nullptr, s));
       // the conv1 of the block that follows (same layer, or the first block of the next one): a candidate for the
@@ -777,7 +803,9 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       const Act& xa = A(x);
       RC(launch_bilinear_ac(xa.p, N, xa.H, xa.W, xch, xa.ld, cb.p, cb.H, cb.W, cb.ld, s));
       const std::string pm = "decoders.project." + std::to_string(i);
-      if (n->convs.count(pm)) {
+      if (proj_done[i]) {
+        // written by the encoder's merged launch (conv1 of the next stage + both projections)
+      } else if (n->convs.count(pm)) {
         // the two decoders project the same low-level map: one pass over it writes both concat buffers (d == 0)
         if (d == 0) {
           const Act& cb2 = A(std::string(decs[1]) + ".stage" + std::to_string(i) + ".cat");
@@ -1078,6 +1106,27 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       int rc = pack_conv(n, pm);
       n->params.erase(pm);
       if (rc) return rc;
+      // ... and, when that level is a ResNet stage output whose next consumer is the following stage's first conv1 (a
+      // 1x1 conv of the same map), all THREE as one conv with three destinations: the map (the widest the projections
+      // read: 1 GiB per 32 tiles at stride 4) is read once instead of twice
+      const int st = c.low_level_stages[i];
+      const std::string c1n = "encoder.layer" + std::to_string(st + 1) + ".0.conv1";
+      if (n->fuse_proj && st >= 1 && st < 4 && n->params.count(c1n)) {
+        const HostParam& h1 = n->params.at(c1n);
+        if (h1.shape.size() == 4 && h1.shape[2] == 1 && h1.shape[3] == 1 && h1.shape[1] == hs.shape[1] && h1.shape[0] % 8 == 0) {
+          HostParam t;
+          t.shape = {h1.shape[0] + m.shape[0], h1.shape[1], 1, 1};
+          t.w = h1.w;
+          t.w.insert(t.w.end(), m.w.begin(), m.w.end());
+          t.b = h1.b;
+          t.b.insert(t.b.end(), m.b.begin(), m.b.end());
+          const std::string tm = c1n + "+project." + std::to_string(i);
+          n->params[tm] = t;
+          rc = pack_conv(n, tm);
+          n->params.erase(tm);
+          if (rc) return rc;
+        }
+      }
     }
   }
   const char* heads[3] = {"semantic_head", "ins_center", "ins_xy"};
