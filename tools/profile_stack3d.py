@@ -1,7 +1,7 @@
 """cProfile of one axis (yz) and of tracker_consensus on the 512^3 bench volume (host-side hot spots of the 3-D job).
     python tools/profile_stack3d.py"""
 import sys, time, cProfile, pstats, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import __graft_entry__ as graft
 graft.load_package()
