@@ -783,7 +783,13 @@ def _cluster_graph(G, thr):
     CG = nx.Graph()
     for i, comp in enumerate(nx.connected_components(H)):
         CG.add_node(i, cluster=comp)
+    # cluster pairs with no edge of G between them average to exactly 0 and never pass the thresholds: only the pairs
+    # that share an edge are evaluated (in the reference's pair order, with its sums: same graph, same edge order)
+    owner = {v: i for i in CG.nodes for v in CG.nodes[i]['cluster']}
+    linked = {(owner[u], owner[v]) if owner[u] < owner[v] else (owner[v], owner[u]) for u, v in G.edges()}
     for a, b in combinations(CG.nodes, 2):
+        if (a, b) not in linked:
+            continue
         ca, cb = CG.nodes[a]['cluster'], CG.nodes[b]['cluster']
         wi, wo = _avg_weight(G, ca, cb, 'iou'), _avg_weight(G, ca, cb, 'overlap')
         if wi > MIN_IOU or wo > MIN_OVERLAP:
