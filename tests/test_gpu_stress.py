@@ -119,3 +119,64 @@ def test_conv3x3_c64_repeatable_and_equal_to_implicit_gemm():
     for _ in range(20):
         assert torch.equal(run2(96), first2)
     assert torch.equal(first2, run2(16 + 3))
+
+
+@pytest.mark.parametrize('shape', [
+    # N, H, W, Cin, Cout, k, dil, res        (full-chip sizes: every CU holds one or two workgroups)
+    (8, 64, 64, 512, 2048, 1, 1, True),      # layer4 conv3: short K, wide N, residual
+    (8, 128, 128, 512, 128, 1, 1, False),    # layer2 conv1: the 256 x 128 half tile
+    (8, 64, 64, 256, 256, 3, 1, False),      # 72 K-tiles, tap walk
+    (1, 64, 64, 2048, 256, 3, 4, False),     # ASPP 3x3 at batch 1: 576 K-tiles through the deep ring
+])
+def test_half_tile_and_deep_ring_tiles_repeatable_and_equal_to_128_tile(shape):
+    """conv_igemm_h256_kernel (tile code 5) and conv_igemm_s64_kernel (7) keep LDS-DMA in flight across raw barriers with
+    counted vmcnt waits, like the 256x256 kernel: repeated runs must agree bit for bit with each other and with the
+    two-stage 128x128 tile."""
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    N, H, W, Cin, Cout, k, d, use_res = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.float16).to(dev())
+    w = (torch.randn((Cout, k * k, Cin), generator=g) / np.sqrt(Cin * k * k)).to(torch.float16).to(dev())
+    b = torch.randn((Cout,), generator=g).to(dev())
+    res = torch.randn((N, H, W, Cout), generator=g).to(torch.float16).to(dev()) if use_res else None
+    pad = d * (k - 1) // 2
+
+    def run(variant):
+        out = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev())
+        _abi.check(lib.emp_conv2d_nhwc_f16(_abi.ptr(x), N, H, W, Cin, Cin, _abi.ptr(w), _abi.ptr(b), None,
+                                           _abi.ptr(res) if use_res else None, Cout if use_res else 0, _abi.ptr(out), Cout,
+                                           Cout, k, k, 1, pad, d, 1, variant, _abi.stream_ptr(dev())), 'conv')
+        return out
+
+    ref = run(16 + 3)
+    for tile in (5, 7):
+        for rep in range(10):
+            assert torch.equal(run(16 * tile + 3), ref), f'tile code {tile}, repetition {rep}'
+
+
+def test_back_to_back_fusion_repeatable_at_batch_32():
+    """The fused conv3 -> next conv1 launch (conv_igemm256_kernel<0, true>) reuses the LDS ring for the finished tile and a
+    second GEMM behind one barrier: at the bench size (32 x 1024^2, one workgroup on every CU for 32 tiles each) repeated
+    forwards must reproduce layer1's maps bit for bit."""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=2), cfg)
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    base = synth.em_tiles(4, 1024, seed=9)
+    x = torch.from_numpy(normalize(np.concatenate([base] * 8), 0.57571, 0.12765))[:, None].cuda()
+    first = None
+    for rep in range(6):
+        model(x, 2, False)
+        cur = [model.tap(t).clone() for t in ('encoder.layer1.1.c1', 'encoder.layer1.2.c1', 'encoder.layer1.1')]
+        if first is None:
+            first = cur
+            # the batch holds 8 copies of 4 tiles: copies must agree with each other (tile-position independence)
+            for t in cur:
+                assert torch.equal(t[:4], t[4:8]) and torch.equal(t[:4], t[28:32])
+        else:
+            for a, b in zip(first, cur):
+                assert torch.equal(a, b), f'repetition {rep}'
