@@ -281,3 +281,34 @@ def test_back_to_back_conv_fusion_is_bit_identical_and_active(family, tmp_path, 
     assert gone <= set(logs['0'][0]) and gone <= set(logs['0'][1])
     assert not (gone & set(logs['1'][0])), 'the fused launches did not replace conv1 at 1024^2'
     assert gone <= set(logs['1'][1]), 'a 256^2 tile has too few 256x256 tiles: the separate launches must run'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('family', ['pdl', 'bifpn'])
+def test_two_stream_decoders_equal_the_single_stream_forward(family, monkeypatch):
+    """Small problems run the instance decoder + heads on a second stream (pdl_net.hip, EMP_PAR_DECODERS): same kernels on
+    disjoint buffers, so heads and decoder maps must equal the single-stream forward bit for bit, run after run, also
+    when the caller's stream is not the default one."""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    cfg = dict(weights.MITONET_PDL_CFG if family == 'pdl' else weights.MITONET_MINI_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=13), cfg)
+    monkeypatch.setenv('EMP_PAR_DECODERS', '0')
+    serial = HipPanopticDeepLab(P, cfg, folded=True)
+    monkeypatch.delenv('EMP_PAR_DECODERS')
+    par = HipPanopticDeepLab(P, cfg, folded=True)
+    side = torch.cuda.Stream()
+    for B, S in ((1, 1024), (3, 512)):
+        x = torch.from_numpy(normalize(synth.em_tiles(B, S, seed=6), 0.57571, 0.12765))[:, None].cuda()
+        for interp in (False, True):
+            want = {k: v.clone() for k, v in serial(x, 2, interp).items()}
+            for rep in range(4):
+                with torch.cuda.stream(side if rep % 2 else torch.cuda.current_stream()):
+                    if rep % 2:
+                        side.wait_stream(torch.cuda.default_stream())
+                    got = par(x, 2, interp)
+                    for k in want:
+                        assert torch.equal(got[k], want[k]), (B, S, interp, rep, k)
+                if rep % 2:
+                    torch.cuda.default_stream().wait_stream(side)

@@ -12,7 +12,7 @@ cfg = dict(weights.MITONET_PDL_CFG)
 P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
 model = HipPanopticDeepLab(P, cfg, folded=True)
 sub, mul = normalize_params(0.57571, 0.12765, 255)
-for B, S in ((1, 1024), (2, 1024), (4, 1024), (8, 1024), (16, 512), (64, 512)):
+for B, S in ((1, 1024), (2, 1024), (4, 1024), (8, 1024), (16, 1024), (32, 1024), (16, 512), (64, 512)):
     x = torch.from_numpy(synth.em_tiles(B, S, seed=1))[:, None].cuda()
     for _ in range(3):
         model(x, 2, False, sub=float(sub), mul=float(mul))
