@@ -13,6 +13,7 @@ import.  Differences, all behind the same results:
 zarr stores (``store_url``, zarr-backed input volumes) go through ``zstore.open_store``: the zarr package when it
 is installed, otherwise this package's own reader / writer of the zarr v2 directory layout.
 """
+import contextlib
 import math
 import os
 from concurrent.futures import ThreadPoolExecutor
@@ -452,8 +453,13 @@ class Engine3d:
         """Per-slice panoptic maps (device, int64 (h,w)) in slice order (see ``iter_slice_chunks``)."""
         return [p for chunk in self.iter_slice_chunks(volume, axis) for p in chunk]
 
-    def iter_slice_chunks(self, volume, axis):
+    def iter_slice_chunks(self, volume, axis, post_stream=None):
         """Generator over consecutive groups of per-slice panoptic maps (device, int64 (h,w)), in slice order.
+
+        ``post_stream``: run everything after the forward (median, voting, merge) on that CUDA stream and hand a group
+        out only after the NEXT batch's forward has been enqueued on the caller's stream -- the caller then works on the
+        group (on ``post_stream`` too) while the GPU already runs the next forward.  The group's tensors belong to
+        ``post_stream``; the generator joins the two streams when it is exhausted.
 
         Same arithmetic as feeding PanopticDeepLabRenderEngine3d.__call__ slice by slice
         (engines.py:363-394): f[z] = raw[z] for the first / last ``mid`` slices, otherwise
@@ -540,6 +546,7 @@ class Engine3d:
         else:
             shp = [s for i, s in enumerate(volume.shape) if i != axis]
             bs = self.slice_batch((math.ceil(shp[0] / ups), math.ceil(shp[1] / ups)))
+        held = None           # post_stream mode: the group computed last, handed out after the next forward is enqueued
         for i0 in range(0, n, bs):
             if raw_path:
                 xb = (moved[i0:i0 + bs].contiguous() if on_dev else
@@ -554,14 +561,35 @@ class Engine3d:
                 x = factor_pad(torch.stack(imgs), eng.padding_factor)
                 mo = eng.model(eng.to_model_device(x), rs, interpolate_ins=not eng.coarse_boundaries)
                 nb = x.shape[0]
-            pend.append((logits_to_prob(mo['sem_logits']), mo['ctr_hmp'].clone(), mo['offsets'].clone()))
+            heads = (logits_to_prob(mo['sem_logits']), mo['ctr_hmp'].clone(), mo['offsets'].clone())
+            if post_stream is not None:
+                # the forward of this batch is enqueued: now let the caller work on the previous group (post stream)
+                if held:
+                    yield held
+                    held = None
+                ready = torch.cuda.Event()
+                ready.record()
+                for t in heads:
+                    t.record_stream(post_stream)
+            pend.append(heads)
             avail += nb
-            chunk = process(min(avail - mid, n - mid) if avail < n else n)
+            with (torch.cuda.stream(post_stream) if post_stream is not None else contextlib.nullcontext()):
+                if post_stream is not None:
+                    post_stream.wait_event(ready)
+                chunk = process(min(avail - mid, n - mid) if avail < n else n)
             if chunk:
-                yield chunk
-        chunk = process(n)
+                if post_stream is not None:
+                    held = chunk
+                else:
+                    yield chunk
+        if held:
+            yield held
+        with (torch.cuda.stream(post_stream) if post_stream is not None else contextlib.nullcontext()):
+            chunk = process(n)
         if chunk:
             yield chunk
+        if post_stream is not None:
+            torch.cuda.current_stream().wait_stream(post_stream)
         eng.reset()
 
     def infer_on_axis(self, volume, axis_name):
@@ -587,13 +615,20 @@ class Engine3d:
 
         worker = self._host_worker()
         jobs = []
-        for pans in self.iter_slice_chunks(volume, axis):
+        # two streams: the forwards stay back to back on the caller's stream; median / voting / merge of a batch, its
+        # dense -> runs extraction and the host syncs that go with it run on a second one, one batch behind
+        dev = self.engine.model.device
+        if getattr(self, '_post_stream', None) is None or self._post_stream.device != dev:
+            self._post_stream = torch.cuda.Stream(device=dev)
+        post = self._post_stream if os.environ.get('EMP_STACK_TWO_STREAMS', '1') != '0' else None
+        for pans in self.iter_slice_chunks(volume, axis, post_stream=post):
             n_seen += len(pans)
-            for i0 in range(0, len(pans), 64):
-                chunk = torch.stack(pans[i0:i0 + 64])
-                per_label = sparse.pan_stack_to_runs(chunk, self.labels, self.label_divisor, self.thing_list,
-                                                     force_connected=True)
-                jobs.append(worker.submit(match_chunk, per_label, chunk.shape[-1]))
+            with (torch.cuda.stream(post) if post is not None else contextlib.nullcontext()):
+                for i0 in range(0, len(pans), 64):
+                    chunk = torch.stack(pans[i0:i0 + 64])
+                    per_label = sparse.pan_stack_to_runs(chunk, self.labels, self.label_divisor, self.thing_list,
+                                                         force_connected=True)
+                    jobs.append(worker.submit(match_chunk, per_label, chunk.shape[-1]))
         assert n_seen == volume.shape[axis]
         needs_gpu = bool(self.label_erosion > 0 or self.label_dilation > 0 or self.fill_holes_in_segmentation
                          or stack is not None)
