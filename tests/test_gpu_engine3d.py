@@ -495,3 +495,26 @@ def test_multigpu_two_ranks_on_one_gpu(monkeypatch, ks):
             _same_instances(ta[0].instances, tb[0].instances)
     finally:
         mg.close()
+
+
+@pytest.mark.parametrize('batch', [None, 5])
+def test_two_stream_axis_pipeline_equals_single_stream(model_config, monkeypatch, batch):
+    """Engine3d.infer_on_axis keeps the forwards on the caller's stream and runs median / voting / merge / dense -> runs of
+    a batch one batch behind on a second stream (EMP_STACK_TWO_STREAMS): the trackers must equal the single-stream run,
+    also with several batches per axis (the group handed out lags the forward by one batch) and with a median window
+    that spans batches."""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine3d
+    vol = synth.blob_volume(37, 48, 40, seed=3, n_blobs=24, fast=True)
+    res = {}
+    for two in ('0', '1'):
+        monkeypatch.setenv('EMP_STACK_TWO_STREAMS', two)
+        eng = Engine3d(model_config, label_divisor=DIV, median_kernel_size=5, nms_kernel=3, nms_threshold=0.1,
+                       confidence_thr=0.5, min_size=20, min_extent=2, batch_size=batch)
+        res[two] = {}
+        for axis in ('xy', 'yz'):
+            _, trs = eng.infer_on_axis(vol, axis)
+            res[two][axis] = trs[0].instances
+    for axis in ('xy', 'yz'):
+        assert len(res['0'][axis]) > 0
+        _same_instances(res['0'][axis], res['1'][axis])
