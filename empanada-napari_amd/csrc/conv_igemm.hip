@@ -442,7 +442,8 @@ bool conv_uses_256(const ConvParams& p) {
   static const int min_k = [] { const char* e = getenv("EMP_CONV_256_MINK"); return e ? atoi(e) : 512; }();
   const int64_t tiles256 = (int64_t)cdiv(p.M, 256) * (p.Cout / 256);
   const int k256 = p.KH * p.KW * p.Cin + (p.in2 ? p.Cin2 : 0);
-  return !no256 && !p.out2 && conv_igemm256_supported(p) && tiles256 >= 192 && k256 >= (p.in2 ? min_k / 4 : min_k);
+  const bool out2_ok = !p.out2 || (!p.out3 && p.split % 256 == 0);      // whole cout tiles to the second tensor
+  return !no256 && out2_ok && conv_igemm256_supported(p) && tiles256 >= 192 && k256 >= (p.in2 ? min_k / 4 : min_k);
 }
 // half tile 256 pixels x 128 couts, two workgroups per CU (conv_igemm256.hip): the 128-cout layers with K >= 256
 // (layer2 conv1 / stride-2 conv2: 350 -> 325 us, 244 -> 230) -- the 128 x 128 tile is LDS-read bound there
@@ -515,7 +516,6 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
       return launch_conv3x3_c64(p, stream);
   }
   if (tile == 4) {
-    EMP_REQUIRE(p.out2 == nullptr, "conv: the 256x256 tile has no second destination");
     return launch_conv_igemm256(p, stream, kg, mode256);      // here kg counts 32-channel slabs
   }
   // K walk (variant bits 8+: 0 auto | g = channel slabs per group): with many input channels and several taps a

@@ -98,7 +98,9 @@ __device__ __forceinline__ void wave_epilogue(const ConvParams& p, f32x4 (&acc)[
   for (int q = 0; q < 8; ++q) {
     const int m = mrow0 + q * 16 + fr;
     if (m >= p.M) continue;
-    half_t* orow = p.out + (size_t)m * p.out_ld + co0 + fq * 8;
+    // second destination (ConvParams::out2): whole cout tiles at or past `split` (a multiple of 256) go there
+    half_t* orow = (p.out2 && co0 >= p.split) ? p.out2 + (size_t)m * p.out2_ld + (co0 - p.split) + fq * 8
+                                              : p.out + (size_t)m * p.out_ld + co0 + fq * 8;
     const float* bn = p.bias_n ? p.bias_n + (size_t)(m / HoWo) * p.Cout + co0 + fq * 8 : nullptr;
 #pragma unroll
     for (int P = 0; P < 2; ++P) {
@@ -687,6 +689,9 @@ static int launch256(const ConvParams& p, int grid, hipStream_t stream) {
 int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode) {
   EMP_REQUIRE(conv_igemm256_supported(p), "conv256: unsupported shape (Cout=%d)", p.Cout);
   EMP_REQUIRE(p.next_w == nullptr || conv_b2b_supported(p), "conv256: the fused next convolution needs Cout == 256 (got %d)", p.Cout);
+  EMP_REQUIRE(p.out2 == nullptr || (p.split % 256 == 0 && p.split > 0 && p.split < p.Cout && p.out3 == nullptr &&
+                                    p.next_w == nullptr && p.out2_ld % 8 == 0 && p.out2_ld >= p.Cout - p.split),
+              "conv256: a second destination takes whole 256-cout tiles (split=%d)", p.split);
   {
     const int CB = p.Cin / KS, KT = p.KH * p.KW;
     static const int env_kg = [] { const char* e = getenv("EMP_CONV256_KGROUP"); return e ? atoi(e) : 0; }();   // A/B runs

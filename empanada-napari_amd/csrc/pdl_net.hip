@@ -63,6 +63,7 @@ struct emp_pdl {
   bool fuse_ds = [] { const char* e = getenv("EMP_FUSE_DS"); return !(e && e[0] == '0'); }();       // conv3 + downsample in one GEMM
   bool fuse_b2b = [] { const char* e = getenv("EMP_FUSE_B2B"); return !(e && e[0] == '0'); }();     // conv3 + the next block's conv1
   bool fuse_proj = [] { const char* e = getenv("EMP_FUSE_PROJ"); return !(e && e[0] == '0'); }();   // low-level projections + the next stage's conv1
+  bool fuse_aspp = [] { const char* e = getenv("EMP_FUSE_ASPP"); return !(e && e[0] == '0'); }();   // the two decoders' ASPP branches as one conv each
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
   bool fuse_pr = [] { const char* e = getenv("EMP_FUSE_PR"); return !(e && e[0] == '0'); }();             // pointrend.hip
 
@@ -806,8 +807,23 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
 
   // ---- decoders ----
   RC(launch_avgpool(p5.p, N, p5.H * p5.W, p5.C, p5.ld, rawp<float>(n, "pooled"), rawp<float>(n, "pool_part"), s));
-  RC(fork());
   const char* decs[2] = {"semantic_decoder", "instance_decoder"};
+  // ASPP branches of BOTH decoders, one conv per branch (couts [0, aspp_ch) -> semantic concat buffer, the rest ->
+  // instance concat buffer) when the merged weights exist (finalize) and the launch goes to the 256x256 tile
+  bool aspp_done[4] = {false, false, false, false};
+  const bool aspp_merged = c.ins_decoder && (int64_t)((N * p5.H * p5.W + 255) / 256) * (2 * n->aspp_ch / 256) >= 192;
+  if (aspp_merged)      // smaller problems keep the separate launches (deep-ring 64x64 tile, two streams)
+    for (int i = 0; i <= 3; ++i) {
+      const std::string pm = "decoders.aspp.convs." + std::to_string(i) + ".0";
+      if (!n->convs.count(pm)) continue;
+      const int r = i == 0 ? 1 : c.atrous_rates[i - 1];
+      const Act& cat0 = A(std::string(decs[0]) + ".aspp.cat");
+      const Act& cat1 = A(std::string(decs[1]) + ".aspp.cat");
+      RC(conv(n, pm, p5, 0, cat0, i * n->aspp_ch, 1, i == 0 ? 0 : r, r, true, nullptr, nullptr, s, 0, nullptr, 1, &cat1,
+              i * n->aspp_ch, n->aspp_ch));
+      aspp_done[i] = true;
+    }
+  RC(fork());
   for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
     hipStream_t s = (par && d == 1) ? n->aux : s_main;
     std::string p = decs[d];
@@ -816,8 +832,9 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
     RC(launch_gemv(rawp<float>(n, "pooled"), N, p5.C, n->f32w.at(p + ".pool.w"), nullptr, n->aspp_ch, 1, poolfeat, s));
     RC(launch_gemv(poolfeat, N, n->aspp_ch, n->f32w.at(p + ".projpool.w"), nullptr, n->aspp_ch, 0, bias_n, s));
     const Act& cat = A(p + ".aspp.cat");
-    RC(conv(n, p + ".aspp.convs.0.0", p5, 0, cat, 0, 1, 0, 1, true, nullptr, nullptr, s));
+    if (!aspp_done[0]) RC(conv(n, p + ".aspp.convs.0.0", p5, 0, cat, 0, 1, 0, 1, true, nullptr, nullptr, s));
     for (int i = 1; i <= 3; ++i) {
+      if (aspp_done[i]) continue;
       const int r = c.atrous_rates[i - 1];
       RC(conv(n, p + ".aspp.convs." + std::to_string(i) + ".0", p5, 0, cat, i * n->aspp_ch, 1, r, r, true, nullptr,
               nullptr, s));
@@ -1088,6 +1105,28 @@ int emp_pdl_finalize(emp_pdl_t* n) {
   for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
     std::string p = decs[d];
     for (int i = 0; i <= 3; ++i) RC(pack_conv(n, p + ".aspp.convs." + std::to_string(i) + ".0"));
+    if (d == 1 && n->fuse_aspp) {
+      // both decoders' ASPP branch i read the same stride-16 map: one conv of 2 x aspp_ch couts, the second 256-cout
+      // tile lands in the instance decoder's concat buffer (ConvParams::out2); the pixel tile is fetched once
+      for (int i = 0; i <= 3; ++i) {
+        const std::string b = ".aspp.convs." + std::to_string(i) + ".0";
+        const HostParam& hs = n->params.at(std::string(decs[0]) + b);
+        const HostParam& hi = n->params.at(std::string(decs[1]) + b);
+        if (hs.shape != hi.shape || hs.shape[0] % 256 != 0) continue;
+        HostParam m;
+        m.shape = hs.shape;
+        m.shape[0] = hs.shape[0] + hi.shape[0];
+        m.w = hs.w;
+        m.w.insert(m.w.end(), hi.w.begin(), hi.w.end());
+        m.b = hs.b;
+        m.b.insert(m.b.end(), hi.b.begin(), hi.b.end());
+        const std::string pm = "decoders" + b;
+        n->params[pm] = m;
+        int rc = pack_conv(n, pm);
+        n->params.erase(pm);
+        if (rc) return rc;
+      }
+    }
     RC(upload_f32(n, p + ".pool.w", n->params[p + ".aspp.convs.4.aspp_pooling.1"].w));  // (aspp, 2048) row-major
     // projection (aspp, 5*aspp): first 4*aspp input channels -> conv, last aspp -> per-image bias GEMV
     {

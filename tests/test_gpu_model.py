@@ -312,3 +312,33 @@ def test_two_stream_decoders_equal_the_single_stream_forward(family, monkeypatch
                         assert torch.equal(got[k], want[k]), (B, S, interp, rep, k)
                 if rep % 2:
                     torch.cuda.default_stream().wait_stream(side)
+
+
+@pytest.mark.gpu
+def test_merged_aspp_branches_are_bit_identical(monkeypatch):
+    """Both decoders' ASPP branch i as ONE conv of 512 couts whose second 256-cout tile lands in the instance decoder's
+    concat buffer (ConvParams::out2 in the 256x256 kernel; runs once the launch has >= 192 tiles: 8 tiles of 1024^2 here):
+    concat buffers, ASPP outputs and heads must equal the separate launches bit for bit."""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=17), cfg)
+    x = torch.from_numpy(normalize(synth.em_tiles(8, 1024, seed=8), 0.57571, 0.12765))[:, None].cuda()
+    taps = ('semantic_decoder.aspp.cat', 'instance_decoder.aspp.cat', 'semantic_decoder.aspp', 'instance_decoder.aspp')
+    res = {}
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('EMP_FUSE_ASPP', fuse)
+        log = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'aspp_layers_{fuse}.log')
+        monkeypatch.setenv('EMP_LAYER_LOG', log)
+        model = HipPanopticDeepLab(P, cfg, folded=True)
+        monkeypatch.delenv('EMP_LAYER_LOG')
+        out = model(x, 2, False)
+        res[fuse] = [out[k].clone() for k in ('sem_logits', 'ctr_hmp', 'offsets')] + [model.tap(t).clone() for t in taps]
+        torch.cuda.synchronize()
+        del model
+        names = [line.split(',')[1] for line in open(log) if ',' in line]
+        assert ('decoders.aspp.convs.1.0' in names) == (fuse == '1')
+        assert ('instance_decoder.aspp.convs.1.0' in names) == (fuse == '0')
+    for a, b in zip(res['0'], res['1']):
+        assert torch.equal(a, b)
