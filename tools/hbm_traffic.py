@@ -17,7 +17,10 @@ def short(name):
     m = re.match(r'_ZN3emp12_GLOBAL__N_1(\d+)(.*)', name)
     if m:
         return m.group(2)[:int(m.group(1))]
-    return re.sub(r'^void ', '', name).split('(')[0].split('<')[0][:60]
+    base = re.sub(r'^void ', '', name).split('(')[0]
+    if base.startswith('conv_igemm256_kernel<') and base.rstrip().endswith('true>'):
+        return 'conv_igemm256_kernel<b2b>'      # the back-to-back instantiation is another kernel (bench.py counts <0, false>)
+    return base.split('<')[0][:60]
 
 
 def collect(d, counter, steps):
