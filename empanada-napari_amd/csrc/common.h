@@ -137,6 +137,17 @@ int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, con
                     const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
                     const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s,
                     int ks = 5);
+// the same block at fp32 accuracy (sepconv_precise.hip): fp32 taps, depthwise result and pointwise weights as fp16
+// hi + lo pairs, three MFMAs per product
+bool sepconvp_supported(int C, int Cout, int head_c);
+// pointwise weights (Cout, pw_ld) fp32 -> 2 * C * Cout fp16 (hi parts, then lo parts) in MFMA fragment order
+int launch_sepconvp_pack_pw(const float* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s);
+// depthwise taps (ks*ks, C) fp32 -> chunk-major [C/64][ks*ks][64] fp32
+int launch_sepconvp_pack_dw(const float* w, int ks, int C, float* packed, hipStream_t s);
+int launch_sepconvp(const half_t* in, int N, int H, int W, int C, int in_ld, const float* dww_packed, const half_t* pww_packed,
+                    const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
+                    const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s,
+                    int ks = 5);
 int launch_head1x1(const half_t* in, int N, int P, int K, int in_ld, const float* w, const float* b, int C,
                    float* out, int64_t plane_size, const int32_t* scatter_idx, hipStream_t s);
 int launch_bilinear_ac_f32_nchw(const float* in, int NC, int h, int w, float* out, int scale, hipStream_t s);

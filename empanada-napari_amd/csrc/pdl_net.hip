@@ -14,6 +14,8 @@
 //    broadcast + concat (decoders/aspp.py:45-48,99-102);
 //  * torch.cat is free: producers write into channel slices of one buffer;
 //  * the unused first semantic_head call of _encode_decode (:107) is skipped.
+#include <string.h>
+
 #include <map>
 #include <memory>
 #include <string>
@@ -66,6 +68,11 @@ struct emp_pdl {
   bool fuse_aspp = [] { const char* e = getenv("EMP_FUSE_ASPP"); return !(e && e[0] == '0'); }();   // the two decoders' ASPP branches as one conv each
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
   bool fuse_pr = [] { const char* e = getenv("EMP_FUSE_PR"); return !(e && e[0] == '0'); }();             // pointrend.hip
+  // Separable blocks computed at fp32 accuracy (sepconv_precise.hip: fp32 taps, fp16 hi + lo operands, 3 MFMAs per
+  // product; +0.4 ms per launch at 32 x 1024^2): 1 (default) = the blocks the CENTRE heat-map depends on -- the
+  // last-stage fusion conv(s) of the decoder that feeds ins_center and the ins_center head -- which is where the
+  // north star's 1e-3 on the heat-maps was missed; 2 = every fused 5x5 block; 0 = none (round-2 numerics).
+  int precise_sepconv = [] { const char* e = getenv("EMP_PRECISE_SEPCONV"); return e ? atoi(e) : 1; }();
 
   // device parameters
   std::map<std::string, DevConv> convs;
@@ -114,6 +121,14 @@ namespace {
 
 const int kLayers[4] = {3, 4, 6, 3};
 const int kPlanes[4] = {64, 128, 256, 512};
+
+// does the separable block `pre` (its parameters are pre.sepconv.0 / pre.sepconv.1) run at fp32 accuracy?
+bool precise_layer(const emp_pdl* n, const std::string& pre) {
+  if (n->precise_sepconv <= 0) return false;
+  if (n->precise_sepconv >= 2) return true;
+  const char* dec = n->cfg.ins_decoder ? "instance_decoder." : "semantic_decoder.";
+  return pre.compare(0, 11, "ins_center.") == 0 || pre.compare(0, strlen(dec), dec) == 0;
+}
 
 void expect(emp_pdl* n, const std::string& name) {
   n->param_names.push_back(name);
@@ -266,6 +281,35 @@ int pack_sepconv_pw(emp_pdl* n, const std::string& name) {
   return EMP_OK;
 }
 
+// fragment-ordered fp16 hi + lo copy of a pointwise weight for the fp32-accurate fused separable conv (sepconv_precise.hip), when its shape
+// qualifies: packed from the fp32 host parameter, so that the pair carries 21 significant bits of it
+int pack_sepconvp_pw(emp_pdl* n, const std::string& name) {
+  const DevConv& dc = n->convs.at(name);
+  if (dc.kh != 1 || dc.kw != 1 || !sepconvp_supported(dc.cin_pad, dc.cout, 0)) return EMP_OK;
+  const HostParam& hp = n->params.at(name);
+  std::vector<float> w32((size_t)dc.cout * dc.cin_pad, 0.f);
+  for (int o = 0; o < dc.cout; ++o)
+    for (int i = 0; i < dc.cin; ++i) w32[(size_t)o * dc.cin_pad + i] = hp.w[(size_t)o * dc.cin + i];
+  void* tmp = nullptr;
+  EMP_CHECK_HIP(hipMalloc(&tmp, w32.size() * sizeof(float)));
+  hipError_t e = hipMemcpy(tmp, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice);
+  void* d = nullptr;
+  if (e == hipSuccess) e = hipMalloc(&d, (size_t)2 * dc.cin_pad * dc.cout * sizeof(half_t));
+  if (e != hipSuccess) {
+    (void)hipFree(tmp);
+    set_error("%s: packing the pointwise weights: %s", name.c_str(), hipGetErrorString(e));
+    return EMP_ERR_HIP;
+  }
+  n->owned.push_back(d);
+  int rc = launch_sepconvp_pack_pw((const float*)tmp, dc.cin_pad, dc.cin_pad, dc.cout, (half_t*)d, nullptr);
+  e = hipStreamSynchronize(nullptr);
+  (void)hipFree(tmp);
+  if (rc) return rc;
+  EMP_CHECK_HIP(e);
+  n->f16w[name + ".packedp"] = (half_t*)d;
+  return EMP_OK;
+}
+
 int upload_f32(emp_pdl* n, const std::string& key, const std::vector<float>& v) {
   void* d;
   int rc = dev_upload(n, v.data(), v.size() * sizeof(float), &d);
@@ -290,7 +334,12 @@ int pack_dw(emp_pdl* n, const std::string& name, int cpad) {
   int rc = dev_upload(n, pk.data(), pk.size() * sizeof(half_t), &d);
   if (rc) return rc;
   n->f16w[name] = (half_t*)d;
-  return EMP_OK;
+  // the fp32-accurate fused separable conv (sepconv_precise.hip) keeps the taps in fp32 (they only meet the fp32 vector pipe), chunk-major
+  // [cpad/64][KK][64]: the order of launch_sepconvp_pack_dw
+  std::vector<float> pk32((size_t)KK * cpad, 0.f);
+  for (int c = 0; c < C; ++c)
+    for (int t = 0; t < KK; ++t) pk32[((size_t)(c >> 6) * KK + t) * 64 + (c & 63)] = hp.w[(size_t)c * KK + t];
+  return upload_f32(n, name + ".f32", pk32);
 }
 
 // ConvTranspose2d(k=2,s=2) weight (Cin,Cout,2,2) -> 1x1 conv with 4*Cout outputs [(dy*2+dx)*Cout + co][Cin]
@@ -787,7 +836,15 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       {
         const DevConv& pwc = n->convs.at(dp + ".fusion.0.sepconv.1");
         const Act& so = A(dp + ".out");
-        if (n->fuse_sepconv && n->f16w.count(dp + ".fusion.0.sepconv.1.packed") && cat.ld == 2 * F && pwc.cin_pad == 2 * F &&
+        if (n->fuse_sepconv && precise_layer(n, dp + ".fusion.0") && n->f16w.count(dp + ".fusion.0.sepconv.1.packedp") &&
+            cat.ld == 2 * F && pwc.cin_pad == 2 * F && so.ld == pwc.cout && sepconvp_supported(2 * F, pwc.cout, 0)) {
+          // the decoder that feeds the centre heat-map: the block at fp32 accuracy (sepconv_precise.hip)
+          RC(launch_sepconvp(cat.p, N, cat.H, cat.W, 2 * F, cat.ld, n->f32w.at(dp + ".fusion.0.sepconv.0.f32"),
+                             n->f16w.at(dp + ".fusion.0.sepconv.1.packedp"), pwc.b, pwc.cout, 1, so.p, so.ld, nullptr, nullptr,
+                             0, nullptr, 0, zero, s));
+          n->flops += 2.0 * (double)N * cat.H * cat.W * pwc.cout * (double)pwc.cin;
+          if (n->layer_log) fprintf(n->layer_log, "sepconvp,%s,%d,%d,%d,5,1,1,0,%d\n", (dp + ".fusion.0").c_str(), N * cat.H * cat.W, 2 * F, pwc.cout, N * cat.H * cat.W);
+        } else if (n->fuse_sepconv && n->f16w.count(dp + ".fusion.0.sepconv.1.packed") && cat.ld == 2 * F && pwc.cin_pad == 2 * F &&
             so.ld == pwc.cout && sepconv5_supported(2 * F, pwc.cout, 0)) {
           RC(launch_sepconv5(cat.p, N, cat.H, cat.W, 2 * F, cat.ld, n->f16w.at(dp + ".fusion.0.sepconv.0"),
                              n->f16w.at(dp + ".fusion.0.sepconv.1.packed"), pwc.b, pwc.cout, 1, so.p, so.ld, nullptr, nullptr,
@@ -823,6 +880,24 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
               i * n->aspp_ch, n->aspp_ch));
       aspp_done[i] = true;
     }
+  // The merged low-level projections ("decoders.project.i": one pass over a pyramid level writes BOTH decoders' concat
+  // buffers) that the encoder did not already run: they read encoder maps only and must be on s_main BEFORE the
+  // instance side forks onto the second stream -- after the fork nothing would order the instance decoder's read of
+  // its concat buffer behind this launch (EMP_FUSE_PROJ=0, low_level_stages with stage 0, odd conv1 shapes).
+  if (c.ins_decoder) {
+    int xch0 = n->aspp_ch;
+    for (int i = 0; i < c.n_stages; ++i) {
+      const std::string pm = "decoders.project." + std::to_string(i);
+      if (!proj_done[i] && n->convs.count(pm)) {
+        const Act& cb1 = A(std::string(decs[0]) + ".stage" + std::to_string(i) + ".cat");
+        const Act& cb2 = A(std::string(decs[1]) + ".stage" + std::to_string(i) + ".cat");
+        RC(conv(n, pm, A(pyr[c.low_level_stages[i]]), 0, cb1, xch0, 1, 0, 1, true, nullptr, nullptr, s, 0, nullptr, 1, &cb2, xch0,
+                c.low_level_proj_sem[i]));
+        proj_done[i] = true;
+      }
+      xch0 = n->dec_ch;
+    }
+  }
   RC(fork());
   for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
     hipStream_t s = (par && d == 1) ? n->aux : s_main;
@@ -850,14 +925,8 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       RC(launch_bilinear_ac(xa.p, N, xa.H, xa.W, xch, xa.ld, cb.p, cb.H, cb.W, cb.ld, s));
       const std::string pm = "decoders.project." + std::to_string(i);
       if (proj_done[i]) {
-        // written by the encoder's merged launch (conv1 of the next stage + both projections)
-      } else if (n->convs.count(pm)) {
-        // the two decoders project the same low-level map: one pass over it writes both concat buffers (d == 0)
-        if (d == 0) {
-          const Act& cb2 = A(std::string(decs[1]) + ".stage" + std::to_string(i) + ".cat");
-          RC(conv(n, pm, A(pyr[st]), 0, cb, xch, 1, 0, 1, true, nullptr, nullptr, s, 0, nullptr, 1, &cb2, xch,
-                  c.low_level_proj_sem[i]));
-        }
+        // written by the encoder's merged launch (conv1 of the next stage + both projections) or by the merged
+        // projection in front of the fork
       } else {
         RC(conv(n, p + ".project." + std::to_string(i) + ".0", A(pyr[st]), 0, cb, xch, 1, 0, 1, true, nullptr, nullptr, s));
       }
@@ -866,7 +935,14 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       {
         const DevConv& pwc = n->convs.at(fz + "1");
         const Act& so = A(q + ".out");
-        if (n->fuse_sepconv && n->f16w.count(fz + "1.packed") && pwc.cin_pad == cb.ld && so.ld == pwc.cout &&
+        if (n->fuse_sepconv && precise_layer(n, p + ".fuse." + std::to_string(i) + ".0") && n->f16w.count(fz + "1.packedp") &&
+            pwc.cin_pad == cb.ld && so.ld == pwc.cout && sepconvp_supported(cb.ld, pwc.cout, 0)) {
+          // the decoder that feeds the centre heat-map: the block at fp32 accuracy (sepconv_precise.hip)
+          RC(launch_sepconvp(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f32w.at(fz + "0.f32"), n->f16w.at(fz + "1.packedp"), pwc.b,
+                             pwc.cout, 1, so.p, so.ld, nullptr, nullptr, 0, nullptr, 0, rawp<half_t>(n, "zero"), s));
+          n->flops += 2.0 * (double)N * cb.H * cb.W * pwc.cout * (double)pwc.cin;
+          if (n->layer_log) fprintf(n->layer_log, "sepconvp,%s,%d,%d,%d,5,1,1,0,%d\n", fz.c_str(), N * cb.H * cb.W, cb.ld, pwc.cout, N * cb.H * cb.W);
+        } else if (n->fuse_sepconv && n->f16w.count(fz + "1.packed") && pwc.cin_pad == cb.ld && so.ld == pwc.cout &&
             sepconv5_supported(cb.ld, pwc.cout, 0)) {
           // depthwise 5x5 -> pointwise -> bias -> ReLU in one launch (sepconv.hip); the depthwise map stays in LDS
           RC(launch_sepconv5(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f16w.at(fz + "0"), n->f16w.at(fz + "1.packed"), pwc.b,
@@ -904,7 +980,16 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
     if (k == 2 && !interp) dst = o_off;
     head_out[k] = dst;
     const DevConv& pwc = n->convs.at(p + ".head.0.0.sepconv.1");
-    if (n->fuse_sepconv && n->f16w.count(p + ".head.0.0.sepconv.1.packed") && xin.C == n->dec_ch &&
+    if (n->fuse_sepconv && precise_layer(n, p + ".head.0.0") && n->f16w.count(p + ".head.0.0.sepconv.1.packedp") &&
+        xin.C == n->dec_ch && pwc.cin_pad == n->dec_ch && pwc.cout == n->dec_ch && hc[k] <= 2 &&
+        sepconvp_supported(n->dec_ch, pwc.cout, hc[k])) {
+      // the centre head at fp32 accuracy (sepconv_precise.hip)
+      RC(launch_sepconvp(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f32w.at(p + ".head.0.0.sepconv.0.f32"),
+                         n->f16w.at(p + ".head.0.0.sepconv.1.packedp"), pwc.b, pwc.cout, 1, nullptr, 0, n->f32w.at(p + ".head.1.w"),
+                         n->f32w.at(p + ".head.1.b"), hc[k], dst, (int64_t)hq * wq, rawp<half_t>(n, "zero"), s));
+      n->flops += 2.0 * (double)N * hq * wq * pwc.cout * (double)pwc.cin;
+      if (n->layer_log) fprintf(n->layer_log, "sepheadp,%s,%d,%d,%d,5,1,1,0,%d\n", p.c_str(), N * hq * wq, n->dec_ch, pwc.cout, N * hq * wq);
+    } else if (n->fuse_sepconv && n->f16w.count(p + ".head.0.0.sepconv.1.packed") && xin.C == n->dec_ch &&
         pwc.cin_pad == n->dec_ch && pwc.cout == n->dec_ch && hc[k] <= 2 &&
         sepconv5_supported(n->dec_ch, pwc.cout, hc[k])) {
       // head.0 (depthwise 5x5 -> pointwise -> ReLU) and head.1 (1x1 -> hc planes) in one launch: neither the
@@ -1096,7 +1181,10 @@ int emp_pdl_finalize(emp_pdl_t* n) {
         EMP_REQUIRE(n->convs[nm].cout == 4 * F, "%s: transposed conv must produce fpn_dim channels", nm.c_str());
       } else {
         RC(pack_conv(n, nm));
-        if (nm.size() > 19 && nm.compare(nm.size() - 19, 19, ".fusion.0.sepconv.1") == 0) RC(pack_sepconv_pw(n, nm));
+        if (nm.size() > 19 && nm.compare(nm.size() - 19, 19, ".fusion.0.sepconv.1") == 0) {
+          RC(pack_sepconv_pw(n, nm));
+          if (precise_layer(n, nm.substr(0, nm.size() - 10))) RC(pack_sepconvp_pw(n, nm));
+        }
         if (nm.find(".after_combines.0.0.sepconv.1") != std::string::npos) RC(pack_sepconv_pw(n, nm));   // BiFPN nodes
       }
     }
@@ -1159,6 +1247,7 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       RC(pack_dw(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.0", cpad));
       RC(pack_conv(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1", cpad));
       RC(pack_sepconv_pw(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1"));
+      if (precise_layer(n, p + ".fuse." + std::to_string(i) + ".0")) RC(pack_sepconvp_pw(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1"));
       xch = n->dec_ch;
     }
   }
@@ -1208,6 +1297,7 @@ int emp_pdl_finalize(emp_pdl_t* n) {
     RC(pack_dw(n, p + ".head.0.0.sepconv.0", n->dec_ch));
     RC(pack_conv(n, p + ".head.0.0.sepconv.1"));
     RC(pack_sepconv_pw(n, p + ".head.0.0.sepconv.1"));
+    if (precise_layer(n, p + ".head.0.0")) RC(pack_sepconvp_pw(n, p + ".head.0.0.sepconv.1"));
     RC(upload_f32(n, p + ".head.1.w", n->params[p + ".head.1"].w));
     RC(upload_f32(n, p + ".head.1.b", n->params[p + ".head.1"].b));
   }

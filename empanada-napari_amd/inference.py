@@ -43,18 +43,43 @@ def take(array, indices, axis=0):
     return array[idx]
 
 
+def resolve_model_file(fpath_or_url):
+    """utils.load_model_to_device (empanada_napari/utils.py:80-106): a local file is used as it is; anything else is a URL
+    whose download the reference caches as ``<torch.hub.get_dir()>/<basename of the URL path>``.  The engine has no
+    network access: it accepts that cached file when a previous run of the plugin (or the user) has put it there."""
+    if os.path.isfile(fpath_or_url):
+        return fpath_or_url
+    from urllib.parse import urlparse
+    filename = os.path.basename(urlparse(fpath_or_url).path)
+    cached = os.path.join(torch.hub.get_dir(), filename) if filename else None
+    if cached and os.path.isfile(cached):
+        return cached
+    raise FileNotFoundError(f'model {fpath_or_url!r} is neither a local TorchScript file nor in the torch-hub cache '
+                            f'({cached}); the engine does not download (no network access)')
+
+
+def load_model_spec(model_config):
+    """-> (state dict, configuration) of ``model_config['model']``: a TorchScript export (file, or URL in the torch-hub
+    cache) or a state dict.  The architecture is read from the export (``weights.infer_cfg``: the reference's YAMLs do not
+    state it); an ``'arch'`` dict in ``model_config`` overrides single keys."""
+    m = model_config['model']
+    if isinstance(m, dict):
+        sd, mod = m, None
+    else:
+        mod = torch.jit.load(resolve_model_file(m), map_location='cpu')
+        sd = mod.state_dict()
+    cfg = weights.infer_cfg(sd, mod)
+    cfg.update(model_config.get('arch', {}))
+    return sd, cfg
+
+
 def load_model(model_config, device):
     """utils.load_model_to_device (empanada_napari/utils.py:80-106) for the HIP engine."""
     m = model_config['model']
     if isinstance(m, HipPanopticDeepLab):
         return m
-    cfg = dict(weights.MITONET_PDL_CFG, **model_config.get('arch', {}))
-    if isinstance(m, dict):
-        return HipPanopticDeepLab(m, cfg, device=device)
-    if isinstance(m, str) and os.path.isfile(m):
-        ts = torch.jit.load(m, map_location='cpu')
-        return HipPanopticDeepLab(ts.state_dict(), cfg, device=device)
-    raise FileNotFoundError(f'model {m!r} is not a local TorchScript file (no network access from the engine)')
+    sd, cfg = load_model_spec(model_config)
+    return HipPanopticDeepLab(sd, cfg, device=device)
 
 
 def _require_scale_one(scale):

@@ -266,3 +266,98 @@ def fold_state_dict(sd, cfg=None):
             b = ((b - mean) * rstd * gamma + beta).astype(np.float32)
         out[n] = (np.ascontiguousarray(w), np.ascontiguousarray(b))
     return out
+
+
+# ----------------------------------------------------------------------------
+# architecture from the export itself
+# ----------------------------------------------------------------------------
+def _conv_attr(mod, attr):
+    """attribute of a (possibly fused) conv of a loaded TorchScript module: ``Conv2d`` carries it itself, the fused
+    ``ConvReLU2d`` / ``Sequential`` keeps the conv as child ``0``."""
+    for _ in range(3):
+        if mod is None:
+            return None
+        try:
+            return getattr(mod, attr)
+        except AttributeError:
+            mod = dict(mod.named_children()).get('0')
+    return None
+
+
+def _child(mod, path):
+    for part in path.split('.'):
+        if mod is None:
+            return None
+        mod = dict(mod.named_children()).get(part)
+    return mod
+
+
+def infer_cfg(state_dict, module=None):
+    """The model configuration (the keys of MITONET_PDL_CFG / MITONET_MINI_CFG) of an exported model, read from the export
+    itself: the reference's YAML descriptors (empanada_napari/configs/*.yaml) carry no architecture, the widgets simply
+    ``torch.jit.load`` the file (empanada_napari/utils.py:80-106) and call it.  Widths, class count, decoder layout and
+    PointRend depth follow from the parameter shapes of ``state_dict`` (either key layout, see ``fold_state_dict``); what
+    is not a parameter -- the ASPP dilations (decoders/aspp.py:51-94), the encoder's output stride
+    (encoders/resnet.py:173-175) and PointRend's point budget (point_rend.py:146-176) -- is read from the attributes of
+    the scripted submodules when ``module`` (the loaded TorchScript model) is given, else left at the training defaults
+    (empanada_napari/training/*.yaml)."""
+    keys = list(state_dict.keys())
+
+    def shape(name):
+        for suf in ('.weight', '.0.weight'):
+            if name + suf in state_dict:
+                return tuple(int(d) for d in state_dict[name + suf].shape)
+        return None
+
+    if shape('encoder.conv1') is None or shape('encoder.layer1.0.conv3') is None:
+        stem = [k for k in keys if k.startswith('encoder.')][:3]
+        raise NotImplementedError(f'only ResNet encoders are built (RegNet exports are not supported yet); encoder keys: {stem}')
+    nblocks = tuple(len({k.split('.')[2] for k in keys if k.startswith(f'encoder.layer{li}.')}) for li in (1, 2, 3, 4))
+    if nblocks != RESNET50_LAYERS or shape('encoder.layer1.0.conv3')[0] != 256:
+        raise NotImplementedError(f'only the resnet50 encoder is built; this export has blocks {nblocks}')
+    ncls = shape('semantic_head.head.1')[0]
+    num_fc = len({k.split('.')[3] for k in keys if k.startswith('semantic_pr.point_head.fc_layers.')})
+    npts = None
+    if module is not None:
+        pr = _child(module, 'semantic_pr')
+        try:
+            npts = int(pr.subdivision_num_points)
+        except Exception:
+            npts = None
+    if any(k.startswith('semantic_fpn.') for k in keys):
+        cfg = dict(MITONET_MINI_CFG)
+        cfg.update(num_classes=ncls, fpn_dim=shape('p2_resample.conv.0')[0], num_fc=num_fc,
+                   fpn_layers=len({k.split('.')[2] for k in keys if k.startswith('semantic_fpn.bifpns.')}),
+                   ins_decoder=any(k.startswith('instance_fpn.') for k in keys),
+                   depthwise=shape('semantic_fpn.bifpns.0.top_down_fpn.after_combines.0.0.sepconv.0') is not None)
+        if not cfg['depthwise']:
+            raise NotImplementedError('BiFPN exports without depthwise-separable node convolutions are not built')
+    else:
+        cfg = dict(MITONET_PDL_CFG)
+        widths = [p * 4 for p in RESNET_PLANES]
+        stages, proj = [], []
+        while shape(f'semantic_decoder.project.{len(stages)}.0') is not None:
+            lp, cin = shape(f'semantic_decoder.project.{len(stages)}.0')[:2]
+            stages.append(widths.index(cin) + 1)
+            proj.append(lp)
+        ins = any(k.startswith('instance_decoder.') for k in keys)
+        dec = shape('semantic_decoder.fuse.0.0.sepconv.1')[0]
+        aspp = shape('semantic_decoder.aspp.convs.0.0')[0]
+        cfg.update(num_classes=ncls, decoder_channels=dec, aspp_channels=None if aspp == dec else aspp, num_fc=num_fc,
+                   low_level_stages=stages, low_level_channels_project=proj, ins_decoder=ins)
+        if ins:
+            cfg['ins_ratio'] = shape('instance_decoder.project.0.0')[0] / proj[0]
+        if module is not None:
+            rates = []
+            for i in (1, 2, 3):
+                d = _conv_attr(_child(module, f'semantic_decoder.aspp.convs.{i}'), 'dilation')
+                if d is not None:
+                    rates.append(int(d[0]))
+            if len(rates) == 3:
+                cfg['atrous_rates'] = rates
+            d4 = _conv_attr(_child(module, 'encoder.layer4.0.conv2'), 'dilation')
+            if d4 is not None:
+                cfg['stage4_stride'] = 16 if int(d4[0]) == 2 else 32
+    if npts:
+        cfg['subdivision_num_points'] = npts
+    return cfg

@@ -7,10 +7,27 @@ Consumes the folded ``name -> (w, b)`` parameters of
 Pinned against the reference itself by ``oracle/gen_golden.py``
 (tests/golden/pdl_forward_*.npz).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
 RESNET50_LAYERS = (3, 4, 6, 3)
+
+
+def precise_block(pre, ins_decoder=True):
+    """Which separable blocks the HIP engine computes at fp32 accuracy (csrc/sepconv_precise.hip: fp32 taps, depthwise
+    result and pointwise weights as fp16 hi + lo pairs) -- the rule of pdl_net.hip's ``precise_layer``: by default the
+    blocks the centre heat-map depends on (the fusion convs of the decoder that feeds ``ins_center`` and the
+    ``ins_center`` head); EMP_PRECISE_SEPCONV=2 every fused 5x5 block, 0 none.  ``pre`` is the block's parameter prefix
+    (``<pre>.sepconv.0`` / ``.1``).  Test infrastructure mirrors the switch so that A/B runs stay comparable."""
+    mode = int(os.environ.get('EMP_PRECISE_SEPCONV', '1'))
+    if mode <= 0:
+        return False
+    if mode >= 2:
+        return True
+    dec = 'instance_decoder.' if ins_decoder else 'semantic_decoder.'
+    return pre.startswith('ins_center.') or pre.startswith(dec)
 
 
 def _t(a):
@@ -135,7 +152,7 @@ def aspp_forward(P, pre, x, rates, taps=None):
     return _conv(torch.cat(res, dim=1), P[f'{pre}.project.0'], relu=True)
 
 
-def decoder_forward(P, pre, pyr, low_level_stages, rates, taps=None):
+def decoder_forward(P, pre, pyr, low_level_stages, rates, taps=None, ins_decoder=True):
     """decoders/panoptic_deeplab.py:68-80."""
     x = aspp_forward(P, f'{pre}.aspp', pyr[-1], rates, taps)
     if taps is not None:
@@ -146,15 +163,19 @@ def decoder_forward(P, pre, pyr, low_level_stages, rates, taps=None):
         x = torch.cat((x, l), dim=1)
         if taps is not None:
             taps[f'{pre}.stage{i}.cat'] = x
-        x = _conv(x, (P[f'{pre}.fuse.{i}.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=True)
-        x = _conv(x, P[f'{pre}.fuse.{i}.0.sepconv.1'], relu=True, site=True)
+        # sepconv_precise.hip: fp32 taps, the depthwise result and the pointwise weights as fp16 hi + lo pairs -- the block
+        # rounds nothing but its fp16 output map; sepconv.hip: fp16 taps, fp16 depthwise result, fp16 weights
+        prec = precise_block(f'{pre}.fuse.{i}.0', ins_decoder)
+        x = _conv(x, (P[f'{pre}.fuse.{i}.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=None if prec else True, w32=prec)
+        x = _conv(x, P[f'{pre}.fuse.{i}.0.sepconv.1'], relu=True, site=True, w32=prec)
     return x
 
 
-def head_forward(P, pre, x):
+def head_forward(P, pre, x, ins_decoder=True):
     """heads.py:12-19."""
-    x = _conv(x, (P[f'{pre}.head.0.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=True)
-    x = _conv(x, P[f'{pre}.head.0.0.sepconv.1'], relu=True)      # fused head: this map stays fp32 on chip (sepconv.hip)
+    prec = precise_block(f'{pre}.head.0.0', ins_decoder) and P[f'{pre}.head.1'][0].shape[0] <= 2
+    x = _conv(x, (P[f'{pre}.head.0.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=None if prec else True, w32=prec)
+    x = _conv(x, P[f'{pre}.head.0.0.sepconv.1'], relu=True, w32=prec)      # fused head: this map stays fp32 on chip
     return _conv(x, P[f'{pre}.head.1'], w32=True)
 
 
@@ -235,11 +256,12 @@ def pdl_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None, emu=
             _EMU = None
     pyr = resnet50_forward(P, x, cfg['stage4_stride'], taps)
     stages, rates = cfg['low_level_stages'], cfg['atrous_rates']
-    semantic_x = decoder_forward(P, 'semantic_decoder', pyr, stages, rates, taps)
-    instance_x = decoder_forward(P, 'instance_decoder', pyr, stages, rates, taps) if cfg['ins_decoder'] else semantic_x
-    sem = head_forward(P, 'semantic_head', semantic_x)
-    ctr = head_forward(P, 'ins_center', instance_x)
-    off = head_forward(P, 'ins_xy', instance_x)
+    insd = bool(cfg['ins_decoder'])
+    semantic_x = decoder_forward(P, 'semantic_decoder', pyr, stages, rates, taps, insd)
+    instance_x = decoder_forward(P, 'instance_decoder', pyr, stages, rates, taps, insd) if insd else semantic_x
+    sem = head_forward(P, 'semantic_head', semantic_x, insd)
+    ctr = head_forward(P, 'ins_center', instance_x, insd)
+    off = head_forward(P, 'ins_xy', instance_x, insd)
     if taps is not None:
         taps.update(semantic_x=semantic_x, instance_x=instance_x, sem_coarse=sem)
     sem_logits = point_rend_forward(P, sem, semantic_x, render_steps,
@@ -398,13 +420,13 @@ def teacher_forced_layers(P, cfg, x, tap):
             up = F.interpolate(tap(xn), size=low.shape[2:], mode='bilinear', align_corners=True)
             yield f'{d}.stage{i}.cat', torch.cat((up, low), dim=1), True
             cat = tap(f'{d}.stage{i}.cat')[:, :up.shape[1] + low.shape[1]]     # the engine pads the concat to 64 channels
-            dw = r16(conv(cat, f'{d}.fuse.{i}.0.sepconv.0', 1, 2, 1, cat.shape[1]))
-            yield f'{d}.stage{i}.out', F.relu(conv(dw, f'{d}.fuse.{i}.0.sepconv.1')), True
+            prec = precise_block(f'{d}.fuse.{i}.0', bool(cfg['ins_decoder']))
+            yield f'{d}.stage{i}.out', F.relu(_tf_sepconv(P, cat, f'{d}.fuse.{i}.0', 2, prec)), True
             xn = f'{d}.stage{i}.out'
     last = len(cfg['low_level_stages']) - 1
     semx = tap(f'semantic_decoder.stage{last}.out')
     insx = tap(f'instance_decoder.stage{last}.out') if cfg['ins_decoder'] else semx
-    yield from _tf_heads(P, semx, insx, tap)
+    yield from _tf_heads(P, semx, insx, tap, bool(cfg['ins_decoder']))
 
 
 def _tf_weights(P, name, fp32=False):
@@ -412,9 +434,20 @@ def _tf_weights(P, name, fp32=False):
     return (_t(w) if fp32 else Fp16Emu.r16(_t(w))), _t(b)
 
 
-def _tf_conv(P, xin, name, stride=1, padding=0, dilation=1, groups=1):
-    w, b = _tf_weights(P, name)
+def _tf_conv(P, xin, name, stride=1, padding=0, dilation=1, groups=1, fp32=False):
+    w, b = _tf_weights(P, name, fp32)
     return F.conv2d(xin, w, b if groups == 1 else None, stride, padding, dilation, groups)
+
+
+def _tf_sepconv(P, xin, pre, pad, precise):
+    """``pre``.sepconv.0 (depthwise) -> ``pre``.sepconv.1 (pointwise + folded BN) before the activation.  precise
+    (sepconv_precise.hip): fp32 taps, the depthwise result and the pointwise weights as fp16 hi + lo pairs -- fp32
+    arithmetic on the engine's fp16 input map.  Otherwise (sepconv.hip, or the unfused dwconv + conv pair, which are
+    bit-identical): fp16 taps, fp16 intermediate map, fp16 pointwise weights."""
+    dw = _tf_conv(P, xin, f'{pre}.sepconv.0', 1, pad, 1, xin.shape[1], fp32=precise)
+    if not precise:
+        dw = Fp16Emu.r16(dw)
+    return _tf_conv(P, dw, f'{pre}.sepconv.1', fp32=precise)
 
 
 def _tf_encoder(P, cfg, x, tap):
@@ -444,14 +477,14 @@ def _tf_encoder(P, cfg, x, tap):
     return pyr
 
 
-def _tf_heads(P, semx, insx, tap):
+def _tf_heads(P, semx, insx, tap, ins_decoder=True):
     """heads.py:12-19 on the engine's decoder outputs: 5x5 separable conv + ReLU + fp32 1x1.  The engine fuses the
     whole head into one launch when it has at most two output planes (the 256-channel map then never leaves the CU,
     fp32); a wider head (multi-class semantic) stores that map in fp16 as ``<head>.pw`` and runs the 1x1 from it."""
     for head, xin in (('semantic_head', semx), ('ins_center', insx), ('ins_xy', insx)):
-        dw = Fp16Emu.r16(_tf_conv(P, xin, f'{head}.head.0.0.sepconv.0', 1, 2, 1, xin.shape[1]))
-        y = F.relu(_tf_conv(P, dw, f'{head}.head.0.0.sepconv.1'))
         w, b = _tf_weights(P, f'{head}.head.1', fp32=True)
+        prec = precise_block(f'{head}.head.0.0', ins_decoder) and w.shape[0] <= 2
+        y = F.relu(_tf_sepconv(P, xin, f'{head}.head.0.0', 2, prec))
         if w.shape[0] > 2:
             yield head + '.pw', y, True
             y = tap(head + '.pw')
@@ -531,9 +564,7 @@ def teacher_forced_layers_bifpn(P, cfg, x, tap):
             up = F.relu(F.conv_transpose2d(tap(xn), w, b, stride=2))     # cat{i-1} carries 2F channels, all of them inputs
             yield f'{dp}.cat{i}', torch.cat([up, tap(skips[i])], dim=1), True
             xn = f'{dp}.cat{i}'
-        cat = tap(xn)
-        dw = r16(conv(cat, f'{dp}.fusion.0.sepconv.0', 1, 2, 1, cat.shape[1]))
-        yield f'{dp}.out', F.relu(conv(dw, f'{dp}.fusion.0.sepconv.1')), True
+        yield f'{dp}.out', F.relu(_tf_sepconv(P, tap(xn), f'{dp}.fusion.0', 2, precise_block(f'{dp}.fusion.0', bool(cfg['ins_decoder'])))), True
     semx = tap('semantic_decoder.out')
     insx = tap('instance_decoder.out') if cfg['ins_decoder'] else semx
-    yield from _tf_heads(P, semx, insx, tap)
+    yield from _tf_heads(P, semx, insx, tap, bool(cfg['ins_decoder']))

@@ -1,0 +1,202 @@
+"""Fused separable conv at fp32 accuracy (csrc/sepconv_precise.hip: depthwise KxK -> pointwise -> bias/act [-> 1x1 head];
+the engine runs it for the blocks the centre heat-map depends on, pdl_net.hip precise_layer): the block computes at fp32
+accuracy -- fp32 depthwise taps on the vector pipe, depthwise result and pointwise weights as
+fp16 hi + lo pairs on the matrix pipe, fp32 accumulation; only its input and output maps are fp16.  Checked against
+
+ (a) an fp64 torch reference of the same op on the same fp16 input and the SAME fp32 weights with nothing rounded in
+     between: the fp16 output must be the correctly rounded value up to summation-order noise
+     (|err| <= half an fp16 ulp of the reference + 2e-6 * scale), the fp32 head output within 4e-6 * scale;
+ (b) the unfused HIP pair dwconv + conv (fp16 taps / intermediate / weights): the fused block must be CLOSER to the fp64
+     truth than the pair -- the reason it exists (profiles/r02_error_budget.csv);
+ (c) itself: repeated launches and a batch vs its images one by one are bit-identical (fixed summation order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # N, H, W, C, in_ld, Cout, act
+    (2, 16, 32, 128, 128, 128, 1),
+    (1, 24, 40, 320, 320, 256, 1),       # W % 16 = 8: ragged tile column
+    (3, 13, 21, 256, 256, 256, 1),       # odd sizes, ragged rows and columns
+    (1, 8, 16, 128, 192, 256, 0),        # channel slice of a wider buffer, no activation
+    (2, 40, 48, 192, 192, 128, 2),       # SiLU
+    (1, 72, 272, 256, 256, 256, 1),      # more tiles than workgroups -> several tiles per workgroup
+    (1, 16, 16, 512, 512, 256, 1),       # 8 channel chunks (the taps are no longer held in LDS: C <= 512)
+]
+
+CASES3 = [
+    # depthwise 3x3: the BiFPN node's separable conv, SiLU after the folded BN
+    (2, 16, 32, 128, 128, 128, 2),
+    (3, 13, 21, 128, 128, 128, 2),       # ragged rows and columns
+    (1, 64, 128, 128, 128, 128, 2),      # one tile per workgroup and more
+    (1, 8, 16, 128, 192, 256, 0),        # channel slice, Cout 256
+    (2, 40, 48, 256, 256, 256, 1),
+    (4, 8, 8, 128, 128, 128, 2),         # a P7-sized map: fewer tiles than workgroups
+]
+
+
+def _operands(case, ks=5, seed=0):
+    N, H, W, Cc, in_ld, Cout, act = case
+    g = torch.Generator().manual_seed(seed + hash(case) % (2 ** 31))
+    x = torch.randn((N, H, W, in_ld), generator=g).to(torch.float16)
+    dw = torch.randn((Cc, ks, ks), generator=g) * (0.2 if ks == 5 else 0.3)          # fp32: NOT representable in fp16
+    pw = torch.randn((Cout, Cc), generator=g) / np.sqrt(Cc)
+    b = torch.randn((Cout,), generator=g) * 0.1
+    return x, dw, pw, b
+
+
+def _apply_act(y, act):
+    if act == 1:
+        return torch.relu(y)
+    if act == 2:
+        return y * torch.sigmoid(y)
+    return y
+
+
+def _ref64(x, dw, pw, b, Cc, act, ks=5):
+    xin = x[..., :Cc].double().permute(0, 3, 1, 2)
+    d = F.conv2d(xin, dw.double()[:, None], padding=ks // 2, groups=Cc)
+    return _apply_act(F.conv2d(d, pw.double()[:, :, None, None], b.double()), act)     # (N,Cout,H,W) fp64
+
+
+def _fused(x, dw, pw, b, case, head=None, ks=5):
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    N, H, W, Cc, in_ld, Cout, act = case
+    xd = x.to(dev())
+    dwu = dw.reshape(Cc, ks * ks).t().contiguous().float().to(dev())          # (ks*ks, C) fp32
+    dwd = torch.empty_like(dwu)                                               # chunk-major [C/64][ks*ks][64]
+    _abi.check(lib.emp_sepconvp_pack_dw(_abi.ptr(dwu), ks, Cc, _abi.ptr(dwd), _abi.stream_ptr(dev())), 'pack_dw')
+    pwu = pw.contiguous().float().to(dev())
+    pwd = torch.empty((2, Cout, Cc), dtype=torch.float16, device=dev())       # hi parts, lo parts
+    _abi.check(lib.emp_sepconvp_pack_pw(_abi.ptr(pwu), Cc, Cc, Cout, _abi.ptr(pwd), _abi.stream_ptr(dev())), 'pack')
+    bd = b.float().to(dev())
+    if head is None:
+        out = torch.full((N, H, W, Cout), 7.0, dtype=torch.float16, device=dev())
+        _abi.check(lib.emp_sepconvp_nhwc_f16(_abi.ptr(xd), N, H, W, Cc, in_ld, ks, _abi.ptr(dwd), _abi.ptr(pwd),
+                                             _abi.ptr(bd), Cout, act, _abi.ptr(out), Cout, None, None, 0, None,
+                                             _abi.stream_ptr(dev())), 'sepconvp')
+        torch.cuda.synchronize()
+        return out
+    hw, hb = head
+    hc = hw.shape[0]
+    hout = torch.full((N, hc, H, W), 7.0, dtype=torch.float32, device=dev())
+    hwd, hbd = hw.float().contiguous().to(dev()), hb.float().to(dev())
+    _abi.check(lib.emp_sepconvp_nhwc_f16(_abi.ptr(xd), N, H, W, Cc, in_ld, ks, _abi.ptr(dwd), _abi.ptr(pwd),
+                                         _abi.ptr(bd), Cout, act, None, 0, _abi.ptr(hwd), _abi.ptr(hbd), hc,
+                                         _abi.ptr(hout), _abi.stream_ptr(dev())), 'sepconvp head')
+    torch.cuda.synchronize()
+    return hout
+
+
+def _unfused(x, dw, pw, b, case, ks=5):
+    """the fp16 pair the fused block replaces: taps, intermediate map and pointwise weights rounded to fp16"""
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    N, H, W, Cc, in_ld, Cout, act = case
+    xd = x.to(dev())
+    dwd = dw.reshape(Cc, ks * ks).t().contiguous().to(torch.float16).to(dev())
+    mid = torch.empty((N, H, W, Cc), dtype=torch.float16, device=dev())
+    _abi.check(lib.emp_dwconv_nhwc_f16(_abi.ptr(xd), N, H, W, Cc, in_ld, _abi.ptr(dwd), ks, _abi.ptr(mid), Cc,
+                                       _abi.stream_ptr(dev())), 'dwconv')
+    out = torch.empty((N, H, W, Cout), dtype=torch.float16, device=dev())
+    pwd = pw.contiguous().to(torch.float16).to(dev())
+    bd = b.float().to(dev())
+    _abi.check(lib.emp_conv2d_nhwc_f16(_abi.ptr(mid), N, H, W, Cc, Cc, _abi.ptr(pwd), _abi.ptr(bd), None, None, 0,
+                                       _abi.ptr(out), Cout, Cout, 1, 1, 1, 0, 1, act, 0, _abi.stream_ptr(dev())),
+               'conv')
+    torch.cuda.synchronize()
+    return out, mid
+
+
+def _half_ulp(ref):
+    """half an fp16 ulp of |ref| (normal range; 2^-25 below it)"""
+    e = torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -14)))
+    return 2.0 ** (e - 11)
+
+
+def _check_fp16_output(y, ref64, what):
+    y = y.double().cpu().permute(0, 3, 1, 2)
+    scale = float(ref64.abs().max())
+    err = (y - ref64).abs()
+    tol = _half_ulp(ref64) + 2e-6 * scale
+    bad = err > tol
+    assert not bool(bad.any()), (f'{what}: {int(bad.sum())} elements beyond half an fp16 ulp; max err {float(err.max()):.3e} '
+                                 f'at ref {float(ref64.flatten()[err.argmax()]):.4f}')
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_fused_is_the_correctly_rounded_fp32_result(case):
+    x, dw, pw, b = _operands(case)
+    _check_fp16_output(_fused(x, dw, pw, b, case), _ref64(x, dw, pw, b, case[3], case[6]), '5x5')
+
+
+@pytest.mark.parametrize('case', CASES3)
+def test_fused_3x3_is_the_correctly_rounded_fp32_result(case):
+    x, dw, pw, b = _operands(case, ks=3)
+    _check_fp16_output(_fused(x, dw, pw, b, case, ks=3), _ref64(x, dw, pw, b, case[3], case[6], ks=3), '3x3')
+
+
+@pytest.mark.parametrize('ks,case', [(5, CASES[1]), (5, CASES[5]), (3, CASES3[2]), (3, CASES3[4])])
+def test_fused_beats_the_fp16_pair(ks, case):
+    x, dw, pw, b = _operands(case, ks=ks, seed=1)
+    ref = _ref64(x, dw, pw, b, case[3], case[6], ks=ks)
+    y = _fused(x, dw, pw, b, case, ks=ks).double().cpu().permute(0, 3, 1, 2)
+    u = _unfused(x, dw, pw, b, case, ks=ks)[0].double().cpu().permute(0, 3, 1, 2)
+    rms_f = float((y - ref).pow(2).mean().sqrt())
+    rms_u = float((u - ref).pow(2).mean().sqrt())
+    print(f'rms error vs fp64: fused {rms_f:.3e}, dwconv + conv {rms_u:.3e}')
+    assert rms_f < 0.6 * rms_u
+
+
+@pytest.mark.parametrize('hc', [1, 2])
+@pytest.mark.parametrize('case', [CASES[4], CASES[2], CASES[0], CASES[5], CASES[1]])
+def test_fused_head(case, hc):
+    x, dw, pw, b = _operands(case, seed=3)
+    Cout = case[5]
+    g = torch.Generator().manual_seed(hc)
+    hw = torch.randn((hc, Cout), generator=g) / np.sqrt(Cout)
+    hb = torch.randn((hc,), generator=g)
+    out = _fused(x, dw, pw, b, case, head=(hw, hb)).double().cpu()
+    y = _ref64(x, dw, pw, b, case[3], case[6])
+    ref = F.conv2d(y, hw.double()[:, :, None, None], hb.double())
+    # error scale: the head sums Cout terms of magnitude |y| * |hw|
+    scale = float((y.abs().amax(1, keepdim=True) * hw.abs().sum(1).max()).max())
+    err = (out - ref).abs()
+    assert float(err.max()) <= 4e-6 * scale, f'max err {float(err.max()):.4e} (scale {scale:.2f})'
+
+
+@pytest.mark.parametrize('ks,case', [(5, CASES[2]), (5, CASES[5]), (3, CASES3[1])])
+def test_repeatable_and_batch_invariant(ks, case):
+    x, dw, pw, b = _operands(case, ks=ks, seed=4)
+    y0 = _fused(x, dw, pw, b, case, ks=ks)
+    for _ in range(3):
+        assert torch.equal(_fused(x, dw, pw, b, case, ks=ks), y0)
+    N = case[0]
+    for i in range(N):
+        one = (1,) + tuple(case[1:])
+        assert torch.equal(_fused(x[i:i + 1].contiguous(), dw, pw, b, one, ks=ks)[0], y0[i]), f'image {i} alone differs'
+    if ks == 5:
+        g = torch.Generator().manual_seed(9)
+        hw, hb = torch.randn((2, case[5]), generator=g) / 16, torch.randn((2,), generator=g)
+        h0 = _fused(x, dw, pw, b, case, head=(hw, hb))
+        for _ in range(3):
+            assert torch.equal(_fused(x, dw, pw, b, case, head=(hw, hb)), h0)
+
+
+def test_unsupported_shape_is_rejected():
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    x = torch.zeros((1, 8, 16, 64), dtype=torch.float16, device=dev())
+    w = torch.zeros((25, 64), dtype=torch.float32, device=dev())
+    p = torch.zeros((2, 64, 64), dtype=torch.float16, device=dev())
+    o = torch.zeros((1, 8, 16, 64), dtype=torch.float16, device=dev())
+    rc = lib.emp_sepconvp_nhwc_f16(_abi.ptr(x), 1, 8, 16, 64, 64, 5, _abi.ptr(w), _abi.ptr(p), None, 64, 1,
+                                   _abi.ptr(o), 64, None, None, 0, None, _abi.stream_ptr(dev()))
+    assert rc != 0 and b'unsupported' in lib.emp_last_error()

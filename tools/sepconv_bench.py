@@ -59,10 +59,22 @@ def main():
                                                    _abi.ptr(b), Cout, 1, None if hc else _abi.ptr(out), Cout,
                                                    _abi.ptr(hw) if hc else None, _abi.ptr(hb) if hc else None, hc,
                                                    _abi.ptr(ho) if hc else None, st), 'fused')
-        tu, tf = timeit(unfused), timeit(fused)
+        # the fp32-accurate block (sepconv_precise.hip): fp32 taps, fp16 hi + lo operands, 3 MFMAs per product
+        dw32 = torch.randn((25, Cc), device=dev) * 0.2
+        pw32 = torch.randn((Cout, Cc), device=dev) / np.sqrt(Cc)
+        dwq, pwq = torch.empty_like(dw32), torch.empty((2, Cout, Cc), device=dev, dtype=torch.float16)
+        _abi.check(lib.emp_sepconvp_pack_dw(_abi.ptr(dw32), 5, Cc, _abi.ptr(dwq), st), 'pack_dw')
+        _abi.check(lib.emp_sepconvp_pack_pw(_abi.ptr(pw32), Cc, Cc, Cout, _abi.ptr(pwq), st), 'pack_pw')
+
+        def precise():
+            _abi.check(lib.emp_sepconvp_nhwc_f16(_abi.ptr(x), B, H, W, Cc, Cc, 5, _abi.ptr(dwq), _abi.ptr(pwq),
+                                                 _abi.ptr(b), Cout, 1, None if hc else _abi.ptr(out), Cout,
+                                                 _abi.ptr(hw) if hc else None, _abi.ptr(hb) if hc else None, hc,
+                                                 _abi.ptr(ho) if hc else None, st), 'precise')
+        tu, tf, tp = timeit(unfused), timeit(fused), timeit(precise)
         gb = (x.numel() + (0 if hc else out.numel())) * 2 / 1e9
         fl = 2.0 * B * H * W * Cc * (25 + Cout) / 1e9
-        print(f'{name:26s} unfused(dw+pw) {tu:6.3f} ms | fused {tf:6.3f} ms  {gb/tf*1e3:6.0f} GB/s alg  {fl/tf:7.1f} GFLOP/ms',
+        print(f'{name:26s} unfused(dw+pw) {tu:6.3f} ms | fused {tf:6.3f} ms | precise {tp:6.3f} ms  {gb/tf*1e3:6.0f} GB/s alg  {fl/tf:7.1f} GFLOP/ms',
               flush=True)
 
 
