@@ -374,7 +374,23 @@ def run_stack3d(args, rank, local_rank, world, dist_on, dev):
     vol = synth.ProceduralVolume((D, S, S), seed=7, cell=48, cache=True)    # synthesised in the warm-up pass
     kw = dict(label_divisor=10000, median_kernel_size=args.ks, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5,
               min_size=500, min_extent=5)
-    if dist_on:
+    ranks_one_gpu = int(os.environ.get('EMP_BENCH_RANKS_ON_ONE_GPU', '0'))
+    n_ranks = world
+    if ranks_one_gpu > 1 and not dist_on:
+        # diagnostic (no multi-GPU box in the builder's reach): R real ranks of the slab pipeline time-share THIS GPU, gloo
+        # transport; the GPU phase is R x slower than on R GPUs, the host-side matcher chain is what it would be there
+        D = args.depth * ranks_one_gpu
+        vol = synth.ProceduralVolume((D, S, S), seed=7, cell=48, cache=True)
+        mc = dict(mc, model=weights.seeded_state_dict(cfg, seed=0))
+        eng = multigpu.MultiGPUEngine3d(mc, world_size=ranks_one_gpu, dist_backend='gloo', devices=[0] * ranks_one_gpu, **kw)
+        host = [None]
+
+        def job():
+            if host[0] is None:
+                host[0] = vol.block(0, 0, D, dev).cpu().numpy()
+            return eng.infer_on_axis(host[0], 'xy')
+        n_ranks = ranks_one_gpu
+    elif dist_on:
         multigpu.MultiGPUEngine3d.MIN_WORLD = 1
         eng = multigpu.MultiGPUEngine3d(mc, **kw)
         job = lambda: eng.infer_on_axis(vol, 'xy')
@@ -419,20 +435,40 @@ def run_stack3d(args, rank, local_rank, world, dist_on, dev):
     per_slice = model.last_flops() / max(1, min(bs, args.depth if args.depth % bs == 0 else args.depth % bs))
     flops = per_slice * D
     tf = flops / sec / 1e12
+    slab = None
+    if getattr(locals().get('eng'), 'last_timing', None):
+        # the slab pipeline's split of a job (last job): per rank the GPU phase (forward, halo / carry, median, voting,
+        # merge, run extraction) and the host matcher (total, and its tail behind the GPU phase: ghosts, chains, tracking);
+        # rank 0 also concatenates the per-slab tracks and filters
+        tm = eng.last_timing
+        r0 = tm[0]
+        slab = {'ranks': len(tm),
+                'gpu_ms_per_slice': round(1e3 * r0['gpu_s'] / max(1, r0['slices']), 4),
+                'rank0_host_ms_per_slice': round(1e3 * (r0['tail_s'] + getattr(eng, 'last_merge_s', 0.0)) / max(1, D), 4),
+                'rank0_matcher_ms_per_own_slice': round(1e3 * r0['host_s'] / max(1, r0['slices']), 4),
+                'per_rank': [{k: round(v, 5) if isinstance(v, float) else v for k, v in t.items()} for t in tm],
+                'merge_and_filter_s': round(getattr(eng, 'last_merge_s', 0.0), 5),
+                'note': 'rank0_host_ms_per_slice = (rank 0 matcher tail behind its GPU phase + track concatenation + size '
+                        'filters) / ALL slices of the job: the sequential host work left on rank 0 per slice; '
+                        'gpu_ms_per_slice = rank 0 GPU phase / its own slices'}
+    if ranks_one_gpu > 1:
+        eng.close()
     return {'metric': 'voxels/sec, 3-D stack (xy) z-slab inference', 'value': round(vox / sec, 1), 'unit': 'voxels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': 1, 'ms_per_step': round(sec * 1e3, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': f'procedural uint8 volume {D}x{S}x{S} ({args.depth} slices per GPU), xy stack inference, '
                                    f'recursive median ks={args.ks}, z-slabs over {world} GPU(s), neighbour halo + filtered '
-                                   f'carry over RCCL, run lists to rank 0, C++ matcher + tracker',
+                                   f'carry over RCCL, slab-wise C++ matcher + tracker on every rank (forward / backward '
+                                   f'state chained through the ranks), per-slab tracks to rank 0',
                        'rccl_ranks': world if dist_on else 0, 'tracked_objects': nobj,
-                       'parallelism': f'z-slab x{world}'},
+                       'ranks_sharing_one_gpu': ranks_one_gpu if ranks_one_gpu > 1 else 0,
+                       'parallelism': f'z-slab x{n_ranks}'},
             'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F16_TFLOPS * world, 'unit': 'TFLOP/s',
                          'frac': round(tf / (PEAK_F16_TFLOPS * world), 4), 'traffic': None,
                          'note': 'whole-job rate: forward FLOPs of every slice / wall time of the job over all ranks (median, '
                                  'voting, merge, run extraction and the host matcher included in the time); kernel-level '
                                  'roofline: the tiles workload', 'forward_flops': flops},
-            'cpu_baseline': None}
+            'slab_pipeline': slab, 'cpu_baseline': None}
 
 
 def main():

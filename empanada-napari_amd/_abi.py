@@ -66,6 +66,10 @@ PROTOTYPES = {
     'emp_sm_push_slice_runs': (c_int, [vp, vp, c_i64, c_i64, c_i64]),
     'emp_sm_push_slice_objects': (c_int, [vp, c_i64, vp, vp, vp, vp, vp]),
     'emp_sm_num_slices': (c_i64, [vp]),
+    'emp_sm_prepare': (c_int, [vp, c_i64, c_i64]),
+    'emp_sm_state_size': (c_int, [vp, c_i64, vp, vp]),
+    'emp_sm_export_state': (c_int, [vp, c_i64, vp, vp, vp, vp]),
+    'emp_sm_import_state': (c_int, [vp, c_i64, c_i64, vp, vp, vp, c_i64, c_int]),
     'emp_sm_begin_backward': (c_int, [vp]),
     'emp_sm_step_begin': (c_int, [vp, c_i64, C.POINTER(c_int), C.POINTER(c_int)]),
     'emp_sm_iou': (vp, [vp]),

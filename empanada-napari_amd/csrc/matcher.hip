@@ -340,6 +340,86 @@ int emp_sm_push_slice_objects(emp_stack_matcher* h, int64_t n, const int64_t* la
 
 int64_t emp_sm_num_slices(const emp_stack_matcher* h) { return h ? (int64_t)h->stack.size() : 0; }
 
+// ---- slab-wise matching (round 3: one matcher per rank, multigpu.py) --------------------------------------------------
+// The passes of patterns.py:68-121 are a chain along the axis: slice z is matched against the RELABELLED slice z-1 (or
+// z+1 on the way back).  What a slice hands to its neighbour is small -- the grouping of its components into labelled
+// objects, in dict order, and the label counter -- while everything expensive (run intersections of neighbouring
+// slices, run joins, the tracker) does not depend on labels.  A rank therefore keeps a matcher for its own slab plus one
+// GHOST slice on either side (the neighbour's boundary slice, pushed from the same runs so that its components carry the
+// same indices), builds every pair table up front, and only the state of a boundary slice travels down the ranks.
+
+// Pair tables of slices (from, to]: the label-independent part of steps from+1 .. to, in any order, ahead of the chain.
+int emp_sm_prepare(emp_stack_matcher* h, int64_t from, int64_t to) {
+  EMP_REQUIRE(h && from >= 0 && to < (int64_t)h->stack.size(), "sm_prepare: bad range");
+  if (!h->do_match) return EMP_OK;
+  for (int64_t i = from + 1; i <= to; ++i)
+    if (!h->stack[(size_t)i].pairs_ready) build_pairs(h->stack[(size_t)i - 1], h->stack[(size_t)i]);
+  return EMP_OK;
+}
+
+int emp_sm_state_size(const emp_stack_matcher* h, int64_t idx, int64_t* n_obj, int64_t* n_mem) {
+  EMP_REQUIRE(h && n_obj && n_mem && idx >= 0 && idx < (int64_t)h->stack.size(), "sm_state_size: bad arguments");
+  const FSlice& sl = h->stack[(size_t)idx];
+  *n_obj = (int64_t)sl.objs.size();
+  int64_t m = 0;
+  for (const FObj& o : sl.objs) m += (int64_t)o.members.size();
+  *n_mem = m;
+  return EMP_OK;
+}
+
+// The matching state of slice idx: its objects in dict order as (label, member components) -- CSR: off has n_obj + 1
+// entries -- and the label counter (RLEMatcher.next_label).
+int emp_sm_export_state(const emp_stack_matcher* h, int64_t idx, int64_t* labels, int64_t* off, int64_t* members,
+                        int64_t* next_label) {
+  EMP_REQUIRE(h && labels && off && members && next_label && idx >= 0 && idx < (int64_t)h->stack.size(),
+              "sm_export_state: bad arguments");
+  const FSlice& sl = h->stack[(size_t)idx];
+  int64_t m = 0;
+  for (size_t i = 0; i < sl.objs.size(); ++i) {
+    labels[i] = sl.objs[i].label;
+    off[i] = m;
+    for (int c : sl.objs[i].members) members[m++] = c;
+  }
+  off[sl.objs.size()] = m;
+  *next_label = h->next_label;
+  return EMP_OK;
+}
+
+// Slice idx becomes the matcher's TARGET with the given objects (a ghost slice: the state its owner exported), the label
+// counter is set (next_label < 0: kept) and assign_new chosen (1: forward pass, 0: backward pass, patterns.py:102-109).
+int emp_sm_import_state(emp_stack_matcher* h, int64_t idx, int64_t n_obj, const int64_t* labels, const int64_t* off,
+                        const int64_t* members, int64_t next_label, int assign_new) {
+  EMP_REQUIRE(h && idx >= 0 && idx < (int64_t)h->stack.size() && n_obj >= 0 && (n_obj == 0 || (labels && off && members)),
+              "sm_import_state: bad arguments");
+  FSlice& sl = h->stack[(size_t)idx];
+  std::vector<FObj> objs((size_t)n_obj);
+  std::vector<char> used((size_t)sl.K, 0);
+  for (int64_t i = 0; i < n_obj; ++i) {
+    FObj& o = objs[(size_t)i];
+    o.label = labels[i];
+    EMP_REQUIRE(off[i + 1] > off[i], "sm_import_state: object %lld has no member", (long long)i);
+    for (int64_t k = off[i]; k < off[i + 1]; ++k) {
+      const int64_t c = members[k];
+      EMP_REQUIRE(c >= 0 && c < sl.K && !used[(size_t)c], "sm_import_state: component %lld out of range or listed twice (the "
+                  "ghost slice must be pushed from the runs its owner pushed)", (long long)c);
+      used[(size_t)c] = 1;
+      const int64_t* b = &sl.box[4 * (size_t)c];
+      if (k == off[i]) std::memcpy(o.box, b, sizeof(o.box));
+      else {
+        o.box[0] = std::min(o.box[0], b[0]); o.box[1] = std::min(o.box[1], b[1]);
+        o.box[2] = std::max(o.box[2], b[2]); o.box[3] = std::max(o.box[3], b[3]);
+      }
+      o.members.push_back((int)c);
+    }
+  }
+  sl.objs.swap(objs);
+  h->target_idx = (int)idx;
+  h->pending = -1;
+  if (next_label >= 0) h->next_label = next_label;
+  h->assign_new = assign_new != 0;
+  return EMP_OK;
+}
+
 // patterns.py:102-109: the backward pass starts from a fresh target and never creates labels
 int emp_sm_begin_backward(emp_stack_matcher* h) {
   EMP_REQUIRE(h != nullptr, "sm_begin_backward: null handle");

@@ -13,8 +13,16 @@ Re-design for MI355X: rank r owns the contiguous slab
     and the last ``mid`` FILTERED maps of rank r-1 (a carry that ripples down the ranks;
     the per-pixel median is a tiny HBM-bound kernel, so the ripple costs ~W median passes);
   * post-processing (voting, merge, connected components, run extraction): per slab, on
-    the GPU; only run-length lists travel to rank 0 (``gather_object``), which does the
-    inherently sequential slice-to-slice matching.
+    the GPU;
+  * slice-to-slice matching and tracking (round 3): per slab too.  The passes of
+    ``patterns.py:68-121`` are a chain along the axis, but a slice hands its neighbour only
+    the grouping of its components into labelled objects and the label counter -- a few KB.
+    Every rank builds the run-intersection tables of its slab up front (the bulk of the
+    work, label-independent, overlapped with its GPU's run extraction), then the forward
+    state ripples down the ranks and the backward state back up (``SlabMatcher``), each
+    rank tracks its own slices, and rank 0 only concatenates the per-slab tracks.
+    Round 2 gathered every run list on rank 0 and matched there: 1 ms of sequential host
+    work per 1024^2 slice against 0.75 ms / ranks of GPU work.
 The exchange uses point-to-point ``isend/irecv`` between neighbours -- xGMI is a
 point-to-point fabric, a ring all-gather of whole maps would be bound by one 153 GB/s link.
 
@@ -175,7 +183,165 @@ def _recv(t, src, group):
         dist.recv(t, src=src, group=group)
 
 
-def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None):
+def _send_obj(obj, dst, group):
+    dist.send_object_list([obj], dst=dst, group=group)
+
+
+def _recv_obj(src, group):
+    box = [None]
+    dist.recv_object_list(box, src=src, group=group)
+    return box[0]
+
+
+class SlabMatcher:
+    """Matching + tracking of ONE rank's slab of slices (all classes), bit-identical to the sequential passes over the
+    whole stack (reference: empanada/inference/patterns.py:68-134, matcher.py:234-326, tracker.py:61-123).
+
+    Local slice order in every class matcher: the rank's own slices [0, n_own) as they are pushed, then the ghost of
+    slice lo-1 (``prev``), then the ghost of slice hi (``next``).  Ghosts are pushed from the owner's entry, so their
+    components carry the owner's indices and an exported state can be imported verbatim.
+
+    ``push(entries)`` may be called per group of slices while the GPU extracts the next group: it runs on a worker
+    thread (the C++ calls release the GIL) and builds the pair tables of consecutive own slices as they arrive.
+    ``finish(...)`` does the neighbour exchange and the two chains and returns the partial trackers of this slab."""
+
+    def __init__(self, labels, thing_list, label_divisor, iou_thr, ioa_thr, width):
+        from concurrent.futures import ThreadPoolExecutor
+        from . import sparse
+        self.labels, self.width = list(labels), int(width)
+        self.things = [c for c in self.labels if c in thing_list]
+        self.sm = {c: sparse.StackMatcher(c, label_divisor, iou_thr, ioa_thr, match=c in thing_list) for c in self.labels}
+        self.n_own = 0
+        self.first_entry = self.last_entry = None
+        self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='emp-slab-match')
+        self._jobs = []
+        self.host_s = 0.0          # host time of this rank's matcher (push + tables + chains + tracking), for the bench
+        self.tail_s = 0.0          # the part of it behind the GPU work (ghosts, the two chains, tracking): not overlapped
+
+    def _push_entry(self, entry):
+        for c, sm in self.sm.items():
+            v = entry[c]
+            if isinstance(v, tuple):
+                sm.push_runs(v[0], self.width, v[1])
+            else:
+                sm.push_objects(v)
+
+    def _push_job(self, entries, start):
+        import time
+        t0 = time.perf_counter()
+        for e in entries:
+            self._push_entry(e)
+        for c in self.things:      # pair tables (start-1 .. start+len-1]: label-independent, ahead of the chain
+            self.sm[c].prepare(max(0, start - 1), start + len(entries) - 1)
+        self.host_s += time.perf_counter() - t0
+
+    def push(self, entries):
+        entries = list(entries)
+        if not entries:
+            return
+        if self.first_entry is None:
+            self.first_entry = entries[0]
+        self.last_entry = entries[-1]
+        self._jobs.append(self._pool.submit(self._push_job, entries, self.n_own))
+        self.n_own += len(entries)
+
+    def finish(self, rank, aw, lo, axis_name, shape3d, group):
+        """-> {class_id: partial instances dict of this slab} (dict order: first seen walking the slab downwards)."""
+        import time
+        for j in self._jobs:
+            j.result()
+        self._pool.shutdown()
+        pushed_s = self.host_s
+        n = self.n_own
+        has_prev, has_next = rank > 0, rank < aw - 1
+        # boundary slices to the neighbours (raw entries: components as extracted); a chain, so the order below cannot
+        # deadlock even where a send blocks until its receive is posted: the last / first rank only receives
+        if has_next:
+            _send_obj(self.last_entry, rank + 1, group)
+        prev_entry = _recv_obj(rank - 1, group) if has_prev else None
+        if has_prev:
+            _send_obj(self.first_entry, rank - 1, group)
+        next_entry = _recv_obj(rank + 1, group) if has_next else None
+        t0 = time.perf_counter()
+        i_prev = i_next = None
+        if has_prev:
+            self._push_entry(prev_entry)
+            i_prev = n
+        if has_next:
+            self._push_entry(next_entry)
+            i_next = n + (1 if has_prev else 0)
+        self.host_s += time.perf_counter() - t0
+        # forward chain (patterns.py:68-100): the state of slice lo-1 comes down from rank-1
+        states = _recv_obj(rank - 1, group) if has_prev and self.things else None
+        t0 = time.perf_counter()
+        for c in self.things:
+            sm = self.sm[c]
+            if has_prev:
+                sm.import_state(i_prev, states[c], assign_new=True)
+            sm.run_range(0, n - 1, +1)
+        out_states = {c: self.sm[c].export_state(n - 1) for c in self.things} if has_next else None
+        self.host_s += time.perf_counter() - t0
+        if has_next and self.things:
+            _send_obj(out_states, rank + 1, group)
+        # backward chain (patterns.py:102-121: fresh target, no new labels): the state of slice hi comes up from rank+1
+        states = _recv_obj(rank + 1, group) if has_next and self.things else None
+        t0 = time.perf_counter()
+        for c in self.things:
+            sm = self.sm[c]
+            if has_next:
+                sm.import_state(i_next, (states[c][0], states[c][1], states[c][2], -1), assign_new=False)
+            else:
+                sm.begin_backward()
+            sm.run_range(0, n - 1, -1)
+        out_states = {c: self.sm[c].export_state(0) for c in self.things} if has_prev else None
+        self.host_s += time.perf_counter() - t0
+        if has_prev and self.things:
+            _send_obj(out_states, rank - 1, group)
+        # tracker of the slab's own slices at their global positions (tracker.py:61-123), walking downwards
+        t0 = time.perf_counter()
+        part = {c: self.sm[c].track_range(axis_name, shape3d, 0, n - 1, lo) for c in self.labels}
+        self.host_s += time.perf_counter() - t0
+        self.tail_s = self.host_s - pushed_s
+        return part
+
+
+def merge_partial_trackers(parts, axis_name):
+    """Per-slab partial trackers (rank order) -> one instances dict per class, as ONE tracker fed downwards over the whole
+    stack would hold it (tracker.py:61-123): labels in first-seen order walking from the last slab to the first; xy / xz
+    runs concatenated in that order (a slab's runs are final); yz runs -- re-encoded per object by ``finish()`` from ALL
+    its voxels (tracker.py:111-120) -- joined across slabs: the slabs cut the x axis, so a run can continue in the next."""
+    from . import sparse
+    classes = list(parts[0].keys()) if parts else []
+    out = {}
+    for c in classes:
+        acc = {}
+        for part in reversed(parts):
+            for label, a in part[c].items():
+                d = acc.get(label)
+                if d is None:
+                    acc[label] = {'box': tuple(int(v) for v in a['box']), 'starts': [a['starts']], 'runs': [a['runs']]}
+                else:
+                    d['box'] = sparse.merge_boxes(tuple(int(v) for v in a['box']), d['box'])
+                    d['starts'].append(a['starts'])
+                    d['runs'].append(a['runs'])
+        for label, d in acc.items():
+            if len(d['starts']) == 1:
+                d['starts'], d['runs'] = d['starts'][0], d['runs'][0]
+            elif axis_name == 'yz':
+                st, rn = np.concatenate(d['starts']), np.concatenate(d['runs'])
+                order = np.argsort(st, kind='stable')
+                st, rn = st[order], rn[order]
+                brk = np.flatnonzero(st[1:] != st[:-1] + rn[:-1]) + 1      # slabs are disjoint: runs touch or leave a gap
+                edges = np.concatenate([[0], brk, [len(st)]])
+                ends = st + rn
+                d['starts'], d['runs'] = st[edges[:-1]], ends[edges[1:] - 1] - st[edges[:-1]]
+            else:
+                d['starts'], d['runs'] = np.concatenate(d['starts']), np.concatenate(d['runs'])
+        out[c] = acc
+    return out
+
+
+def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None, match=None):
     """SPMD body of one axis on one rank.
 
     backend.forward(lo, hi, n_ahead)  -> (sem, stash): ``sem`` a tensor (hi-lo + n_ahead, ...) whose first hi-lo rows
@@ -183,10 +349,14 @@ def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None):
     backend.median_inplace(sem, n_own, hist, n_ahead, first, last, ks)
                                       -> filters rows [0, n_own) of ``sem`` in place; ``hist``: the ``mid`` filtered
                                          maps before the slab (None on the first slab)
-    backend.runs(sem_own, stash)      -> one entry per slice: {class: (runs (n,3) int64, id offset) | instance dict}
-    Returns on rank 0 the per-slice entries of ALL slices in order, elsewhere None.  Tensors travel over ``group``
-    (RCCL on GPUs: neighbour send / recv), the run lists over ``host_group`` (gloo: they are host data that the
-    sequential matcher on rank 0's host consumes; no pickling through device memory)."""
+    backend.runs(sem_own, stash)      -> one entry per slice: {class: (runs (n,3) int64, id offset) | instance dict};
+                                         ``backend.runs_iter`` (optional) yields the entries group by group instead
+    match: dict(labels, thing_list, label_divisor, iou_thr, ioa_thr, width, axis_name, shape3d) -> the slab is matched
+    and tracked HERE (``SlabMatcher``) and rank 0 gets the list of per-slab partial trackers in rank order together
+    with every rank's host time {'parts': [...], 'host_s': [...]}; without it (round-2 behaviour, kept for the driver
+    tests) rank 0 gets the per-slice entries of ALL slices in order.  Elsewhere None.  Tensors travel over ``group``
+    (RCCL on GPUs: neighbour send / recv), host data -- boundary slices, matcher states, tracks -- over
+    ``host_group`` (gloo; no pickling through device memory)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     mid = (ks - 1) // 2
@@ -195,6 +365,8 @@ def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None):
     lo, hi = bounds[rank]
     n_own = hi - lo
     per_slice = []
+    import time
+    t_start = time.perf_counter()
     if n_own > 0:
         has_prev, has_next = rank > 0, rank < aw - 1
         n_ahead = mid if has_next else 0
@@ -211,14 +383,34 @@ def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None):
         backend.median_inplace(sem, n_own, hist, n_ahead, rank == 0, rank == aw - 1, ks)
         if mid and has_next:
             reqs.append(_isend(sem[n_own - mid:n_own], rank + 1, group))
-        per_slice = backend.runs(sem[:n_own], stash)
+        hg = host_group if host_group is not None else group
+        if match is None:
+            per_slice = backend.runs(sem[:n_own], stash)
+        else:
+            sm = SlabMatcher(match['labels'], match['thing_list'], match['label_divisor'], match['iou_thr'], match['ioa_thr'],
+                             match['width'])
+            if hasattr(backend, 'runs_iter'):      # host: push + pair tables of a group while the GPU extracts the next
+                for entries in backend.runs_iter(sem[:n_own], stash):
+                    sm.push(entries)
+            else:
+                sm.push(backend.runs(sem[:n_own], stash))
+            gpu_s = time.perf_counter() - t_start       # forward + exchange + median + run extraction of the slab
+            part = sm.finish(rank, aw, lo, match['axis_name'], match['shape3d'], hg)
+            per_slice = {'part': part, 'host_s': sm.host_s, 'tail_s': sm.tail_s, 'gpu_s': gpu_s, 'slices': n_own}
         for r in reqs:
             r.wait()
+    elif match is not None:
+        per_slice = None
+    hg = host_group if host_group is not None else group
     gathered = [None] * world if rank == 0 else None
-    dist.gather_object(per_slice, gathered, dst=0, group=host_group if host_group is not None else group)
+    dist.gather_object(per_slice, gathered, dst=0, group=hg)
     if rank != 0:
         return None
-    return [s for part in gathered for s in part]
+    if match is None:
+        return [s for part in gathered for s in part]
+    live = [g for g in gathered if g is not None]
+    return {'parts': [g['part'] for g in live], 'host_s': [g['host_s'] for g in live],
+            'timing': [{k: g[k] for k in ('host_s', 'tail_s', 'gpu_s', 'slices')} for g in live]}
 
 
 class HipSlabBackend:
@@ -296,20 +488,22 @@ class HipSlabBackend:
                                                      sem[0].numel(), _abi.stream_ptr(sem.device)), 'emp_median_recursive')
 
     @torch.no_grad()
-    def runs(self, sem, stash):
+    def runs_iter(self, sem, stash):
+        """per-slice entries in launch groups of 64 slices (the caller's matcher works on a group while the GPU extracts
+        the next one)"""
         from . import sparse
         e3, eng = self.e3, self.eng
         ctr, off = stash
         h, w = self.size
-        out = []
         for i0 in range(0, sem.shape[0], 64):
             sl = slice(i0, i0 + 64)
             cells, _, _, kmax = eng.instance_cells_int(ctr[sl], off[sl], 1)
             pan = eng.panoptic_merge_int(sem[sl], cells, kmax)[:, :h, :w]
             per_label = sparse.pan_stack_to_runs(pan, e3.labels, e3.label_divisor, e3.thing_list, force_connected=True)
-            for j in range(pan.shape[0]):
-                out.append({label: (rl[j], o) for label, (rl, o) in per_label.items()})
-        return out
+            yield [{label: (rl[j], o) for label, (rl, o) in per_label.items()} for j in range(pan.shape[0])]
+
+    def runs(self, sem, stash):
+        return [e for group in self.runs_iter(sem, stash) for e in group]
 
 
 def _free_port():
@@ -351,11 +545,11 @@ def _rank_main(rank, world, port, dist_backend, model_config, engine_kwargs, bac
             cmd = cmd_q.get()
             if cmd[0] == 'stop':
                 break
-            _, volume, axis_name, ks = cmd
+            _, volume, axis_name, ks, match = cmd
             if isinstance(volume, torch.Tensor):       # a numpy volume travels as a shared-memory tensor
                 volume = volume.numpy()
             axis = {'xy': 0, 'xz': 1, 'yz': 2}[axis_name]
-            segs = slab_stack_inference(volume.shape[axis], make(volume, axis), ks, None, host_group)
+            segs = slab_stack_inference(volume.shape[axis], make(volume, axis), ks, None, host_group, match)
             res_q.put(('done', rank, segs))
         dist.barrier()
         dist.destroy_process_group()
@@ -501,7 +695,7 @@ class MultiGPUEngine3d:
         if isinstance(volume, np.ndarray):
             payload = torch.from_numpy(np.ascontiguousarray(volume)).share_memory_()   # one copy, mapped by every rank
         for q in self._cmd:
-            q.put(('axis', payload, axis_name, self.ks))
+            q.put(('axis', payload, axis_name, self.ks, self._match_desc(volume.shape, axis_name)))
         return self._collect('done')[0]
 
     def _segs_spmd(self, volume, axis_name):
@@ -513,7 +707,14 @@ class MultiGPUEngine3d:
             if dist.get_backend(self.group) == 'nccl':
                 self._host_group = dist.new_group(backend='gloo')
         axis = self.axes[axis_name]
-        return slab_stack_inference(volume.shape[axis], self._make(volume, axis), self.ks, self.group, self._host_group)
+        return slab_stack_inference(volume.shape[axis], self._make(volume, axis), self.ks, self.group, self._host_group,
+                                    self._match_desc(volume.shape, axis_name))
+
+    def _match_desc(self, shape, axis_name):
+        shape = tuple(int(v) for v in shape)
+        width = [v for i, v in enumerate(shape) if i != self.axes[axis_name]][1]
+        return dict(labels=list(self.labels), thing_list=list(self.thing_list), label_divisor=self.label_divisor,
+                    iou_thr=self.merge_iou_thr, ioa_thr=self.merge_ioa_thr, width=width, axis_name=axis_name, shape3d=shape)
 
     def infer_on_axis(self, volume, axis_name):
         from . import sparse
@@ -521,27 +722,21 @@ class MultiGPUEngine3d:
         if segs is None:
             return None, None
         shape = tuple(int(s) for s in volume.shape)
-        assert len(segs) == shape[self.axes[axis_name]]
         trackers = self.create_trackers(shape, axis_name)
         priv = self.create_trackers(shape, axis_name)
-        width = [s for i, s in enumerate(shape) if i != self.axes[axis_name]][1]
         min_size, min_extent = self.min_size, self.min_extent
         stack = self.create_panoptic_stack(axis_name, shape)
+        self.last_host_s = list(segs['host_s'])      # every rank's matcher time
+        self.last_timing = list(segs['timing'])      # per rank: matcher time, its un-overlapped tail, GPU phase, slices
 
         def tail():
-            # forward matching (patterns.py:279-350), backward matching and tracking (multigpu.py:240-252) of the
-            # gathered run lists, per class, in C++ (sparse.StackMatcher)
+            # forward matching (patterns.py:279-350), backward matching and tracking (multigpu.py:240-252) ran per slab on
+            # the ranks (SlabMatcher); what is left here is the concatenation of the per-slab tracks and the size filters
+            import time
+            t0 = time.perf_counter()
+            merged = merge_partial_trackers(segs['parts'], axis_name)
             for tr in priv:
-                sm = sparse.StackMatcher(tr.class_id, self.label_divisor, self.merge_iou_thr, self.merge_ioa_thr,
-                                         match=tr.class_id in self.thing_list)
-                for s in segs:
-                    v = s[tr.class_id]
-                    if isinstance(v, tuple):
-                        sm.push_runs(v[0], width, v[1])
-                    else:
-                        sm.push_objects(v)
-                sm.forward()
-                tr.instances = sm.backward_and_track(axis_name, shape)
+                tr.instances = merged[tr.class_id]
                 tr.finished = True
             for tr in priv:
                 sparse.remove_small_objects(tr, min_size=min_size)
@@ -549,6 +744,7 @@ class MultiGPUEngine3d:
             for tr, pv in zip(trackers, priv):
                 tr.__dict__['_instances'] = pv.instances
                 tr.finished = True
+            self.last_merge_s = time.perf_counter() - t0
 
         if stack is None:
             # host-only work: runs behind the caller (the next axis' GPU work, typically); reading ``tracker.instances``

@@ -498,6 +498,49 @@ class StackMatcher:
         _abi.check(self.lib.emp_sm_tracker_finish(self._h), 'emp_sm_tracker_finish')
         return self.instances()
 
+    # ---- slab-wise matching (multigpu.py: one matcher per rank, ghost slices at the slab's ends) ----
+    def prepare(self, first=0, last=None):
+        """pair tables of slices (first, last]: the label-independent bulk of their steps, ahead of the chain"""
+        last = len(self) - 1 if last is None else last
+        if last > first:
+            _abi.check(self.lib.emp_sm_prepare(self._h, int(first), int(last)), 'emp_sm_prepare')
+
+    def export_state(self, idx):
+        """matching state of slice ``idx``: (labels, CSR offsets, member components, next_label) as int64 arrays / int"""
+        no, nm = C.c_int64(0), C.c_int64(0)
+        _abi.check(self.lib.emp_sm_state_size(self._h, int(idx), C.byref(no), C.byref(nm)), 'emp_sm_state_size')
+        labels, off, mem = np.empty(no.value, dtype=i64), np.empty(no.value + 1, dtype=i64), np.empty(nm.value, dtype=i64)
+        nl = C.c_int64(0)
+        _abi.check(self.lib.emp_sm_export_state(self._h, int(idx), _hp(labels), _hp(off), _hp(mem), C.byref(nl)),
+                   'emp_sm_export_state')
+        return labels, off, mem, int(nl.value)
+
+    def import_state(self, idx, state, assign_new):
+        """slice ``idx`` (a ghost: pushed from its owner's runs) gets the owner's objects and becomes the target"""
+        labels, off, mem, nl = state
+        labels, off, mem = (np.ascontiguousarray(a, dtype=i64) for a in (labels, off, mem))
+        _abi.check(self.lib.emp_sm_import_state(self._h, int(idx), len(labels), _hp(labels), _hp(off), _hp(mem), int(nl),
+                                                int(bool(assign_new))), 'emp_sm_import_state')
+
+    def run_range(self, first, last, direction):
+        """steps over slices first..last (inclusive) in ``direction`` (+1: first -> last, -1: last -> first)"""
+        n = last - first + 1
+        if n > 0:
+            self._run(first if direction > 0 else last, direction, n, False)
+
+    def begin_backward(self):
+        _abi.check(self.lib.emp_sm_begin_backward(self._h), 'emp_sm_begin_backward')
+
+    def track_range(self, axis_name, shape3d, first, last, global_first):
+        """tracker over local slices last..first (descending, as backward_matching feeds it, patterns.py:102-134) at their
+        GLOBAL positions global_first + (i - first); returns the partial tracker's instances (dict order = first seen)"""
+        D, H, W = [int(v) for v in shape3d]
+        _abi.check(self.lib.emp_sm_tracker_init(self._h, InstanceTracker.AXES[axis_name], D, H, W), 'emp_sm_tracker_init')
+        for i in range(last, first - 1, -1):
+            _abi.check(self.lib.emp_sm_track(self._h, int(i), int(global_first + i - first)), 'emp_sm_track')
+        _abi.check(self.lib.emp_sm_tracker_finish(self._h), 'emp_sm_tracker_finish')
+        return self.instances()
+
     def instances(self):
         out = {}
         lab, n = C.c_int64(0), C.c_int64(0)

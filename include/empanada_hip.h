@@ -365,6 +365,23 @@ EMP_API int emp_sm_push_slice_runs(emp_stack_matcher_t* h, const int64_t* h_runs
 EMP_API int emp_sm_push_slice_objects(emp_stack_matcher_t* h, int64_t n, const int64_t* labels, const int64_t* boxes,
                               const int64_t* off, const int64_t* starts, const int64_t* runs);
 EMP_API int64_t emp_sm_num_slices(const emp_stack_matcher_t* h);
+/* Slab-wise matching (one matcher per rank: multigpu.py).  The forward / backward passes of patterns.py:68-121 are a chain
+ * along the axis, but what a slice hands to its neighbour is small: the grouping of its components into labelled objects
+ * (dict order) and RLEMatcher.next_label (matcher.py:254-268).  A rank pushes its own slab plus the neighbours' boundary
+ * slices ("ghosts": same runs, hence same component indices), builds all pair tables up front with emp_sm_prepare (the
+ * label-independent bulk: run intersections of neighbouring slices), imports the state of a ghost slice as its target and
+ * runs emp_sm_run over its own slices only; emp_sm_track takes the GLOBAL slice position.
+ *   emp_sm_prepare     : pair tables of local slices (from, to]
+ *   emp_sm_state_size / emp_sm_export_state : objects of local slice idx as labels[n_obj], CSR off[n_obj+1], members[n_mem]
+ *                        (component indices), and the label counter
+ *   emp_sm_import_state: slice idx gets these objects and becomes the target; next_label < 0 keeps the counter;
+ *                        assign_new 1 = forward pass, 0 = backward pass (patterns.py:102-109) */
+EMP_API int emp_sm_prepare(emp_stack_matcher_t* h, int64_t from, int64_t to);
+EMP_API int emp_sm_state_size(const emp_stack_matcher_t* h, int64_t idx, int64_t* n_obj, int64_t* n_mem);
+EMP_API int emp_sm_export_state(const emp_stack_matcher_t* h, int64_t idx, int64_t* labels, int64_t* off, int64_t* members,
+                                int64_t* next_label);
+EMP_API int emp_sm_import_state(emp_stack_matcher_t* h, int64_t idx, int64_t n_obj, const int64_t* labels, const int64_t* off,
+                                const int64_t* members, int64_t next_label, int assign_new);
 EMP_API int emp_sm_begin_backward(emp_stack_matcher_t* h);
 /* First half of RLEMatcher.__call__ (matcher.py:280-326) for slice idx.  nt / nm: number of target / slice objects;
  * nt < 0: nothing to assign (target initialised / class not matched).  The overlap matrix is held sparse (candidates by a

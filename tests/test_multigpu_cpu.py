@@ -135,6 +135,45 @@ def test_public_multigpu_engine_spawns_its_ranks(golden_dir, world, ks):
     assert eng._procs is None
 
 
+@pytest.mark.parametrize('world', [2, 3])
+def test_public_multigpu_engine_multiclass_slab_matching(world):
+    """Several classes through the public API on gloo (BASELINE configs[4]'s class structure: two instance classes and a
+    semantic one): every rank matches and tracks its own slab (multigpu.SlabMatcher) -- ghost slices, forward state down
+    the ranks, backward state up, partial trackers to the caller -- and the result equals the sequential C++ matcher over
+    the whole stack (itself pinned by the reference goldens, tests/test_host_sparse.py), size filters included, on all
+    three axes."""
+    import mg_oracle_backend as mgb
+    import test_slab_matcher as tsm
+    from empanada_napari_amd import multigpu
+    from empanada_napari_amd import sparse as ps
+    shape = tsm.SHAPE
+    mc = {'seed': 40, 'thing_list': tsm.THINGS, 'labels': tsm.LABELS, 'class_names': {1: 'a', 2: 'b', 3: 'c'},
+          'padding_factor': 16, 'norms': {'mean': 0.5, 'std': 0.1}}
+    eng = multigpu.MultiGPUEngine3d(mc, label_divisor=tsm.DIV, median_kernel_size=3, min_size=12, min_extent=2,
+                                    world_size=world, dist_backend='gloo', backend_factory=mgb.label_stack_backend_factory)
+    try:
+        vol = np.zeros(shape, np.uint8)
+        for axis_name, axis in (('xy', 0), ('xz', 1), ('yz', 2)):
+            _, trackers = eng.infer_on_axis(vol, axis_name)
+            want = tsm._sequential(tsm._stack(shape, axis, 40 + axis), axis_name, shape)
+            assert [t.class_id for t in trackers] == tsm.LABELS
+            for tr in trackers:
+                ref = ps.InstanceTracker(tr.class_id, tsm.DIV, shape, axis_name)
+                ref.instances = want[tr.class_id]
+                ref.finished = True
+                ps.remove_small_objects(ref, min_size=12)
+                ps.remove_pancakes(ref, min_span=2)
+                got = tr.instances
+                assert len(ref.instances) > 0 and [int(k) for k in got] == [int(k) for k in ref.instances]
+                for k in got:
+                    assert tuple(int(v) for v in got[k]['box']) == tuple(int(v) for v in ref.instances[k]['box'])
+                    np.testing.assert_array_equal(got[k]['starts'], ref.instances[k]['starts'])
+                    np.testing.assert_array_equal(got[k]['runs'], ref.instances[k]['runs'])
+            assert len(eng.last_host_s) == world
+    finally:
+        eng.close()
+
+
 def test_public_multigpu_engine_errors():
     from empanada_napari_amd import multigpu
     mc = {'model': 'nowhere.pth', 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
