@@ -66,6 +66,7 @@ PROTOTYPES = {
     'emp_sm_push_slice_runs': (c_int, [vp, vp, c_i64, c_i64, c_i64]),
     'emp_sm_push_slice_objects': (c_int, [vp, c_i64, vp, vp, vp, vp, vp]),
     'emp_sm_num_slices': (c_i64, [vp]),
+    'emp_lsa_maximize': (c_int, [vp, c_i64, c_i64, vp, vp]),
     'emp_sm_prepare': (c_int, [vp, c_i64, c_i64]),
     'emp_sm_state_size': (c_int, [vp, c_i64, vp, vp]),
     'emp_sm_export_state': (c_int, [vp, c_i64, vp, vp, vp, vp]),

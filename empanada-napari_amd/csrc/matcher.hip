@@ -58,6 +58,95 @@ struct Track {
   std::vector<int64_t> yz;   // yz stacks before finish(): (start in the (D,H) plane, length, x) triples
 };
 
+// ---- linear sum assignment -------------------------------------------------------------------------------------------
+// The reference solves every slice's IoU matrix with scipy.optimize.linear_sum_assignment(maximize=True)
+// (matcher.py:218).  WHICH optimal assignment comes out of tied matrices is a property of that implementation, and the
+// label maps must be bit-identical, so this is scipy's algorithm restated step for step: the shortest-augmenting-path
+// method of D. F. Crouse, "On implementing 2D rectangular assignment algorithms", IEEE Trans. Aerospace and Electronic
+// Systems 52(4), 2016, as scipy >= 1.6 implements it (scipy/optimize/rectangular_lsap/rectangular_lsap.cpp; the build
+// pins scipy 1.15.3) -- tall matrices are transposed, maximisation negates the costs, the column candidates are visited
+// in DESCENDING index order (so that a constant matrix yields the identity), and among columns of equal reduced cost an
+// unassigned one wins.  tests/test_lsa.py pins it against scipy itself on random, integer-valued (heavily tied), sparse
+// and rectangular matrices.
+int lsa_maximize(int64_t nr, int64_t nc, const double* cost_in, std::vector<int64_t>& rows, std::vector<int64_t>& cols) {
+  rows.clear();
+  cols.clear();
+  if (nr == 0 || nc == 0) return 0;
+  const bool transpose = nc < nr;
+  std::vector<double> cost((size_t)(nr * nc));
+  if (transpose) {
+    for (int64_t i = 0; i < nr; ++i)
+      for (int64_t j = 0; j < nc; ++j) cost[(size_t)(j * nr + i)] = -cost_in[i * nc + j];
+    std::swap(nr, nc);
+  } else {
+    for (int64_t k = 0; k < nr * nc; ++k) cost[(size_t)k] = -cost_in[k];
+  }
+  for (double v : cost)
+    if (v != v || v == -INFINITY) return -1;
+  std::vector<double> u((size_t)nr, 0.0), v((size_t)nc, 0.0), spc((size_t)nc);
+  std::vector<int64_t> path((size_t)nc, -1), col4row((size_t)nr, -1), row4col((size_t)nc, -1), remaining((size_t)nc);
+  std::vector<char> SR((size_t)nr), SC((size_t)nc);
+  for (int64_t cur = 0; cur < nr; ++cur) {
+    // shortest augmenting path from row `cur`
+    double min_val = 0.0;
+    int64_t num_remaining = nc;
+    for (int64_t it = 0; it < nc; ++it) remaining[(size_t)it] = nc - it - 1;
+    std::fill(SR.begin(), SR.end(), 0);
+    std::fill(SC.begin(), SC.end(), 0);
+    std::fill(spc.begin(), spc.end(), INFINITY);
+    int64_t sink = -1, i = cur;
+    while (sink == -1) {
+      int64_t index = -1;
+      double lowest = INFINITY;
+      SR[(size_t)i] = 1;
+      for (int64_t it = 0; it < num_remaining; ++it) {
+        const int64_t j = remaining[(size_t)it];
+        const double r = min_val + cost[(size_t)(i * nc + j)] - u[(size_t)i] - v[(size_t)j];
+        if (r < spc[(size_t)j]) {
+          path[(size_t)j] = i;
+          spc[(size_t)j] = r;
+        }
+        if (spc[(size_t)j] < lowest || (spc[(size_t)j] == lowest && row4col[(size_t)j] == -1)) {
+          lowest = spc[(size_t)j];
+          index = it;
+        }
+      }
+      min_val = lowest;
+      if (min_val == INFINITY) return -1;      // infeasible
+      const int64_t j = remaining[(size_t)index];
+      if (row4col[(size_t)j] == -1) sink = j;
+      else i = row4col[(size_t)j];
+      SC[(size_t)j] = 1;
+      remaining[(size_t)index] = remaining[(size_t)--num_remaining];
+    }
+    // dual variables
+    u[(size_t)cur] += min_val;
+    for (int64_t r = 0; r < nr; ++r)
+      if (SR[(size_t)r] && r != cur) u[(size_t)r] += min_val - spc[(size_t)col4row[(size_t)r]];
+    for (int64_t j = 0; j < nc; ++j)
+      if (SC[(size_t)j]) v[(size_t)j] -= min_val - spc[(size_t)j];
+    // augment
+    int64_t j = sink;
+    while (true) {
+      const int64_t r = path[(size_t)j];
+      row4col[(size_t)j] = r;
+      std::swap(col4row[(size_t)r], j);
+      if (r == cur) break;
+    }
+  }
+  rows.resize((size_t)nr);
+  cols.resize((size_t)nr);
+  if (transpose) {       // (rows of the transposed problem are the caller's columns) sorted by the caller's row
+    std::vector<int64_t> order((size_t)nr);
+    for (int64_t k = 0; k < nr; ++k) order[(size_t)k] = k;
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return col4row[(size_t)a] < col4row[(size_t)b]; });
+    for (int64_t k = 0; k < nr; ++k) { rows[(size_t)k] = col4row[(size_t)order[(size_t)k]]; cols[(size_t)k] = order[(size_t)k]; }
+  } else {
+    for (int64_t k = 0; k < nr; ++k) { rows[(size_t)k] = k; cols[(size_t)k] = col4row[(size_t)k]; }
+  }
+  return 0;
+}
+
 int64_t intersection_sorted(const int64_t* s1, const int64_t* r1, size_t n1, const int64_t* s2, const int64_t* r2, size_t n2) {
   size_t i = 0, j = 0;
   int64_t acc = 0;
@@ -340,6 +429,17 @@ int emp_sm_push_slice_objects(emp_stack_matcher* h, int64_t n, const int64_t* la
 
 int64_t emp_sm_num_slices(const emp_stack_matcher* h) { return h ? (int64_t)h->stack.size() : 0; }
 
+// scipy.optimize.linear_sum_assignment(cost, maximize=True) on a dense row-major (nr, nc) float64 matrix: min(nr, nc)
+// pairs, rows ascending -- the library's own solver (lsa_maximize above), exported so that tests can pin it against scipy
+int emp_lsa_maximize(const double* cost, int64_t nr, int64_t nc, int64_t* rows, int64_t* cols) {
+  EMP_REQUIRE(nr >= 0 && nc >= 0 && (cost || nr * nc == 0) && ((rows && cols) || nr == 0 || nc == 0), "lsa_maximize: bad arguments");
+  std::vector<int64_t> rr, cc;
+  EMP_REQUIRE(lsa_maximize(nr, nc, cost, rr, cc) == 0, "lsa_maximize: cost matrix is infeasible (NaN or +inf entries)");
+  std::copy(rr.begin(), rr.end(), rows);
+  std::copy(cc.begin(), cc.end(), cols);
+  return EMP_OK;
+}
+
 // ---- slab-wise matching (round 3: one matcher per rank, multigpu.py) --------------------------------------------------
 // The passes of patterns.py:68-121 are a chain along the axis: slice z is matched against the RELABELLED slice z-1 (or
 // z+1 on the way back).  What a slice hands to its neighbour is small -- the grouping of its components into labelled
@@ -619,8 +719,20 @@ int emp_sm_run(emp_stack_matcher* h, int64_t idx, int dir, int64_t count, int tr
     int rc = emp_sm_step_begin(h, i, &nt, &nm);
     if (rc) return rc;
     if (nt >= 0) {
-      if (!h->blk_rows.empty()) { *stopped_at = i; return EMP_OK; }      // a real assignment problem: the caller solves it
-      rc = emp_sm_step_apply(h, nullptr, nullptr, 0);
+      if (!h->blk_rows.empty()) {
+        // a real assignment problem.  Round 3: solved here (lsa_maximize = scipy's algorithm restated); with
+        // EMP_SM_SCIPY=1 the step is handed back to the caller, who solves it with scipy itself as round 2 did
+        const char* e = getenv("EMP_SM_SCIPY");      // read per call: tests run both solvers in one process
+        if (e && e[0] == '1') { *stopped_at = i; return EMP_OK; }
+        std::vector<int64_t> rr, cc;
+        if (lsa_maximize((int64_t)h->blk_rows.size(), (int64_t)h->blk_cols.size(), h->iou.data(), rr, cc) != 0) {
+          set_error("sm_run: the IoU block of slice %lld is not a valid cost matrix", (long long)i);
+          return EMP_ERR_INVALID;
+        }
+        rc = emp_sm_step_apply(h, rr.data(), cc.data(), (int64_t)rr.size());
+      } else {
+        rc = emp_sm_step_apply(h, nullptr, nullptr, 0);
+      }
       if (rc) return rc;
     }
     if (track) {

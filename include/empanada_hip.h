@@ -376,6 +376,10 @@ EMP_API int64_t emp_sm_num_slices(const emp_stack_matcher_t* h);
  *                        (component indices), and the label counter
  *   emp_sm_import_state: slice idx gets these objects and becomes the target; next_label < 0 keeps the counter;
  *                        assign_new 1 = forward pass, 0 = backward pass (patterns.py:102-109) */
+/* scipy.optimize.linear_sum_assignment(cost, maximize=True), as matcher.py:218 calls it, on a dense row-major (nr, nc)
+ * float64 matrix: min(nr, nc) pairs with ascending rows.  The library's own solver (scipy's shortest-augmenting-path
+ * algorithm restated, ties included); emp_sm_run uses it for the assignment blocks unless EMP_SM_SCIPY=1. */
+EMP_API int emp_lsa_maximize(const double* cost, int64_t nr, int64_t nc, int64_t* rows, int64_t* cols);
 EMP_API int emp_sm_prepare(emp_stack_matcher_t* h, int64_t from, int64_t to);
 EMP_API int emp_sm_state_size(const emp_stack_matcher_t* h, int64_t idx, int64_t* n_obj, int64_t* n_mem);
 EMP_API int emp_sm_export_state(const emp_stack_matcher_t* h, int64_t idx, int64_t* labels, int64_t* off, int64_t* members,

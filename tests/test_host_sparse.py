@@ -283,16 +283,32 @@ def test_oracle_morphology_restatement_basics():
 
 
 def test_cpp_stack_matcher_solver_only_where_needed(monkeypatch):
-    """emp_sm_run: slices whose IoU matrix has at most one non-zero per row and column are assigned in C++ (every such
-    pair is in any optimal assignment); the others still go through scipy.  Both kinds occur in the reference case whose
-    trackers are compared with the reference's goldens above."""
+    """emp_sm_run: slices whose IoU matrix has at most one non-zero per row and column are assigned directly (every such
+    pair is in any optimal assignment); the others need an assignment solver -- since round 3 the library's own
+    (lsa_maximize: scipy's algorithm restated, tests/test_lsa.py), with EMP_SM_SCIPY=1 scipy itself as in round 2.  Both
+    kinds of slices occur in the reference case whose trackers are compared with the reference's goldens above; both
+    solvers give the same trackers."""
     calls = []
     orig = ps.StackMatcher._solve_pending
     monkeypatch.setattr(ps.StackMatcher, '_solve_pending', lambda self: (calls.append(1), orig(self))[1])
-    n_slices = 0
-    for name, slices, fwd, inst, sm in _stack_matcher_trackers(_push_objects):
-        n_slices += 2 * len(slices)
-    assert 0 < len(calls) < n_slices // 2, (len(calls), n_slices)
+    res = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('EMP_SM_SCIPY', flag)
+        calls.clear()
+        n_slices, res[flag] = 0, []
+        for name, slices, fwd, inst, sm in _stack_matcher_trackers(_push_objects):
+            n_slices += 2 * len(slices)
+            res[flag].append(inst)
+        if flag == '0':
+            assert len(calls) == 0, 'the default path must not come back to Python for the assignment'
+        else:
+            assert 0 < len(calls) < n_slices // 2, (len(calls), n_slices)
+    for a, b in zip(res['0'], res['1']):
+        assert list(a) == list(b)
+        for k in a:
+            assert a[k]['box'] == b[k]['box']
+            np.testing.assert_array_equal(a[k]['starts'], b[k]['starts'])
+            np.testing.assert_array_equal(a[k]['runs'], b[k]['runs'])
 
 
 def test_vote_with_many_unsorted_stretches_uses_radix_sort_and_matches_oracle():
