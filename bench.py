@@ -446,7 +446,8 @@ def run_stack3d(args, rank, local_rank, world, dist_on, dev):
                 'gpu_ms_per_slice': round(1e3 * r0['gpu_s'] / max(1, r0['slices']), 4),
                 'rank0_host_ms_per_slice': round(1e3 * (r0['tail_s'] + getattr(eng, 'last_merge_s', 0.0)) / max(1, D), 4),
                 'rank0_matcher_ms_per_own_slice': round(1e3 * r0['host_s'] / max(1, r0['slices']), 4),
-                'per_rank': [{k: round(v, 5) if isinstance(v, float) else v for k, v in t.items()} for t in tm],
+                'per_rank': [{k: (round(v, 5) if isinstance(v, float) else
+                                  {a: round(b, 5) for a, b in v.items()} if isinstance(v, dict) else v) for k, v in t.items()} for t in tm],
                 'merge_and_filter_s': round(getattr(eng, 'last_merge_s', 0.0), 5),
                 'note': 'rank0_host_ms_per_slice = (rank 0 matcher tail behind its GPU phase + track concatenation + size '
                         'filters) / ALL slices of the job: the sequential host work left on rank 0 per slice; '

@@ -186,14 +186,39 @@ void object_runs(const FSlice& sl, const FObj& o, std::vector<int64_t>& st, std:
     rn.assign(sl.lens.begin() + sl.run_off[(size_t)c], sl.lens.begin() + sl.run_off[(size_t)c + 1]);
     return;
   }
-  std::vector<std::pair<int64_t, int64_t>> rg;
-  for (int c : o.members)
-    for (int64_t i = sl.run_off[(size_t)c]; i < sl.run_off[(size_t)c + 1]; ++i)
-      rg.emplace_back(sl.starts[(size_t)i], sl.starts[(size_t)i] + sl.lens[(size_t)i]);
-  std::stable_sort(rg.begin(), rg.end(), [](const std::pair<int64_t, int64_t>& a, const std::pair<int64_t, int64_t>& b) {
-    return a.first < b.first;
-  });
-  for (const auto& r : rg) {
+  // every member's list is ascending and the members are disjoint pixel sets (distinct starts): merge the lists pairwise
+  // (two scratch buffers, ping-pong) instead of sorting their concatenation -- the tracker calls this for every
+  // multi-member object of every slice
+  static thread_local std::vector<std::pair<int64_t, int64_t>> bufa, bufb;
+  bufa.clear();
+  if (o.members.size() > 4) {      // many members (a label that collected dozens of fragments): one sort of the lot
+    for (int c : o.members)
+      for (int64_t i = sl.run_off[(size_t)c]; i < sl.run_off[(size_t)c + 1]; ++i)
+        bufa.emplace_back(sl.starts[(size_t)i], sl.starts[(size_t)i] + sl.lens[(size_t)i]);
+    std::sort(bufa.begin(), bufa.end());      // starts are distinct: no stability needed
+  } else
+  for (size_t m = 0; m < o.members.size(); ++m) {
+    const int c = o.members[m];
+    const size_t n0 = bufa.size();
+    const int64_t o0 = sl.run_off[(size_t)c], o1 = sl.run_off[(size_t)c + 1];
+    bool ordered = true;      // this member's runs all lie behind what is merged so far: append
+    if (n0 > 0 && o1 > o0 && sl.starts[(size_t)o0] < bufa.back().first) ordered = false;
+    if (ordered) {
+      for (int64_t i = o0; i < o1; ++i) bufa.emplace_back(sl.starts[(size_t)i], sl.starts[(size_t)i] + sl.lens[(size_t)i]);
+    } else {
+      bufb.resize(n0 + (size_t)(o1 - o0));
+      size_t a = 0, k = 0;
+      int64_t b = o0;
+      while (a < n0 && b < o1) {
+        if (bufa[a].first <= sl.starts[(size_t)b]) bufb[k++] = bufa[a++];
+        else { bufb[k++] = {sl.starts[(size_t)b], sl.starts[(size_t)b] + sl.lens[(size_t)b]}; ++b; }
+      }
+      while (a < n0) bufb[k++] = bufa[a++];
+      for (; b < o1; ++b) bufb[k++] = {sl.starts[(size_t)b], sl.starts[(size_t)b] + sl.lens[(size_t)b]};
+      bufa.swap(bufb);
+    }
+  }
+  for (const auto& r : bufa) {
     if (!st.empty() && st.back() + rn.back() >= r.first) {
       const int64_t end = std::max(st.back() + rn.back(), r.second);
       rn.back() = end - st.back();
@@ -609,11 +634,27 @@ int emp_sm_step_begin(emp_stack_matcher* h, int64_t idx, int* nt, int* nm) {
   std::vector<char> root_conflict((size_t)(nt_ + nm_), 0);
   for (int i = 0; i < nt_; ++i) if (deg_r[(size_t)i] > 1) root_conflict[(size_t)find(i)] = 1;
   for (int j = 0; j < nm_; ++j) if (h->col_ent[(size_t)j].size() > 1) root_conflict[(size_t)find(nt_ + j)] = 1;
-  for (int i = 0; i < nt_; ++i) if (deg_r[(size_t)i] > 0 && root_conflict[(size_t)find(i)]) h->blk_rows.push_back(i);
-  for (int j = 0; j < nm_; ++j) {
-    if (h->col_ent[(size_t)j].empty()) continue;
-    if (root_conflict[(size_t)find(nt_ + j)]) h->blk_cols.push_back(j);
-    else { h->pair_rows.push_back(h->col_ent[(size_t)j][0].t); h->pair_cols.push_back(j); }
+  // A slice with competing overlaps hands the solver the WHOLE nt x nm matrix, exactly as matcher.py:216-218 hands it to
+  // scipy.  Round 2 restricted it to the conflict components (single pairs are in every optimal assignment): the same
+  // optimum VALUE always and the same assignment whenever the optimum is unique, but with exactly tied IoU sums which
+  // optimum scipy returns depends on the matrix it is given -- on tie-heavy synthetic matrices 17 % of the restricted
+  // solutions differ from the full one (tests/test_lsa.py), and duplicate IoU values (1/2, 1/3 of few-pixel fragments)
+  // sit in nearly every block of the bench stack.  The full matrix costs +35 % on the forward pass of 1024^2 slices
+  // (390 objects: 0.27 instead of 0.20 ms per slice) and removes the exposure; EMP_SM_FULL_LSA=0 restores the block.
+  const char* full_env = getenv("EMP_SM_FULL_LSA");
+  const bool full = !(full_env && full_env[0] == '0');
+  bool any_conflict = false;
+  for (size_t k = 0; k < root_conflict.size(); ++k) any_conflict |= root_conflict[k] != 0;
+  if (full && any_conflict) {
+    for (int i = 0; i < nt_; ++i) h->blk_rows.push_back(i);
+    for (int j = 0; j < nm_; ++j) h->blk_cols.push_back(j);
+  } else {
+    for (int i = 0; i < nt_; ++i) if (deg_r[(size_t)i] > 0 && root_conflict[(size_t)find(i)]) h->blk_rows.push_back(i);
+    for (int j = 0; j < nm_; ++j) {
+      if (h->col_ent[(size_t)j].empty()) continue;
+      if (root_conflict[(size_t)find(nt_ + j)]) h->blk_cols.push_back(j);
+      else { h->pair_rows.push_back(h->col_ent[(size_t)j][0].t); h->pair_cols.push_back(j); }
+    }
   }
   if (!h->blk_rows.empty()) {
     const size_t bt = h->blk_rows.size(), bm = h->blk_cols.size();
@@ -784,20 +825,38 @@ int emp_sm_track(emp_stack_matcher* h, int64_t idx, int64_t index2d) {
       t = &h->tracks[it->second];
       for (int k = 0; k < 3; ++k) { t->box[k] = std::min(t->box[k], box[k]); t->box[3 + k] = std::max(t->box[3 + k], box[3 + k]); }
     }
-    object_runs(sl, o, ost, orn);
-    for (size_t i = 0; i < ost.size(); ++i) {
-      const int64_t st = ost[i], rn = orn[i];
-      if (h->axis == 0) {                     // plane (H,W) at depth index2d
-        t->starts.push_back(st + index2d * (H * W));
-        t->runs.push_back(rn);
-      } else if (h->axis == 1) {              // plane (D,W) at row index2d: runs along x stay runs
-        t->starts.push_back((st / W) * (H * W) + index2d * W + (st % W));
-        t->runs.push_back(rn);
-      } else {                                // plane (D,H) at column index2d: every voxel is its own run;
-        t->yz.push_back(st);                  // kept as the 2-D run until finish() turns the object around
-        t->yz.push_back(rn);
-        t->yz.push_back(index2d);
-      }
+    // the object's runs: a single member's component list is used where it lies (the common case), several members'
+    // lists are sorted and joined first (merge_attrs)
+    const int64_t* ps;
+    const int64_t* pr;
+    size_t n;
+    if (o.members.size() == 1) {
+      const size_t c = (size_t)o.members[0];
+      ps = sl.starts.data() + sl.run_off[c];
+      pr = sl.lens.data() + sl.run_off[c];
+      n = (size_t)(sl.run_off[c + 1] - sl.run_off[c]);
+    } else {
+      object_runs(sl, o, ost, orn);
+      ps = ost.data(); pr = orn.data(); n = ost.size();
+    }
+    if (h->axis == 0) {                       // plane (H,W) at depth index2d
+      const int64_t base = index2d * (H * W);
+      const size_t at = t->starts.size();
+      t->starts.resize(at + n);
+      t->runs.insert(t->runs.end(), pr, pr + n);
+      int64_t* dst = t->starts.data() + at;
+      for (size_t i = 0; i < n; ++i) dst[i] = ps[i] + base;
+    } else if (h->axis == 1) {                // plane (D,W) at row index2d: runs along x stay runs
+      const size_t at = t->starts.size();
+      t->starts.resize(at + n);
+      t->runs.insert(t->runs.end(), pr, pr + n);
+      int64_t* dst = t->starts.data() + at;
+      for (size_t i = 0; i < n; ++i) dst[i] = (ps[i] / W) * (H * W) + index2d * W + (ps[i] % W);
+    } else {                                  // plane (D,H) at column index2d: every voxel is its own run;
+      const size_t at = t->yz.size();         // kept as the 2-D run until finish() turns the object around
+      t->yz.resize(at + 3 * n);
+      int64_t* dst = t->yz.data() + at;
+      for (size_t i = 0; i < n; ++i) { dst[3 * i] = ps[i]; dst[3 * i + 1] = pr[i]; dst[3 * i + 2] = index2d; }
     }
   }
   return EMP_OK;

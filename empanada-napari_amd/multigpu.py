@@ -270,7 +270,8 @@ class SlabMatcher:
         if has_next:
             self._push_entry(next_entry)
             i_next = n + (1 if has_prev else 0)
-        self.host_s += time.perf_counter() - t0
+        self.phase_s = {'ghosts': time.perf_counter() - t0}
+        self.host_s += self.phase_s['ghosts']
         # forward chain (patterns.py:68-100): the state of slice lo-1 comes down from rank-1
         states = _recv_obj(rank - 1, group) if has_prev and self.things else None
         t0 = time.perf_counter()
@@ -280,7 +281,8 @@ class SlabMatcher:
                 sm.import_state(i_prev, states[c], assign_new=True)
             sm.run_range(0, n - 1, +1)
         out_states = {c: self.sm[c].export_state(n - 1) for c in self.things} if has_next else None
-        self.host_s += time.perf_counter() - t0
+        self.phase_s['forward'] = time.perf_counter() - t0
+        self.host_s += self.phase_s['forward']
         if has_next and self.things:
             _send_obj(out_states, rank + 1, group)
         # backward chain (patterns.py:102-121: fresh target, no new labels): the state of slice hi comes up from rank+1
@@ -294,13 +296,15 @@ class SlabMatcher:
                 sm.begin_backward()
             sm.run_range(0, n - 1, -1)
         out_states = {c: self.sm[c].export_state(0) for c in self.things} if has_prev else None
-        self.host_s += time.perf_counter() - t0
+        self.phase_s['backward'] = time.perf_counter() - t0
+        self.host_s += self.phase_s['backward']
         if has_prev and self.things:
             _send_obj(out_states, rank - 1, group)
         # tracker of the slab's own slices at their global positions (tracker.py:61-123), walking downwards
         t0 = time.perf_counter()
         part = {c: self.sm[c].track_range(axis_name, shape3d, 0, n - 1, lo) for c in self.labels}
-        self.host_s += time.perf_counter() - t0
+        self.phase_s['track'] = time.perf_counter() - t0
+        self.host_s += self.phase_s['track']
         self.tail_s = self.host_s - pushed_s
         return part
 
@@ -396,7 +400,8 @@ def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None, mat
                 sm.push(backend.runs(sem[:n_own], stash))
             gpu_s = time.perf_counter() - t_start       # forward + exchange + median + run extraction of the slab
             part = sm.finish(rank, aw, lo, match['axis_name'], match['shape3d'], hg)
-            per_slice = {'part': part, 'host_s': sm.host_s, 'tail_s': sm.tail_s, 'gpu_s': gpu_s, 'slices': n_own}
+            per_slice = {'part': part, 'host_s': sm.host_s, 'tail_s': sm.tail_s, 'gpu_s': gpu_s, 'slices': n_own,
+                         'phases': dict(sm.phase_s)}
         for r in reqs:
             r.wait()
     elif match is not None:
@@ -410,7 +415,7 @@ def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None, mat
         return [s for part in gathered for s in part]
     live = [g for g in gathered if g is not None]
     return {'parts': [g['part'] for g in live], 'host_s': [g['host_s'] for g in live],
-            'timing': [{k: g[k] for k in ('host_s', 'tail_s', 'gpu_s', 'slices')} for g in live]}
+            'timing': [{k: g[k] for k in ('host_s', 'tail_s', 'gpu_s', 'slices', 'phases')} for g in live]}
 
 
 class HipSlabBackend:

@@ -38,6 +38,9 @@ t1 = time.perf_counter()
 nruns = [len(r) for r in runs_all]
 nobj = [len(np.unique(r[:, 2])) for r in runs_all]
 print(f'dense->runs {1e3*(t1-t0):.1f} ms; runs per slice mean {np.mean(nruns):.0f} max {max(nruns)}; objects per slice mean {np.mean(nobj):.0f} max {max(nobj)}')
+if os.environ.get('EMP_DUMP_RUNS'):      # the run lists as a fixture for profiling the host matcher without a GPU
+    np.savez_compressed(os.environ['EMP_DUMP_RUNS'], off=np.int64(off), S=np.int64(S), n=np.array(nruns, dtype=np.int64),
+                        runs=np.concatenate(runs_all).astype(np.int32))
 sm = sparse.StackMatcher(1, 10000, 0.25, 0.25, match=True)
 t0 = time.perf_counter()
 for r in runs_all:
