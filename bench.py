@@ -197,7 +197,7 @@ def stack3d_line(model, size, cfg=None, P=None, with_cpu=True):
 def traffic_from_profiles():
     """HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes (tools/hbm_traffic.py): NOT measured in
     this run -- the JSON names the file and the commit it was taken at."""
-    for name in ('r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+    for name in ('r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
         p = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(p):
             try:
@@ -344,6 +344,12 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
             res['engine2d_tiles_per_s'] = {'error': f'{type(e).__name__}: {e}'}
     if world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(cfg, P, S, args.cpu_tiles, 1234)
+        # vs_baseline stays null: BASELINE.md holds no published number for this metric (its section 1: "Nothing").  The
+        # ratio to the CPU port timed in this very run is given under its own name -- a reported baseline, not a target.
+        try:
+            res['vs_cpu_baseline'] = round(res['value'] / res['cpu_baseline']['value'], 1)
+        except Exception:
+            res['vs_cpu_baseline'] = None
     else:
         res['cpu_baseline'] = None
     # the 3-D half of the headline metric, outside the timed region of `value` (rank 0, one GPU)

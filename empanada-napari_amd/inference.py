@@ -82,6 +82,14 @@ def load_model(model_config, device):
     return HipPanopticDeepLab(sd, cfg, device=device)
 
 
+def _is_chunked_store(v):
+    """a zarr array, this package's zstore.DirArray or a dask array: known to support full ``[...]`` indexing"""
+    if isinstance(v, zstore.DirArray):
+        return True
+    mod = type(v).__module__.split('.')[0]
+    return mod in ('zarr', 'dask') and hasattr(v, 'dtype') and hasattr(v, 'shape')
+
+
 def _require_scale_one(scale):
     """inference_scale is a power of two (volume_dataset.py:26-27)."""
     if not math.log(scale, 2).is_integer():
@@ -494,10 +502,13 @@ class Engine3d:
         eng = self.engine
         lib = eng.lib
         from . import _abi
-        if not isinstance(volume, np.ndarray) and hasattr(volume, 'dtype') and hasattr(volume, 'shape') and \
+        if isinstance(volume, torch.Tensor):
+            volume = volume.detach().cpu().numpy()
+        elif not isinstance(volume, np.ndarray) and _is_chunked_store(volume) and \
                 int(np.prod(volume.shape)) * np.dtype(volume.dtype).itemsize <= (8 << 30):
-            # chunked stores (zarr arrays, zstore.DirArray): one sequential read of the chunks instead of a strided
-            # gather per slice (the reference's VolumeDataset indexes the store per slice, volume_dataset.py:39)
+            # chunked stores (zarr arrays, zstore.DirArray, dask arrays): one sequential read of the chunks instead of a
+            # strided gather per slice (the reference's VolumeDataset indexes the store per slice, volume_dataset.py:39).
+            # Anything else -- e.g. synth.ProceduralVolume, which only offers .block() -- keeps per-slice access.
             volume = np.asarray(volume[...])
         n = volume.shape[axis]
         ks, mid = eng.ks, eng.mid_idx

@@ -657,15 +657,24 @@ class MultiGPUEngine3d:
         self._collect('ready')
 
     def _collect(self, what):
+        import queue
+        import time
         out = {}
+        # overall deadline (EMP_MG_TIMEOUT seconds, default one hour per call): ranks that are all alive but blocked --
+        # e.g. in a recv whose peer never sends -- must surface as an error, not as a hang of the caller
+        deadline = time.monotonic() + float(os.environ.get('EMP_MG_TIMEOUT', '3600'))
         while len(out) < self.world:
             try:
                 kind, rank, payload = self._res.get(timeout=5.0)
-            except Exception:       # queue.Empty: make sure nobody died without a message
+            except queue.Empty:     # make sure nobody died without a message
                 dead = [i for i, p in enumerate(self._procs) if not p.is_alive() and i not in out]
                 if dead:
                     self.close(kill=True)
                     raise RuntimeError(f'multi-GPU rank process(es) {dead} exited unexpectedly')
+                if time.monotonic() > deadline:
+                    self.close(kill=True)
+                    raise RuntimeError(f'multi-GPU ranks did not answer within EMP_MG_TIMEOUT (waiting for {what!r} from '
+                                       f'{sorted(set(range(self.world)) - set(out))})')
                 continue
             if kind == 'error':
                 self.close(kill=True)
@@ -698,7 +707,13 @@ class MultiGPUEngine3d:
             self._start()
         payload = volume
         if isinstance(volume, np.ndarray):
-            payload = torch.from_numpy(np.ascontiguousarray(volume)).share_memory_()   # one copy, mapped by every rank
+            # one copy, mapped by every rank; kept for the following axes of the same volume (the widget calls xy, xz, yz on
+            # one array: _volume_inference.py:336-348) instead of copying it into shared memory again per call
+            key = (id(volume), volume.shape, volume.dtype.str, volume.__array_interface__['data'][0])
+            if getattr(self, '_shm_key', None) != key:
+                self._shm = torch.from_numpy(np.ascontiguousarray(volume)).share_memory_()
+                self._shm_key = key
+            payload = self._shm
         for q in self._cmd:
             q.put(('axis', payload, axis_name, self.ks, self._match_desc(volume.shape, axis_name)))
         return self._collect('done')[0]

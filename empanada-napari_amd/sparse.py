@@ -152,6 +152,7 @@ def force_connected(pan, thing_list, label_divisor, out=None):
     return out
 
 
+@torch.no_grad()
 def pan_stack_to_runs(pan, labels, label_divisor, thing_list, force_connected=True):
     """The GPU half of pan_stack_to_rle_segs without building Python objects: pan (N,H,W) ->
     {class: (list of N (n_i,3) int64 {start, length, label} arrays in raster order, id offset)} for StackMatcher.push_runs."""

@@ -36,7 +36,7 @@ def run(B, S):
 
 def join(trace_dir, log, out=None):
     f = glob.glob(os.path.join(trace_dir, '**', '*kernel_trace.csv'), recursive=True)[0]
-    ks = [r for r in csv.DictReader(open(f)) if ('conv_igemm' in r['Kernel_Name'] or 'sepconv5' in r['Kernel_Name'] or 'conv3x3_c' in r['Kernel_Name']) and 'pack' not in r['Kernel_Name']]
+    ks = [r for r in csv.DictReader(open(f)) if ('conv_igemm' in r['Kernel_Name'] or 'sepconv5' in r['Kernel_Name'] or 'sepconvp_kernel' in r['Kernel_Name'] or 'conv3x3_c' in r['Kernel_Name']) and 'pack' not in r['Kernel_Name']]
     ks.sort(key=lambda r: int(r['Start_Timestamp']))
     fw, cur = [], []
     for line in open(log):
@@ -57,7 +57,7 @@ def join(trace_dir, log, out=None):
         if kind == 'conv':
             flops = 2.0 * M * cout * cin * kh * kh
             by = 2.0 * (inpix * cin + M * cout * (2 if res else 1) + cout * cin * kh * kh)
-        elif kind == 'sepconv':
+        elif kind in ('sepconv', 'sepconvp'):
             flops = 2.0 * M * cin * (25 + cout)
             by = 2.0 * (M * cin + M * cout)
         else:
