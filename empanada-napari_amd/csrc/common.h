@@ -137,10 +137,10 @@ int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, con
                     const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
                     const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s,
                     int ks = 5);
-// the same block at fp32 accuracy (sepconv_precise.hip): fp32 taps, depthwise result and pointwise weights as fp16
-// hi + lo pairs, three MFMAs per product
+// the same block with an exact depthwise half (sepconv_precise.hip): fp32 taps, depthwise result as an fp16 hi + lo pair
+// (two MFMAs per product), fp16 pointwise weights
 bool sepconvp_supported(int C, int Cout, int head_c);
-// pointwise weights (Cout, pw_ld) fp32 -> 2 * C * Cout fp16 (hi parts, then lo parts) in MFMA fragment order
+// pointwise weights (Cout, pw_ld) fp32 -> C * Cout fp16 in MFMA fragment order
 int launch_sepconvp_pack_pw(const float* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s);
 // depthwise taps (ks*ks, C) fp32 -> chunk-major [C/64][ks*ks][64] fp32
 int launch_sepconvp_pack_dw(const float* w, int ks, int C, float* packed, hipStream_t s);

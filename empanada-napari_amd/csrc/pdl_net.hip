@@ -68,8 +68,8 @@ struct emp_pdl {
   bool fuse_aspp = [] { const char* e = getenv("EMP_FUSE_ASPP"); return !(e && e[0] == '0'); }();   // the two decoders' ASPP branches as one conv each
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
   bool fuse_pr = [] { const char* e = getenv("EMP_FUSE_PR"); return !(e && e[0] == '0'); }();             // pointrend.hip
-  // Separable blocks computed at fp32 accuracy (sepconv_precise.hip: fp32 taps, fp16 hi + lo operands, 3 MFMAs per
-  // product; +0.4 ms per launch at 32 x 1024^2): 1 (default) = the blocks the CENTRE heat-map depends on -- the
+  // Separable blocks with an exact depthwise half (sepconv_precise.hip: fp32 taps, depthwise result as fp16 hi + lo, 2
+  // MFMAs per product): 1 (default) = the blocks the CENTRE heat-map depends on -- the
   // last-stage fusion conv(s) of the decoder that feeds ins_center and the ins_center head -- which is where the
   // north star's 1e-3 on the heat-maps was missed; 2 = every fused 5x5 block; 0 = none (round-2 numerics).
   int precise_sepconv = [] { const char* e = getenv("EMP_PRECISE_SEPCONV"); return e ? atoi(e) : 1; }();
@@ -122,7 +122,7 @@ namespace {
 const int kLayers[4] = {3, 4, 6, 3};
 const int kPlanes[4] = {64, 128, 256, 512};
 
-// does the separable block `pre` (its parameters are pre.sepconv.0 / pre.sepconv.1) run at fp32 accuracy?
+// does the separable block `pre` (its parameters are pre.sepconv.0 / pre.sepconv.1) run with the exact depthwise half (sepconv_precise.hip)?
 bool precise_layer(const emp_pdl* n, const std::string& pre) {
   if (n->precise_sepconv <= 0) return false;
   if (n->precise_sepconv >= 2) return true;
@@ -281,8 +281,8 @@ int pack_sepconv_pw(emp_pdl* n, const std::string& name) {
   return EMP_OK;
 }
 
-// fragment-ordered fp16 hi + lo copy of a pointwise weight for the fp32-accurate fused separable conv (sepconv_precise.hip), when its shape
-// qualifies: packed from the fp32 host parameter, so that the pair carries 21 significant bits of it
+// fragment-ordered fp16 copy of a pointwise weight for the fused separable conv with the exact depthwise half
+// (sepconv_precise.hip), when its shape qualifies
 int pack_sepconvp_pw(emp_pdl* n, const std::string& name) {
   const DevConv& dc = n->convs.at(name);
   if (dc.kh != 1 || dc.kw != 1 || !sepconvp_supported(dc.cin_pad, dc.cout, 0)) return EMP_OK;
@@ -294,7 +294,7 @@ int pack_sepconvp_pw(emp_pdl* n, const std::string& name) {
   EMP_CHECK_HIP(hipMalloc(&tmp, w32.size() * sizeof(float)));
   hipError_t e = hipMemcpy(tmp, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice);
   void* d = nullptr;
-  if (e == hipSuccess) e = hipMalloc(&d, (size_t)2 * dc.cin_pad * dc.cout * sizeof(half_t));
+  if (e == hipSuccess) e = hipMalloc(&d, (size_t)dc.cin_pad * dc.cout * sizeof(half_t));
   if (e != hipSuccess) {
     (void)hipFree(tmp);
     set_error("%s: packing the pointwise weights: %s", name.c_str(), hipGetErrorString(e));
@@ -838,7 +838,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
         const Act& so = A(dp + ".out");
         if (n->fuse_sepconv && precise_layer(n, dp + ".fusion.0") && n->f16w.count(dp + ".fusion.0.sepconv.1.packedp") &&
             cat.ld == 2 * F && pwc.cin_pad == 2 * F && so.ld == pwc.cout && sepconvp_supported(2 * F, pwc.cout, 0)) {
-          // the decoder that feeds the centre heat-map: the block at fp32 accuracy (sepconv_precise.hip)
+          // the decoder that feeds the centre heat-map: the block with the exact depthwise half (sepconv_precise.hip)
           RC(launch_sepconvp(cat.p, N, cat.H, cat.W, 2 * F, cat.ld, n->f32w.at(dp + ".fusion.0.sepconv.0.f32"),
                              n->f16w.at(dp + ".fusion.0.sepconv.1.packedp"), pwc.b, pwc.cout, 1, so.p, so.ld, nullptr, nullptr,
                              0, nullptr, 0, zero, s));
@@ -937,7 +937,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
         const Act& so = A(q + ".out");
         if (n->fuse_sepconv && precise_layer(n, p + ".fuse." + std::to_string(i) + ".0") && n->f16w.count(fz + "1.packedp") &&
             pwc.cin_pad == cb.ld && so.ld == pwc.cout && sepconvp_supported(cb.ld, pwc.cout, 0)) {
-          // the decoder that feeds the centre heat-map: the block at fp32 accuracy (sepconv_precise.hip)
+          // the decoder that feeds the centre heat-map: the block with the exact depthwise half (sepconv_precise.hip)
           RC(launch_sepconvp(cb.p, N, cb.H, cb.W, cb.ld, cb.ld, n->f32w.at(fz + "0.f32"), n->f16w.at(fz + "1.packedp"), pwc.b,
                              pwc.cout, 1, so.p, so.ld, nullptr, nullptr, 0, nullptr, 0, rawp<half_t>(n, "zero"), s));
           n->flops += 2.0 * (double)N * cb.H * cb.W * pwc.cout * (double)pwc.cin;
@@ -983,7 +983,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
     if (n->fuse_sepconv && precise_layer(n, p + ".head.0.0") && n->f16w.count(p + ".head.0.0.sepconv.1.packedp") &&
         xin.C == n->dec_ch && pwc.cin_pad == n->dec_ch && pwc.cout == n->dec_ch && hc[k] <= 2 &&
         sepconvp_supported(n->dec_ch, pwc.cout, hc[k])) {
-      // the centre head at fp32 accuracy (sepconv_precise.hip)
+      // the centre head with the exact depthwise half (sepconv_precise.hip)
       RC(launch_sepconvp(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f32w.at(p + ".head.0.0.sepconv.0.f32"),
                          n->f16w.at(p + ".head.0.0.sepconv.1.packedp"), pwc.b, pwc.cout, 1, nullptr, 0, n->f32w.at(p + ".head.1.w"),
                          n->f32w.at(p + ".head.1.b"), hc[k], dst, (int64_t)hq * wq, rawp<half_t>(n, "zero"), s));

@@ -8,16 +8,20 @@
 // There is no non-linearity between the depthwise and the pointwise conv, so the depthwise output is
 // only ever the B operand of the pointwise GEMM: it is produced straight into LDS, in fp32.
 //
-// Round 3: the block computes in (nearly) fp32 although it runs on the fp16 matrix pipe.  Its three rounding sites --
-// the depthwise taps, the depthwise output and the pointwise weights stored as fp16 -- were half of the end-to-end
-// error of the centre heat-map against the fp32 reference (profiles/r02_error_budget.csv).  Now
-//   * the depthwise taps are fp32 (they only ever meet the fp32 vector pipe),
-//   * the depthwise output goes to LDS as an fp16 hi tile + an fp16 lo tile (hi = rtz(x), lo = rtz(x - hi): 21
-//     significant bits; split ONCE by the depthwise wave that produced it -- a first build that stored fp32 and let each of
-//     the four mma waves split its own B fragments spent 4x the conversions and ran at half the speed),
-//   * the pointwise weights arrive as fp16 hi + lo pairs (sepconvp_pack_pw_kernel), and
-//   * each product is three MFMAs, hi*hi + lo*hi + hi*lo (the lo*lo term is below fp32 resolution).
-// The matrix pipe had the slack: the fp32 depthwise on the vector pipe bounds the step.
+// Round 3: the depthwise half of the block is exact although the block runs on the fp16 matrix pipe.  Its rounding sites
+// -- the depthwise taps, the depthwise output and the pointwise weights stored as fp16 -- were a large part of the
+// end-to-end error of the centre heat-map against the fp32 reference (profiles/r02_error_budget.csv).  A what-if with
+// the format-emulating oracle on the two blocks the heat-map depends on (256^2 tile, ctr rms; DESIGN finding 24):
+//     fp16 everywhere 8.03e-4 | fp32 taps 7.99e-4 | + depthwise output kept to 21 bits 7.32e-4 | + pointwise weights
+//     as hi + lo pairs too 7.28e-4
+// so the kernel keeps
+//   * the depthwise taps in fp32 (they only ever meet the fp32 vector pipe: free), and
+//   * the depthwise output as an fp16 hi tile + an fp16 lo tile in LDS (hi = rtz(x), lo = rtz(x - hi): 21 significant
+//     bits; split ONCE by the depthwise wave that produced it -- a first build that stored fp32 and let each of the four
+//     mma waves split its own B fragments spent 4x the conversions and ran at half the speed), multiplied as
+//     w*hi + w*lo: two MFMAs per product,
+// and leaves the pointwise weights in fp16: their hi + lo form (a third MFMA per product, twice the weight traffic, 32
+// more registers) bought 0.5 % of the error for a third of the matrix work, and was removed.
 //
 // One persistent workgroup per CU, 512 threads = 8 waves with two roles (one wave of each per SIMD, so
 // the vector ALU and the matrix pipe of every SIMD are both fed):
@@ -25,7 +29,7 @@
 //                     12x20-pixel x 64-channel halo tile in LDS into two 128-pixel x 64-channel fp16
 //                     B tiles in LDS (hi and lo parts, XOR-swizzled rows of 128 B); taps straight from L2 into registers.
 //   waves 4-7  "mma": LDS-DMA (global_load_lds) of the NEXT halo tile, then the pointwise GEMM of the
-//                     PREVIOUS B tile: 16x16x32 f16 MFMA, A fragments (pointwise weights, hi + lo) straight
+//                     PREVIOUS B tile: 16x16x32 f16 MFMA, A fragments (pointwise weights) straight
 //                     from L2, accumulators (Cout/4 x 128 pixels per wave) resident across the C/64 channel
 //                     chunks and initialised with the bias; epilogue act + 16-byte NHWC stores (or the head
 //                     reduction).
@@ -36,7 +40,7 @@
 // one-step prefetch and a full __syncthreads the mma role alone took 1.07 ms of a 1.15 ms launch.]
 //
 // Summation order: depthwise taps ky-major, kx-minor, fp32 fma chain from 0; GEMM ascending 32-channel K-steps,
-// per step hi*hi, lo*hi, hi*lo, from the bias.  Fixed, so a batch of N equals N batch-1 calls bit for bit.
+// per step w*hi, w*lo, from the bias.  Fixed, so a batch of N equals N batch-1 calls bit for bit.
 #include "common.h"
 
 namespace emp {
@@ -59,7 +63,7 @@ struct SepParams {
   const half_t* in;
   int N, H, W, C, in_ld;
   const float* dww;      // [C/64][KS*KS][64] fp32 (sepconv5_pack_dw)
-  const half_t* pww;     // pointwise weights in MFMA-fragment order, hi then lo (sepconv5_pack_pw)
+  const half_t* pww;     // pointwise weights (fp16) in MFMA-fragment order (sepconvp_pack_pw)
   const float* bias;     // [Cout] (never null: the launcher substitutes zeros)
   half_t* out;           // (N,H,W,out_ld) or nullptr (head mode)
   int out_ld, act;
@@ -273,26 +277,21 @@ __global__ void __launch_bounds__(64 * (SC_NDW + SC_NMW), 1) sepconvp_kernel(con
     // ------------------------------------------------------------------ mma role
     const int wm = wave - NDW, g16 = lane >> 4, n16 = lane & 15;
     __builtin_amdgcn_s_setprio(3);      // few instructions, long latencies: issue ahead of the VALU-bound dw wave
-    // Pointwise weights, pre-packed in fragment order [hi|lo][chunk][wave][tile][k-half][lane][8]: every load
+    // Pointwise weights, pre-packed in fragment order [chunk][wave][tile][k-half][lane][8]: every load
     // instruction reads 1 KiB of whole cache lines.  The fragments of k-step 0 of the NEXT chunk are requested as soon
     // as this chunk's k-step 0 MFMAs are issued, those of k-step 1 at the end of the step: each half has half a step
     // to arrive (with all of them requested at the end of the step a full L2 round trip was exposed every step).
     // These waves issue no LDS-DMA, so the compiler's own counted waits are exact here.
     const f16x8* const abase = reinterpret_cast<const f16x8*>(p.pww) + (size_t)wm * MT * 2 * 64 + lane;
     constexpr int A_CHUNK = NMW * MT * 2 * 64;          // fragments (16 B) per 64-channel chunk
-    const size_t a_lo = (size_t)p.C * COUT / 8;         // offset of the lo parts, in fragments
     // bias of this lane's accumulator rows: tile t, element e <-> cout wm*16*MT + (t>>1)*32 + g16*8 + (t&1)*4 + e
     const f32x4* const bbase = reinterpret_cast<const f32x4*>(p.bias + wm * 16 * MT + g16 * 8);
     f32x4 acc[MT][8];
-    f16x8 ah[MT][2], al[MT][2];           // fragments of the chunk being multiplied
-    f16x8 nah[MT][2], nal[MT][2];         // in flight: the next chunk's
-    auto load_a = [&](int ch, int ks) {     // 2 * MT loads
+    f16x8 ah[MT][2];                      // fragments of the chunk being multiplied
+    f16x8 nah[MT][2];                     // in flight: the next chunk's
+    auto load_a = [&](int ch, int ks) {     // MT loads
 #pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const f16x8* ap = abase + (size_t)ch * A_CHUNK + t * (2 * 64) + ks * 64;
-        nah[t][ks] = ap[0];
-        nal[t][ks] = ap[a_lo];
-      }
+      for (int t = 0; t < MT; ++t) nah[t][ks] = abase[(size_t)ch * A_CHUNK + t * (2 * 64) + ks * 64];
     };
     // head finishing lanes: output idx = wm*64 + lane -> (class h = idx >> 7, pixel idx & 127)
     const int fidx = wm * 64 + lane, fh = fidx >> 7, fpx = fidx & 127;
@@ -328,7 +327,7 @@ __global__ void __launch_bounds__(64 * (SC_NDW + SC_NMW), 1) sepconvp_kernel(con
       auto bfrag = [&](int i, int part) {   // i = nt*2 + ks; part 0 = hi, 1 = lo
         return *reinterpret_cast<const f16x8*>(bb + part * SC_BT_HALF + (i >> 1) * 16 * 128 + ((((i & 1) * 4 + g16) ^ (n16 & 7)) << 4));
       };
-      auto half = [&](const int ks) {       // the 8 pixel tiles x MT cout tiles of k-step ks: 3 MFMAs per product
+      auto half = [&](const int ks) {       // the 8 pixel tiles x MT cout tiles of k-step ks: 2 MFMAs per product
         f16x8 bh = bfrag(ks, 0), bl = bfrag(ks, 1);
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
@@ -337,8 +336,6 @@ __global__ void __launch_bounds__(64 * (SC_NDW + SC_NMW), 1) sepconvp_kernel(con
 #pragma unroll
           for (int t = 0; t < MT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][ks], bh, acc[t][nt], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < MT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t][ks], bh, acc[t][nt], 0, 0, 0);
-#pragma unroll
           for (int t = 0; t < MT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][ks], bl, acc[t][nt], 0, 0, 0);
           if (nt + 1 < 8) { bh = nh; bl = nl; }
         }
@@ -346,13 +343,13 @@ __global__ void __launch_bounds__(64 * (SC_NDW + SC_NMW), 1) sepconvp_kernel(con
       const int cn = c1 + 1 == NC ? 0 : c1 + 1;     // chunk g % NC, multiplied in step g+1
       // k-step 0: take over the fragments requested in the middle of the previous step, multiply, request the next ones
 #pragma unroll
-      for (int t = 0; t < MT; ++t) { ah[t][0] = nah[t][0]; al[t][0] = nal[t][0]; }
+      for (int t = 0; t < MT; ++t) ah[t][0] = nah[t][0];
       if (do_mma) half(0);
       __builtin_amdgcn_sched_barrier(0);
       load_a(cn, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < MT; ++t) { ah[t][1] = nah[t][1]; al[t][1] = nal[t][1]; }
+      for (int t = 0; t < MT; ++t) ah[t][1] = nah[t][1];
       if (do_mma) half(1);
       __builtin_amdgcn_sched_barrier(0);
       load_a(cn, 1);
@@ -430,8 +427,7 @@ __global__ void __launch_bounds__(256) sepconvp_pack_dw_kernel(const float* __re
   }
 }
 
-// (Cout, pw_ld) fp32 row-major -> fp16 hi + lo parts in the fragment order of the kernel above (MT = Cout / 64):
-// out[0 .. C*Cout) = hi = rne(w), out[C*Cout .. 2*C*Cout) = lo = rne(w - hi)
+// (Cout, pw_ld) fp32 row-major -> fp16 in the fragment order of the kernel above (MT = Cout / 64)
 __global__ void __launch_bounds__(256) sepconvp_pack_pw_kernel(const float* __restrict__ w, int pw_ld, int C, int Cout,
                                                                int MT, half_t* __restrict__ out) {
   const int total = C * Cout / 8;      // 16-byte fragments
@@ -445,14 +441,10 @@ __global__ void __launch_bounds__(256) sepconvp_pack_pw_kernel(const float* __re
     const int n16 = lane & 15, g16 = lane >> 4, tp = t & 1;
     const int co = wm * 16 * MT + (t >> 1) * 32 + ((n16 >> 2) << 3) + (tp << 2) + (n16 & 3);
     const float* src = w + (size_t)co * pw_ld + ch * 64 + ks * 32 + g16 * 8;
-    f16x8 hi, lo;
+    f16x8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      hi[e] = (half_t)src[e];
-      lo[e] = (half_t)(src[e] - (float)hi[e]);
-    }
-    *reinterpret_cast<f16x8*>(out + (size_t)i * 8) = hi;
-    *reinterpret_cast<f16x8*>(out + (size_t)C * Cout + (size_t)i * 8) = lo;
+    for (int e = 0; e < 8; ++e) v[e] = (half_t)src[e];
+    *reinterpret_cast<f16x8*>(out + (size_t)i * 8) = v;
   }
 }
 
@@ -488,7 +480,7 @@ bool sepconvp_supported(int C, int Cout, int head_c) {
          sepconvp_lds_bytes(Cout, head_c) <= 160 * 1024;
 }
 
-// packed: 2 * C * Cout fp16 (hi parts, then lo parts)
+// packed: C * Cout fp16
 int launch_sepconvp_pack_pw(const float* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s) {
   EMP_REQUIRE(C % 64 == 0 && (Cout == 128 || Cout == 256) && pw_ld >= C, "sepconvp pack_pw: bad shape");
   const int total = C * Cout / 8;

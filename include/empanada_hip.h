@@ -210,15 +210,16 @@ EMP_API int emp_sepconv3x3_nhwc_f16(const void* d_in, int N, int H, int W, int C
                             const void* d_pw_w, const float* d_bias, int Cout, int act, void* d_out, int out_ld,
                             void* stream);
 
-/* The separable block at fp32 accuracy (round 3; csrc/sepconv_precise.hip): the three places where the block above
- * rounds to fp16 -- depthwise taps, depthwise result, pointwise weights -- were a large part of the centre heat-map's
+/* The separable block with an exact depthwise half (round 3; csrc/sepconv_precise.hip): where the block above rounds
+ * to fp16 inside -- depthwise taps, depthwise result, pointwise weights -- was a large part of the centre heat-map's
  * distance to the fp32 reference forward (models/quantization/panoptic_deeplab.py:238-250 run in fp32).  Here the taps
- * stay fp32 on the vector pipe and the depthwise result and the pointwise weights go to the matrix pipe as fp16
- * hi + lo pairs (three MFMAs per product, fp32 accumulation): only x and y are fp16.
+ * stay fp32 on the vector pipe and the depthwise result goes to the matrix pipe as an fp16 hi + lo pair (two MFMAs per
+ * product, fp32 accumulation); the pointwise weights stay fp16 (their hi + lo form bought 0.5 % of the error for a third
+ * more matrix work: measured, removed).  x and y are fp16.
  *   K       : depthwise kernel size, 5 or 3 (3: no head mode)
  *   d_dw_w  : the (K*K, C) fp32 taps re-ordered by emp_sepconvp_pack_dw (chunk-major [C/64][K*K][64] fp32)
- *   d_pw_w  : the (Cout, C) fp32 pointwise weights (row stride pw_ld) re-ordered by emp_sepconvp_pack_pw:
- *             2*C*Cout fp16, hi parts then lo parts, MFMA fragment order
+ *   d_pw_w  : the (Cout, C) fp32 pointwise weights (row stride pw_ld) rounded to fp16 and re-ordered by
+ *             emp_sepconvp_pack_pw (C*Cout fp16, MFMA fragment order)
  *   C % 64 == 0, 128 <= C <= 512, Cout in {128,256}, head_c in 0..2; other arguments as emp_sepconv5x5_nhwc_f16 */
 EMP_API int emp_sepconvp_pack_dw(const void* d_dw_w, int K, int C, void* d_packed, void* stream);
 EMP_API int emp_sepconvp_pack_pw(const void* d_pw_w, int pw_ld, int C, int Cout, void* d_packed, void* stream);

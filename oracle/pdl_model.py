@@ -16,8 +16,8 @@ RESNET50_LAYERS = (3, 4, 6, 3)
 
 
 def precise_block(pre, ins_decoder=True):
-    """Which separable blocks the HIP engine computes at fp32 accuracy (csrc/sepconv_precise.hip: fp32 taps, depthwise
-    result and pointwise weights as fp16 hi + lo pairs) -- the rule of pdl_net.hip's ``precise_layer``: by default the
+    """Which separable blocks the HIP engine computes with an exact depthwise half (csrc/sepconv_precise.hip: fp32 taps,
+    depthwise result carried as an fp16 hi + lo pair; pointwise weights fp16) -- the rule of pdl_net.hip's ``precise_layer``: by default the
     blocks the centre heat-map depends on (the fusion convs of the decoder that feeds ``ins_center`` and the
     ``ins_center`` head); EMP_PRECISE_SEPCONV=2 every fused 5x5 block, 0 none.  ``pre`` is the block's parameter prefix
     (``<pre>.sepconv.0`` / ``.1``).  Test infrastructure mirrors the switch so that A/B runs stay comparable."""
@@ -163,11 +163,11 @@ def decoder_forward(P, pre, pyr, low_level_stages, rates, taps=None, ins_decoder
         x = torch.cat((x, l), dim=1)
         if taps is not None:
             taps[f'{pre}.stage{i}.cat'] = x
-        # sepconv_precise.hip: fp32 taps, the depthwise result and the pointwise weights as fp16 hi + lo pairs -- the block
-        # rounds nothing but its fp16 output map; sepconv.hip: fp16 taps, fp16 depthwise result, fp16 weights
+        # sepconv_precise.hip: fp32 taps, the depthwise result as an fp16 hi + lo pair (not rounded), fp16 pointwise
+        # weights; sepconv.hip: fp16 taps, fp16 depthwise result, fp16 weights
         prec = precise_block(f'{pre}.fuse.{i}.0', ins_decoder)
         x = _conv(x, (P[f'{pre}.fuse.{i}.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=None if prec else True, w32=prec)
-        x = _conv(x, P[f'{pre}.fuse.{i}.0.sepconv.1'], relu=True, site=True, w32=prec)
+        x = _conv(x, P[f'{pre}.fuse.{i}.0.sepconv.1'], relu=True, site=True)
     return x
 
 
@@ -175,7 +175,7 @@ def head_forward(P, pre, x, ins_decoder=True):
     """heads.py:12-19."""
     prec = precise_block(f'{pre}.head.0.0', ins_decoder) and P[f'{pre}.head.1'][0].shape[0] <= 2
     x = _conv(x, (P[f'{pre}.head.0.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=None if prec else True, w32=prec)
-    x = _conv(x, P[f'{pre}.head.0.0.sepconv.1'], relu=True, w32=prec)      # fused head: this map stays fp32 on chip
+    x = _conv(x, P[f'{pre}.head.0.0.sepconv.1'], relu=True)      # fused head: this map stays fp32 on chip
     return _conv(x, P[f'{pre}.head.1'], w32=True)
 
 
@@ -441,13 +441,13 @@ def _tf_conv(P, xin, name, stride=1, padding=0, dilation=1, groups=1, fp32=False
 
 def _tf_sepconv(P, xin, pre, pad, precise):
     """``pre``.sepconv.0 (depthwise) -> ``pre``.sepconv.1 (pointwise + folded BN) before the activation.  precise
-    (sepconv_precise.hip): fp32 taps, the depthwise result and the pointwise weights as fp16 hi + lo pairs -- fp32
-    arithmetic on the engine's fp16 input map.  Otherwise (sepconv.hip, or the unfused dwconv + conv pair, which are
-    bit-identical): fp16 taps, fp16 intermediate map, fp16 pointwise weights."""
+    (sepconv_precise.hip): fp32 taps and the depthwise result carried as an fp16 hi + lo pair -- an exact depthwise half
+    on the engine's fp16 input map -- with fp16 pointwise weights.  Otherwise (sepconv.hip, or the unfused dwconv + conv
+    pair, which are bit-identical): fp16 taps, fp16 intermediate map, fp16 pointwise weights."""
     dw = _tf_conv(P, xin, f'{pre}.sepconv.0', 1, pad, 1, xin.shape[1], fp32=precise)
     if not precise:
         dw = Fp16Emu.r16(dw)
-    return _tf_conv(P, dw, f'{pre}.sepconv.1', fp32=precise)
+    return _tf_conv(P, dw, f'{pre}.sepconv.1')
 
 
 def _tf_encoder(P, cfg, x, tap):

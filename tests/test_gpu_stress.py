@@ -65,7 +65,7 @@ def test_sepconv_repeatable_and_equal_to_unfused():
 
 
 def test_sepconv_precise_repeatable():
-    """the fp32-accurate block (sepconv_precise.hip: halo DMA from the depthwise waves, compiler-tracked tap / weight loads,
+    """the block with the exact depthwise half (sepconv_precise.hip: halo DMA from the depthwise waves, compiler-tracked tap / weight loads,
     raw barriers) at 16 tiles per workgroup: 20 launches bit-identical, image 3 equal to the fp64 reference (race screen)"""
     from gpu_common import dev
     from empanada_napari_amd import _abi
@@ -77,7 +77,7 @@ def test_sepconv_precise_repeatable():
     dw = (torch.randn((25, Cc), generator=g) * 0.2).to(dev())
     pw = (torch.randn((Cout, Cc), generator=g) / np.sqrt(Cc)).to(dev())
     b = torch.randn((Cout,), generator=g).to(dev())
-    pwp = torch.empty((2, Cout, Cc), dtype=torch.float16, device=dev())
+    pwp = torch.empty((Cout, Cc), dtype=torch.float16, device=dev())
     dwp = torch.empty_like(dw)
     st = _abi.stream_ptr(dev())
     _abi.check(lib.emp_sepconvp_pack_pw(_abi.ptr(pw), Cc, Cc, Cout, _abi.ptr(pwp), st), 'pack_pw')
@@ -94,7 +94,7 @@ def test_sepconv_precise_repeatable():
         assert torch.equal(fused(), first)
     xin = x[3:4].double().cpu().permute(0, 3, 1, 2)
     d = F.conv2d(xin, dw.double().cpu().t().reshape(Cc, 1, 5, 5), padding=2, groups=Cc)
-    ref = torch.relu(F.conv2d(d, pw.double().cpu()[:, :, None, None], b.double().cpu()))
+    ref = torch.relu(F.conv2d(d, pw.to(torch.float16).double().cpu()[:, :, None, None], b.double().cpu()))
     err = (first[3:4].double().cpu().permute(0, 3, 1, 2) - ref).abs()
     tol = 2.0 ** (torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -14))) - 11) + 2e-6 * float(ref.abs().max())
     assert bool((err <= tol).all()), float(err.max())

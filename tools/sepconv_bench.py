@@ -59,10 +59,10 @@ def main():
                                                    _abi.ptr(b), Cout, 1, None if hc else _abi.ptr(out), Cout,
                                                    _abi.ptr(hw) if hc else None, _abi.ptr(hb) if hc else None, hc,
                                                    _abi.ptr(ho) if hc else None, st), 'fused')
-        # the fp32-accurate block (sepconv_precise.hip): fp32 taps, fp16 hi + lo operands, 3 MFMAs per product
+        # the block with the exact depthwise half (sepconv_precise.hip): fp32 taps, depthwise result as fp16 hi + lo, 2 MFMAs per product
         dw32 = torch.randn((25, Cc), device=dev) * 0.2
         pw32 = torch.randn((Cout, Cc), device=dev) / np.sqrt(Cc)
-        dwq, pwq = torch.empty_like(dw32), torch.empty((2, Cout, Cc), device=dev, dtype=torch.float16)
+        dwq, pwq = torch.empty_like(dw32), torch.empty((Cout, Cc), device=dev, dtype=torch.float16)
         _abi.check(lib.emp_sepconvp_pack_dw(_abi.ptr(dw32), 5, Cc, _abi.ptr(dwq), st), 'pack_dw')
         _abi.check(lib.emp_sepconvp_pack_pw(_abi.ptr(pw32), Cc, Cc, Cout, _abi.ptr(pwq), st), 'pack_pw')
 
