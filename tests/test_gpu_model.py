@@ -47,16 +47,21 @@ def test_heads_match_reference_golden(golden_dir, setup, case):
     sem = out['sem_logits'].cpu().numpy()
     assert sem.shape == g[f'{case}_sem_logits'].shape
     assert ctr.shape == g[f'{case}_ctr_hmp'].shape and off.shape == g[f'{case}_offsets'].shape
-    # centre heat-map: raw head output (the reference thresholds it un-squashed), tolerance 1e-3 abs
-    # is the north-star bar; fp16 activations give ~3e-3 on O(1) values, asserted at 1e-2 and reported.
-    e_ctr = np.abs(ctr - g[f'{case}_ctr_hmp']).max()
+    # centre heat-map: raw head output (the reference thresholds it un-squashed).  The north star's 1e-3 is asserted in rms
+    # (as at full size, tests/test_gpu_parity_fullsize.py); the max norm -- fp16 maps give 1.5e-3 ... 4.1e-3 on O(1) values --
+    # and the offsets at 1.3 x what is measured (round 3: max|dctr| <= 4.1e-3, max|doff| <= 4.9e-2 px over the four cases).
+    d_ctr = np.abs(ctr - g[f'{case}_ctr_hmp'])
+    e_ctr = d_ctr.max()
+    r_ctr = float(np.sqrt((d_ctr.astype(np.float64) ** 2).mean()))
     e_off = np.abs(off - g[f'{case}_offsets']).max()
     p, pr = _sig(sem), _sig(g[f'{case}_sem_logits'])
     e_sem = np.abs(p - pr)
     print(f'[{case}] max|dctr|={e_ctr:.2e} max|doff|={e_off:.2e} max|dprob|={e_sem.max():.2e} '
           f'mean|dprob|={e_sem.mean():.2e} frac(dprob>1e-3)={np.mean(e_sem > 1e-3):.4f}')
-    assert e_ctr < 1e-2
-    assert e_off < 1e-1           # offsets are O(10) pixels
+    print(f'[{case}] rms dctr = {r_ctr:.2e}')
+    assert r_ctr < 1e-3, r_ctr
+    assert e_ctr < 5.4e-3, e_ctr
+    assert e_off < 6.4e-2, e_off           # offsets are O(10) pixels
     # PointRend refines the 8192 most uncertain cells: a cell selected by one side only differs by
     # (refined - interpolated); such flips must stay rare, everything else within 1e-2 in probability
     assert np.mean(e_sem > 1e-2) < 5e-3
@@ -162,7 +167,8 @@ def test_bifpn_heads_match_reference_golden(golden_dir, tag, ncls, case):
         print(f'[{tag}{case}] {name}: max abs {err.max():.3e} (mean |ref| {scale:.3f}), rms rel {np.sqrt((err**2).mean())/scale:.3e}, '
               f'frac>1%*scale {np.mean(err > 0.05 * scale):.4f}')
         if name != 'sem_logits':
-            assert np.sqrt((err ** 2).mean()) / scale < 1e-2
+            # relative to the map's mean magnitude; round 3 measures 1.2e-3 ... 1.8e-3 (centre) and 1.6e-3 ... 2.1e-3 (offsets)
+            assert np.sqrt((err ** 2).mean()) / scale < (2.3e-3 if name == 'ctr_hmp' else 2.8e-3)
         else:
             # PointRend cell selection can differ on near-ties; the bulk must agree
             assert np.mean(err > 0.05 * scale) < 2e-2
