@@ -148,16 +148,6 @@ int launch_sepconvp(const half_t* in, int N, int H, int W, int C, int in_ld, con
                     const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
                     const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s,
                     int ks = 5);
-// the same block with the depthwise conv on the matrix pipe (sepconv_mma.hip): fp16 taps as block-diagonal MFMA fragments;
-// lo != 0 carries the depthwise result as an fp16 hi + lo pair (two pointwise MFMAs per product)
-bool sepconvm_supported(int C, int Cout, int head_c);
-int launch_sepconvm_pack_pw(const float* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s);
-// depthwise taps (ks*ks, C) fp32 -> (C / 16) * ((ks*ks + 1) / 2) * 512 fp16 block-diagonal fragments
-int launch_sepconvm_pack_dw(const float* w, int ks, int C, half_t* packed, hipStream_t s);
-int launch_sepconvm(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* dww_packed, const half_t* pww_packed,
-                    const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
-                    const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s,
-                    int ks, int lo);
 int launch_head1x1(const half_t* in, int N, int P, int K, int in_ld, const float* w, const float* b, int C,
                    float* out, int64_t plane_size, const int32_t* scatter_idx, hipStream_t s);
 int launch_bilinear_ac_f32_nchw(const float* in, int NC, int h, int w, float* out, int scale, hipStream_t s);

@@ -229,20 +229,6 @@ EMP_API int emp_sepconvp_nhwc_f16(const void* d_in, int N, int H, int W, int C, 
                         const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
                         void* stream);
 
-/* The separable block with its depthwise conv on the matrix pipe (round 3; csrc/sepconv_mma.hip): the K x K depthwise
- * taps of a 16-channel block become block-diagonal MFMA B fragments (K = 2 taps x 16 channels), the halo tile feeds the A
- * fragments straight from LDS; 13 MFMAs per 16 pixels x 16 channels instead of ~200 vector instructions.  fp16 taps, fp32
- * accumulation; lo != 0 carries the depthwise result to the pointwise conv as an fp16 hi + lo pair (as
- * emp_sepconvp_nhwc_f16), lo == 0 rounds it to fp16 (as emp_sepconv5x5_nhwc_f16).  Same operator: models/blocks.py:15-33.
- *   d_dw_w : the (K*K, C) fp32 taps through emp_sepconvm_pack_dw: (C/16) * ((K*K+1)/2) * 512 fp16
- *   d_pw_w : the (Cout, C) fp32 pointwise weights through emp_sepconvp_pack_pw (C*Cout fp16, fragment order) */
-EMP_API int emp_sepconvm_pack_dw(const void* d_dw_w, int K, int C, void* d_packed, void* stream);
-EMP_API int emp_sepconvm_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld, int K, int lo,
-                        const void* d_dw_w, const void* d_pw_w, const float* d_bias,
-                        int Cout, int act, void* d_out, int out_ld,
-                        const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
-                        void* stream);
-
 /* ------------------------------------------------------------------------
  * 3. Instance post-processing (hot loop 2), one launch group per batch
  * ---------------------------------------------------------------------- */

@@ -71,22 +71,10 @@ def main():
                                                  _abi.ptr(b), Cout, 1, None if hc else _abi.ptr(out), Cout,
                                                  _abi.ptr(hw) if hc else None, _abi.ptr(hb) if hc else None, hc,
                                                  _abi.ptr(ho) if hc else None, st), 'precise')
-        # depthwise on the matrix pipe (sepconv_mma.hip): lo = 0 (fp16 depthwise result) / 1 (hi + lo)
-        dwm = torch.empty((Cc // 16) * 13 * 512, device=dev, dtype=torch.float16)
-        _abi.check(lib.emp_sepconvm_pack_dw(_abi.ptr(dw32), 5, Cc, _abi.ptr(dwm), st), 'pack_dwm')
-
-        def mma(lo):
-            def run():
-                _abi.check(lib.emp_sepconvm_nhwc_f16(_abi.ptr(x), B, H, W, Cc, Cc, 5, lo, _abi.ptr(dwm), _abi.ptr(pwq),
-                                                     _abi.ptr(b), Cout, 1, None if hc else _abi.ptr(out), Cout,
-                                                     _abi.ptr(hw) if hc else None, _abi.ptr(hb) if hc else None, hc,
-                                                     _abi.ptr(ho) if hc else None, st), 'mma')
-            return run
         tu, tf, tp = timeit(unfused), timeit(fused), timeit(precise)
-        tm0, tm1 = timeit(mma(0)), timeit(mma(1))
         gb = (x.numel() + (0 if hc else out.numel())) * 2 / 1e9
         fl = 2.0 * B * H * W * Cc * (25 + Cout) / 1e9
-        print(f'{name:26s} unfused(dw+pw) {tu:6.3f} ms | fused {tf:6.3f} ms | precise {tp:6.3f} ms | mma {tm0:6.3f} / lo {tm1:6.3f} ms  {gb/tf*1e3:6.0f} GB/s alg  {fl/tf:7.1f} GFLOP/ms',
+        print(f'{name:26s} unfused(dw+pw) {tu:6.3f} ms | fused {tf:6.3f} ms | precise {tp:6.3f} ms  {gb/tf*1e3:6.0f} GB/s alg  {fl/tf:7.1f} GFLOP/ms',
               flush=True)
 
 
