@@ -64,6 +64,7 @@ PROTOTYPES = {
     'emp_sm_create': (vp, [c_i64, c_i64, c_f64, c_f64, c_int]),
     'emp_sm_destroy': (None, [vp]),
     'emp_sm_push_slice_runs': (c_int, [vp, vp, c_i64, c_i64, c_i64]),
+    'emp_sm_push_slices_runs': (c_int, [vp, c_i64, vp, vp, c_i64, c_i64]),
     'emp_sm_push_slice_objects': (c_int, [vp, c_i64, vp, vp, vp, vp, vp]),
     'emp_sm_num_slices': (c_i64, [vp]),
     'emp_lsa_maximize': (c_int, [vp, c_i64, c_i64, vp, vp]),
@@ -79,10 +80,13 @@ PROTOTYPES = {
     'emp_sm_pending_shape': (c_int, [vp, vp, vp]),
     'emp_sm_tracker_init': (c_int, [vp, c_int, c_i64, c_i64, c_i64]),
     'emp_sm_track': (c_int, [vp, c_i64, c_i64]),
+    'emp_sm_track_range': (c_int, [vp, c_i64, c_i64, c_i64]),
     'emp_sm_tracker_finish': (c_int, [vp]),
     'emp_sm_num_tracks': (c_i64, [vp]),
     'emp_sm_track_info': (c_int, [vp, c_i64, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64)]),
     'emp_sm_track_runs': (c_int, [vp, c_i64, vp, vp]),
+    'emp_sm_tracks_info': (c_int, [vp, vp, vp, vp, C.POINTER(c_i64)]),
+    'emp_sm_tracks_runs': (c_int, [vp, vp, vp]),
     'emp_sm_slice_num_objects': (c_i64, [vp, c_i64]),
     'emp_sm_slice_object_info': (c_int, [vp, c_i64, c_i64, C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64)]),
     'emp_sm_slice_object_runs': (c_int, [vp, c_i64, c_i64, vp, vp]),

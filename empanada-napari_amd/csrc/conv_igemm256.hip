@@ -234,9 +234,19 @@ __device__ __forceinline__ void wave_epilogue_any(const ConvParams& p, f32x4 (&a
 
 // DMA_EARLY: how many of the 4 LDS-DMA pieces of K-tile t+3 a wave issues in its LOAD slot (before the wait), the
 // rest go out in the shadow of its MFMAs
+#ifdef EMP_CLOCK_STAMP
+// DIAGNOSTIC BUILD ONLY (tools/conv256_clock.py; the product library is built without this macro and executes no stamp):
+// wave 0 of every workgroup stamps the shader clock (s_memtime) and the 100 MHz reference (s_memrealtime) around its K
+// loop; their quotient is the clock the chip holds INSIDE the loop (MI355X_MICROARCH.md, DVFS give-back item 6).
+__device__ unsigned long long emp_clock_stamp_buf[2 * 8192];
+#endif
+
 template <int DMA_EARLY, bool B2B>
 __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
+#ifdef EMP_CLOCK_STAMP
+  const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const int bid = blockIdx.x;
   const int xcd = bid & 7, j = bid >> 3;
@@ -471,6 +481,12 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
   if (grp == 0) lds_barrier();      // equal barrier count for both groups
   }
 
+#ifdef EMP_CLOCK_STAMP
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    emp_clock_stamp_buf[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - stamp_c0;
+    emp_clock_stamp_buf[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+  }
+#endif
   if constexpr (B2B) {      // n0 == 0: the launcher guarantees Cout == 256
     if (p.act == 1) wave_epilogue_b2b<1>(p, acc, lds, m0, grp, wc, wave, fr, fq, HoWo);
     else wave_epilogue_b2b<0>(p, acc, lds, m0, grp, wc, wave, fr, fq, HoWo);
@@ -746,3 +762,10 @@ int launch_conv_igemm_h256(ConvParams p, hipStream_t stream, int kg) {
 }
 
 }  // namespace emp
+
+#ifdef EMP_CLOCK_STAMP
+extern "C" __attribute__((visibility("default"))) int emp_diag_clock_stamps(unsigned long long* host, int n_workgroups) {
+  if (!host || n_workgroups <= 0 || n_workgroups > 8192) return -1;
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(emp::emp_clock_stamp_buf), sizeof(unsigned long long) * 2 * (size_t)n_workgroups);
+}
+#endif

@@ -28,6 +28,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <thread>
+
 #include "common.h"
 
 namespace {
@@ -45,6 +47,7 @@ struct FSlice {
   std::vector<int64_t> area, box;              // (K), (4K)
   std::vector<int64_t> run_off, starts, lens;  // CSR by component, runs ascending by start
   std::vector<FObj> objs;                      // current objects, in dict order
+  std::vector<int> raster_comp;                // slices from the run extractor: component of every run in raster order
   // overlaps with the PREVIOUS pushed slice: by own component (fwd) and by the previous slice's component (rev)
   bool pairs_ready = false;
   std::vector<int64_t> fwd_off, rev_off;
@@ -354,30 +357,7 @@ void finish_slice(emp_stack_matcher* h, FSlice& sl, const std::vector<int64_t>& 
   (void)h;
 }
 
-}  // namespace
-
-extern "C" {
-
-emp_stack_matcher* emp_sm_create(int64_t class_id, int64_t label_divisor, double iou_thr, double ioa_thr, int do_match) {
-  emp_stack_matcher* h = new emp_stack_matcher();
-  h->class_id = class_id;
-  h->divisor = label_divisor;
-  h->iou_thr = iou_thr;
-  h->ioa_thr = ioa_thr;
-  h->do_match = do_match != 0;
-  h->next_label = class_id * label_divisor + 1;
-  return h;
-}
-
-void emp_sm_destroy(emp_stack_matcher* h) { delete h; }
-
-// Append a slice from the run extractor: `runs` is (n,3) {start, length, label} in raster order, labels > 0; the slice
-// plane is `width` pixels wide.  Components are created in ascending label order (regionprops order) with half-open
-// boxes, exactly like rle.pan_seg_to_rle_seg; `id_offset` is added to every label (component index -> class id range).
-int emp_sm_push_slice_runs(emp_stack_matcher* h, const int64_t* runs, int64_t n, int64_t width, int64_t id_offset) {
-  EMP_REQUIRE(h && (runs || n == 0) && n >= 0 && width > 0, "sm_push_slice_runs: bad arguments");
-  h->stack.emplace_back();
-  FSlice& sl = h->stack.back();
+int build_slice_from_runs(emp_stack_matcher* h, FSlice& sl, const int64_t* runs, int64_t n, int64_t width, int64_t id_offset) {
   // distinct labels, ascending: a counting pass when they are dense (component ids 1..K), a sort otherwise
   int64_t maxlab = 0;
   for (int64_t i = 0; i < n; ++i) {
@@ -428,8 +408,73 @@ int emp_sm_push_slice_runs(emp_stack_matcher* h, const int64_t* runs, int64_t n,
     sl.starts[(size_t)pos] = s;
     sl.lens[(size_t)pos] = ln;
   }
+  sl.raster_comp = std::move(comp_of_run);
   finish_slice(h, sl, labels);
   return EMP_OK;
+}
+
+// worker threads of the label-independent bulk work (slice construction, pair tables): EMP_SM_THREADS, default 4
+int sm_threads() {
+  static const int n = [] { const char* e = getenv("EMP_SM_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+  return n;
+}
+
+// fn(i) for i in [0, count) on up to sm_threads() threads (static interleaved split); returns the first non-zero result
+template <typename F>
+int parallel_for(int64_t count, F fn) {
+  const int T = (int)std::min<int64_t>(sm_threads(), count);
+  if (T <= 1) {
+    for (int64_t i = 0; i < count; ++i) { const int rc = fn(i); if (rc) return rc; }
+    return EMP_OK;
+  }
+  std::vector<int> rcs((size_t)T, EMP_OK);
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t] {
+      for (int64_t i = t; i < count; i += T) { const int rc = fn(i); if (rc) { rcs[(size_t)t] = rc; return; } }
+    });
+  for (auto& x : th) x.join();
+  for (int rc : rcs) if (rc) return rc;
+  return EMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+emp_stack_matcher* emp_sm_create(int64_t class_id, int64_t label_divisor, double iou_thr, double ioa_thr, int do_match) {
+  emp_stack_matcher* h = new emp_stack_matcher();
+  h->class_id = class_id;
+  h->divisor = label_divisor;
+  h->iou_thr = iou_thr;
+  h->ioa_thr = ioa_thr;
+  h->do_match = do_match != 0;
+  h->next_label = class_id * label_divisor + 1;
+  return h;
+}
+
+void emp_sm_destroy(emp_stack_matcher* h) { delete h; }
+
+// Append a slice from the run extractor: `runs` is (n,3) {start, length, label} in raster order, labels > 0; the slice
+// plane is `width` pixels wide.  Components are created in ascending label order (regionprops order) with half-open
+// boxes, exactly like rle.pan_seg_to_rle_seg; `id_offset` is added to every label (component index -> class id range).
+int emp_sm_push_slice_runs(emp_stack_matcher* h, const int64_t* runs, int64_t n, int64_t width, int64_t id_offset) {
+  EMP_REQUIRE(h && (runs || n == 0) && n >= 0 && width > 0, "sm_push_slice_runs: bad arguments");
+  h->stack.emplace_back();
+  return build_slice_from_runs(h, h->stack.back(), runs, n, width, id_offset);
+}
+
+// `count` slices at once (a launch group of the run extractor): runs[k] / n[k] as in emp_sm_push_slice_runs; the slices
+// are built on worker threads (nothing in a slice depends on another)
+int emp_sm_push_slices_runs(emp_stack_matcher* h, int64_t count, const int64_t* const* runs, const int64_t* n, int64_t width,
+                            int64_t id_offset) {
+  EMP_REQUIRE(h && count >= 0 && (count == 0 || (runs && n)) && width > 0, "sm_push_slices_runs: bad arguments");
+  for (int64_t k = 0; k < count; ++k) EMP_REQUIRE(n[k] >= 0 && (runs[k] || n[k] == 0), "sm_push_slices_runs: bad slice %lld", (long long)k);
+  const size_t base = h->stack.size();
+  h->stack.resize(base + (size_t)count);
+  const int rc = parallel_for(count, [&](int64_t k) { return build_slice_from_runs(h, h->stack[base + (size_t)k], runs[k], n[k], width, id_offset); });
+  if (rc) h->stack.resize(base);
+  return rc;
 }
 
 // Append a slice given as objects (labels, (n,4) boxes, CSR runs): the generic form of the above; every object is one
@@ -477,9 +522,11 @@ int emp_lsa_maximize(const double* cost, int64_t nr, int64_t nc, int64_t* rows, 
 int emp_sm_prepare(emp_stack_matcher* h, int64_t from, int64_t to) {
   EMP_REQUIRE(h && from >= 0 && to < (int64_t)h->stack.size(), "sm_prepare: bad range");
   if (!h->do_match) return EMP_OK;
-  for (int64_t i = from + 1; i <= to; ++i)
+  return parallel_for(to - from, [&](int64_t k) {      // slice i's tables are written by one thread, slice i-1 is only read
+    const int64_t i = from + 1 + k;
     if (!h->stack[(size_t)i].pairs_ready) build_pairs(h->stack[(size_t)i - 1], h->stack[(size_t)i]);
-  return EMP_OK;
+    return (int)EMP_OK;
+  });
 }
 
 int emp_sm_state_size(const emp_stack_matcher* h, int64_t idx, int64_t* n_obj, int64_t* n_mem) {
@@ -801,11 +848,93 @@ int emp_sm_tracker_init(emp_stack_matcher* h, int axis, int64_t D, int64_t H, in
   return EMP_OK;
 }
 
+// InstanceTracker.update for a slice that came from the run extractor, in ONE pass over its runs in raster order: every
+// run goes to the track of the object its component belongs to, joined to that object's previous run of THIS slice where
+// they touch.  Same lists as object_runs() builds per object (a member's own runs never touch -- the extractor joined them
+// -- and the members' lists merged by start ARE the raster order), without a sort or a merge per object.
+static int track_raster(emp_stack_matcher* h, const FSlice& sl, int64_t index2d) {
+  const int64_t H = h->H, W = h->W;
+  static thread_local std::vector<int> obj_of_comp;
+  static thread_local std::vector<int64_t> cursor, last_start, last_end;
+  static thread_local std::vector<size_t> tidx;
+  const size_t no = sl.objs.size();
+  obj_of_comp.assign((size_t)sl.K, -1);
+  cursor.assign(sl.run_off.begin(), sl.run_off.end() - 1);
+  tidx.resize(no);
+  last_start.assign(no, 0);
+  last_end.assign(no, INT64_MIN);               // no run of this slice yet
+  for (size_t k = 0; k < no; ++k) {
+    const FObj& o = sl.objs[k];
+    int64_t box[6];
+    const int64_t y1 = o.box[0], x1 = o.box[1], y2 = o.box[2], x2 = o.box[3];
+    if (h->axis == 0) { box[0] = index2d; box[1] = y1; box[2] = x1; box[3] = index2d + 1; box[4] = y2; box[5] = x2; }
+    else if (h->axis == 1) { box[0] = y1; box[1] = index2d; box[2] = x1; box[3] = y2; box[4] = index2d + 1; box[5] = x2; }
+    else { box[0] = y1; box[1] = x1; box[2] = index2d; box[3] = y2; box[4] = x2; box[5] = index2d + 1; }
+    auto it = h->track_of.find(o.label);
+    if (it == h->track_of.end()) {
+      h->track_of.emplace(o.label, h->tracks.size());
+      tidx[k] = h->tracks.size();
+      h->tracks.emplace_back();
+      Track& t = h->tracks.back();
+      t.label = o.label;
+      std::memcpy(t.box, box, sizeof(box));
+    } else {
+      tidx[k] = it->second;
+      Track& t = h->tracks[it->second];
+      for (int q = 0; q < 3; ++q) { t.box[q] = std::min(t.box[q], box[q]); t.box[3 + q] = std::max(t.box[3 + q], box[3 + q]); }
+    }
+    size_t nruns = 0;
+    for (int c : o.members) {
+      obj_of_comp[(size_t)c] = (int)k;
+      nruns += (size_t)(sl.run_off[(size_t)c + 1] - sl.run_off[(size_t)c]);
+    }
+    Track& t = h->tracks[tidx[k]];
+    if (h->axis == 2) t.yz.reserve(t.yz.size() + 3 * nruns);
+    else if (t.starts.capacity() < t.starts.size() + nruns) {
+      const size_t want = std::max(t.starts.size() + nruns, 2 * t.starts.capacity());
+      t.starts.reserve(want);
+      t.runs.reserve(want);
+    }
+  }
+  const int axis = h->axis;
+  const int64_t plane = H * W;
+  const size_t n = sl.raster_comp.size();
+  for (size_t i = 0; i < n; ++i) {
+    const int c = sl.raster_comp[i];
+    const int k = obj_of_comp[(size_t)c];
+    const int64_t pos = cursor[(size_t)c]++;
+    if (k < 0) continue;
+    const int64_t s = sl.starts[(size_t)pos], e = s + sl.lens[(size_t)pos];
+    Track& t = h->tracks[tidx[(size_t)k]];
+    if (last_end[(size_t)k] >= s) {               // touches (or overlaps) the object's previous run of this slice
+      if (e > last_end[(size_t)k]) {
+        last_end[(size_t)k] = e;
+        if (axis == 2) t.yz[t.yz.size() - 2] = e - last_start[(size_t)k];
+        else t.runs.back() = e - last_start[(size_t)k];
+      }
+      continue;
+    }
+    last_start[(size_t)k] = s;
+    last_end[(size_t)k] = e;
+    if (axis == 0) {
+      t.starts.push_back(s + index2d * plane);
+      t.runs.push_back(e - s);
+    } else if (axis == 1) {
+      t.starts.push_back((s / W) * plane + index2d * W + (s % W));
+      t.runs.push_back(e - s);
+    } else {
+      t.yz.push_back(s); t.yz.push_back(e - s); t.yz.push_back(index2d);
+    }
+  }
+  return EMP_OK;
+}
+
 // InstanceTracker.update for slice idx of the stack at position index2d along the axis
 int emp_sm_track(emp_stack_matcher* h, int64_t idx, int64_t index2d) {
   EMP_REQUIRE(h && !h->finished && idx >= 0 && idx < (int64_t)h->stack.size(), "sm_track: bad arguments");
   const int64_t H = h->H, W = h->W;
   const FSlice& sl = h->stack[(size_t)idx];
+  if (!sl.raster_comp.empty() && sl.raster_comp.size() == sl.starts.size()) return track_raster(h, sl, index2d);
   std::vector<int64_t> ost, orn;
   for (const FObj& o : sl.objs) {
     int64_t box[6];
@@ -858,6 +987,48 @@ int emp_sm_track(emp_stack_matcher* h, int64_t idx, int64_t index2d) {
       int64_t* dst = t->yz.data() + at;
       for (size_t i = 0; i < n; ++i) { dst[3 * i] = ps[i]; dst[3 * i + 1] = pr[i]; dst[3 * i + 2] = index2d; }
     }
+  }
+  return EMP_OK;
+}
+
+// InstanceTracker.update for local slices last, last-1, ..., first (the order backward_matching feeds the tracker,
+// patterns.py:102-134) at positions global_first + (i - first).  Sizes every track once (an upper bound: joins only
+// shrink a list) before the slices are walked, so no list is regrown on the way.
+int emp_sm_track_range(emp_stack_matcher* h, int64_t first, int64_t last, int64_t global_first) {
+  EMP_REQUIRE(h && !h->finished && first >= 0 && last < (int64_t)h->stack.size(), "sm_track_range: bad arguments");
+  if (h->axis != 2) {
+    std::unordered_map<int64_t, size_t> need;
+    for (int64_t i = last; i >= first; --i) {
+      const FSlice& sl = h->stack[(size_t)i];
+      for (const FObj& o : sl.objs) {
+        size_t n = 0;
+        for (int c : o.members) n += (size_t)(sl.run_off[(size_t)c + 1] - sl.run_off[(size_t)c]);
+        need[o.label] += n;
+      }
+    }
+    for (int64_t i = last; i >= first; --i)
+      for (const FObj& o : h->stack[(size_t)i].objs) {
+        auto it = need.find(o.label);
+        if (it == need.end() || it->second == 0) continue;
+        auto tk = h->track_of.find(o.label);
+        if (tk == h->track_of.end()) {       // create in first-seen order, exactly where emp_sm_track would
+          h->track_of.emplace(o.label, h->tracks.size());
+          h->tracks.emplace_back();
+          Track& t = h->tracks.back();
+          t.label = o.label;
+          t.box[0] = t.box[1] = t.box[2] = INT64_MAX;
+          t.box[3] = t.box[4] = t.box[5] = INT64_MIN;
+          tk = h->track_of.find(o.label);
+        }
+        Track& t = h->tracks[tk->second];
+        t.starts.reserve(t.starts.size() + it->second);
+        t.runs.reserve(t.runs.size() + it->second);
+        it->second = 0;
+      }
+  }
+  for (int64_t i = last; i >= first; --i) {
+    const int rc = emp_sm_track(h, i, global_first + (i - first));
+    if (rc != EMP_OK) return rc;
   }
   return EMP_OK;
 }
@@ -966,6 +1137,32 @@ int emp_sm_track_runs(const emp_stack_matcher* h, int64_t k, int64_t* starts, in
   const Track& t = h->tracks[(size_t)k];
   std::memcpy(starts, t.starts.data(), t.starts.size() * sizeof(int64_t));
   std::memcpy(runs, t.runs.data(), t.runs.size() * sizeof(int64_t));
+  return EMP_OK;
+}
+
+// All tracks at once, in first-seen order: labels (T), boxes (T,6), run counts (T); then the run lists back to back.
+int emp_sm_tracks_info(const emp_stack_matcher* h, int64_t* labels, int64_t* boxes6, int64_t* counts, int64_t* total_runs) {
+  EMP_REQUIRE(h && total_runs, "sm_tracks_info: bad arguments");
+  int64_t tot = 0;
+  for (size_t k = 0; k < h->tracks.size(); ++k) {
+    const Track& t = h->tracks[k];
+    if (labels) labels[k] = t.label;
+    if (boxes6) std::memcpy(boxes6 + 6 * k, t.box, sizeof(t.box));
+    if (counts) counts[k] = (int64_t)t.starts.size();
+    tot += (int64_t)t.starts.size();
+  }
+  *total_runs = tot;
+  return EMP_OK;
+}
+
+int emp_sm_tracks_runs(const emp_stack_matcher* h, int64_t* starts, int64_t* runs) {
+  EMP_REQUIRE(h && starts && runs, "sm_tracks_runs: bad arguments");
+  size_t at = 0;
+  for (const Track& t : h->tracks) {
+    std::memcpy(starts + at, t.starts.data(), t.starts.size() * sizeof(int64_t));
+    std::memcpy(runs + at, t.runs.data(), t.runs.size() * sizeof(int64_t));
+    at += t.starts.size();
+  }
   return EMP_OK;
 }
 

@@ -193,6 +193,35 @@ def _recv_obj(src, group):
     return box[0]
 
 
+def _send_part(res, dst, group):
+    """a rank's result of slab_stack_inference (None for a rank without slices) to ``dst``"""
+    if res is None:
+        _send_obj(None, dst, group)
+        return
+    head = dict(res, part={c: (p[0], p[1], p[2]) for c, p in res['part'].items()})
+    _send_obj(head, dst, group)
+    for c, p in res['part'].items():
+        if len(p[3]):
+            dist.send(torch.from_numpy(p[3]), dst=dst, group=group)
+            dist.send(torch.from_numpy(p[4]), dst=dst, group=group)
+
+
+def _recv_part(src, group):
+    res = _recv_obj(src, group)
+    if res is None:
+        return None
+    part = {}
+    for c, (labels, boxes, counts) in res['part'].items():
+        n = int(counts.sum())
+        starts, runs = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+        if n:
+            dist.recv(torch.from_numpy(starts), src=src, group=group)
+            dist.recv(torch.from_numpy(runs), src=src, group=group)
+        part[c] = (labels, boxes, counts, starts, runs)
+    res['part'] = part
+    return res
+
+
 class SlabMatcher:
     """Matching + tracking of ONE rank's slab of slices (all classes), bit-identical to the sequential passes over the
     whole stack (reference: empanada/inference/patterns.py:68-134, matcher.py:234-326, tracker.py:61-123).
@@ -205,13 +234,14 @@ class SlabMatcher:
     thread (the C++ calls release the GIL) and builds the pair tables of consecutive own slices as they arrive.
     ``finish(...)`` does the neighbour exchange and the two chains and returns the partial trackers of this slab."""
 
-    def __init__(self, labels, thing_list, label_divisor, iou_thr, ioa_thr, width):
+    def __init__(self, labels, thing_list, label_divisor, iou_thr, ioa_thr, width, head=False):
         from concurrent.futures import ThreadPoolExecutor
         from . import sparse
         self.labels, self.width = list(labels), int(width)
         self.things = [c for c in self.labels if c in thing_list]
         self.sm = {c: sparse.StackMatcher(c, label_divisor, iou_thr, ioa_thr, match=c in thing_list) for c in self.labels}
         self.n_own = 0
+        self.head = bool(head)     # first slab of the stack: its forward chain needs no neighbour and runs as the groups arrive
         self.first_entry = self.last_entry = None
         self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='emp-slab-match')
         self._jobs = []
@@ -229,10 +259,20 @@ class SlabMatcher:
     def _push_job(self, entries, start):
         import time
         t0 = time.perf_counter()
-        for e in entries:
-            self._push_entry(e)
+        for c, sm in self.sm.items():      # a group from the run extractor goes in as one call (built on the library's threads)
+            vals = [e[c] for e in entries]
+            if all(isinstance(v, tuple) for v in vals) and len({v[1] for v in vals}) == 1:
+                sm.push_runs_many([v[0] for v in vals], self.width, vals[0][1])
+            else:
+                for v in vals:
+                    if isinstance(v, tuple):
+                        sm.push_runs(v[0], self.width, v[1])
+                    else:
+                        sm.push_objects(v)
         for c in self.things:      # pair tables (start-1 .. start+len-1]: label-independent, ahead of the chain
             self.sm[c].prepare(max(0, start - 1), start + len(entries) - 1)
+            if self.head:          # forward steps of the new slices (patterns.py:68-100), behind the GPU work of the next group
+                self.sm[c].run_range(start, start + len(entries) - 1, +1)
         self.host_s += time.perf_counter() - t0
 
     def push(self, entries):
@@ -246,7 +286,8 @@ class SlabMatcher:
         self.n_own += len(entries)
 
     def finish(self, rank, aw, lo, axis_name, shape3d, group):
-        """-> {class_id: partial instances dict of this slab} (dict order: first seen walking the slab downwards)."""
+        """-> {class_id: partial instances of this slab as flat arrays (sparse.StackMatcher.instances_packed; track order:
+        first seen walking the slab downwards)}."""
         import time
         for j in self._jobs:
             j.result()
@@ -279,7 +320,8 @@ class SlabMatcher:
             sm = self.sm[c]
             if has_prev:
                 sm.import_state(i_prev, states[c], assign_new=True)
-            sm.run_range(0, n - 1, +1)
+            if not self.head:
+                sm.run_range(0, n - 1, +1)
         out_states = {c: self.sm[c].export_state(n - 1) for c in self.things} if has_next else None
         self.phase_s['forward'] = time.perf_counter() - t0
         self.host_s += self.phase_s['forward']
@@ -302,7 +344,7 @@ class SlabMatcher:
             _send_obj(out_states, rank - 1, group)
         # tracker of the slab's own slices at their global positions (tracker.py:61-123), walking downwards
         t0 = time.perf_counter()
-        part = {c: self.sm[c].track_range(axis_name, shape3d, 0, n - 1, lo) for c in self.labels}
+        part = {c: self.sm[c].track_range(axis_name, shape3d, 0, n - 1, lo, packed=True) for c in self.labels}
         self.phase_s['track'] = time.perf_counter() - t0
         self.host_s += self.phase_s['track']
         self.tail_s = self.host_s - pushed_s
@@ -320,7 +362,8 @@ def merge_partial_trackers(parts, axis_name):
     for c in classes:
         acc = {}
         for part in reversed(parts):
-            for label, a in part[c].items():
+            inst = part[c] if isinstance(part[c], dict) else sparse.unpack_instances(part[c])
+            for label, a in inst.items():
                 d = acc.get(label)
                 if d is None:
                     acc[label] = {'box': tuple(int(v) for v in a['box']), 'starts': [a['starts']], 'runs': [a['runs']]}
@@ -392,7 +435,7 @@ def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None, mat
             per_slice = backend.runs(sem[:n_own], stash)
         else:
             sm = SlabMatcher(match['labels'], match['thing_list'], match['label_divisor'], match['iou_thr'], match['ioa_thr'],
-                             match['width'])
+                             match['width'], head=rank == 0)
             if hasattr(backend, 'runs_iter'):      # host: push + pair tables of a group while the GPU extracts the next
                 for entries in backend.runs_iter(sem[:n_own], stash):
                     sm.push(entries)
@@ -407,12 +450,16 @@ def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None, mat
     elif match is not None:
         per_slice = None
     hg = host_group if host_group is not None else group
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(per_slice, gathered, dst=0, group=hg)
-    if rank != 0:
-        return None
     if match is None:
-        return [s for part in gathered for s in part]
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(per_slice, gathered, dst=0, group=hg)
+        return [s for part in gathered for s in part] if rank == 0 else None
+    # per-slab tracks to rank 0: the small tables (labels, boxes, counts, timings) as one object, the run lists as the int64
+    # tensors they are -- nothing of size is pickled, and rank 0's own slab does not travel at all
+    if rank != 0:
+        _send_part(per_slice, 0, hg)
+        return None
+    gathered = [per_slice] + [_recv_part(r, hg) for r in range(1, world)]
     live = [g for g in gathered if g is not None]
     return {'parts': [g['part'] for g in live], 'host_s': [g['host_s'] for g in live],
             'timing': [{k: g[k] for k in ('host_s', 'tail_s', 'gpu_s', 'slices', 'phases')} for g in live]}

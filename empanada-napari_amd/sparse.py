@@ -429,6 +429,16 @@ class StackMatcher:
         _abi.check(self.lib.emp_sm_push_slice_runs(self._h, _hp(runs), len(runs), int(width), int(id_offset)),
                    'emp_sm_push_slice_runs')
 
+    def push_runs_many(self, runs_list, width, id_offset=0):
+        """several slices at once (one launch group of the extractor): built on the library's worker threads"""
+        arrs = [np.ascontiguousarray(r, dtype=i64).reshape(-1, 3) for r in runs_list]
+        if not arrs:
+            return
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        ns = np.array([len(a) for a in arrs], dtype=i64)
+        _abi.check(self.lib.emp_sm_push_slices_runs(self._h, len(arrs), ptrs, _hp(ns), int(width), int(id_offset)),
+                   'emp_sm_push_slices_runs')
+
     def push_objects(self, instance_rles):
         """instance_rles: {label: {'box','starts','runs'}} of one slice (dict order kept)."""
         labels = np.array([int(k) for k in instance_rles], dtype=i64)
@@ -532,27 +542,29 @@ class StackMatcher:
     def begin_backward(self):
         _abi.check(self.lib.emp_sm_begin_backward(self._h), 'emp_sm_begin_backward')
 
-    def track_range(self, axis_name, shape3d, first, last, global_first):
+    def track_range(self, axis_name, shape3d, first, last, global_first, packed=False):
         """tracker over local slices last..first (descending, as backward_matching feeds it, patterns.py:102-134) at their
         GLOBAL positions global_first + (i - first); returns the partial tracker's instances (dict order = first seen)"""
         D, H, W = [int(v) for v in shape3d]
         _abi.check(self.lib.emp_sm_tracker_init(self._h, InstanceTracker.AXES[axis_name], D, H, W), 'emp_sm_tracker_init')
-        for i in range(last, first - 1, -1):
-            _abi.check(self.lib.emp_sm_track(self._h, int(i), int(global_first + i - first)), 'emp_sm_track')
+        _abi.check(self.lib.emp_sm_track_range(self._h, int(first), int(last), int(global_first)), 'emp_sm_track_range')
         _abi.check(self.lib.emp_sm_tracker_finish(self._h), 'emp_sm_tracker_finish')
-        return self.instances()
+        return self.instances_packed() if packed else self.instances()
+
+    def instances_packed(self):
+        """the tracker's instances as flat arrays: (labels (T), boxes (T,6), counts (T), starts, runs) -- the run lists back
+        to back in track (= first-seen) order; what travels between ranks (multigpu.py) without pickling"""
+        T = int(self.lib.emp_sm_num_tracks(self._h))
+        labels, boxes, counts = np.empty(T, dtype=i64), np.empty((T, 6), dtype=i64), np.empty(T, dtype=i64)
+        tot = C.c_int64(0)
+        _abi.check(self.lib.emp_sm_tracks_info(self._h, _hp(labels), _hp(boxes), _hp(counts), C.byref(tot)), 'emp_sm_tracks_info')
+        starts, runs = np.empty(tot.value, dtype=i64), np.empty(tot.value, dtype=i64)
+        if tot.value:
+            _abi.check(self.lib.emp_sm_tracks_runs(self._h, _hp(starts), _hp(runs)), 'emp_sm_tracks_runs')
+        return labels, boxes, counts, starts, runs
 
     def instances(self):
-        out = {}
-        lab, n = C.c_int64(0), C.c_int64(0)
-        box = (C.c_int64 * 6)()
-        for k in range(int(self.lib.emp_sm_num_tracks(self._h))):
-            _abi.check(self.lib.emp_sm_track_info(self._h, k, C.byref(lab), box, C.byref(n)), 'emp_sm_track_info')
-            st, rn = np.empty(n.value, dtype=i64), np.empty(n.value, dtype=i64)
-            if n.value:
-                _abi.check(self.lib.emp_sm_track_runs(self._h, k, _hp(st), _hp(rn)), 'emp_sm_track_runs')
-            out[int(lab.value)] = {'box': tuple(int(v) for v in box), 'starts': st, 'runs': rn}
-        return out
+        return unpack_instances(self.instances_packed())
 
     def slice_objects(self, idx):
         """Current labelling of slice ``idx`` as the reference's dict (tests, save_panoptic)."""
@@ -566,6 +578,18 @@ class StackMatcher:
                 _abi.check(self.lib.emp_sm_slice_object_runs(self._h, int(idx), k, _hp(st), _hp(rn)), 'slice runs')
             out[int(lab.value)] = {'box': tuple(int(v) for v in box), 'starts': st, 'runs': rn}
         return out
+
+
+def unpack_instances(packed):
+    """flat tracker arrays (StackMatcher.instances_packed) -> the reference's instances dict (tracker.py:61-123); the run
+    lists are views into the two flat arrays"""
+    labels, boxes, counts, starts, runs = packed
+    out = {}
+    at = 0
+    for lab, box, n in zip(labels.tolist(), boxes.tolist(), counts.tolist()):
+        out[lab] = {'box': tuple(box), 'starts': starts[at:at + n], 'runs': runs[at:at + n]}
+        at += n
+    return out
 
 
 def create_matchers(thing_list, label_divisor, merge_iou_thr, merge_ioa_thr):

@@ -362,6 +362,10 @@ EMP_API emp_stack_matcher_t* emp_sm_create(int64_t class_id, int64_t label_divis
 EMP_API void emp_sm_destroy(emp_stack_matcher_t* h);
 /* append a slice: (n,3) {start, length, label} runs in raster order (emp_rle_extract output), plane width, id offset */
 EMP_API int emp_sm_push_slice_runs(emp_stack_matcher_t* h, const int64_t* h_runs, int64_t n, int64_t width, int64_t id_offset);
+/* `count` slices at once (one launch group of the run extractor), built on the library's worker threads (EMP_SM_THREADS,
+ * default 4; emp_sm_prepare uses the same threads for the pair tables) */
+EMP_API int emp_sm_push_slices_runs(emp_stack_matcher_t* h, int64_t count, const int64_t* const* runs, const int64_t* n,
+                                    int64_t width, int64_t id_offset);
 /* append a slice as objects: labels (n), boxes (n,4), CSR offsets (n+1), starts, runs */
 EMP_API int emp_sm_push_slice_objects(emp_stack_matcher_t* h, int64_t n, const int64_t* labels, const int64_t* boxes,
                               const int64_t* off, const int64_t* starts, const int64_t* runs);
@@ -409,10 +413,17 @@ EMP_API int emp_sm_run(emp_stack_matcher_t* h, int64_t idx, int dir, int64_t cou
 EMP_API int emp_sm_pending_shape(const emp_stack_matcher_t* h, int* nt, int* nm);
 EMP_API int emp_sm_tracker_init(emp_stack_matcher_t* h, int axis /* 0 xy, 1 xz, 2 yz */, int64_t D, int64_t H, int64_t W);
 EMP_API int emp_sm_track(emp_stack_matcher_t* h, int64_t idx, int64_t index2d);
+/* InstanceTracker.update over local slices last, last-1, ..., first at positions global_first + (i - first) (the order
+ * backward_matching feeds the tracker: empanada/inference/patterns.py:102-134, tracker.py:61-97), every track sized once. */
+EMP_API int emp_sm_track_range(emp_stack_matcher_t* h, int64_t first, int64_t last, int64_t global_first);
 EMP_API int emp_sm_tracker_finish(emp_stack_matcher_t* h);
 EMP_API int64_t emp_sm_num_tracks(const emp_stack_matcher_t* h);
 EMP_API int emp_sm_track_info(const emp_stack_matcher_t* h, int64_t k, int64_t* label, int64_t* box6, int64_t* n_runs);
 EMP_API int emp_sm_track_runs(const emp_stack_matcher_t* h, int64_t k, int64_t* starts, int64_t* runs);
+/* the same for ALL tracks in one call each (tracker.instances as flat arrays: labels (T), boxes (T,6), run counts (T) --
+ * any of the three may be NULL -- and the run lists back to back in track order) */
+EMP_API int emp_sm_tracks_info(const emp_stack_matcher_t* h, int64_t* labels, int64_t* boxes6, int64_t* counts, int64_t* total_runs);
+EMP_API int emp_sm_tracks_runs(const emp_stack_matcher_t* h, int64_t* starts, int64_t* runs);
 EMP_API int64_t emp_sm_slice_num_objects(const emp_stack_matcher_t* h, int64_t idx);
 EMP_API int emp_sm_slice_object_info(const emp_stack_matcher_t* h, int64_t idx, int64_t k, int64_t* label, int64_t* box4,
                              int64_t* n_runs);

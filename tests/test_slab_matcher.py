@@ -72,8 +72,27 @@ class _Mailboxes:
         return self.box(src, self.rank.value).get(timeout=60)
 
 
-def _distributed(entries, axis_name, shape, world, monkeypatch, group_size=5):
+def _as_runs(entries):
+    """the entries in the GPU extractor's form: per class ((n,3) {start, length, component id} in raster order, id offset)
+    -- the matcher then keeps the raster order and tracks a slice in one pass (csrc/matcher.hip track_raster)"""
+    out = []
+    for e in entries:
+        d = {}
+        for c, inst in e.items():
+            if c not in THINGS:          # a semantic class is one object labelled c * DIV: stays an instance dict
+                d[c] = inst
+                continue
+            rows = [np.stack([a['starts'], a['runs'], np.full(len(a['starts']), lab - c * DIV)], 1) for lab, a in inst.items()]
+            r = np.concatenate(rows) if rows else np.zeros((0, 3), np.int64)
+            d[c] = (np.ascontiguousarray(r[np.argsort(r[:, 0], kind='stable')].astype(np.int64)), c * DIV)
+        out.append(d)
+    return out
+
+
+def _distributed(entries, axis_name, shape, world, monkeypatch, group_size=5, as_runs=False):
     n = len(entries)
+    if as_runs:
+        entries = _as_runs(entries)
     width = [s for a, s in enumerate(shape) if a != ps.InstanceTracker.AXES[axis_name]][1]
     bounds = [b for b in multigpu.slab_bounds(n, world) if b[1] > b[0]]
     aw = len(bounds)
@@ -86,7 +105,7 @@ def _distributed(entries, axis_name, shape, world, monkeypatch, group_size=5):
         try:
             mail.rank.value = r
             lo, hi = bounds[r]
-            sm = multigpu.SlabMatcher(LABELS, THINGS, DIV, 0.25, 0.25, width)
+            sm = multigpu.SlabMatcher(LABELS, THINGS, DIV, 0.25, 0.25, width, head=as_runs and r == 0)
             for i0 in range(lo, hi, group_size):                 # pushed group by group, as the GPU extractor delivers
                 sm.push(entries[i0:min(hi, i0 + group_size)])
             parts[r] = sm.finish(r, aw, lo, axis_name, shape, None)
@@ -124,6 +143,17 @@ def test_slab_matching_equals_sequential_passes(axis_name, world, monkeypatch):
     want = _sequential(entries, axis_name, SHAPE)
     assert sum(len(v) for v in want.values()) > 20
     _assert_same(_distributed(entries, axis_name, SHAPE, world, monkeypatch), want)
+
+
+@pytest.mark.parametrize('axis_name', ['xy', 'xz', 'yz'])
+@pytest.mark.parametrize('world', [1, 3])
+def test_extractor_form_entries_and_head_slab_chain(axis_name, world, monkeypatch):
+    """the same stacks pushed the way the GPU extractor delivers them (raster-ordered run triples): the one-pass tracker and
+    the first slab's forward chain running group by group behind the pushes give the trackers of the sequential passes"""
+    axis = ps.InstanceTracker.AXES[axis_name]
+    entries = _stack(SHAPE, axis, seed=31 + axis)
+    want = _sequential(entries, axis_name, SHAPE)
+    _assert_same(_distributed(entries, axis_name, SHAPE, world, monkeypatch, group_size=4, as_runs=True), want)
 
 
 def test_empty_boundary_slices_and_one_slice_slabs(monkeypatch):
