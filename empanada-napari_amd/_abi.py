@@ -68,6 +68,7 @@ PROTOTYPES = {
     'emp_sm_push_slice_objects': (c_int, [vp, c_i64, vp, vp, vp, vp, vp]),
     'emp_sm_num_slices': (c_i64, [vp]),
     'emp_lsa_maximize': (c_int, [vp, c_i64, c_i64, vp, vp]),
+    'emp_lsa_maximize_sparse': (c_int, [c_i64, c_i64, c_i64, vp, vp, vp, vp, vp]),
     'emp_sm_prepare': (c_int, [vp, c_i64, c_i64]),
     'emp_sm_state_size': (c_int, [vp, c_i64, vp, vp]),
     'emp_sm_export_state': (c_int, [vp, c_i64, vp, vp, vp, vp]),
@@ -77,6 +78,7 @@ PROTOTYPES = {
     'emp_sm_iou': (vp, [vp]),
     'emp_sm_step_apply': (c_int, [vp, vp, vp, c_i64]),
     'emp_sm_run': (c_int, [vp, c_i64, c_int, c_i64, c_int, vp]),
+    'emp_sm_solver_stats': (c_int, [vp, C.POINTER(c_i64), C.POINTER(c_i64)]),
     'emp_sm_pending_shape': (c_int, [vp, vp, vp]),
     'emp_sm_tracker_init': (c_int, [vp, c_int, c_i64, c_i64, c_i64]),
     'emp_sm_track': (c_int, [vp, c_i64, c_i64]),

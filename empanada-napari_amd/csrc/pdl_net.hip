@@ -125,9 +125,12 @@ const int kPlanes[4] = {64, 128, 256, 512};
 // does the separable block `pre` (its parameters are pre.sepconv.0 / pre.sepconv.1) run with the exact depthwise half (sepconv_precise.hip)?
 bool precise_layer(const emp_pdl* n, const std::string& pre) {
   if (n->precise_sepconv <= 0) return false;
-  if (n->precise_sepconv >= 2) return true;
+  if (n->precise_sepconv == 2) return true;
   const char* dec = n->cfg.ins_decoder ? "instance_decoder." : "semantic_decoder.";
-  return pre.compare(0, 11, "ins_center.") == 0 || pre.compare(0, strlen(dec), dec) == 0;
+  const bool head = pre.compare(0, 11, "ins_center.") == 0, fuse = pre.compare(0, strlen(dec), dec) == 0;
+  if (n->precise_sepconv == 3) return head;      // A/B switches: only the head / only the decoder's fusion convs
+  if (n->precise_sepconv == 4) return fuse;
+  return head || fuse;
 }
 
 void expect(emp_pdl* n, const std::string& name) {

@@ -429,6 +429,12 @@ class StackMatcher:
         _abi.check(self.lib.emp_sm_push_slice_runs(self._h, _hp(runs), len(runs), int(width), int(id_offset)),
                    'emp_sm_push_slice_runs')
 
+    def solver_stats(self):
+        """(assignment steps solved by the sparse solver, steps handed to a dense solver call) so far"""
+        u, d = C.c_int64(0), C.c_int64(0)
+        _abi.check(self.lib.emp_sm_solver_stats(self._h, C.byref(u), C.byref(d)), 'emp_sm_solver_stats')
+        return int(u.value), int(d.value)
+
     def push_runs_many(self, runs_list, width, id_offset=0):
         """several slices at once (one launch group of the extractor): built on the library's worker threads"""
         arrs = [np.ascontiguousarray(r, dtype=i64).reshape(-1, 3) for r in runs_list]

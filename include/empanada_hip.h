@@ -385,6 +385,11 @@ EMP_API int64_t emp_sm_num_slices(const emp_stack_matcher_t* h);
  * float64 matrix: min(nr, nc) pairs with ascending rows.  The library's own solver (scipy's shortest-augmenting-path
  * algorithm restated, ties included); emp_sm_run uses it for the assignment blocks unless EMP_SM_SCIPY=1. */
 EMP_API int emp_lsa_maximize(const double* cost, int64_t nr, int64_t nc, int64_t* rows, int64_t* cols);
+/* the same assignment from the matrix's non-zero entries only (er[k], ec[k]) -> ew[k] (an IoU matrix is almost all
+ * zeros): the algorithm, its floating-point values and its tie-breaking are those of the dense form, the per-step scan of
+ * all columns is replaced by a segment tree -- what the slice matcher calls (csrc/matcher.hip lsa_maximize_sparse) */
+EMP_API int emp_lsa_maximize_sparse(int64_t nr, int64_t nc, int64_t nnz, const int64_t* er, const int64_t* ec, const double* ew,
+                                    int64_t* rows, int64_t* cols);
 EMP_API int emp_sm_prepare(emp_stack_matcher_t* h, int64_t from, int64_t to);
 EMP_API int emp_sm_state_size(const emp_stack_matcher_t* h, int64_t idx, int64_t* n_obj, int64_t* n_mem);
 EMP_API int emp_sm_export_state(const emp_stack_matcher_t* h, int64_t idx, int64_t* labels, int64_t* off, int64_t* members,
@@ -410,6 +415,9 @@ EMP_API int emp_sm_step_apply(emp_stack_matcher_t* h, const int64_t* rows, const
  * Replaces the per-slice Python loop of forward_matching / backward_matching, patterns.py:68-121. */
 EMP_API int emp_sm_run(emp_stack_matcher_t* h, int64_t idx, int dir, int64_t count, int track, int64_t* stopped_at);
 /* shape of the pending step's solver block */
+/* steps with competing overlaps solved so far by the sparse solver (default) / by a dense solver call on the IoU matrix
+ * (EMP_SM_FULL_LSA=1 the whole matrix as the reference hands it to scipy, empanada/inference/matcher.py:216-218; =0 the conflict block) */
+EMP_API int emp_sm_solver_stats(const emp_stack_matcher_t* h, int64_t* sparse_steps, int64_t* dense_steps);
 EMP_API int emp_sm_pending_shape(const emp_stack_matcher_t* h, int* nt, int* nm);
 EMP_API int emp_sm_tracker_init(emp_stack_matcher_t* h, int axis /* 0 xy, 1 xz, 2 yz */, int64_t D, int64_t H, int64_t W);
 EMP_API int emp_sm_track(emp_stack_matcher_t* h, int64_t idx, int64_t index2d);

@@ -24,10 +24,15 @@ def precise_block(pre, ins_decoder=True):
     mode = int(os.environ.get('EMP_PRECISE_SEPCONV', '1'))
     if mode <= 0:
         return False
-    if mode >= 2:
+    if mode == 2:
         return True
     dec = 'instance_decoder.' if ins_decoder else 'semantic_decoder.'
-    return pre.startswith('ins_center.') or pre.startswith(dec)
+    head, fuse = pre.startswith('ins_center.'), pre.startswith(dec)
+    if mode == 3:          # A/B switches of the engine: only the head / only the decoder's fusion convs
+        return head
+    if mode == 4:
+        return fuse
+    return head or fuse
 
 
 def _t(a):

@@ -285,9 +285,10 @@ def test_oracle_morphology_restatement_basics():
 def test_cpp_stack_matcher_solver_only_where_needed(monkeypatch):
     """emp_sm_run: slices whose IoU matrix has at most one non-zero per row and column are assigned directly (every such
     pair is in any optimal assignment); the others need an assignment solver -- since round 3 the library's own
-    (lsa_maximize: scipy's algorithm restated, tests/test_lsa.py), with EMP_SM_SCIPY=1 scipy itself as in round 2.  Both
-    kinds of slices occur in the reference case whose trackers are compared with the reference's goldens above; both
-    solvers give the same trackers."""
+    (lsa_maximize_sparse: scipy's algorithm restated on the non-zero entries, tests/test_lsa.py); with EMP_SM_SCIPY=1 the
+    whole dense IoU matrix goes to scipy itself, the reference's call (matcher.py:216-218).  Both kinds of slices occur in
+    the reference case whose trackers are compared with the reference's goldens above; both solvers give the same
+    trackers."""
     calls = []
     orig = ps.StackMatcher._solve_pending
     monkeypatch.setattr(ps.StackMatcher, '_solve_pending', lambda self: (calls.append(1), orig(self))[1])

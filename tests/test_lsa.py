@@ -1,4 +1,5 @@
-"""The library's assignment solver (csrc/matcher.hip lsa_maximize, exported as emp_lsa_maximize) against
+"""The library's assignment solvers (csrc/matcher.hip lsa_maximize, exported as emp_lsa_maximize, and its sparse form
+lsa_maximize_sparse = emp_lsa_maximize_sparse, the one the slice matcher calls) against
 scipy.optimize.linear_sum_assignment(maximize=True) -- the call of the reference's matcher (empanada/inference/matcher.py:218)
 -- INCLUDING which optimum is returned for tied matrices: label maps must be bit-identical, and with competing equal IoUs
 the choice decides which slice object inherits which label.  Matrices: continuous random, small integers (heavy ties),
@@ -26,10 +27,27 @@ def _ours(m):
     return rows, cols
 
 
+def _ours_sparse(m):
+    """the matcher's solver: the same algorithm fed with the non-zero entries only (emp_lsa_maximize_sparse)"""
+    lib = _abi.load()
+    m = np.asarray(m, dtype=np.float64)
+    nr, nc = m.shape
+    er, ec = np.nonzero(m)
+    ew = np.ascontiguousarray(m[er, ec], dtype=np.float64)
+    er, ec = np.ascontiguousarray(er, dtype=np.int64), np.ascontiguousarray(ec, dtype=np.int64)
+    k = min(nr, nc)
+    rows, cols = np.empty(k, np.int64), np.empty(k, np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    _abi.check(lib.emp_lsa_maximize_sparse(nr, nc, len(er), vp(er), vp(ec), vp(ew), vp(rows), vp(cols)), 'emp_lsa_maximize_sparse')
+    return rows, cols
+
+
 def _check(m):
     r, c = linear_sum_assignment(m, maximize=True)
     rr, cc = _ours(m)
     assert np.array_equal(r, rr) and np.array_equal(c, cc), f'\n{m}\nscipy {list(zip(r, c))}\nours  {list(zip(rr, cc))}'
+    rr, cc = _ours_sparse(m)
+    assert np.array_equal(r, rr) and np.array_equal(c, cc), f'\n{m}\nscipy {list(zip(r, c))}\nsparse {list(zip(rr, cc))}'
 
 
 @pytest.mark.parametrize('kind', ['uniform', 'ints', 'sparse', 'iou'])
@@ -56,6 +74,59 @@ def test_larger_and_degenerate_shapes():
         _check(np.zeros((nr, nc)))
         _check(np.full((nr, nc), 0.5))
     assert _ours(np.zeros((0, 5)))[0].size == 0 and _ours(np.zeros((4, 0)))[0].size == 0
+
+
+def test_sparse_solver_on_block_structured_matrices():
+    """IoU-like matrices (small dense blocks, permuted, padded with empty rows / columns; tie-heavy and continuous values,
+    both orientations) up to 300 x 400: the sparse solver returns scipy's assignment, pair for pair"""
+    rng = np.random.default_rng(21)
+    for it in range(600):
+        k = rng.integers(3, 60)
+        shapes = [(rng.integers(1, 5), rng.integers(1, 5)) for _ in range(k)]
+        nr, nc = sum(a for a, _ in shapes) + rng.integers(0, 30), sum(b for _, b in shapes) + rng.integers(0, 80)
+        M = np.zeros((nr, nc))
+        r0 = c0 = 0
+        for a, b in shapes:
+            M[r0:r0 + a, c0:c0 + b] = rng.choice([0.0, 0.25, 0.5, 0.5, 1 / 3], size=(a, b)) if it % 2 else \
+                rng.random((a, b)) * (rng.random((a, b)) < 0.8)
+            r0, c0 = r0 + a, c0 + b
+        M = M[rng.permutation(nr)][:, rng.permutation(nc)]
+        if it % 5 == 0:
+            M = M.T.copy()
+        r, c = linear_sum_assignment(M, maximize=True)
+        rr, cc = _ours_sparse(M)
+        assert np.array_equal(r, rr) and np.array_equal(c, cc), (it, M.shape)
+
+
+def test_sparse_solver_does_not_scale_with_the_empty_part():
+    """7 600 objects with two overlaps each (a 4096^2 slice): the dense algorithm needs ~0.3 s for this matrix, the sparse
+    form a few milliseconds -- asserted loosely (< 0.2 s) so that a regression to a dense scan is caught"""
+    import time
+    rng = np.random.default_rng(5)
+    nr, nc = 7600, 8300
+    er = np.repeat(np.arange(nr), 2)
+    ec = np.clip(er + rng.integers(-1, 2, len(er)), 0, nc - 1)
+    _, idx = np.unique(er * nc + ec, return_index=True)
+    er, ec = np.ascontiguousarray(er[idx], dtype=np.int64), np.ascontiguousarray(ec[idx], dtype=np.int64)
+    ew = rng.random(len(er))
+    lib = _abi.load()
+    rows, cols = np.empty(nr, np.int64), np.empty(nr, np.int64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    t0 = time.perf_counter()
+    _abi.check(lib.emp_lsa_maximize_sparse(nr, nc, len(er), vp(er), vp(ec), vp(ew), vp(rows), vp(cols)), 'sparse')
+    dt = time.perf_counter() - t0
+    assert dt < 0.2, dt
+    assert len(set(cols.tolist())) == nr and np.array_equal(rows, np.arange(nr))
+    val = {(int(a), int(b)): w for a, b, w in zip(er, ec, ew)}
+    got = sum(val.get((int(a), int(b)), 0.0) for a, b in zip(rows, cols))
+    # the optimum of this banded matrix from scipy on its 60 x 66 leading block is not comparable; check optimality by duality
+    # on a sample instead: no single swap of two rows' columns improves the value
+    for _ in range(2000):
+        i, j = rng.integers(0, nr, 2)
+        cur = val.get((int(i), int(cols[i])), 0.0) + val.get((int(j), int(cols[j])), 0.0)
+        alt = val.get((int(i), int(cols[j])), 0.0) + val.get((int(j), int(cols[i])), 0.0)
+        assert alt <= cur + 1e-12
+    assert got > 0
 
 
 def _square(y0, x0, h, w, W):
