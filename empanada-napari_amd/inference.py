@@ -645,8 +645,9 @@ class Engine3d:
         def match_chunk(per_label, width):
             for label, (runs_list, off) in per_label.items():
                 sm = sms[label]
-                for runs in runs_list:
-                    sm.push_runs(runs, width, off)
+                first = len(sm)
+                sm.push_runs_many(runs_list, width, off)      # slices and pair tables on the library's worker threads
+                sm.prepare(max(0, first - 1), len(sm) - 1)
                 sm.step_to(len(sm))
 
         worker = self._host_worker()
