@@ -285,15 +285,80 @@ class SlabMatcher:
         self._jobs.append(self._pool.submit(self._push_job, entries, self.n_own))
         self.n_own += len(entries)
 
-    def finish(self, rank, aw, lo, axis_name, shape3d, group):
-        """-> {class_id: partial instances of this slab as flat arrays (sparse.StackMatcher.instances_packed; track order:
-        first seen walking the slab downwards)}."""
-        import time
+    # ---- the phases of a slab, in the order the chain runs them (finish() strings them together for ONE slab per rank) ----
+    def wait_pushed(self):
         for j in self._jobs:
             j.result()
         self._pool.shutdown()
-        pushed_s = self.host_s
+        self._pushed_s = self.host_s
+        self.phase_s = {'ghosts': 0.0, 'forward': 0.0, 'backward': 0.0, 'track': 0.0}
+
+    def _timed(self, key, t0):
+        import time
+        dt = time.perf_counter() - t0
+        self.phase_s[key] += dt
+        self.host_s += dt
+
+    def forward_chain(self, prev_entry=None, states=None):
+        """forward pass over the slab (patterns.py:68-100).  ``prev_entry`` / ``states``: the raw entry of slice lo-1 and its
+        matching state from the slab before (None on the first slab, whose chain already ran behind its pushes when
+        ``head``) -> the state of this slab's last slice for the next one ({class: state})."""
+        import time
         n = self.n_own
+        self.i_prev = None
+        if prev_entry is not None:
+            t0 = time.perf_counter()
+            self._push_entry(prev_entry)
+            self.i_prev = n
+            self._timed('ghosts', t0)
+        t0 = time.perf_counter()
+        for c in self.things:
+            sm = self.sm[c]
+            if prev_entry is not None:
+                sm.import_state(self.i_prev, states[c], assign_new=True)
+            if not self.head:
+                sm.run_range(0, n - 1, +1)
+        out = {c: self.sm[c].export_state(n - 1) for c in self.things}
+        self._timed('forward', t0)
+        return out
+
+    def backward_chain(self, next_entry=None, states=None):
+        """backward pass (patterns.py:102-121: fresh target, no new labels).  ``next_entry`` / ``states``: the raw entry of
+        slice hi and its backward state from the slab behind (None on the last slab) -> the state of this slab's first
+        slice for the slab before."""
+        import time
+        n = self.n_own
+        i_next = None
+        if next_entry is not None:
+            t0 = time.perf_counter()
+            self._push_entry(next_entry)
+            i_next = n + (1 if self.i_prev is not None else 0)
+            self._timed('ghosts', t0)
+        t0 = time.perf_counter()
+        for c in self.things:
+            sm = self.sm[c]
+            if next_entry is not None:
+                sm.import_state(i_next, (states[c][0], states[c][1], states[c][2], -1), assign_new=False)
+            else:
+                sm.begin_backward()
+            sm.run_range(0, n - 1, -1)
+        out = {c: self.sm[c].export_state(0) for c in self.things}
+        self._timed('backward', t0)
+        return out
+
+    def track(self, lo, axis_name, shape3d):
+        """tracker of the slab's own slices at their global positions (tracker.py:61-123), walking downwards -> {class_id:
+        partial instances as flat arrays (sparse.StackMatcher.instances_packed; track order: first seen)}"""
+        import time
+        t0 = time.perf_counter()
+        part = {c: self.sm[c].track_range(axis_name, shape3d, 0, self.n_own - 1, lo, packed=True) for c in self.labels}
+        self._timed('track', t0)
+        self.tail_s = self.host_s - self._pushed_s
+        return part
+
+    def finish(self, rank, aw, lo, axis_name, shape3d, group):
+        """ONE contiguous slab per rank: neighbour exchange, the two chains, tracking -> the slab's partial trackers."""
+        self.wait_pushed()
         has_prev, has_next = rank > 0, rank < aw - 1
         # boundary slices to the neighbours (raw entries: components as extracted); a chain, so the order below cannot
         # deadlock even where a send blocks until its receive is posted: the last / first rank only receives
@@ -303,52 +368,15 @@ class SlabMatcher:
         if has_prev:
             _send_obj(self.first_entry, rank - 1, group)
         next_entry = _recv_obj(rank + 1, group) if has_next else None
-        t0 = time.perf_counter()
-        i_prev = i_next = None
-        if has_prev:
-            self._push_entry(prev_entry)
-            i_prev = n
-        if has_next:
-            self._push_entry(next_entry)
-            i_next = n + (1 if has_prev else 0)
-        self.phase_s = {'ghosts': time.perf_counter() - t0}
-        self.host_s += self.phase_s['ghosts']
-        # forward chain (patterns.py:68-100): the state of slice lo-1 comes down from rank-1
         states = _recv_obj(rank - 1, group) if has_prev and self.things else None
-        t0 = time.perf_counter()
-        for c in self.things:
-            sm = self.sm[c]
-            if has_prev:
-                sm.import_state(i_prev, states[c], assign_new=True)
-            if not self.head:
-                sm.run_range(0, n - 1, +1)
-        out_states = {c: self.sm[c].export_state(n - 1) for c in self.things} if has_next else None
-        self.phase_s['forward'] = time.perf_counter() - t0
-        self.host_s += self.phase_s['forward']
+        out_states = self.forward_chain(prev_entry, states if states is not None else {})
         if has_next and self.things:
             _send_obj(out_states, rank + 1, group)
-        # backward chain (patterns.py:102-121: fresh target, no new labels): the state of slice hi comes up from rank+1
         states = _recv_obj(rank + 1, group) if has_next and self.things else None
-        t0 = time.perf_counter()
-        for c in self.things:
-            sm = self.sm[c]
-            if has_next:
-                sm.import_state(i_next, (states[c][0], states[c][1], states[c][2], -1), assign_new=False)
-            else:
-                sm.begin_backward()
-            sm.run_range(0, n - 1, -1)
-        out_states = {c: self.sm[c].export_state(0) for c in self.things} if has_prev else None
-        self.phase_s['backward'] = time.perf_counter() - t0
-        self.host_s += self.phase_s['backward']
+        out_states = self.backward_chain(next_entry, states if states is not None else {})
         if has_prev and self.things:
             _send_obj(out_states, rank - 1, group)
-        # tracker of the slab's own slices at their global positions (tracker.py:61-123), walking downwards
-        t0 = time.perf_counter()
-        part = {c: self.sm[c].track_range(axis_name, shape3d, 0, n - 1, lo, packed=True) for c in self.labels}
-        self.phase_s['track'] = time.perf_counter() - t0
-        self.host_s += self.phase_s['track']
-        self.tail_s = self.host_s - pushed_s
-        return part
+        return self.track(lo, axis_name, shape3d)
 
 
 def merge_partial_trackers(parts, axis_name):
@@ -465,6 +493,201 @@ def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None, mat
             'timing': [{k: g[k] for k in ('host_s', 'tail_s', 'gpu_s', 'slices', 'phases')} for g in live]}
 
 
+def block_slices(backend):
+    """slices per block of the interleaved schedule: EMP_MG_BLOCK (0 = one contiguous slab per rank, the round-3a schedule),
+    else what the backend forwards at a time (``backend.block_slices``), else 16"""
+    e = os.environ.get('EMP_MG_BLOCK')
+    if e is not None:
+        return max(0, int(e))
+    return int(getattr(backend, 'block_slices', 16))
+
+
+def stack_inference(n_slices, backend, ks, group=None, host_group=None, match=None, chain_group=None):
+    """the schedule the engine runs: block-interleaved when the slices are matched on the ranks, contiguous slabs otherwise"""
+    blk = block_slices(backend) if match is not None else 0
+    if blk <= 0:
+        return slab_stack_inference(n_slices, backend, ks, group, host_group, match)
+    if chain_group is None:          # the chain thread's messages must not share a group with this thread's
+        chain_group = dist.new_group(backend='gloo')
+    return block_stack_inference(n_slices, backend, ks, match, blk, group, host_group, chain_group)
+
+
+def block_bounds(n_slices, block, ks):
+    """near-equal blocks of about ``block`` slices, none shorter than the median's look-ahead"""
+    mid = (ks - 1) // 2
+    b = max(int(block), mid, 1)
+    return slab_bounds(n_slices, max(1, n_slices // b))
+
+
+def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_group=None, chain_group=None):
+    """SPMD body of one axis on one rank, BLOCK-INTERLEAVED: the stack is cut into blocks of about ``block`` slices (one
+    forward batch) and rank r owns blocks r, r + W, r + 2W, ...  Same results as ``slab_stack_inference`` (one contiguous
+    slab per rank = W blocks); what changes is WHEN things can run:
+
+      * the forward matching chain is serial over the slices of the whole stack (SlabMatcher); with one slab per rank it
+        starts on rank r only when ranks 0..r-1 are through theirs, i.e. behind everybody's GPU phase.  Here block b's chain
+        step runs as soon as block b-1's has (a chain thread per rank, host messages on ``chain_group``) while the GPUs
+        are already on the next round of blocks: the chain costs one block per block, hidden behind the GPU work as long
+        as W chain steps fit into one round (0.08 ms against 0.9 ms per 1024^2 slice: W <= 11);
+      * only the backward chain (fresh target, no new labels: the cheap one) and the tracking of the last blocks stay
+        behind the last round.
+
+    GPU side of a round (block b of this rank; left / right = the owners of blocks b-1 / b+1, a ring): the forward of the
+    NEXT round is enqueued first and its first raw maps go to the left neighbour at once -- the look-ahead a block's median
+    waits for never waits for a forward that has not been started (the ring's wrap-around would otherwise idle the last
+    rank for a round); then look-ahead in, filtered carry in, median in place, carry out, voting / merge / run extraction,
+    push to the block's matcher.  Between two ranks a direction carries one kind of message (look-ahead leftwards, carry
+    rightwards; with W = 2 both kinds share a pair and alternate in the same order on both sides), so stream-ordered RCCL
+    point-to-point calls match without tags.
+
+    -> on rank 0: {'parts': per-block partial trackers in block order, 'host_s', 'timing'}, elsewhere None."""
+    import threading
+    import time
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mid = (ks - 1) // 2
+    bounds = block_bounds(n_slices, block, ks)
+    NB = len(bounds)
+    owner = lambda b: b % world
+    mine = [b for b in range(NB) if owner(b) == rank]
+    hg = host_group if host_group is not None else group
+    cg = chain_group if chain_group is not None else hg
+    sms = [SlabMatcher(match['labels'], match['thing_list'], match['label_divisor'], match['iou_thr'], match['ioa_thr'],
+                       match['width'], head=(b == 0)) for b in mine]
+    pushed = [threading.Event() for _ in mine]
+    parts = [None] * len(mine)
+    err = []
+    t_start = time.perf_counter()
+    t_chain_end = [t_start]
+
+    def chain():
+        """this rank's blocks through the forward chain in block order, then through the backward chain in reverse"""
+        try:
+            local = {}
+            for k, b in enumerate(mine):
+                pushed[k].wait()
+                sm = sms[k]
+                sm.wait_pushed()
+                if b > 0:
+                    prev_entry, states = local.pop(('f', b - 1)) if owner(b - 1) == rank else _recv_obj(owner(b - 1), cg)
+                    out = sm.forward_chain(prev_entry, states)
+                else:
+                    out = sm.forward_chain()
+                if b + 1 < NB:
+                    msg = (sm.last_entry, out)
+                    if owner(b + 1) == rank:
+                        local[('f', b)] = msg
+                    else:
+                        _send_obj(msg, owner(b + 1), cg)
+            for k in range(len(mine) - 1, -1, -1):
+                b, sm = mine[k], sms[k]
+                if b + 1 < NB:
+                    next_entry, states = local.pop(('b', b + 1)) if owner(b + 1) == rank else _recv_obj(owner(b + 1), cg)
+                    out = sm.backward_chain(next_entry, states)
+                else:
+                    out = sm.backward_chain()
+                if b > 0:
+                    msg = (sm.first_entry, out)
+                    if owner(b - 1) == rank:
+                        local[('b', b)] = msg
+                    else:
+                        _send_obj(msg, owner(b - 1), cg)
+                parts[k] = sm.track(bounds[b][0], match['axis_name'], match['shape3d'])
+            t_chain_end[0] = time.perf_counter()
+        except Exception:       # noqa: BLE001 -- re-raised by the main thread
+            err.append(traceback.format_exc())
+            for e in pushed:
+                e.set()
+
+    th = threading.Thread(target=chain, name='emp-block-chain', daemon=True)
+    th.start()
+    reqs = []
+    try:
+        def forward(k):
+            b = mine[k]
+            lo, hi = bounds[b]
+            sem, stash = backend.forward(lo, hi, mid if b + 1 < NB else 0)
+            if mid and b > 0 and owner(b - 1) != rank:      # my first raw maps are the look-ahead of the block before
+                reqs.append(_isend(sem[:mid], owner(b - 1), group))
+            return sem, stash
+
+        fw = {0: forward(0)} if mine else {}
+        carry = None                                         # W = 1: the filtered tail of the block before, kept here
+        for k, b in enumerate(mine):
+            if k + 1 < len(mine):
+                fw[k + 1] = forward(k + 1)
+            sem, stash = fw.pop(k)
+            lo, hi = bounds[b]
+            n_own = hi - lo
+            has_prev, has_next = b > 0, b + 1 < NB
+            if mid and has_next:
+                if owner(b + 1) == rank:
+                    sem[n_own:].copy_(fw[k + 1][0][:mid])
+                else:
+                    _recv(sem[n_own:], owner(b + 1), group)
+            hist = None
+            if mid and has_prev:
+                if owner(b - 1) == rank:
+                    hist = carry
+                else:
+                    hist = torch.empty_like(sem[:mid])
+                    _recv(hist, owner(b - 1), group)
+            backend.median_inplace(sem, n_own, hist, mid if has_next else 0, b == 0, b == NB - 1, ks)
+            if mid and has_next:
+                if owner(b + 1) == rank:
+                    carry = sem[n_own - mid:n_own].clone()
+                else:
+                    reqs.append(_isend(sem[n_own - mid:n_own], owner(b + 1), group))
+            if hasattr(backend, 'runs_iter'):
+                for entries in backend.runs_iter(sem[:n_own], stash):
+                    sms[k].push(entries)
+            else:
+                sms[k].push(backend.runs(sem[:n_own], stash))
+            pushed[k].set()
+            if err:
+                break
+        gpu_s = time.perf_counter() - t_start
+        for r in reqs:
+            r.wait()
+    finally:
+        for e in pushed:
+            e.set()
+        th.join()
+    if err:
+        raise RuntimeError('block chain failed on rank %d:\n%s' % (rank, err[0]))
+    res = None
+    if mine:
+        ph = {key: sum(sm.phase_s[key] for sm in sms) for key in ('ghosts', 'forward', 'backward', 'track')}
+        res = {'blocks': [{'block': b, 'part': p} for b, p in zip(mine, parts)],
+               'host_s': sum(sm.host_s for sm in sms), 'tail_s': max(0.0, t_chain_end[0] - t_start - gpu_s), 'gpu_s': gpu_s,
+               'slices': sum(bounds[b][1] - bounds[b][0] for b in mine), 'phases': ph}
+    if rank != 0:
+        _send_blocks(res, 0, hg)
+        return None
+    gathered = [res] + [_recv_blocks(r, hg) for r in range(1, world)]
+    live = [g for g in gathered if g is not None]
+    by_block = {blk['block']: blk['part'] for g in live for blk in g['blocks']}
+    return {'parts': [by_block[b] for b in range(NB)], 'host_s': [g['host_s'] for g in live],
+            'timing': [{k: g[k] for k in ('host_s', 'tail_s', 'gpu_s', 'slices', 'phases')} for g in live]}
+
+
+def _send_blocks(res, dst, group):
+    if res is None:
+        _send_obj(None, dst, group)
+        return
+    _send_obj({k: v for k, v in res.items() if k != 'blocks'} | {'n_blocks': len(res['blocks'])}, dst, group)
+    for blk in res['blocks']:
+        _send_part({'block': blk['block'], 'part': blk['part']}, dst, group)
+
+
+def _recv_blocks(src, group):
+    res = _recv_obj(src, group)
+    if res is None:
+        return None
+    res['blocks'] = [_recv_part(src, group) for _ in range(res.pop('n_blocks'))]
+    return res
+
+
 class HipSlabBackend:
     """The arithmetic of one rank on its MI355X (through ``Engine3d``'s engine and the C ABI)."""
 
@@ -486,6 +709,11 @@ class HipSlabBackend:
         if self.raw:
             from .preprocess import normalize_params
             self.sub, self.mul = normalize_params(e3.preprocessor.mean, e3.preprocessor.std, np.iinfo(vdt).max)
+
+    @property
+    def block_slices(self):
+        """slices per block of the interleaved schedule = one forward batch"""
+        return int(self.e3.slice_batch(self.pad_to))
 
     def _block(self, i0, i1):
         """slices [i0, i1) along the axis as an (n,1,h,w) tensor on the model's device"""
@@ -591,6 +819,7 @@ def _rank_main(rank, world, port, dist_backend, model_config, engine_kwargs, bac
         else:
             dist.init_process_group(dist_backend, rank=rank, world_size=world)
             host_group = None
+        chain_group = dist.new_group(backend='gloo')      # the block chain's own messages (its thread runs beside the GPU loop)
         make = (backend_factory or _default_backend_factory)(model_config, engine_kwargs, rank)
         res_q.put(('ready', rank, None))
         while True:
@@ -601,7 +830,7 @@ def _rank_main(rank, world, port, dist_backend, model_config, engine_kwargs, bac
             if isinstance(volume, torch.Tensor):       # a numpy volume travels as a shared-memory tensor
                 volume = volume.numpy()
             axis = {'xy': 0, 'xz': 1, 'yz': 2}[axis_name]
-            segs = slab_stack_inference(volume.shape[axis], make(volume, axis), ks, None, host_group, match)
+            segs = stack_inference(volume.shape[axis], make(volume, axis), ks, None, host_group, match, chain_group)
             res_q.put(('done', rank, segs))
         dist.barrier()
         dist.destroy_process_group()
@@ -666,6 +895,7 @@ class MultiGPUEngine3d:
         self._procs = None
         self._make = None
         self._host_group = None
+        self._chain_group = None
 
     # ---- the reference's helpers (multigpu.py:186-212) ----
     def create_trackers(self, shape3d, axis_name):
@@ -773,9 +1003,10 @@ class MultiGPUEngine3d:
             self._make = factory(self.model_config, self.engine_kwargs, local)
             if dist.get_backend(self.group) == 'nccl':
                 self._host_group = dist.new_group(backend='gloo')
+            self._chain_group = dist.new_group(backend='gloo')
         axis = self.axes[axis_name]
-        return slab_stack_inference(volume.shape[axis], self._make(volume, axis), self.ks, self.group, self._host_group,
-                                    self._match_desc(volume.shape, axis_name))
+        return stack_inference(volume.shape[axis], self._make(volume, axis), self.ks, self.group, self._host_group,
+                               self._match_desc(volume.shape, axis_name), self._chain_group)
 
     def _match_desc(self, shape, axis_name):
         shape = tuple(int(v) for v in shape)
