@@ -193,6 +193,36 @@ def _recv_obj(src, group):
     return box[0]
 
 
+class _SentObj:
+    """a pickled object on its way (two isends: size, bytes) together with the buffers they read"""
+
+    def __init__(self, works, bufs):
+        self.works, self.bufs = works, bufs
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.bufs = None
+
+
+def _isend_pickled(obj, dst, group):
+    """non-blocking counterpart of _send_obj for the chain thread (received with _recv_pickled): the sender never waits for
+    the receiver to come round to it"""
+    import pickle
+    data = torch.frombuffer(bytearray(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)), dtype=torch.uint8)
+    size = torch.tensor([data.numel()], dtype=torch.int64)
+    return _SentObj([dist.isend(size, dst=dst, group=group), dist.isend(data, dst=dst, group=group)], [size, data])
+
+
+def _recv_pickled(src, group):
+    import pickle
+    size = torch.zeros(1, dtype=torch.int64)
+    dist.recv(size, src=src, group=group)
+    data = torch.empty(int(size.item()), dtype=torch.uint8)
+    dist.recv(data, src=src, group=group)
+    return pickle.loads(data.numpy().tobytes())
+
+
 def _send_part(res, dst, group):
     """a rank's result of slab_stack_inference (None for a rank without slices) to ``dst``"""
     if res is None:
@@ -291,6 +321,7 @@ class SlabMatcher:
             j.result()
         self._pool.shutdown()
         self._pushed_s = self.host_s
+        self.i_prev = self.i_next = None
         self.phase_s = {'ghosts': 0.0, 'forward': 0.0, 'backward': 0.0, 'track': 0.0}
 
     def _timed(self, key, t0):
@@ -299,22 +330,32 @@ class SlabMatcher:
         self.phase_s[key] += dt
         self.host_s += dt
 
-    def forward_chain(self, prev_entry=None, states=None):
-        """forward pass over the slab (patterns.py:68-100).  ``prev_entry`` / ``states``: the raw entry of slice lo-1 and its
-        matching state from the slab before (None on the first slab, whose chain already ran behind its pushes when
-        ``head``) -> the state of this slab's last slice for the next one ({class: state})."""
+    def push_prev_ghost(self, entry):
+        """the raw entry of slice lo-1 (the last slice of the slab before) as a ghost behind the own slices"""
+        import time
+        t0 = time.perf_counter()
+        self._push_entry(entry)
+        self.i_prev = self.n_own
+        self._timed('ghosts', t0)
+
+    def push_next_ghost(self, entry):
+        """the raw entry of slice hi (the first slice of the slab behind) as a ghost (after the previous-slice ghost, if any)"""
+        import time
+        t0 = time.perf_counter()
+        self._push_entry(entry)
+        self.i_next = self.n_own + (1 if self.i_prev is not None else 0)
+        self._timed('ghosts', t0)
+
+    def forward_chain(self, states=None):
+        """forward pass over the slab (patterns.py:68-100).  ``states``: the matching state of slice lo-1 from the slab
+        before ({class: state}; its ghost is pushed) or None on the first slab (whose chain already ran behind its pushes
+        when ``head``) -> the state of this slab's last slice for the next one."""
         import time
         n = self.n_own
-        self.i_prev = None
-        if prev_entry is not None:
-            t0 = time.perf_counter()
-            self._push_entry(prev_entry)
-            self.i_prev = n
-            self._timed('ghosts', t0)
         t0 = time.perf_counter()
         for c in self.things:
             sm = self.sm[c]
-            if prev_entry is not None:
+            if states is not None:
                 sm.import_state(self.i_prev, states[c], assign_new=True)
             if not self.head:
                 sm.run_range(0, n - 1, +1)
@@ -322,23 +363,16 @@ class SlabMatcher:
         self._timed('forward', t0)
         return out
 
-    def backward_chain(self, next_entry=None, states=None):
-        """backward pass (patterns.py:102-121: fresh target, no new labels).  ``next_entry`` / ``states``: the raw entry of
-        slice hi and its backward state from the slab behind (None on the last slab) -> the state of this slab's first
-        slice for the slab before."""
+    def backward_chain(self, states=None):
+        """backward pass (patterns.py:102-121: fresh target, no new labels).  ``states``: the backward state of slice hi from
+        the slab behind (its ghost is pushed) or None on the last slab -> the state of this slab's first slice."""
         import time
         n = self.n_own
-        i_next = None
-        if next_entry is not None:
-            t0 = time.perf_counter()
-            self._push_entry(next_entry)
-            i_next = n + (1 if self.i_prev is not None else 0)
-            self._timed('ghosts', t0)
         t0 = time.perf_counter()
         for c in self.things:
             sm = self.sm[c]
-            if next_entry is not None:
-                sm.import_state(i_next, (states[c][0], states[c][1], states[c][2], -1), assign_new=False)
+            if states is not None:
+                sm.import_state(self.i_next, (states[c][0], states[c][1], states[c][2], -1), assign_new=False)
             else:
                 sm.begin_backward()
             sm.run_range(0, n - 1, -1)
@@ -368,12 +402,16 @@ class SlabMatcher:
         if has_prev:
             _send_obj(self.first_entry, rank - 1, group)
         next_entry = _recv_obj(rank + 1, group) if has_next else None
+        if has_prev:
+            self.push_prev_ghost(prev_entry)
+        if has_next:
+            self.push_next_ghost(next_entry)
         states = _recv_obj(rank - 1, group) if has_prev and self.things else None
-        out_states = self.forward_chain(prev_entry, states if states is not None else {})
+        out_states = self.forward_chain((states if states is not None else {}) if has_prev else None)
         if has_next and self.things:
             _send_obj(out_states, rank + 1, group)
         states = _recv_obj(rank + 1, group) if has_next and self.things else None
-        out_states = self.backward_chain(next_entry, states if states is not None else {})
+        out_states = self.backward_chain((states if states is not None else {}) if has_next else None)
         if has_prev and self.things:
             _send_obj(out_states, rank - 1, group)
         return self.track(lo, axis_name, shape3d)
@@ -507,6 +545,7 @@ def stack_inference(n_slices, backend, ks, group=None, host_group=None, match=No
     blk = block_slices(backend) if match is not None else 0
     if blk <= 0:
         return slab_stack_inference(n_slices, backend, ks, group, host_group, match)
+    blk = min(blk, max(1, n_slices // dist.get_world_size(group)))      # a short stack: still a block for every rank
     if chain_group is None:          # the chain thread's messages must not share a group with this thread's
         chain_group = dist.new_group(backend='gloo')
     return block_stack_inference(n_slices, backend, ks, match, blk, group, host_group, chain_group)
@@ -561,38 +600,67 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
     t_chain_end = [t_start]
 
     def chain():
-        """this rank's blocks through the forward chain in block order, then through the backward chain in reverse"""
+        """this rank's blocks through the forward chain in block order, then through the backward chain in reverse.  What a
+        hop of the chain waits for is small (the O(objects) state of one slice): the boundary slices themselves -- the
+        ghosts a block's pair tables need, 360 KB at 1024^2 -- leave as soon as a block is extracted (non-blocking sends)
+        and are pushed while the state is still on its way.  Per block the messages to a neighbour go out in one fixed
+        order (first entry leftwards, last entry rightwards, forward state rightwards; in the second phase the backward
+        state leftwards) and are received in that order, so that one group carries them without tags (W = 2: both
+        neighbours are the same rank)."""
         try:
-            local = {}
+            sent = []
+            fwd_state = None                      # W = 1: handed from block to block here
+            def drain_next_ghost(k):              # block mine[k]'s next ghost = the first entry of block mine[k] + 1
+                b = mine[k]
+                if b + 1 < NB:
+                    e = sms[k + 1].first_entry if owner(b + 1) == rank else _recv_pickled(owner(b + 1), cg)
+                    sms[k].push_next_ghost(e)
             for k, b in enumerate(mine):
                 pushed[k].wait()
+                if err:
+                    return
                 sm = sms[k]
                 sm.wait_pushed()
+                if k > 0 and owner(mine[k - 1] + 1) == rank:
+                    drain_next_ghost(k - 1)       # (this very block: its first entry exists now)
+                if b > 0 and owner(b - 1) != rank:
+                    sent.append(_isend_pickled(sm.first_entry, owner(b - 1), cg))
+                if b + 1 < NB and owner(b + 1) != rank:
+                    sent.append(_isend_pickled(sm.last_entry, owner(b + 1), cg))
+                if k > 0 and owner(mine[k - 1] + 1) != rank:
+                    drain_next_ghost(k - 1)
                 if b > 0:
-                    prev_entry, states = local.pop(('f', b - 1)) if owner(b - 1) == rank else _recv_obj(owner(b - 1), cg)
-                    out = sm.forward_chain(prev_entry, states)
+                    if owner(b - 1) == rank:
+                        sm.push_prev_ghost(sms[k - 1].last_entry)
+                        states = fwd_state
+                    else:
+                        sm.push_prev_ghost(_recv_pickled(owner(b - 1), cg))
+                        states = _recv_pickled(owner(b - 1), cg)
+                    out = sm.forward_chain(states)
                 else:
                     out = sm.forward_chain()
                 if b + 1 < NB:
-                    msg = (sm.last_entry, out)
                     if owner(b + 1) == rank:
-                        local[('f', b)] = msg
+                        fwd_state = out
                     else:
-                        _send_obj(msg, owner(b + 1), cg)
+                        sent.append(_isend_pickled(out, owner(b + 1), cg))
+            if mine and owner(mine[-1] + 1) != rank:
+                drain_next_ghost(len(mine) - 1)
+            bwd_state = None
             for k in range(len(mine) - 1, -1, -1):
                 b, sm = mine[k], sms[k]
                 if b + 1 < NB:
-                    next_entry, states = local.pop(('b', b + 1)) if owner(b + 1) == rank else _recv_obj(owner(b + 1), cg)
-                    out = sm.backward_chain(next_entry, states)
+                    out = sm.backward_chain(bwd_state if owner(b + 1) == rank else _recv_pickled(owner(b + 1), cg))
                 else:
                     out = sm.backward_chain()
                 if b > 0:
-                    msg = (sm.first_entry, out)
                     if owner(b - 1) == rank:
-                        local[('b', b)] = msg
+                        bwd_state = out
                     else:
-                        _send_obj(msg, owner(b - 1), cg)
+                        sent.append(_isend_pickled(out, owner(b - 1), cg))
                 parts[k] = sm.track(bounds[b][0], match['axis_name'], match['shape3d'])
+            for w in sent:
+                w.wait()
             t_chain_end[0] = time.perf_counter()
         except Exception:       # noqa: BLE001 -- re-raised by the main thread
             err.append(traceback.format_exc())
