@@ -1183,8 +1183,9 @@ static int track_raster(emp_stack_matcher* h, const FSlice& sl, int64_t index2d)
       nruns += (size_t)(sl.run_off[(size_t)c + 1] - sl.run_off[(size_t)c]);
     }
     Track& t = h->tracks[tidx[k]];
-    if (h->axis == 2) t.yz.reserve(t.yz.size() + 3 * nruns);
-    else if (t.starts.capacity() < t.starts.size() + nruns) {
+    if (h->axis == 2) {
+      if (t.yz.capacity() < t.yz.size() + 3 * nruns) t.yz.reserve(std::max(t.yz.size() + 3 * nruns, 2 * t.yz.capacity()));      // (geometric: an exact reserve per slice re-copies the list every time)
+    } else if (t.starts.capacity() < t.starts.size() + nruns) {
       const size_t want = std::max(t.starts.size() + nruns, 2 * t.starts.capacity());
       t.starts.reserve(want);
       t.runs.reserve(want);
