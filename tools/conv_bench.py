@@ -31,6 +31,7 @@ SHAPES = [
     ('l4.conv3 512->2048', 64, 64, 512, 2048, 1, 1, 0, 1),
     ('l4.conv1 2048->512', 64, 64, 2048, 512, 1, 1, 0, 1),
     ('aspp 3x3 d4 2048->256', 64, 64, 2048, 256, 3, 1, 4, 4),
+    ('aspp 3x3 d4 2048->512 (both decoders)', 64, 64, 2048, 512, 3, 1, 4, 4),
     ('aspp 1x1 2048->256', 64, 64, 2048, 256, 1, 1, 0, 1),
     ('fuse pw 320->256', 256, 256, 320, 256, 1, 1, 0, 1),
     ('head pw 256->256', 256, 256, 256, 256, 1, 1, 0, 1),

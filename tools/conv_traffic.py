@@ -55,11 +55,11 @@ def join(fd, wd, B):
     fe, wr = counters(fd, 'FETCH_SIZE'), counters(wd, 'WRITE_SIZE')
     alg = alg_bytes(B)
     assert len(fe) == len(alg) == len(wr), (len(fe), len(wr), len(alg))
-    print(f'{"shape":24s} {"alg read MB":>12s} {"fetched MB":>11s} {"ratio":>6s} {"alg write MB":>13s} {"written MB":>11s}')
+    print(f'{"shape":40s} {"alg read MB":>12s} {"fetched MB":>11s} {"ratio":>6s} {"alg write MB":>13s} {"written MB":>11s}')
     for (name, rb, wb), f, w in zip(alg, fe, wr):
         f = f * 1024 * 2          # KiB units, gfx950 request-size correction (MI355X_MICROARCH.md)
         w = w * 1024
-        print(f'{name:24s} {rb/1e6:12.1f} {f/1e6:11.1f} {f/rb:6.2f} {wb/1e6:13.1f} {w/1e6:11.1f}')
+        print(f'{name:40s} {rb/1e6:12.1f} {f/1e6:11.1f} {f/rb:6.2f} {wb/1e6:13.1f} {w/1e6:11.1f}')
 
 
 if __name__ == '__main__':
