@@ -18,6 +18,9 @@ namespace emp {
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef half_t f16x2 __attribute__((ext_vector_type(2)));
+
 constexpr int PT = 8;                 // pooled tile side
 constexpr int ST = 2 * PT + 1;        // conv ("stem") tile side: 17
 constexpr int NSP = ST * ST;          // 289 conv pixels
@@ -69,17 +72,23 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const T* __restrict__ im
   const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;        // conv tile origin (may be -1)
   const int iy0 = 2 * sy0 - 3, ix0 = 2 * sx0 - 3;        // input patch origin
   const T* src = img + (size_t)n * vh * vw;
-  for (int i = tid; i < IP * IP; i += 256) {
+  // branch-free (clamped address, masked value): the 7 loads of a thread are in flight together instead of one per
+  // loop-carried branch
+#pragma unroll
+  for (int k = 0; k < (IP * IP + 255) / 256; ++k) {
+    const int i = tid + 256 * k;
     const int r = i / IP, c = i - r * IP;
     const int iy = iy0 + r, ix = ix0 + c;
-    float v = 0.f;
-    if (iy >= 0 && iy < vh && ix >= 0 && ix < vw) {
-      v = (float)src[(size_t)iy * vw + ix];
-      if (normalise) { v -= sub; v *= mul; }
-    }
+    const bool ok = i < IP * IP && iy >= 0 && iy < vh && ix >= 0 && ix < vw;
+    const int cy = min(max(iy, 0), vh - 1), cx = min(max(ix, 0), vw - 1);
+    float v = (float)src[(size_t)cy * vw + cx];
+    if (normalise) { v -= sub; v *= mul; }
+    v = ok ? v : 0.f;
     const half_t h = (half_t)v;
-    ph[r][c] = h;
-    pl[r][c] = (half_t)(v - (float)h);
+    if (i < IP * IP) {
+      ph[r][c] = h;
+      pl[r][c] = (half_t)(v - (float)h);
+    }
   }
   __syncthreads();
 
@@ -108,15 +117,20 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const T* __restrict__ im
     // conv pixel outside the conv map -> -inf (max-pool padding); lane owns couts ct*16 + fq*4 + [0,4) of pixel q
     const int gy = sy0 + sy, gx = sx0 + sx;
     const bool inside = gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+    const uint32_t keep = inside ? 0xFFFFFFFFu : 0u;
+    // packed epilogue: fp32 bias add on pairs, one conversion per pair, ReLU on the packed fp16 pair (rounding is monotone
+    // and keeps 0: the same values as ReLU before the rounding), border select on the packed word
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
-      f16x4 o;
+      union { f16x2 h[2]; uint32_t u[2]; f16x4 v; } o;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = acc[ct][r] + bv[ct][r];
-        o[r] = inside ? (half_t)(v > 0.f ? v : 0.f) : (half_t)(-INFINITY);
+      for (int r = 0; r < 2; ++r) {
+        const f32x2 s2 = f32x2{acc[ct][2 * r], acc[ct][2 * r + 1]} + f32x2{bv[ct][2 * r], bv[ct][2 * r + 1]};
+        const f16x2 h2 = __builtin_convertvector(s2, f16x2);
+        o.h[r] = __builtin_elementwise_max(h2, f16x2{(half_t)0.f, (half_t)0.f});
+        o.u[r] = (o.u[r] & keep) | (0xFC00FC00u & ~keep);      // outside the conv map: (-inf, -inf); a bit select, no branch
       }
-      *reinterpret_cast<f16x4*>(&st[q][ct * 16 + fq * 4]) = o;
+      *reinterpret_cast<f16x4*>(&st[q][ct * 16 + fq * 4]) = o.v;
     }
   }
   __syncthreads();

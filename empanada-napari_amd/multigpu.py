@@ -717,10 +717,16 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
         gpu_s = time.perf_counter() - t_start
         for r in reqs:
             r.wait()
-    finally:
+    except BaseException:
+        # this rank's GPU side failed: report it now -- the chain thread may sit in a receive that its peers will never
+        # answer (it is a daemon thread; the caller ends the ranks)
+        err.append('main thread failed')
         for e in pushed:
             e.set()
-        th.join()
+        raise
+    for e in pushed:
+        e.set()
+    th.join()
     if err:
         raise RuntimeError('block chain failed on rank %d:\n%s' % (rank, err[0]))
     res = None

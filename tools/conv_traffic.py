@@ -46,7 +46,7 @@ def run(B):
 
 def counters(d, name):
     f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
-    rows = [r for r in csv.DictReader(open(f)) if 'conv_igemm' in r['Kernel_Name'] and r['Counter_Name'] == name]
+    rows = [r for r in csv.DictReader(open(f)) if ('conv_igemm' in r['Kernel_Name'] or 'conv3x3_c' in r['Kernel_Name']) and r['Counter_Name'] == name]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     return [float(r['Counter_Value']) for r in rows]
 
