@@ -97,8 +97,10 @@ def _require_scale_one(scale):
 
 
 def _open_zarr(store_url, mode=None):
-    """``zarr.open(store_url[, mode])`` (inference.py:58,113,404,464)."""
-    return zstore.open_store(store_url, mode)
+    """``zarr.open(store_url[, mode])`` (inference.py:58,113,404,464).  A store created here is zarr v2 unless
+    ``EMP_ZARR_FORMAT=3`` asks for the v3 layout (what zarr-python 3's ``create_array`` writes by default)."""
+    fmt = os.environ.get('EMP_ZARR_FORMAT')
+    return zstore.open_store(store_url, mode, zarr_format=int(fmt) if fmt else None)
 
 
 def _device(device=None):

@@ -1,4 +1,4 @@
-"""zarr v2 directory stores without the zarr package.
+"""zarr v2 / v3 directory stores without the zarr package.
 
 The reference hands its dense outputs to zarr: ``zarr.open(store_url, mode='w')`` then
 ``create_array(name, shape=, dtype=, chunks=, overwrite=True)`` (empanada_napari/inference.py:100-103,
@@ -14,17 +14,31 @@ writes the zarr v2 *directory store* layout
     <store>/<array>/<i>.<j>.<k>          one raw C-order chunk of the full chunk shape (edge chunks padded)
 
 so that any zarr v2 reader (zarr-python 2.x / 3.x, napari, dask) opens what the engine wrote, and the engine
-opens uncompressed v2 stores written by them.  Compressed chunks are refused loudly (no codec library here).
-When the real ``zarr`` package is importable, ``open_store`` returns zarr's own objects instead.
+opens v2 stores written by them -- and, since round 3, the zarr **v3** directory layout that ``create_array`` of
+zarr-python 3 (the spelling at inference.py:100-103) writes:
+
+    <store>/zarr.json                    {"zarr_format": 3, "node_type": "group"}
+    <store>/<array>/zarr.json            {"zarr_format": 3, "node_type": "array", "shape", "data_type" (name),
+                                          "chunk_grid": {"name": "regular", "configuration": {"chunk_shape"}},
+                                          "chunk_key_encoding": {"name": "default", "configuration": {"separator": "/"}},
+                                          "codecs": [{"name": "bytes", "configuration": {"endian": "little"}}], "fill_value"}
+    <store>/<array>/c/<i>/<j>/<k>        one C-order chunk
+
+Codecs: uncompressed chunks and the two the standard library can decode -- zlib / gzip (v2 ``compressor`` ids
+``zlib`` / ``gzip``; v3 codec ``gzip`` behind ``bytes``).  Blosc, zstd, lz4, sharding and transposes are refused loudly
+(no codec library in this image).  When the real ``zarr`` package is importable, ``open_store`` returns zarr's own
+objects instead.
 
 Only what the reference's path touches is implemented: groups, n-d arrays, basic indexing with integers and
 unit-step slices (``array[z0:z1] = block``, ``array[...]``, ``array[i]``), ``shape / dtype / chunks / nchunks``.
 """
+import gzip
 import itertools
 import json
 import math
 import os
 import shutil
+import zlib
 
 import numpy as np
 
@@ -44,16 +58,32 @@ class DirArray:
     def __init__(self, path, mode='r'):
         self.path = path
         self.read_only = mode == 'r'
-        meta_path = os.path.join(path, '.zarray')
-        if not os.path.isfile(meta_path):
-            raise FileNotFoundError(f'{path} is not a zarr v2 array (.zarray missing)')
+        v2, v3 = os.path.join(path, '.zarray'), os.path.join(path, 'zarr.json')
+        if os.path.isfile(v2):
+            self._init_v2(v2)
+        elif os.path.isfile(v3):
+            self._init_v3(v3)
+        else:
+            raise FileNotFoundError(f'{path} is not a zarr array (.zarray / zarr.json missing)')
+        self.ndim = len(self.shape)
+
+    def _init_v2(self, meta_path):
+        path = self.path
         with open(meta_path) as f:
             m = json.load(f)
         if m.get('zarr_format') != 2:
-            raise ValueError(f'{path}: zarr_format {m.get("zarr_format")} (only the v2 layout is written/read here)')
-        if m.get('compressor') is not None or m.get('filters'):
-            raise NotImplementedError(f'{path}: compressed / filtered chunks need the zarr package (compressor='
-                                      f'{m.get("compressor")})')
+            raise ValueError(f'{path}: .zarray with zarr_format {m.get("zarr_format")}')
+        self.zarr_format = 2
+        comp = m.get('compressor')
+        if comp is None:
+            self.codec = None
+        elif comp.get('id') in ('zlib', 'gzip'):
+            self.codec, self.level = comp['id'], int(comp.get('level', 1))
+        else:
+            raise NotImplementedError(f'{path}: compressor {comp} needs the zarr package (the standard library decodes '
+                                      f'zlib / gzip only)')
+        if m.get('filters'):
+            raise NotImplementedError(f'{path}: filtered chunks need the zarr package (filters={m.get("filters")})')
         if m.get('order', 'C') != 'C':
             raise NotImplementedError(f'{path}: only C-order chunks')
         self.shape = tuple(int(s) for s in m['shape'])
@@ -62,11 +92,55 @@ class DirArray:
         fv = m.get('fill_value', 0)
         self.fill_value = 0 if fv is None else fv
         self.sep = m.get('dimension_separator', '.')
-        self.ndim = len(self.shape)
+        self.key_prefix = ''
+
+    _V3_TYPES = {'bool': '?', 'int8': 'i1', 'int16': 'i2', 'int32': 'i4', 'int64': 'i8', 'uint8': 'u1', 'uint16': 'u2',
+                 'uint32': 'u4', 'uint64': 'u8', 'float16': 'f2', 'float32': 'f4', 'float64': 'f8'}
+
+    def _init_v3(self, meta_path):
+        path = self.path
+        with open(meta_path) as f:
+            m = json.load(f)
+        if m.get('zarr_format') != 3 or m.get('node_type') != 'array':
+            raise ValueError(f'{path}: zarr.json is not a zarr v3 array (zarr_format {m.get("zarr_format")}, node_type '
+                             f'{m.get("node_type")})')
+        self.zarr_format = 3
+        self.shape = tuple(int(x) for x in m['shape'])
+        grid = m.get('chunk_grid', {})
+        if grid.get('name') != 'regular':
+            raise NotImplementedError(f'{path}: chunk grid {grid.get("name")}')
+        self.chunks = tuple(int(c) for c in grid['configuration']['chunk_shape'])
+        if m['data_type'] not in self._V3_TYPES:
+            raise NotImplementedError(f'{path}: data_type {m["data_type"]}')
+        kind = self._V3_TYPES[m['data_type']]
+        enc = m.get('chunk_key_encoding', {'name': 'default'})
+        conf = enc.get('configuration', {}) or {}
+        if enc.get('name') == 'default':
+            self.sep, self.key_prefix = conf.get('separator', '/'), 'c'
+        elif enc.get('name') == 'v2':
+            self.sep, self.key_prefix = conf.get('separator', '.'), ''
+        else:
+            raise NotImplementedError(f'{path}: chunk key encoding {enc.get("name")}')
+        endian, self.codec, self.level = '<', None, 5
+        codecs = m.get('codecs', [])
+        if not codecs or codecs[0].get('name') != 'bytes':
+            raise NotImplementedError(f'{path}: the first codec must be "bytes" (got {[c.get("name") for c in codecs]}): '
+                                      f'transposes / sharding need the zarr package')
+        if (codecs[0].get('configuration') or {}).get('endian', 'little') == 'big':
+            endian = '>'
+        for c in codecs[1:]:
+            if c.get('name') == 'gzip' and self.codec is None:
+                self.codec, self.level = 'gzip', int((c.get('configuration') or {}).get('level', 5))
+            else:
+                raise NotImplementedError(f'{path}: codec {c.get("name")} needs the zarr package (the standard library '
+                                          f'decodes gzip only)')
+        self.dtype = np.dtype(kind if kind in ('?', 'i1', 'u1') else endian + kind)
+        fv = m.get('fill_value', 0)
+        self.fill_value = 0 if fv is None else fv
 
     # ---- creation ----
     @classmethod
-    def create(cls, path, shape, dtype, chunks, overwrite=False, fill_value=0):
+    def create(cls, path, shape, dtype, chunks, overwrite=False, fill_value=0, zarr_format=2, compressor=None):
         if os.path.exists(path):
             if not overwrite:
                 raise FileExistsError(path)
@@ -80,9 +154,31 @@ class DirArray:
             raise ValueError(f'chunks {chunks} do not match shape {shape}')
         chunks = tuple(max(1, min(c, s)) if s > 0 else max(1, c) for c, s in zip(chunks, shape))
         dt = np.dtype(dtype)
-        _write_json(os.path.join(path, '.zarray'), {
-            'zarr_format': 2, 'shape': list(shape), 'chunks': list(chunks), 'dtype': dt.str, 'compressor': None,
-            'fill_value': fill_value, 'order': 'C', 'filters': None, 'dimension_separator': '.'})
+        if compressor not in (None, 'gzip', 'zlib'):
+            raise NotImplementedError(f'compressor {compressor!r}: None, "gzip" or "zlib"')
+        if zarr_format == 2:
+            _write_json(os.path.join(path, '.zarray'), {
+                'zarr_format': 2, 'shape': list(shape), 'chunks': list(chunks), 'dtype': dt.str,
+                'compressor': None if compressor is None else {'id': compressor, 'level': 1},
+                'fill_value': fill_value, 'order': 'C', 'filters': None, 'dimension_separator': '.'})
+        elif zarr_format == 3:
+            names = {v: k for k, v in cls._V3_TYPES.items()}
+            key = dt.str.lstrip('<>|=')
+            if key not in names or dt.byteorder == '>':
+                raise NotImplementedError(f'zarr v3 data type for {dt}')
+            if compressor == 'zlib':
+                raise NotImplementedError('zarr v3 has a gzip codec, no zlib codec')
+            codecs = [{'name': 'bytes', 'configuration': {'endian': 'little'}}]
+            if compressor == 'gzip':
+                codecs.append({'name': 'gzip', 'configuration': {'level': 1}})
+            fv = bool(fill_value) if dt.kind == 'b' else (float(fill_value) if dt.kind == 'f' else int(fill_value))
+            _write_json(os.path.join(path, 'zarr.json'), {
+                'zarr_format': 3, 'node_type': 'array', 'shape': list(shape), 'data_type': names[key],
+                'chunk_grid': {'name': 'regular', 'configuration': {'chunk_shape': list(chunks)}},
+                'chunk_key_encoding': {'name': 'default', 'configuration': {'separator': '/'}},
+                'fill_value': fv, 'codecs': codecs, 'attributes': {}})
+        else:
+            raise ValueError(f'zarr_format {zarr_format}: 2 or 3')
         return cls(path, mode='a')
 
     # ---- geometry ----
@@ -102,13 +198,21 @@ class DirArray:
         return self.shape[0]
 
     def _chunk_path(self, idx):
-        return os.path.join(self.path, self.sep.join(str(i) for i in idx))
+        key = self.sep.join(([self.key_prefix] if self.key_prefix else []) + [str(i) for i in idx])
+        if not idx and self.key_prefix:
+            key = self.key_prefix                  # zero-dimensional v3 array: the single chunk is "c"
+        return os.path.join(self.path, *key.split('/'))
 
     def _read_chunk(self, idx):
         p = self._chunk_path(idx)
         if not os.path.isfile(p):
             return None
-        a = np.fromfile(p, dtype=self.dtype)
+        if self.codec is None:
+            a = np.fromfile(p, dtype=self.dtype)
+        else:
+            with open(p, 'rb') as f:
+                raw = f.read()
+            a = np.frombuffer(gzip.decompress(raw) if self.codec == 'gzip' else zlib.decompress(raw), dtype=self.dtype)
         if a.size != int(np.prod(self.chunks)):
             raise ValueError(f'{p}: {a.size} items, expected a full chunk of {self.chunks}')
         return a.reshape(self.chunks)
@@ -119,7 +223,13 @@ class DirArray:
         if d != self.path:
             os.makedirs(d, exist_ok=True)
         tmp = p + '.partial'
-        np.ascontiguousarray(block, dtype=self.dtype).tofile(tmp)
+        block = np.ascontiguousarray(block, dtype=self.dtype)
+        if self.codec is None:
+            block.tofile(tmp)
+        else:
+            data = block.tobytes()
+            with open(tmp, 'wb') as f:
+                f.write(gzip.compress(data, self.level, mtime=0) if self.codec == 'gzip' else zlib.compress(data, self.level))
         os.replace(tmp, p)
 
     def _normalise(self, key):
@@ -202,34 +312,64 @@ class DirArray:
         return f'<DirArray {self.path} {self.shape} {self.dtype} chunks={self.chunks}>'
 
 
-class DirGroup:
-    """A zarr v2 group in a directory: ``create_array`` (zarr-python 3 spelling, inference.py:100) and
-    ``create_dataset`` (zarr-python 2 spelling, multigpu.py:202) both create a ``DirArray``."""
+def _is_array(p):
+    if os.path.isfile(os.path.join(p, '.zarray')):
+        return True
+    j = os.path.join(p, 'zarr.json')
+    if os.path.isfile(j):
+        with open(j) as f:
+            return json.load(f).get('node_type') == 'array'
+    return False
 
-    def __init__(self, path, mode='a'):
+
+def _is_group(p):
+    if os.path.isfile(os.path.join(p, '.zgroup')):
+        return True
+    j = os.path.join(p, 'zarr.json')
+    if os.path.isfile(j):
+        with open(j) as f:
+            return json.load(f).get('node_type') == 'group'
+    return False
+
+
+class DirGroup:
+    """A zarr group in a directory (v2 ``.zgroup`` or v3 ``zarr.json``): ``create_array`` (zarr-python 3 spelling,
+    inference.py:100) and ``create_dataset`` (zarr-python 2 spelling, multigpu.py:202) both create a ``DirArray`` in the
+    group's own format; ``zarr_format`` (2, the default, or 3) applies when the group is created."""
+
+    def __init__(self, path, mode='a', zarr_format=None):
         self.path = path
         self.mode = mode
         if mode == 'w':
             if os.path.isdir(path):
-                # zarr.open(mode='w') deletes what is there -- only ever a store (has .zgroup/.zarray or is empty)
+                # zarr.open(mode='w') deletes what is there -- only ever a store (has zarr metadata or is empty)
                 entries = os.listdir(path)
-                if entries and not any(e in ('.zgroup', '.zarray', '.zattrs') for e in entries):
+                if entries and not any(e in ('.zgroup', '.zarray', '.zattrs', 'zarr.json') for e in entries):
                     raise FileExistsError(f'{path} exists and is not a zarr store; refusing to overwrite it')
                 shutil.rmtree(path)
             os.makedirs(path)
-            _write_json(os.path.join(path, '.zgroup'), {'zarr_format': 2})
+            self._create_meta(zarr_format or 2)
         elif mode == 'a':
             os.makedirs(path, exist_ok=True)
-            if not os.path.isfile(os.path.join(path, '.zgroup')):
-                _write_json(os.path.join(path, '.zgroup'), {'zarr_format': 2})
-        elif not os.path.isfile(os.path.join(path, '.zgroup')):
-            raise FileNotFoundError(f'{path} is not a zarr v2 group (.zgroup missing)')
+            if not _is_group(path):
+                self._create_meta(zarr_format or 2)
+        elif not _is_group(path):
+            raise FileNotFoundError(f'{path} is not a zarr group (.zgroup / zarr.json missing)')
+        self.zarr_format = 3 if os.path.isfile(os.path.join(path, 'zarr.json')) else 2
 
-    def create_array(self, name, shape, dtype, chunks=None, overwrite=False, fill_value=0, **ignored):
+    def _create_meta(self, fmt):
+        if fmt == 2:
+            _write_json(os.path.join(self.path, '.zgroup'), {'zarr_format': 2})
+        elif fmt == 3:
+            _write_json(os.path.join(self.path, 'zarr.json'), {'zarr_format': 3, 'node_type': 'group', 'attributes': {}})
+        else:
+            raise ValueError(f'zarr_format {fmt}: 2 or 3')
+
+    def create_array(self, name, shape, dtype, chunks=None, overwrite=False, fill_value=0, compressor=None, **ignored):
         if self.mode == 'r':
             raise PermissionError(f'{self.path} was opened read-only')
         return DirArray.create(os.path.join(self.path, name), shape, dtype, chunks, overwrite=overwrite,
-                               fill_value=fill_value)
+                               fill_value=fill_value, zarr_format=self.zarr_format, compressor=compressor)
 
     create_dataset = create_array
 
@@ -237,46 +377,48 @@ class DirGroup:
         p = os.path.join(self.path, name)
         if overwrite and os.path.isdir(p):
             shutil.rmtree(p)
-        return DirGroup(p, mode='a')
+        return DirGroup(p, mode='a', zarr_format=self.zarr_format)
 
     def __contains__(self, name):
         p = os.path.join(self.path, name)
-        return os.path.isfile(os.path.join(p, '.zarray')) or os.path.isfile(os.path.join(p, '.zgroup'))
+        return _is_array(p) or _is_group(p)
 
     def __getitem__(self, name):
         p = os.path.join(self.path, name)
-        if os.path.isfile(os.path.join(p, '.zarray')):
+        if _is_array(p):
             return DirArray(p, mode='r' if self.mode == 'r' else 'a')
-        if os.path.isfile(os.path.join(p, '.zgroup')):
+        if _is_group(p):
             return DirGroup(p, mode='r' if self.mode == 'r' else 'a')
         raise KeyError(name)
 
     def array_keys(self):
-        return sorted(n for n in os.listdir(self.path) if os.path.isfile(os.path.join(self.path, n, '.zarray')))
+        return sorted(n for n in os.listdir(self.path) if os.path.isdir(os.path.join(self.path, n)) and _is_array(os.path.join(self.path, n)))
 
     keys = array_keys
 
     def __repr__(self):
-        return f'<DirGroup {self.path} arrays={self.array_keys()}>'
+        return f'<DirGroup {self.path} v{self.zarr_format} arrays={self.array_keys()}>'
 
 
-def open_store(store_url, mode=None):
+def open_store(store_url, mode=None, zarr_format=None):
     """``zarr.open(store_url[, mode])`` of the reference (inference.py:58,113,404,464): the zarr package when it is
     installed, otherwise the directory-store reader / writer above.  ``mode``: 'w' create (delete what is there),
-    'a' read / write (create if missing), 'r' read only; None = zarr's default 'a'."""
+    'a' read / write (create if missing), 'r' read only; None = zarr's default 'a'.  ``zarr_format`` (2 or 3) applies
+    to a store this call creates (default: 2 here, the package's own default with the package)."""
     try:
         import zarr
     except ImportError:
         zarr = None
     if zarr is not None:
-        return zarr.open(store_url, mode=mode) if mode else zarr.open(store_url)
+        kw = {'zarr_format': zarr_format} if zarr_format else {}
+        return zarr.open(store_url, mode=mode, **kw) if mode else zarr.open(store_url, **kw)
     url = str(store_url)
     if '://' in url and not url.startswith('file://'):
         raise NotImplementedError(f'{url}: only local directory stores without the zarr package')
     path = url[len('file://'):] if url.startswith('file://') else url
     mode = mode or 'a'
-    if mode in ('r', 'r+', 'a') and os.path.isfile(os.path.join(path, '.zarray')):
+    if mode in ('r', 'r+', 'a') and os.path.isdir(path) and _is_array(path):
         return DirArray(path, mode='r' if mode == 'r' else 'a')
     if mode == 'r+':
         mode = 'a' if os.path.isdir(path) else 'r'
-    return DirGroup(path, mode=mode)
+    return DirGroup(path, mode=mode, zarr_format=zarr_format)
