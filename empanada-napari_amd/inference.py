@@ -482,7 +482,8 @@ class Engine3d:
         16 of 1024^2, one of 4096^2) -- enough pixels to fill 256 CUs in the deep layers without growing the arena."""
         if self.batch_size:
             return int(self.batch_size)
-        return int(max(1, min(64, (1 << 24) // max(1, int(padded_hw[0]) * int(padded_hw[1])))))
+        budget = int(os.environ.get('EMP_SLICE_BATCH_PIXELS', 1 << 24))
+        return int(max(1, min(64, budget // max(1, int(padded_hw[0]) * int(padded_hw[1])))))
 
     def predict_slices(self, volume, axis):
         """Per-slice panoptic maps (device, int64 (h,w)) in slice order (see ``iter_slice_chunks``)."""
