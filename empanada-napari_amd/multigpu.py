@@ -786,8 +786,9 @@ class HipSlabBackend:
 
     @property
     def block_slices(self):
-        """slices per block of the interleaved schedule = one forward batch"""
-        return int(self.e3.slice_batch(self.pad_to))
+        """slices per block of the interleaved schedule: one forward batch, but at least 8 slices -- a block costs two
+        ghost slices and two chain hops whatever its length (a 4096^2 slice is a forward batch of its own)"""
+        return max(8, int(self.e3.slice_batch(self.pad_to)))
 
     def _block(self, i0, i1):
         """slices [i0, i1) along the axis as an (n,1,h,w) tensor on the model's device"""
