@@ -73,6 +73,8 @@ struct emp_pdl {
   // last-stage fusion conv(s) of the decoder that feeds ins_center and the ins_center head -- which is where the
   // north star's 1e-3 on the heat-maps was missed; 2 = every fused 5x5 block; 0 = none (round-2 numerics).
   int precise_sepconv = [] { const char* e = getenv("EMP_PRECISE_SEPCONV"); return e ? atoi(e) : 1; }();
+  // BiFPN nodes run fused once the map has this many 8 x 16 tiles (a tile per CU); EMP_SEPCONV_MIN_TILES for A/B runs
+  int sepconv_min_tiles = [] { const char* e = getenv("EMP_SEPCONV_MIN_TILES"); return e ? atoi(e) : 256; }();
 
   // device parameters
   std::map<std::string, DevConv> convs;
@@ -760,9 +762,20 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
           const std::string pwn = dirpre + ".after_combines.0.0.sepconv.1";
           const DevConv& pwc = n->convs.at(pwn);
           const Act& on = A(outname);
+          // EMP_PRECISE_SEPCONV=2 / 5 (all blocks / the BiFPN nodes only): the node's 3x3 block with the exact depthwise half
+          if (n->fuse_sepconv && (n->precise_sepconv == 2 || n->precise_sepconv == 5) && n->f16w.count(pwn + ".packedp") &&
+              pwc.cin_pad == F && fz.ld == F && on.ld == pwc.cout && sepconvp_supported(F, pwc.cout, 0) &&
+              (int64_t)N * ((fz.H + 7) / 8) * ((fz.W + 15) / 16) >= n->sepconv_min_tiles) {
+            RC(launch_sepconvp(fz.p, N, fz.H, fz.W, F, fz.ld, n->f32w.at(dirpre + ".after_combines.0.0.sepconv.0.f32"),
+                               n->f16w.at(pwn + ".packedp"), pwc.b, pwc.cout, 2, on.p, on.ld, nullptr, nullptr, 0, nullptr, 0,
+                               zero, s, 3));
+            n->flops += 2.0 * (double)N * fz.H * fz.W * pwc.cout * (double)pwc.cin;
+            if (n->layer_log) fprintf(n->layer_log, "sepconvp,%s,%d,%d,%d,3,1,1,0,%d\n", pwn.c_str(), N * fz.H * fz.W, F, pwc.cout, N * fz.H * fz.W);
+            return EMP_OK;
+          }
           // depthwise 3x3 -> pointwise -> BN -> SiLU in one launch (sepconv.hip, KS = 3) once the map has a tile per CU
           if (n->fuse_sepconv && n->f16w.count(pwn + ".packed") && pwc.cin_pad == F && fz.ld == F && on.ld == pwc.cout &&
-              sepconv5_supported(F, pwc.cout, 0) && (int64_t)N * ((fz.H + 7) / 8) * ((fz.W + 15) / 16) >= 256) {
+              sepconv5_supported(F, pwc.cout, 0) && (int64_t)N * ((fz.H + 7) / 8) * ((fz.W + 15) / 16) >= n->sepconv_min_tiles) {
             RC(launch_sepconv5(fz.p, N, fz.H, fz.W, F, fz.ld, n->f16w.at(dirpre + ".after_combines.0.0.sepconv.0"),
                                n->f16w.at(pwn + ".packed"), pwc.b, pwc.cout, 2, on.p, on.ld, nullptr, nullptr, 0, nullptr, 0,
                                zero, s, 3));
@@ -1188,7 +1201,10 @@ int emp_pdl_finalize(emp_pdl_t* n) {
           RC(pack_sepconv_pw(n, nm));
           if (precise_layer(n, nm.substr(0, nm.size() - 10))) RC(pack_sepconvp_pw(n, nm));
         }
-        if (nm.find(".after_combines.0.0.sepconv.1") != std::string::npos) RC(pack_sepconv_pw(n, nm));   // BiFPN nodes
+        if (nm.find(".after_combines.0.0.sepconv.1") != std::string::npos) {      // BiFPN nodes
+          RC(pack_sepconv_pw(n, nm));
+          if (n->precise_sepconv == 2 || n->precise_sepconv == 5) RC(pack_sepconvp_pw(n, nm));
+        }
       }
     }
   } else {
