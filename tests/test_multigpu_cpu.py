@@ -102,7 +102,7 @@ def _oracle_tracker(pans, shape, min_size, min_extent):
 
 
 @pytest.mark.parametrize('block', ['0', '2', '3'])
-@pytest.mark.parametrize('world,ks', [(2, 3), (3, 5)])
+@pytest.mark.parametrize('world,ks', [(2, 3), (3, 5), (2, 7)])
 def test_public_multigpu_engine_spawns_its_ranks(golden_dir, world, ks, block, monkeypatch):
     """The PUBLIC API as the widget calls it (empanada_napari/multigpu.py:121-260): construct in one process, call
     infer_on_axis, get (stack, trackers).  The engine spawns ``world`` rank processes itself (gloo here, RCCL on GPUs),
