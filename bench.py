@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument('--engine2d', type=int, default=1, help='tiles workload: also measure the Engine2d-level rate (0 = skip)')
     ap.add_argument('--latency', type=int, default=1, help='tiles workload: also measure the batch-1 latency (0 = skip)')
     ap.add_argument('--depth', type=int, default=128, help='stack3d workload: slices per GPU')
+    ap.add_argument('--slab-size', type=int, default=4096, help='tiles workload, N > 1: slice side of the z-slab job of the `stack3d` block')
+    ap.add_argument('--slab-depth', type=int, default=16, help='tiles workload, N > 1: slices per rank of that job')
     ap.add_argument('--ks', type=int, default=3, help='stack3d workload: median kernel size')
     return ap.parse_args()
 
@@ -59,6 +61,8 @@ def launch_ranks(args):
     import socket
     import torch
     have = torch.cuda.device_count()
+    if os.environ.get('EMP_BENCH_SHARE_GPU') == '1' and have >= 1:
+        have = args.gpus      # diagnostic: the N ranks time-share GPU 0, gloo transport (main)
     if have < args.gpus:
         print(f'bench.py: --gpus {args.gpus} requested but {have} GPU(s) visible; refusing to report a smaller job',
               file=sys.stderr)
@@ -73,28 +77,68 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(cfg, P, tile_size, n_tiles, seed):
-    """Oracle (CPU restatement of the reference engine) on a bounded sample of the same workload."""
+def cpu_baseline(cfg, P, tile_size, n_tiles, seed, keep=None):
+    """Oracle (CPU restatement of the reference engine) on a bounded sample of the same workload.  keep: a dict that
+    receives the oracle's head tensors and label map of tile 0 (the checker side of the line's `parity` block)."""
     import torch
     from empanada_napari_amd import synth
     from empanada_napari_amd.preprocess import normalize
     from oracle import pdl_model, postprocess as opp
     torch.set_num_threads(min(os.cpu_count() or 1, 32))  # oneDNN convs stop scaling beyond ~32 threads
     tiles = synth.em_tiles(n_tiles, tile_size, seed=seed)
+    heads = []
 
     def model(x, rs, interp):
-        o = pdl_model.pdl_forward(P, torch.from_numpy(x), cfg, rs, interp)
-        return {k: v.numpy() for k, v in o.items()}
+        taps = {}
+        o = pdl_model.pdl_forward(P, torch.from_numpy(x), cfg, rs, interp, taps)
+        o = {k: v.numpy() for k, v in o.items()}
+        if keep is not None and not heads:
+            heads.append(dict(o, sem_coarse=taps['sem_coarse'].numpy()))
+        return o
 
     eng = opp.RenderEngine(model, [1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
                            padding_factor=16, coarse_boundaries=True)
     t0 = time.perf_counter()
-    for t in tiles:  # the reference asserts batch 1 (engines.py:306): sequential calls
-        eng(normalize(t, 0.57571, 0.12765)[None, None], t.shape, 1)
+    for i, t in enumerate(tiles):  # the reference asserts batch 1 (engines.py:306): sequential calls
+        pan = eng(normalize(t, 0.57571, 0.12765)[None, None], t.shape, 1)
+        if keep is not None and i == 0:
+            keep.update(heads[0], pan=pan, tile=t)
     dt = time.perf_counter() - t0
     return {'value': round(n_tiles / dt, 4), 'unit': 'tiles/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'{n_tiles} x {tile_size}x{tile_size} uint8 EM-like tiles, fp32, sequential batch-1 calls '
                       f'({dt:.1f} s)'}
+
+
+def parity_block(model, eng, ref, sub, mul, dev):
+    """Distance of the engine's float outputs to the fp32 oracle forward on tile 0 of the CPU-baseline sample (the oracle
+    ran it anyway: cpu_baseline(keep=)) -- the north star's "within 1e-3 on the float semantic / center heatmaps", stated
+    with the numbers: rms AND max, the share of final semantic cells beyond 1e-3 (PointRend refines the 8192 most uncertain
+    cells per step; a cell refined on one side only differs by refined - interpolated), and the share of pixels whose
+    foreground differs after both pipelines' post-processing.  Gated in tests/test_gpu_parity_fullsize.py."""
+    import numpy as np
+    import torch
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v.astype(np.float64)))
+    x = torch.from_numpy(ref['tile'])[None, None].to(dev)
+    o = {k: v.float().cpu().numpy() for k, v in model(x, 2, interpolate_ins=False, sub=float(sub), mul=float(mul)).items()}
+    h4, w4 = o['ctr_hmp'].shape[-2:]
+    coarse = model.tap_raw('semantic_head.out', (1, o['sem_logits'].shape[1], h4, w4)).float().cpu().numpy()
+    pan = eng.call_raw(x, sub, mul).cpu().numpy()
+    e_ctr = np.abs(o['ctr_hmp'] - ref['ctr_hmp'])
+    e_off = np.abs(o['offsets'] - ref['offsets'])
+    e_sem = np.abs(sig(coarse) - sig(ref['sem_coarse']))
+    e_prob = np.abs(sig(o['sem_logits']) - sig(ref['sem_logits']))
+    rms = lambda e: float(np.sqrt((e.astype(np.float64) ** 2).mean()))
+    want = np.asarray(ref['pan']).reshape(pan.shape)
+    return {'tile': 'tile 0 of the cpu_baseline sample, batch-1 call', 'vs': 'fp32 oracle forward (= the reference forward, tests/golden)',
+            'ctr_rms': round(rms(e_ctr), 6), 'ctr_max': round(float(e_ctr.max()), 6),
+            'sem_rms': round(rms(e_sem), 6), 'sem_max': round(float(e_sem.max()), 6),
+            'sem_note': 'semantic head probability before PointRend (256 x 256 per 1024^2 tile)',
+            'off_rms_px': round(rms(e_off), 5), 'off_max_px': round(float(e_off.max()), 5),
+            'final_prob_rms': round(rms(e_prob), 6), 'final_prob_frac_over_1e3': round(float((e_prob > 1e-3).mean()), 6),
+            'fg_flip_frac': round(float(((pan > 0) != (want > 0)).mean()), 6),
+            'foreground_fraction': round(float((want > 0).mean()), 4),
+            'tolerance': 'north star: 1e-3; met in rms on the centre / semantic heat-maps, NOT in the max norm with fp16 maps '
+                         '(DESIGN.md section 2); label maps are bit-exact given identical head tensors'}
 
 
 def cpu_stack_baseline(cfg, P, vol, n_slices=12):
@@ -263,14 +307,20 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     dom_ms, dom_flops, dom_launches = model.profile_read()
     model.profile(False)
-    fwd_total_ms = sum(a.elapsed_time(b) for a, b in fwd_ms)
     flops_fwd = model.last_flops() * (B / mb)  # per step (last_flops is per forward call of mb tiles)
+    slab_block = None
+    if dist_on and args.stack3d > 0:        # every rank takes part (SPMD); outside the timed region of `value`
+        try:
+            slab_block = slab_job_block(args, model, rank, world, dev)
+        except Exception as e:              # the headline line must not depend on the extra measurement
+            slab_block = {'error': f'{type(e).__name__}: {e}'}
+    fwd_total_ms = sum(a.elapsed_time(b) for a, b in fwd_ms)
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * args.steps / dt
     if rank != 0:
@@ -292,7 +342,9 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
                                f'GPU, resident in HBM when the timed region starts), batch {B} per GPU, forward + instance '
                                f'post-processing to int64 label maps on the device',
                    'tile': S, 'batch_per_gpu': B, 'micro_batch': mb, 'weights': 'seeded random init (seed 0)',
-                   'parallelism': f'tile-sharded x{world}, no data-path collective; RCCL ranks: {world if dist_on else 0}'},
+                   'parallelism': f'tile-sharded x{world}, no data-path collective; RCCL ranks: '
+                                  f'{world if dist_on and dist.get_backend() == "nccl" else 0}',
+                   'ranks_sharing_one_gpu': world if dist_on and dist.get_backend() != 'nccl' else 0},
         'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(achieved / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
                      'traffic_note': 'average HBM bytes per launch of this kernel (2*FETCH_SIZE + WRITE_SIZE, separate '
@@ -343,7 +395,12 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
         except Exception as e:
             res['engine2d_tiles_per_s'] = {'error': f'{type(e).__name__}: {e}'}
     if world == 1 and not args.no_cpu_baseline:
-        res['cpu_baseline'] = cpu_baseline(cfg, P, S, args.cpu_tiles, 1234)
+        ref0 = {}
+        res['cpu_baseline'] = cpu_baseline(cfg, P, S, args.cpu_tiles, 1234, keep=ref0)
+        try:
+            res['parity'] = parity_block(model, eng, ref0, sub, mul, dev)
+        except Exception as e:
+            res['parity'] = {'error': f'{type(e).__name__}: {e}'}
         # vs_baseline stays null: BASELINE.md holds no published number for this metric (its section 1: "Nothing").  The
         # ratio to the CPU port timed in this very run is given under its own name -- a reported baseline, not a target.
         try:
@@ -353,13 +410,75 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
     else:
         res['cpu_baseline'] = None
     # the 3-D half of the headline metric, outside the timed region of `value` (rank 0, one GPU)
-    res['stack3d'] = None
-    if world == 1 and args.stack3d > 0:
+    res['stack3d'] = slab_block
+    if world == 1 and not dist_on and args.stack3d > 0:
         try:
             res['stack3d'] = stack3d_line(model, args.stack3d, cfg, P, with_cpu=not args.no_cpu_baseline)
         except Exception as e:      # the headline line must not depend on the extra measurement
             res['stack3d'] = {'error': f'{type(e).__name__}: {e}'}
     return res
+
+
+def slab_job_block(args, model, rank, world, dev):
+    """N > 1: the 3-D half of BASELINE's metric on the SAME ranks, after the tile measurement and outside its timed region --
+    configs[3] in small: a procedural uint8 volume of `--slab-depth` slices of `--slab-size`^2 PER RANK, xy stack inference
+    through MultiGPUEngine3d on RCCL (z-slab / block-interleaved schedule, neighbour halo + filtered carry, slab-wise
+    matcher chained through the ranks).  Every rank calls it (SPMD); rank 0 returns the block.  Whatever `--gpus N`
+    command the driver runs therefore records the 3-D scaling as well (weak: fixed slices per rank)."""
+    import torch
+    import torch.distributed as dist
+    from empanada_napari_amd import multigpu, synth
+    S, D = args.slab_size, args.slab_depth * world
+    mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.57571, 'std': 0.12765}}
+    vol = synth.ProceduralVolume((D, S, S), seed=7, cell=48, cache=True)
+    multigpu.MultiGPUEngine3d.MIN_WORLD = 1
+    shared = dist.get_backend() != 'nccl'      # EMP_BENCH_SHARE_GPU: all ranks on this one device
+    eng = multigpu.MultiGPUEngine3d(mc, label_divisor=10000, median_kernel_size=args.ks, nms_kernel=3, nms_threshold=0.1,
+                                    confidence_thr=0.5, min_size=500, min_extent=5,
+                                    devices=[dev.index] * world if shared else None)
+
+    def job():
+        st, tr = eng.infer_on_axis(vol, 'xy')
+        return len(tr[0].instances) if tr is not None else 0
+
+    job()                                   # untimed: procedural synthesis (cached), first launches at this size
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    jobs = 2
+    nobj = 0
+    for _ in range(jobs):
+        nobj = job()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], device='cpu' if shared else dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank != 0:
+        return None
+    sec = float(t.item()) / jobs
+    per_slice = model.last_flops()          # one slice per forward at 4096^2 (Engine3d.slice_batch); else per batch
+    bs = max(1, min(64, (1 << 24) // (S * S)))
+    flops = per_slice / max(1, min(bs, args.slab_depth)) * D
+    tf = flops / sec / 1e12
+    tm = getattr(eng, 'last_timing', None) or []
+    slab = None
+    if tm:
+        r0 = tm[0]
+        slab = {'ranks': len(tm), 'gpu_ms_per_slice': round(1e3 * r0['gpu_s'] / max(1, r0['slices']), 4),
+                'rank0_host_ms_per_slice': round(1e3 * (r0['tail_s'] + getattr(eng, 'last_merge_s', 0.0)) / max(1, D), 4),
+                'per_rank': [{k: (round(v, 5) if isinstance(v, float) else
+                                  {a: round(b, 5) for a, b in v.items()} if isinstance(v, dict) else v) for k, v in x.items()} for x in tm]}
+    return {'metric': 'voxels/sec, 3-D stack (xy) z-slab inference', 'value': round(float(D) * S * S / sec, 1), 'unit': 'voxels/s',
+            'n_gpus': 1 if shared else world, 'rccl_ranks': 0 if shared else world, 'ranks_sharing_one_gpu': world if shared else 0,
+            'scaling': 'weak', 'seconds_per_job': round(sec, 4), 'jobs_timed': jobs,
+            'volume': [D, S, S], 'slices_per_rank': args.slab_depth, 'ks': args.ks, 'tracked_objects': nobj,
+            'schedule': 'block-interleaved' if os.environ.get('EMP_MG_BLOCK', '1') != '0' else 'contiguous slabs',
+            'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F16_TFLOPS * world, 'unit': 'TFLOP/s',
+                         'frac': round(tf / (PEAK_F16_TFLOPS * world), 4), 'traffic': None, 'forward_flops': flops,
+                         'note': 'whole-job rate over all ranks: forward FLOPs of every slice / wall time (median, voting, '
+                                 'merge, run extraction, matcher chain included)'},
+            'slab_pipeline': slab, 'cpu_baseline': None}
 
 
 def run_stack3d(args, rank, local_rank, world, dist_on, dev):
@@ -429,7 +548,7 @@ def run_stack3d(args, rank, local_rank, world, dist_on, dev):
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist_on:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
@@ -492,13 +611,22 @@ def main():
             print(f'bench.py: --gpus {args.gpus} does not match the launcher\'s WORLD_SIZE {world}', file=sys.stderr)
         sys.exit(2)
     dist_on = world > 1 or os.environ.get('EMP_BENCH_FORCE_DIST') == '1'   # the env switch runs the RCCL path on one GPU
+    # EMP_BENCH_SHARE_GPU=1 (diagnostic; the builder's boxes have ONE GPU): the N ranks time-share GPU 0 and talk over gloo
+    # (device maps staged through the host) -- the same code path of every rank as on N GPUs, not a scaling measurement;
+    # the JSON line says so (`ranks_sharing_one_gpu`)
+    share = world > 1 and os.environ.get('EMP_BENCH_SHARE_GPU') == '1'
+    if share:
+        local_rank = 0
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if share:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     graft.load_package()

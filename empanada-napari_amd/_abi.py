@@ -60,6 +60,9 @@ PROTOTYPES = {
     'emp_sepconvp_pack_pw': (c_int, [vp, c_int, c_int, c_int, vp, vp]),
     'emp_sepconvp_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_int, c_int, vp,
                                       c_int, vp, vp, c_int, vp, vp]),
+    'emp_sepconvp_ws_pack_pw': (c_int, [vp, c_int, c_int, c_int, vp, vp]),
+    'emp_sepconvp_ws_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_int, c_int, vp,
+                                         c_int, vp, vp, c_int, vp, vp]),
     'emp_sepconv3x3_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_int, c_int, vp, c_int, vp]),
     'emp_sm_create': (vp, [c_i64, c_i64, c_f64, c_f64, c_int]),
     'emp_sm_destroy': (None, [vp]),

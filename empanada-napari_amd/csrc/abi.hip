@@ -157,6 +157,25 @@ int emp_sepconvp_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_l
                          (int64_t)H * W, zero, (hipStream_t)stream, K);
 }
 
+int emp_sepconvp_ws_pack_pw(const void* d_pw_w, int pw_ld, int C, int Cout, void* d_packed, void* stream) {
+  EMP_REQUIRE(d_pw_w && d_packed, "sepconvp pack_pw: null pointer");
+  return launch_sepconvp_pack_pw((const float*)d_pw_w, pw_ld, C, Cout, (half_t*)d_packed, (hipStream_t)stream, 1);
+}
+
+int emp_sepconvp_ws_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld, int K, const void* d_dw_w,
+                             const void* d_pw_w, const float* d_bias, int Cout, int act, void* d_out, int out_ld,
+                             const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out, void* stream) {
+  EMP_REQUIRE(d_in && d_dw_w && d_pw_w, "sepconvp: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0, "sepconvp: bad geometry");
+  EMP_REQUIRE(head_c == 0 || (d_head_w && d_head_out), "sepconvp: head pointers missing");
+  EMP_REQUIRE(head_c != 0 || d_out, "sepconvp: output pointer missing");
+  const half_t* zero = (const half_t*)zero_page();
+  EMP_REQUIRE(zero != nullptr, "sepconvp: could not allocate the zero page");
+  return launch_sepconvp((const half_t*)d_in, N, H, W, C, in_ld, (const float*)d_dw_w, (const half_t*)d_pw_w, d_bias, Cout,
+                         act, head_c ? nullptr : (half_t*)d_out, out_ld, d_head_w, d_head_b, head_c, d_head_out,
+                         (int64_t)H * W, zero, (hipStream_t)stream, K, 1);
+}
+
 int emp_sepconv3x3_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld, const void* d_dw_w, const void* d_pw_w,
                             const float* d_bias, int Cout, int act, void* d_out, int out_ld, void* stream) {
   EMP_REQUIRE(d_in && d_dw_w && d_pw_w && d_out, "sepconv3x3: null pointer");

@@ -118,8 +118,9 @@ int launch_dwconv(const half_t* in, int N, int H, int W, int C, int in_ld, const
                   half_t* out, int out_ld, const half_t* zero, hipStream_t s);
 // BiFPN fast-normalised fusion (bifpn.py:52-69,106-134): out = ca*resize(a) + cb*b (+ cc*c)
 //   mode 0: a is at half resolution, nearest x2 up-sampling; mode 1: a is at double resolution, 3x3/2 max-pool
+//   out_lo != nullptr: the result as an fp16 hi + lo pair (hi -> out, lo -> out_lo), rows out_ld apart (0: C)
 int launch_fuse_combine(const half_t* a, const half_t* b, const half_t* c, float ca, float cb, float cc, int mode,
-                        int N, int H, int W, int C, half_t* out, hipStream_t s);
+                        int N, int H, int W, int C, half_t* out, hipStream_t s, half_t* out_lo = nullptr, int out_ld = 0);
 int launch_bilinear_ac(const half_t* in, int N, int h, int w, int C, int in_ld, half_t* out, int H, int W,
                        int out_ld, hipStream_t s);
 int launch_avgpool(const half_t* in, int N, int HW, int C, int in_ld, float* out /*N x C*/, float* part,
@@ -140,14 +141,16 @@ int launch_sepconv5(const half_t* in, int N, int H, int W, int C, int in_ld, con
 // the same block with an exact depthwise half (sepconv_precise.hip): fp32 taps, depthwise result as an fp16 hi + lo pair
 // (two MFMAs per product), fp16 pointwise weights
 bool sepconvp_supported(int C, int Cout, int head_c);
-// pointwise weights (Cout, pw_ld) fp32 -> C * Cout fp16 in MFMA fragment order
-int launch_sepconvp_pack_pw(const float* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s);
+// hi + lo pointwise weights (a third MFMA per product: w_lo * x_hi) for the 128-cout blocks
+bool sepconvp_wsplit_supported(int Cout);
+// pointwise weights (Cout, pw_ld) fp32 -> C * Cout fp16 in MFMA fragment order (wsplit: 2 * C * Cout, hi then lo)
+int launch_sepconvp_pack_pw(const float* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s, int wsplit = 0);
 // depthwise taps (ks*ks, C) fp32 -> chunk-major [C/64][ks*ks][64] fp32
 int launch_sepconvp_pack_dw(const float* w, int ks, int C, float* packed, hipStream_t s);
 int launch_sepconvp(const half_t* in, int N, int H, int W, int C, int in_ld, const float* dww_packed, const half_t* pww_packed,
                     const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
                     const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s,
-                    int ks = 5);
+                    int ks = 5, int wsplit = 0);
 int launch_head1x1(const half_t* in, int N, int P, int K, int in_ld, const float* w, const float* b, int C,
                    float* out, int64_t plane_size, const int32_t* scatter_idx, hipStream_t s);
 int launch_bilinear_ac_f32_nchw(const float* in, int NC, int h, int w, float* out, int scale, hipStream_t s);

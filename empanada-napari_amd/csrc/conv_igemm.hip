@@ -480,7 +480,9 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
                 "conv: third destination: split3=%d must be a multiple of 8 inside (split=%d, Cout=%d)", p.split3, p.split, p.Cout);
   }
   if (p.in2) {
-    EMP_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.ps_cout == 0,
+    // (a pixel-shuffle store is fine: the second source only extends the K walk, the store is the epilogue's business --
+    // round 4: the transposed convs of the BiFPN decoder carry their weights as [hi | lo] pairs against the same input)
+    EMP_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0,
                 "conv: a second source needs a 1x1 / stride 1 main convolution");
     EMP_REQUIRE(p.Cin2 > 0 && p.Cin2 % BK == 0 && p.in2_ld % 8 == 0 && p.in2_ld >= p.Cin2 && ((uintptr_t)p.in2 % 16) == 0,
                 "conv: second source: Cin2=%d must be a positive multiple of 64, in2_ld=%d >= Cin2", p.Cin2, p.in2_ld);

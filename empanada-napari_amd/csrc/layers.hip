@@ -249,10 +249,14 @@ __global__ void __launch_bounds__(256, 2) dwconv_kernel(const half_t* __restrict
 //   mode 0 (top-down, bifpn.py:60-67): a is (N,H/2,W/2,C), nearest x2 up-sampling (Resize2d 'up')
 //   mode 1 (bottom-up, bifpn.py:119-131): a is (N,2H,2W,C), 3x3 stride-2 pad-1 max-pool (Resize2d 'down')
 // ---------------------------------------------------------------------------
+// out_lo != nullptr (round 4): the fused value leaves as an fp16 hi + lo PAIR -- hi to out, lo = fp16(v - hi) to out_lo, both
+// with row stride out_ld -- so that the node's separable conv (sepconv_precise.hip, channels [hi | lo] with duplicated taps
+// and pointwise weights: dw and pw are linear) sees the fp32 sum to ~2^-22 instead of its fp16 rounding.
 __global__ void __launch_bounds__(256) fuse_combine_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b,
                                                            const half_t* __restrict__ c, float ca, float cb, float cc,
                                                            int mode, int N, int H, int W, int C,
-                                                           half_t* __restrict__ out, int64_t total) {
+                                                           half_t* __restrict__ out, half_t* __restrict__ out_lo, int out_ld,
+                                                           int64_t total) {
   const int CG = C >> 3;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int cg = (int)(i % CG);
@@ -285,17 +289,27 @@ __global__ void __launch_bounds__(256) fuse_combine_kernel(const half_t* __restr
       }
     }
     const size_t o = (((size_t)n * H + y) * W + x) * C + cg * 8;
+    const size_t oo = (((size_t)n * H + y) * W + x) * out_ld + cg * 8;
     const f16x8 vb = *reinterpret_cast<const f16x8*>(b + o);
-    f16x8 r;
+    float v[8];
     if (c) {
       const f16x8 vc = *reinterpret_cast<const f16x8*>(c + o);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) r[k] = (half_t)(ca * ra[k] + cb * (float)vb[k] + cc * (float)vc[k]);
+      for (int k = 0; k < 8; ++k) v[k] = ca * ra[k] + cb * (float)vb[k] + cc * (float)vc[k];
     } else {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) r[k] = (half_t)(ca * ra[k] + cb * (float)vb[k]);
+      for (int k = 0; k < 8; ++k) v[k] = ca * ra[k] + cb * (float)vb[k];
     }
-    *reinterpret_cast<f16x8*>(out + o) = r;
+    f16x8 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (half_t)v[k];
+    *reinterpret_cast<f16x8*>(out + oo) = r;
+    if (out_lo) {
+      f16x8 l;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) l[k] = (half_t)(v[k] - (float)r[k]);
+      *reinterpret_cast<f16x8*>(out_lo + oo) = l;
+    }
   }
 }
 
@@ -631,12 +645,14 @@ int launch_dwconv(const half_t* in, int N, int H, int W, int C, int in_ld, const
 }
 
 int launch_fuse_combine(const half_t* a, const half_t* b, const half_t* c, float ca, float cb, float cc, int mode, int N,
-                        int H, int W, int C, half_t* out, hipStream_t s) {
+                        int H, int W, int C, half_t* out, hipStream_t s, half_t* out_lo, int out_ld) {
   EMP_REQUIRE(C % 8 == 0 && (mode == 0 || mode == 1), "fuse_combine: bad arguments");
+  if (out_ld == 0) out_ld = C;
+  EMP_REQUIRE(out_ld % 8 == 0 && out_ld >= C, "fuse_combine: bad output stride %d", out_ld);
   EMP_REQUIRE(mode == 1 || (H % 2 == 0 && W % 2 == 0), "fuse_combine: up-sampled operand needs even H, W");
   const int64_t total = (int64_t)N * H * W * (C / 8);
   hipLaunchKernelGGL(fuse_combine_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, a, b, c, ca, cb, cc,
-                     mode, N, H, W, C, out, total);
+                     mode, N, H, W, C, out, out_lo, out_ld, total);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }

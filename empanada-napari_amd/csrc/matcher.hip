@@ -25,12 +25,16 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
 #include <thread>
 
 #include "common.h"
+
 
 namespace {
 
@@ -566,6 +570,11 @@ struct emp_stack_matcher {
       if (e.t == r) return (double)e.inter / (double)(ta[(size_t)r] + ma[(size_t)c] - e.inter);
     return 0.0;
   }
+  // step_apply's regrouping scratch: label -> group index (open addressing, cleared by epoch), group of every object
+  std::vector<int64_t> ht_key, grp_label;
+  std::vector<int> ht_val, grp_of, grp_count;
+  std::vector<uint32_t> ht_stamp;
+  uint32_t ht_epoch = 0;
   // scratch pair table for a target that is not the neighbouring slice (never on the pipeline's path)
   FSlice scratch;
   // tracker
@@ -662,7 +671,10 @@ int sm_threads() {
   return n;
 }
 
-// fn(i) for i in [0, count) on up to sm_threads() threads (static interleaved split); returns the first non-zero result
+// fn(i) for i in [0, count) on up to sm_threads() threads (static interleaved split); returns the first non-zero result.
+// The library's error text is thread-local (abi.hip): a worker's message (an EMP_REQUIRE inside fn) is captured on the
+// worker and re-issued on the CALLING thread after the join, so that emp_last_error() names it; an exception thrown in a
+// worker (std::bad_alloc) would otherwise reach std::terminate -- it is caught there and reported as EMP_ERR_NOMEM.
 template <typename F>
 int parallel_for(int64_t count, F fn) {
   const int T = (int)std::min<int64_t>(sm_threads(), count);
@@ -671,13 +683,27 @@ int parallel_for(int64_t count, F fn) {
     return EMP_OK;
   }
   std::vector<int> rcs((size_t)T, EMP_OK);
+  std::vector<std::string> msgs((size_t)T);
   std::vector<std::thread> th;
   for (int t = 0; t < T; ++t)
     th.emplace_back([&, t] {
-      for (int64_t i = t; i < count; i += T) { const int rc = fn(i); if (rc) { rcs[(size_t)t] = rc; return; } }
+      try {
+        for (int64_t i = t; i < count; i += T) {
+          const int rc = fn(i);
+          if (rc) { rcs[(size_t)t] = rc; msgs[(size_t)t] = emp_last_error(); return; }
+        }
+      } catch (const std::bad_alloc&) {
+        rcs[(size_t)t] = EMP_ERR_NOMEM; msgs[(size_t)t] = "out of host memory in a matcher worker thread";
+      } catch (const std::exception& e) {
+        rcs[(size_t)t] = EMP_ERR_STATE; msgs[(size_t)t] = std::string("exception in a matcher worker thread: ") + e.what();
+      }
     });
   for (auto& x : th) x.join();
-  for (int rc : rcs) if (rc) return rc;
+  for (int t = 0; t < T; ++t)
+    if (rcs[(size_t)t]) {
+      set_error("%s", msgs[(size_t)t].c_str());
+      return rcs[(size_t)t];
+    }
   return EMP_OK;
 }
 
@@ -1027,10 +1053,20 @@ int emp_sm_step_apply(emp_stack_matcher* h, const int64_t* rows, const int64_t* 
       if (h->iou_of(r, c) >= h->iou_thr) matched_t[(size_t)c] = r;
     }
   }
-  // new label per object, groups in first-occurrence order
-  std::vector<int64_t> group_label;
-  std::vector<std::vector<int>> members;
-  std::unordered_map<int64_t, size_t> gi;
+  // new label per object, groups in first-occurrence order.  [Round 4: this loop and the regrouping below were the pole of
+  // a step at thousands of objects per slice (1.0 of 1.6 ms at 7 600: one hash-map node, one member vector and several
+  // re-allocations PER OBJECT); now two passes over flat arrays -- group index per object through an open-addressing
+  // table kept in the handle, counts, then every group's member list sized once.]
+  std::vector<int64_t>& group_label = h->grp_label;
+  std::vector<int>& gidx = h->grp_of;
+  group_label.clear();
+  gidx.assign((size_t)nm, 0);
+  size_t cap = 16;
+  while (cap < (size_t)nm * 2 + 2) cap <<= 1;
+  if (h->ht_key.size() < cap) { h->ht_key.assign(cap, 0); h->ht_val.assign(cap, 0); h->ht_stamp.assign(cap, 0); h->ht_epoch = 0; }
+  if (++h->ht_epoch == 0) { std::fill(h->ht_stamp.begin(), h->ht_stamp.end(), 0u); h->ht_epoch = 1; }
+  const size_t hmask = h->ht_key.size() - 1;
+  const uint32_t epoch = h->ht_epoch;
   for (int c = 0; c < nm; ++c) {
     int64_t nl;
     if (matched_t[(size_t)c] >= 0) {
@@ -1049,28 +1085,34 @@ int emp_sm_step_apply(emp_stack_matcher* h, const int64_t* rows, const int64_t* 
       else if (h->assign_new) nl = h->next_label++;
       else nl = cur.objs[(size_t)c].label;
     }
-    auto it = gi.find(nl);
-    if (it == gi.end()) {
-      gi.emplace(nl, members.size());
+    size_t slot = ((uint64_t)nl * 0x9E3779B97F4A7C15ull >> 20) & hmask;
+    while (h->ht_stamp[slot] == epoch && h->ht_key[slot] != nl) slot = (slot + 1) & hmask;
+    if (h->ht_stamp[slot] != epoch) {
+      h->ht_stamp[slot] = epoch;
+      h->ht_key[slot] = nl;
+      h->ht_val[slot] = (int)group_label.size();
       group_label.push_back(nl);
-      members.emplace_back(1, c);
-    } else {
-      members[it->second].push_back(c);
     }
+    gidx[(size_t)c] = h->ht_val[slot];
   }
-  std::vector<FObj> out(members.size());
-  for (size_t g = 0; g < members.size(); ++g) {
-    FObj& o = out[g];
-    o.label = group_label[g];
-    const std::vector<int>& mem = members[g];
-    // merge_attrs folded over the group: box union; the runs are joined when the object is read out
-    std::memcpy(o.box, cur.objs[(size_t)mem[0]].box, sizeof(o.box));
-    for (int c : mem) {
-      const FObj& sobj = cur.objs[(size_t)c];
+  const size_t G = group_label.size();
+  std::vector<int>& gcount = h->grp_count;       // member COMPONENTS per group
+  gcount.assign(G, 0);
+  for (int c = 0; c < nm; ++c) gcount[(size_t)gidx[(size_t)c]] += (int)cur.objs[(size_t)c].members.size();
+  std::vector<FObj> out(G);
+  for (size_t g = 0; g < G; ++g) { out[g].label = group_label[g]; out[g].members.reserve((size_t)gcount[g]); }
+  // merge_attrs folded over the group, objects in ascending order (= first-occurrence order inside a group): box union;
+  // the runs are joined when the object is read out
+  for (int c = 0; c < nm; ++c) {
+    FObj& o = out[(size_t)gidx[(size_t)c]];
+    const FObj& sobj = cur.objs[(size_t)c];
+    if (o.members.empty()) {
+      std::memcpy(o.box, sobj.box, sizeof(o.box));
+    } else {
       o.box[0] = std::min(o.box[0], sobj.box[0]); o.box[1] = std::min(o.box[1], sobj.box[1]);
       o.box[2] = std::max(o.box[2], sobj.box[2]); o.box[3] = std::max(o.box[3], sobj.box[3]);
-      o.members.insert(o.members.end(), sobj.members.begin(), sobj.members.end());
     }
+    o.members.insert(o.members.end(), sobj.members.begin(), sobj.members.end());
   }
   cur.objs.swap(out);
   h->target_idx = h->pending;      // update_target

@@ -44,6 +44,7 @@ struct DevConv {  // packed conv weights
   float* b = nullptr;
   int cout = 0, cin = 0, cin_pad = 0, kh = 1, kw = 1;
   int cin2 = 0, cin2_pad = 0;     // K-concatenated second source (conv3 + projection shortcut)
+  bool wsplit = false;            // the "second source" is the SAME input again, against the lo halves of an fp16 hi + lo weight pair
 };
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -69,10 +70,28 @@ struct emp_pdl {
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
   bool fuse_pr = [] { const char* e = getenv("EMP_FUSE_PR"); return !(e && e[0] == '0'); }();             // pointrend.hip
   // Separable blocks with an exact depthwise half (sepconv_precise.hip: fp32 taps, depthwise result as fp16 hi + lo, 2
-  // MFMAs per product): 1 (default) = the blocks the CENTRE heat-map depends on -- the
-  // last-stage fusion conv(s) of the decoder that feeds ins_center and the ins_center head -- which is where the
-  // north star's 1e-3 on the heat-maps was missed; 2 = every fused 5x5 block; 0 = none (round-2 numerics).
+  // MFMAs per product).  EMP_PRECISE_SEPCONV:
+  //   1 (default) = the blocks the CENTRE heat-map and the offsets depend on: the last-stage fusion conv(s) of the decoder
+  //                 that feeds ins_center, the ins_center head and -- BiFPN networks, round 4 -- the ins_xy head and every
+  //                 3x3 node of the FPN that feeds that decoder.  The precise nodes ALWAYS run fused (no tile-count threshold): one kernel,
+  //                 one rounding sequence at every batch size, so a tile's result does not depend on the batch it
+  //                 arrives in;
+  //   2 = every fused block and node; 0 = none (round-2 numerics);
+  //   A/B switches: 3 = the ins_center head only, 4 = the decoder's fusion convs only, 5 = 1 + the nodes of BOTH FPNs,
+  //   6 = 1 + the ins_xy head, 7 = round 3's default (head + fusion convs, no nodes).
   int precise_sepconv = [] { const char* e = getenv("EMP_PRECISE_SEPCONV"); return e ? atoi(e) : 1; }();
+  // BiFPN networks (round 4): the weights of the layers the centre heat-map is most sensitive to as fp16 hi + lo PAIRS --
+  // the pointwise convs of the precise 128-cout blocks (a third MFMA per product, sepconv_precise.hip WS) and the
+  // transposed convs of the decoder that feeds the centre head (the lo halves ride as a K-concatenated "second source"
+  // on the same input: ConvParams::in2).  tools/error_budget.py --arch bifpn: those roundings are 80 % of the weight-side
+  // variance; 512^2 tile, ctr rms / scale 1.13e-3 -> 0.96e-3.  EMP_PRECISE_WSPLIT=0 switches it off (A/B).
+  bool precise_wsplit = [] { const char* e = getenv("EMP_PRECISE_WSPLIT"); return !(e && e[0] == '0'); }();
+  // ... and the FUSED MAPS of those nodes (the fast-normalised sum a node's separable conv reads) as fp16 hi + lo pairs too:
+  // fuse_combine writes channels [hi | lo] of a 2F-wide buffer and the node runs with 2F input channels, duplicated
+  // depthwise taps and pointwise weights (depthwise and pointwise are linear: dw(hi) W + dw(lo) W = dw(hi + lo) W).  The
+  // 24 fused-map roundings of an FPN were worth more than their share of the variance: 512^2 tile, ctr rms / scale
+  // 0.96e-3 -> 0.78e-3 (format-emulating oracle).  EMP_PRECISE_FSPLIT=0 switches it off (A/B).
+  bool precise_fsplit = [] { const char* e = getenv("EMP_PRECISE_FSPLIT"); return !(e && e[0] == '0'); }();
   // BiFPN nodes run fused once the map has this many 8 x 16 tiles (a tile per CU); EMP_SEPCONV_MIN_TILES for A/B runs
   int sepconv_min_tiles = [] { const char* e = getenv("EMP_SEPCONV_MIN_TILES"); return e ? atoi(e) : 256; }();
 
@@ -126,13 +145,39 @@ const int kPlanes[4] = {64, 128, 256, 512};
 
 // does the separable block `pre` (its parameters are pre.sepconv.0 / pre.sepconv.1) run with the exact depthwise half (sepconv_precise.hip)?
 bool precise_layer(const emp_pdl* n, const std::string& pre) {
-  if (n->precise_sepconv <= 0) return false;
-  if (n->precise_sepconv == 2) return true;
+  const int mode = n->precise_sepconv;
+  if (mode <= 0) return false;
+  if (mode == 2) return true;
   const char* dec = n->cfg.ins_decoder ? "instance_decoder." : "semantic_decoder.";
   const bool head = pre.compare(0, 11, "ins_center.") == 0, fuse = pre.compare(0, strlen(dec), dec) == 0;
-  if (n->precise_sepconv == 3) return head;      // A/B switches: only the head / only the decoder's fusion convs
-  if (n->precise_sepconv == 4) return fuse;
+  if (mode == 3) return head;      // A/B switches: only the head / only the decoder's fusion convs
+  if (mode == 4) return fuse;
+  // the offsets head: mode 6, and by default on BiFPN networks (there the offsets sat at 1.1e-3 of their scale with it in
+  // fp16 and the block is a 128-channel one: +0.5 % of a forward; the Panoptic-DeepLab offsets are at 7e-4 without it)
+  if ((mode == 6 || (mode == 1 && n->cfg.arch == 1)) && pre.compare(0, 7, "ins_xy.") == 0) return true;
   return head || fuse;
+}
+
+// does the 3x3 separable node block of the BiFPN whose parameter names start with `name` ("semantic_fpn..." /
+// "instance_fpn...") run with the exact depthwise half?  Default: the FPN that feeds the centre / offset heads.
+bool precise_node(const emp_pdl* n, const std::string& name) {
+  const int mode = n->precise_sepconv;
+  if (mode == 2 || mode == 5) return true;
+  if (mode != 1 && mode != 6) return false;
+  const char* fp = n->cfg.ins_decoder ? "instance_fpn." : "semantic_fpn.";
+  return name.compare(0, strlen(fp), fp) == 0;
+}
+
+// hi + lo weight pairs (emp_pdl::precise_wsplit): BiFPN networks, the modes with precise nodes
+bool wsplit_on(const emp_pdl* n) {
+  const int mode = n->precise_sepconv;
+  return n->cfg.arch == 1 && n->precise_wsplit && (mode == 1 || mode == 2 || mode == 5 || mode == 6);
+}
+
+// the fused maps of this FPN's nodes travel as hi + lo pairs (emp_pdl::precise_fsplit): name starts with "<dec>_fpn."
+bool fsplit_on(const emp_pdl* n, const std::string& name) {
+  const int F = n->cfg.fpn_dim;
+  return wsplit_on(n) && n->precise_fsplit && n->fuse_sepconv && precise_node(n, name) && sepconvp_supported(2 * F, F, 0);
 }
 
 void expect(emp_pdl* n, const std::string& name) {
@@ -288,30 +333,37 @@ int pack_sepconv_pw(emp_pdl* n, const std::string& name) {
 
 // fragment-ordered fp16 copy of a pointwise weight for the fused separable conv with the exact depthwise half
 // (sepconv_precise.hip), when its shape qualifies
-int pack_sepconvp_pw(emp_pdl* n, const std::string& name) {
+// dup: the weight rows twice, [W | W] -- for an input that arrives as channels [hi | lo] (fsplit_on)
+int pack_sepconvp_pw(emp_pdl* n, const std::string& name, bool dup = false) {
   const DevConv& dc = n->convs.at(name);
-  if (dc.kh != 1 || dc.kw != 1 || !sepconvp_supported(dc.cin_pad, dc.cout, 0)) return EMP_OK;
+  const int cin_eff = (dup ? 2 : 1) * dc.cin_pad;
+  if (dc.kh != 1 || dc.kw != 1 || !sepconvp_supported(cin_eff, dc.cout, 0)) return EMP_OK;
   const HostParam& hp = n->params.at(name);
-  std::vector<float> w32((size_t)dc.cout * dc.cin_pad, 0.f);
+  std::vector<float> w32((size_t)dc.cout * cin_eff, 0.f);
   for (int o = 0; o < dc.cout; ++o)
-    for (int i = 0; i < dc.cin; ++i) w32[(size_t)o * dc.cin_pad + i] = hp.w[(size_t)o * dc.cin + i];
+    for (int i = 0; i < dc.cin; ++i) {
+      w32[(size_t)o * cin_eff + i] = hp.w[(size_t)o * dc.cin + i];
+      if (dup) w32[(size_t)o * cin_eff + dc.cin_pad + i] = hp.w[(size_t)o * dc.cin + i];
+    }
   void* tmp = nullptr;
   EMP_CHECK_HIP(hipMalloc(&tmp, w32.size() * sizeof(float)));
   hipError_t e = hipMemcpy(tmp, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice);
   void* d = nullptr;
-  if (e == hipSuccess) e = hipMalloc(&d, (size_t)dc.cin_pad * dc.cout * sizeof(half_t));
+  const bool ws = wsplit_on(n) && sepconvp_wsplit_supported(dc.cout);
+  if (e == hipSuccess) e = hipMalloc(&d, (size_t)(ws ? 2 : 1) * cin_eff * dc.cout * sizeof(half_t));
   if (e != hipSuccess) {
     (void)hipFree(tmp);
     set_error("%s: packing the pointwise weights: %s", name.c_str(), hipGetErrorString(e));
     return EMP_ERR_HIP;
   }
   n->owned.push_back(d);
-  int rc = launch_sepconvp_pack_pw((const float*)tmp, dc.cin_pad, dc.cin_pad, dc.cout, (half_t*)d, nullptr);
+  int rc = launch_sepconvp_pack_pw((const float*)tmp, cin_eff, cin_eff, dc.cout, (half_t*)d, nullptr, ws ? 1 : 0);
+  n->convs[name].wsplit = ws;
   e = hipStreamSynchronize(nullptr);
   (void)hipFree(tmp);
   if (rc) return rc;
   EMP_CHECK_HIP(e);
-  n->f16w[name + ".packedp"] = (half_t*)d;
+  n->f16w[name + (dup ? ".packedpd" : ".packedp")] = (half_t*)d;
   return EMP_OK;
 }
 
@@ -324,7 +376,7 @@ int upload_f32(emp_pdl* n, const std::string& key, const std::vector<float>& v) 
 }
 
 // depthwise (C,1,5,5) -> [25][Cpad] fp16
-int pack_dw(emp_pdl* n, const std::string& name, int cpad) {
+int pack_dw(emp_pdl* n, const std::string& name, int cpad, bool dup = false) {
   const HostParam& hp = n->params.at(name);
   const int C = (int)hp.shape[0];
   EMP_REQUIRE(hp.shape.size() == 4 && hp.shape[1] == 1 && hp.shape[2] == hp.shape[3] &&
@@ -344,11 +396,20 @@ int pack_dw(emp_pdl* n, const std::string& name, int cpad) {
   std::vector<float> pk32((size_t)KK * cpad, 0.f);
   for (int c = 0; c < C; ++c)
     for (int t = 0; t < KK; ++t) pk32[((size_t)(c >> 6) * KK + t) * 64 + (c & 63)] = hp.w[(size_t)c * KK + t];
+  if (dup) {      // the same taps for channels [0, cpad) and [cpad, 2 cpad): the input arrives as [hi | lo] (fsplit_on)
+    std::vector<float> d2((size_t)2 * KK * cpad, 0.f);
+    std::copy(pk32.begin(), pk32.end(), d2.begin());
+    std::copy(pk32.begin(), pk32.end(), d2.begin() + (size_t)KK * cpad);
+    const int rc2 = upload_f32(n, name + ".f32d", d2);
+    if (rc2) return rc2;
+  }
   return upload_f32(n, name + ".f32", pk32);
 }
 
 // ConvTranspose2d(k=2,s=2) weight (Cin,Cout,2,2) -> 1x1 conv with 4*Cout outputs [(dy*2+dx)*Cout + co][Cin]
-int pack_convT(emp_pdl* n, const std::string& name) {
+// split: rows [hi | lo] -- the fp16 residuals of the weights behind them, multiplied with the same input as a
+// K-concatenated second source (ConvParams::in2 = in): w*x = hi*x + lo*x in one fp32 accumulation
+int pack_convT(emp_pdl* n, const std::string& name, bool split = false) {
   const HostParam& hp = n->params.at(name);
   EMP_REQUIRE(hp.shape.size() == 4 && hp.shape[2] == 2 && hp.shape[3] == 2, "%s: expected (Cin,Cout,2,2)", name.c_str());
   DevConv dc;
@@ -357,13 +418,19 @@ int pack_convT(emp_pdl* n, const std::string& name) {
   dc.cout = 4 * co;
   dc.cin_pad = round_up(dc.cin, 64);
   dc.kh = dc.kw = 1;
-  std::vector<half_t> pk((size_t)dc.cout * dc.cin_pad, (half_t)0.f);
+  if (split) { dc.cin2 = dc.cin; dc.cin2_pad = dc.cin_pad; dc.wsplit = true; }
+  const size_t K = (size_t)dc.cin_pad + dc.cin2_pad;
+  std::vector<half_t> pk((size_t)dc.cout * K, (half_t)0.f);
   std::vector<float> b((size_t)dc.cout, 0.f);
   for (int q = 0; q < 4; ++q)
     for (int o = 0; o < co; ++o) {
       b[(size_t)q * co + o] = hp.b[o];
-      for (int i = 0; i < dc.cin; ++i)
-        pk[((size_t)q * co + o) * dc.cin_pad + i] = (half_t)hp.w[(((size_t)i * co + o) * 2 + (q >> 1)) * 2 + (q & 1)];
+      for (int i = 0; i < dc.cin; ++i) {
+        const float w = hp.w[(((size_t)i * co + o) * 2 + (q >> 1)) * 2 + (q & 1)];
+        const half_t hi = (half_t)w;
+        pk[((size_t)q * co + o) * K + i] = hi;
+        if (split) pk[((size_t)q * co + o) * K + dc.cin_pad + i] = (half_t)(w - (float)hi);
+      }
     }
   void* d;
   int rc = dev_upload(n, pk.data(), pk.size() * sizeof(half_t), &d);
@@ -479,8 +546,9 @@ int plan(emp_pdl* n, int N, int H, int W, int RS, hipStream_t stream) {
         for (int lv = 0; lv < 5; ++lv) {
           std::string q = L + ".P" + std::to_string(3 + lv);
           if (li == 0 && lv < 3) { add_act(n, pl, q + ".rtd", N, lh[lv], lw[lv], F); add_act(n, pl, q + ".rbu", N, lh[lv], lw[lv], F); }
-          add_act(n, pl, q + ".fuse", N, lh[lv], lw[lv], F);
-          if (lv > 0) add_act(n, pl, q + ".fuseb", N, lh[lv], lw[lv], F);   // bottom-up node's fused input (kept for taps)
+          const int FZ = fsplit_on(n, fp + ".") ? 2 * F : F;      // [hi | lo] pair of the fused map (emp_pdl::precise_fsplit)
+          add_act(n, pl, q + ".fuse", N, lh[lv], lw[lv], FZ);
+          if (lv > 0) add_act(n, pl, q + ".fuseb", N, lh[lv], lw[lv], FZ);   // bottom-up node's fused input (kept for taps)
           add_act(n, pl, q + ".dw", N, lh[lv], lw[lv], F);
           add_act(n, pl, q + ".td", N, lh[lv], lw[lv], F);
           add_act(n, pl, q + ".bu", N, lh[lv], lw[lv], F);
@@ -618,7 +686,7 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
       p.next_w = nullptr; p.next_b = nullptr; p.next_out = nullptr; p.next_cout = 0; p.next_ld = 0;
     }
   }
-  const double kflop = (double)(dc.cin * dc.kh * dc.kw + dc.cin2);
+  const double kflop = (double)(dc.cin * dc.kh * dc.kw + (dc.wsplit ? 0 : dc.cin2));      // a hi + lo weight pair is one product
   n->flops += 2.0 * (double)p.M * dc.cout * kflop;
   if (n->layer_log)   // EMP_LAYER_LOG=<file>: one line per MFMA launch, in launch order (tools/layer_roofline.py)
     fprintf(n->layer_log, "conv,%s,%d,%d,%d,%d,%d,%d,%d,%d\n", wname.c_str(), p.M, dc.cin_pad + dc.cin2_pad, dc.cout, dc.kh,
@@ -757,18 +825,29 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
         auto node = [&](const std::string& dirpre, const std::string& q, const half_t* a, const half_t* b2,
                         const half_t* c3, float ca, float cb, float cc, int mode, const std::string& outname) -> int {
           const Act& fz = A(q + (mode ? ".fuseb" : ".fuse"));
-          RC(launch_fuse_combine(a, b2, c3, ca, cb, cc, mode, N, fz.H, fz.W, F, fz.p, s));
-          n->flops += 2.0 * 9.0 * (double)N * fz.H * fz.W * F;
           const std::string pwn = dirpre + ".after_combines.0.0.sepconv.1";
           const DevConv& pwc = n->convs.at(pwn);
           const Act& on = A(outname);
-          // EMP_PRECISE_SEPCONV=2 / 5 (all blocks / the BiFPN nodes only): the node's 3x3 block with the exact depthwise half
-          if (n->fuse_sepconv && (n->precise_sepconv == 2 || n->precise_sepconv == 5) && n->f16w.count(pwn + ".packedp") &&
-              pwc.cin_pad == F && fz.ld == F && on.ld == pwc.cout && sepconvp_supported(F, pwc.cout, 0) &&
-              (int64_t)N * ((fz.H + 7) / 8) * ((fz.W + 15) / 16) >= n->sepconv_min_tiles) {
+          n->flops += 2.0 * 9.0 * (double)N * fz.H * fz.W * F;
+          if (fz.ld == 2 * F && n->f16w.count(pwn + ".packedpd") && on.ld == pwc.cout) {
+            // fused map as an fp16 hi + lo pair in channels [0, F) | [F, 2F); the node's block reads all 2F with duplicated
+            // taps and pointwise weights (fsplit_on): always fused, one rounding sequence at every batch size
+            RC(launch_fuse_combine(a, b2, c3, ca, cb, cc, mode, N, fz.H, fz.W, F, fz.p, s, fz.p + F, 2 * F));
+            RC(launch_sepconvp(fz.p, N, fz.H, fz.W, 2 * F, fz.ld, n->f32w.at(dirpre + ".after_combines.0.0.sepconv.0.f32d"),
+                               n->f16w.at(pwn + ".packedpd"), pwc.b, pwc.cout, 2, on.p, on.ld, nullptr, nullptr, 0, nullptr, 0,
+                               zero, s, 3, pwc.wsplit ? 1 : 0));
+            n->flops += 2.0 * (double)N * fz.H * fz.W * pwc.cout * (double)pwc.cin;
+            if (n->layer_log) fprintf(n->layer_log, "sepconvp,%s,%d,%d,%d,3,1,1,0,%d\n", pwn.c_str(), N * fz.H * fz.W, 2 * F, pwc.cout, N * fz.H * fz.W);
+            return EMP_OK;
+          }
+          RC(launch_fuse_combine(a, b2, c3, ca, cb, cc, mode, N, fz.H, fz.W, F, fz.p, s));
+          // the node's 3x3 block with the exact depthwise half (precise_node): fused at EVERY size -- the kernel is the
+          // only implementation of this rounding sequence, so no tile-count threshold may pick another one
+          if (n->fuse_sepconv && precise_node(n, pwn) && n->f16w.count(pwn + ".packedp") &&
+              pwc.cin_pad == F && fz.ld == F && on.ld == pwc.cout && sepconvp_supported(F, pwc.cout, 0)) {
             RC(launch_sepconvp(fz.p, N, fz.H, fz.W, F, fz.ld, n->f32w.at(dirpre + ".after_combines.0.0.sepconv.0.f32"),
                                n->f16w.at(pwn + ".packedp"), pwc.b, pwc.cout, 2, on.p, on.ld, nullptr, nullptr, 0, nullptr, 0,
-                               zero, s, 3));
+                               zero, s, 3, pwc.wsplit ? 1 : 0));
             n->flops += 2.0 * (double)N * fz.H * fz.W * pwc.cout * (double)pwc.cin;
             if (n->layer_log) fprintf(n->layer_log, "sepconvp,%s,%d,%d,%d,3,1,1,0,%d\n", pwn.c_str(), N * fz.H * fz.W, F, pwc.cout, N * fz.H * fz.W);
             return EMP_OK;
@@ -842,7 +921,8 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       std::string x = feat[4];
       for (int i = 0; i < 5; ++i) {
         const Act& cat = A(dp + ".cat" + std::to_string(i));
-        RC(conv(n, dp + ".upsamplings." + std::to_string(i) + ".0", A(x), 0, cat, 0, 1, 0, 1, 1, nullptr, nullptr, s, F));
+        const std::string un = dp + ".upsamplings." + std::to_string(i) + ".0";
+        RC(conv(n, un, A(x), 0, cat, 0, 1, 0, 1, 1, nullptr, nullptr, s, F, n->convs.at(un).wsplit ? &A(x) : nullptr, 1));
         const Act& sk = A(skips[i]);
         RC(launch_bilinear_ac(sk.p, N, sk.H, sk.W, F, sk.ld, cat.p + F, cat.H, cat.W, cat.ld, s));  // same size: strided copy
         x = dp + ".cat" + std::to_string(i);
@@ -857,7 +937,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
           // the decoder that feeds the centre heat-map: the block with the exact depthwise half (sepconv_precise.hip)
           RC(launch_sepconvp(cat.p, N, cat.H, cat.W, 2 * F, cat.ld, n->f32w.at(dp + ".fusion.0.sepconv.0.f32"),
                              n->f16w.at(dp + ".fusion.0.sepconv.1.packedp"), pwc.b, pwc.cout, 1, so.p, so.ld, nullptr, nullptr,
-                             0, nullptr, 0, zero, s));
+                             0, nullptr, 0, zero, s, 5, pwc.wsplit ? 1 : 0));
           n->flops += 2.0 * (double)N * cat.H * cat.W * pwc.cout * (double)pwc.cin;
           if (n->layer_log) fprintf(n->layer_log, "sepconvp,%s,%d,%d,%d,5,1,1,0,%d\n", (dp + ".fusion.0").c_str(), N * cat.H * cat.W, 2 * F, pwc.cout, N * cat.H * cat.W);
         } else if (n->fuse_sepconv && n->f16w.count(dp + ".fusion.0.sepconv.1.packed") && cat.ld == 2 * F && pwc.cin_pad == 2 * F &&
@@ -1002,7 +1082,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
       // the centre head with the exact depthwise half (sepconv_precise.hip)
       RC(launch_sepconvp(xin.p, N, hq, wq, n->dec_ch, xin.ld, n->f32w.at(p + ".head.0.0.sepconv.0.f32"),
                          n->f16w.at(p + ".head.0.0.sepconv.1.packedp"), pwc.b, pwc.cout, 1, nullptr, 0, n->f32w.at(p + ".head.1.w"),
-                         n->f32w.at(p + ".head.1.b"), hc[k], dst, (int64_t)hq * wq, rawp<half_t>(n, "zero"), s));
+                         n->f32w.at(p + ".head.1.b"), hc[k], dst, (int64_t)hq * wq, rawp<half_t>(n, "zero"), s, 5, pwc.wsplit ? 1 : 0));
       n->flops += 2.0 * (double)N * hq * wq * pwc.cout * (double)pwc.cin;
       if (n->layer_log) fprintf(n->layer_log, "sepheadp,%s,%d,%d,%d,5,1,1,0,%d\n", p.c_str(), N * hq * wq, n->dec_ch, pwc.cout, N * hq * wq);
     } else if (n->fuse_sepconv && n->f16w.count(p + ".head.0.0.sepconv.1.packed") && xin.C == n->dec_ch &&
@@ -1191,9 +1271,10 @@ int emp_pdl_finalize(emp_pdl_t* n) {
         n->fusew[nm] = w;
       } else if (nm.find(".sepconv.0") != std::string::npos) {
         const HostParam& hp = n->params[nm];
-        RC(pack_dw(n, nm, round_up((int)hp.shape[0], 64)));
+        RC(pack_dw(n, nm, round_up((int)hp.shape[0], 64), nm.find(".after_combines.") != std::string::npos && fsplit_on(n, nm)));
       } else if (nm.find(".upsamplings.") != std::string::npos) {
-        RC(pack_convT(n, nm));
+        const char* cdec = c.ins_decoder ? "instance_decoder." : "semantic_decoder.";
+        RC(pack_convT(n, nm, wsplit_on(n) && nm.compare(0, strlen(cdec), cdec) == 0));
         EMP_REQUIRE(n->convs[nm].cout == 4 * F, "%s: transposed conv must produce fpn_dim channels", nm.c_str());
       } else {
         RC(pack_conv(n, nm));
@@ -1203,7 +1284,8 @@ int emp_pdl_finalize(emp_pdl_t* n) {
         }
         if (nm.find(".after_combines.0.0.sepconv.1") != std::string::npos) {      // BiFPN nodes
           RC(pack_sepconv_pw(n, nm));
-          if (n->precise_sepconv == 2 || n->precise_sepconv == 5) RC(pack_sepconvp_pw(n, nm));
+          if (fsplit_on(n, nm)) RC(pack_sepconvp_pw(n, nm, true));
+          else if (precise_node(n, nm)) RC(pack_sepconvp_pw(n, nm));
         }
       }
     }

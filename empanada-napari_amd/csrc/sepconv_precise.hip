@@ -21,7 +21,13 @@
 //     mma waves split its own B fragments spent 4x the conversions and ran at half the speed), multiplied as
 //     w*hi + w*lo: two MFMAs per product,
 // and leaves the pointwise weights in fp16: their hi + lo form (a third MFMA per product, twice the weight traffic, 32
-// more registers) bought 0.5 % of the error for a third of the matrix work, and was removed.
+// more registers) bought 0.5 % of the error of the Panoptic-DeepLab network for a third of the matrix work, and was removed.
+//
+// Round 4: the hi + lo pointwise weights are back as a template switch (WS) for the 128-cout blocks of the BiFPN network
+// (MT = 2: the second fragment set fits the registers).  There the budget is different (tools/error_budget.py --arch
+// bifpn): the six pointwise weight matrices of the FPN nodes -- each shared by four nodes -- the decoder's fusion conv and
+// the centre head are 65 % of the weight-rounding variance of the centre heat-map, and with them carried as pairs the
+// heat-map comes under 1e-3 of its scale (1.13e-3 -> 0.97e-3 at 512^2).  Third MFMA per product: w_lo * x_hi.
 //
 // One persistent workgroup per CU, 512 threads = 8 waves with two roles (one wave of each per SIMD, so
 // the vector ALU and the matrix pipe of every SIMD are both fed):
@@ -40,7 +46,7 @@
 // one-step prefetch and a full __syncthreads the mma role alone took 1.07 ms of a 1.15 ms launch.]
 //
 // Summation order: depthwise taps ky-major, kx-minor, fp32 fma chain from 0; GEMM ascending 32-channel K-steps,
-// per step w*hi, w*lo, from the bias.  Fixed, so a batch of N equals N batch-1 calls bit for bit.
+// per step w*hi, w*lo (WS: then w_lo*hi), from the bias.  Fixed, so a batch of N equals N batch-1 calls bit for bit.
 #include "common.h"
 
 namespace emp {
@@ -121,7 +127,7 @@ __device__ __forceinline__ void split_hi_lo(const f32x2& x, f16x2& hi, f16x2& lo
 // ordinary load the compiler tracks.  The cost of that, its vmcnt(0) behind LDS-DMA traffic, is avoided by program
 // order instead: the depthwise wave consumes the taps of step g (requested a step earlier) BEFORE it issues the DMA
 // batch of step g+2, so the wait it gets covers only loads that are a whole step old; the mma waves issue no DMA.
-template <int KS, int MT, bool HEAD, int ACT>
+template <int KS, int MT, bool HEAD, int ACT, bool WS>
 __global__ void __launch_bounds__(64 * (SC_NDW + SC_NMW), 1) sepconvp_kernel(const SepParams p) {
   constexpr int NDW = SC_NDW, NMW = SC_NMW;
   constexpr int KK = KS * KS, PAD = KS / 2;
@@ -289,9 +295,17 @@ __global__ void __launch_bounds__(64 * (SC_NDW + SC_NMW), 1) sepconvp_kernel(con
     f32x4 acc[MT][8];
     f16x8 ah[MT][2];                      // fragments of the chunk being multiplied
     f16x8 nah[MT][2];                     // in flight: the next chunk's
-    auto load_a = [&](int ch, int ks) {     // MT loads
+    // WS: the lo halves of the weights (w = hi + lo to 2^-22), packed behind the hi fragments in the same order
+    constexpr int MTL = WS ? MT : 1;
+    f16x8 al[MTL][2], nal[MTL][2];
+    const size_t lo_off = (size_t)NC * A_CHUNK;
+    auto load_a = [&](int ch, int ks) {     // MT (2 MT) loads
 #pragma unroll
       for (int t = 0; t < MT; ++t) nah[t][ks] = abase[(size_t)ch * A_CHUNK + t * (2 * 64) + ks * 64];
+      if (WS) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) nal[t][ks] = abase[lo_off + (size_t)ch * A_CHUNK + t * (2 * 64) + ks * 64];
+      }
     };
     // head finishing lanes: output idx = wm*64 + lane -> (class h = idx >> 7, pixel idx & 127)
     const int fidx = wm * 64 + lane, fh = fidx >> 7, fpx = fidx & 127;
@@ -337,6 +351,10 @@ __global__ void __launch_bounds__(64 * (SC_NDW + SC_NMW), 1) sepconvp_kernel(con
           for (int t = 0; t < MT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][ks], bh, acc[t][nt], 0, 0, 0);
 #pragma unroll
           for (int t = 0; t < MT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t][ks], bl, acc[t][nt], 0, 0, 0);
+          if (WS) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t][ks], bh, acc[t][nt], 0, 0, 0);
+          }
           if (nt + 1 < 8) { bh = nh; bl = nl; }
         }
       };
@@ -344,12 +362,20 @@ __global__ void __launch_bounds__(64 * (SC_NDW + SC_NMW), 1) sepconvp_kernel(con
       // k-step 0: take over the fragments requested in the middle of the previous step, multiply, request the next ones
 #pragma unroll
       for (int t = 0; t < MT; ++t) ah[t][0] = nah[t][0];
+      if (WS) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) al[t][0] = nal[t][0];
+      }
       if (do_mma) half(0);
       __builtin_amdgcn_sched_barrier(0);
       load_a(cn, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < MT; ++t) ah[t][1] = nah[t][1];
+      if (WS) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) al[t][1] = nal[t][1];
+      }
       if (do_mma) half(1);
       __builtin_amdgcn_sched_barrier(0);
       load_a(cn, 1);
@@ -428,8 +454,9 @@ __global__ void __launch_bounds__(256) sepconvp_pack_dw_kernel(const float* __re
 }
 
 // (Cout, pw_ld) fp32 row-major -> fp16 in the fragment order of the kernel above (MT = Cout / 64)
+// lo != 0: the residuals fp16(w - fp16(w)) instead (the second half of a hi + lo weight pair)
 __global__ void __launch_bounds__(256) sepconvp_pack_pw_kernel(const float* __restrict__ w, int pw_ld, int C, int Cout,
-                                                               int MT, half_t* __restrict__ out) {
+                                                               int MT, half_t* __restrict__ out, int lo) {
   const int total = C * Cout / 8;      // 16-byte fragments
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
     int r = i;
@@ -443,29 +470,32 @@ __global__ void __launch_bounds__(256) sepconvp_pack_pw_kernel(const float* __re
     const float* src = w + (size_t)co * pw_ld + ch * 64 + ks * 32 + g16 * 8;
     f16x8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (half_t)src[e];
+    for (int e = 0; e < 8; ++e) {
+      const half_t h = (half_t)src[e];
+      v[e] = lo ? (half_t)(src[e] - (float)h) : h;
+    }
     *reinterpret_cast<f16x8*>(out + (size_t)i * 8) = v;
   }
 }
 
-template <int KS, int MT, bool HEAD, int ACT>
+template <int KS, int MT, bool HEAD, int ACT, bool WS>
 int launch_act(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconvp_kernel<KS, MT, HEAD, ACT>),
+    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconvp_kernel<KS, MT, HEAD, ACT, WS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((sepconvp_kernel<KS, MT, HEAD, ACT>), dim3(grid), dim3(64 * (SC_NDW + SC_NMW)), lds_bytes, s, p);
+  hipLaunchKernelGGL((sepconvp_kernel<KS, MT, HEAD, ACT, WS>), dim3(grid), dim3(64 * (SC_NDW + SC_NMW)), lds_bytes, s, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
 
-template <int KS, int MT, bool HEAD>
+template <int KS, int MT, bool HEAD, bool WS = false>
 int launch_one(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
-  if (p.act == 1) return launch_act<KS, MT, HEAD, 1>(p, lds_bytes, grid, s);
-  if (p.act == 2) return launch_act<KS, MT, HEAD, 2>(p, lds_bytes, grid, s);
-  return launch_act<KS, MT, HEAD, 0>(p, lds_bytes, grid, s);
+  if (p.act == 1) return launch_act<KS, MT, HEAD, 1, WS>(p, lds_bytes, grid, s);
+  if (p.act == 2) return launch_act<KS, MT, HEAD, 2, WS>(p, lds_bytes, grid, s);
+  return launch_act<KS, MT, HEAD, 0, WS>(p, lds_bytes, grid, s);
 }
 
 }  // namespace
@@ -480,12 +510,20 @@ bool sepconvp_supported(int C, int Cout, int head_c) {
          sepconvp_lds_bytes(Cout, head_c) <= 160 * 1024;
 }
 
-// packed: C * Cout fp16
-int launch_sepconvp_pack_pw(const float* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s) {
+bool sepconvp_wsplit_supported(int Cout) { return Cout == 128; }      // MT = 2: the lo fragments fit the registers
+
+// packed: C * Cout fp16; wsplit: 2 * C * Cout (the hi fragments, then the lo fragments in the same order)
+int launch_sepconvp_pack_pw(const float* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s, int wsplit) {
   EMP_REQUIRE(C % 64 == 0 && (Cout == 128 || Cout == 256) && pw_ld >= C, "sepconvp pack_pw: bad shape");
+  EMP_REQUIRE(!wsplit || sepconvp_wsplit_supported(Cout), "sepconvp pack_pw: hi + lo weights need Cout == 128");
   const int total = C * Cout / 8;
-  hipLaunchKernelGGL(sepconvp_pack_pw_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, pw_ld, C, Cout, Cout / 64, packed);
+  hipLaunchKernelGGL(sepconvp_pack_pw_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, pw_ld, C, Cout, Cout / 64, packed, 0);
   EMP_LAUNCH_CHECK();
+  if (wsplit) {
+    hipLaunchKernelGGL(sepconvp_pack_pw_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w, pw_ld, C, Cout, Cout / 64,
+                       packed + (size_t)C * Cout, 1);
+    EMP_LAUNCH_CHECK();
+  }
   return EMP_OK;
 }
 
@@ -502,8 +540,9 @@ int launch_sepconvp_pack_dw(const float* w, int ks, int C, float* packed, hipStr
 int launch_sepconvp(const half_t* in, int N, int H, int W, int C, int in_ld, const float* dww, const half_t* pww,
                     const float* bias, int Cout, int act, half_t* out, int out_ld, const float* head_w,
                     const float* head_b, int head_c, float* hout, int64_t plane, const half_t* zero, hipStream_t s,
-                    int ks) {
+                    int ks, int wsplit) {
   EMP_REQUIRE(ks == 5 || (ks == 3 && head_c == 0), "sepconv: depthwise kernel %d unsupported", ks);
+  EMP_REQUIRE(!wsplit || sepconvp_wsplit_supported(Cout), "sepconvp: hi + lo pointwise weights need Cout == 128");
   EMP_REQUIRE(sepconvp_supported(C, Cout, head_c), "sepconvp: unsupported shape C=%d Cout=%d head=%d", C, Cout, head_c);
   EMP_REQUIRE(act >= 0 && act <= 2, "sepconvp: bad activation %d", act);
   EMP_REQUIRE((head_c > 0) != (out != nullptr), "sepconvp: exactly one of the feature / head outputs");
@@ -529,10 +568,11 @@ int launch_sepconvp(const half_t* in, int N, int H, int W, int C, int in_ld, con
   const size_t lds_bytes = sepconvp_lds_bytes(Cout, head_c, ks);
   if (ks == 3) {     // BiFPN nodes (depthwise 3x3 -> pointwise -> BN -> SiLU); no head mode
     if (Cout == 256) return launch_one<3, 4, false>(p, lds_bytes, grid, s);
-    return launch_one<3, 2, false>(p, lds_bytes, grid, s);
+    return wsplit ? launch_one<3, 2, false, true>(p, lds_bytes, grid, s) : launch_one<3, 2, false>(p, lds_bytes, grid, s);
   }
   if (Cout == 256)
     return head_c ? launch_one<5, 4, true>(p, lds_bytes, grid, s) : launch_one<5, 4, false>(p, lds_bytes, grid, s);
+  if (wsplit) return head_c ? launch_one<5, 2, true, true>(p, lds_bytes, grid, s) : launch_one<5, 2, false, true>(p, lds_bytes, grid, s);
   return head_c ? launch_one<5, 2, true>(p, lds_bytes, grid, s) : launch_one<5, 2, false>(p, lds_bytes, grid, s);
 }
 

@@ -70,10 +70,11 @@ class HipPanopticDeepLab:
             c.aspp_channels = cfgd['aspp_channels'] or 0
             stages = cfgd['low_level_stages']
             c.n_stages = len(stages)
+            ins_proj = weights.ins_projection_widths(cfgd)
             for i, s in enumerate(stages):
                 c.low_level_stages[i] = s
                 c.low_level_proj_sem[i] = cfgd['low_level_channels_project'][i]
-                c.low_level_proj_ins[i] = int(cfgd['low_level_channels_project'][i] * cfgd['ins_ratio'])
+                c.low_level_proj_ins[i] = ins_proj[i]
             for i, r in enumerate(cfgd['atrous_rates']):
                 c.atrous_rates[i] = r
         c.ins_decoder = int(bool(cfgd['ins_decoder']))

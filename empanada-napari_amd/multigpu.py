@@ -214,6 +214,15 @@ def _isend_pickled(obj, dst, group):
     return _SentObj([dist.isend(size, dst=dst, group=group), dist.isend(data, dst=dst, group=group)], [size, data])
 
 
+def chain_timeout():
+    """timeout of the block chain's host group (EMP_MG_CHAIN_TIMEOUT seconds, default 600): a chain receive whose peer
+    failed -- and therefore never sends -- raises after this long instead of hanging the job for ever.  [gloo completes an
+    irecv only inside wait() (is_completed() stays False with the data already there), so the bound is the GROUP's timeout
+    on a blocking receive, not a poll.]"""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get('EMP_MG_CHAIN_TIMEOUT', '600')))
+
+
 def _recv_pickled(src, group):
     import pickle
     size = torch.zeros(1, dtype=torch.int64)
@@ -540,6 +549,20 @@ def block_slices(backend):
     return int(getattr(backend, 'block_slices', 16))
 
 
+_CHAIN_GROUPS = {}
+
+
+def _default_chain_group(group):
+    """ONE gloo group per parent group for the block chain's messages, created on first use and kept (a new group per
+    call -- one per axis -- would leak a process group each time; every rank calls this in the same order)"""
+    key = id(group) if group is not None else None
+    g = _CHAIN_GROUPS.get(key)
+    if g is None:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        g = _CHAIN_GROUPS[key] = dist.new_group(ranks=ranks, backend='gloo', timeout=chain_timeout())
+    return g
+
+
 def stack_inference(n_slices, backend, ks, group=None, host_group=None, match=None, chain_group=None):
     """the schedule the engine runs: block-interleaved when the slices are matched on the ranks, contiguous slabs otherwise"""
     blk = block_slices(backend) if match is not None else 0
@@ -547,7 +570,7 @@ def stack_inference(n_slices, backend, ks, group=None, host_group=None, match=No
         return slab_stack_inference(n_slices, backend, ks, group, host_group, match)
     blk = min(blk, max(1, n_slices // dist.get_world_size(group)))      # a short stack: still a block for every rank
     if chain_group is None:          # the chain thread's messages must not share a group with this thread's
-        chain_group = dist.new_group(backend='gloo')
+        chain_group = _default_chain_group(group)
     return block_stack_inference(n_slices, backend, ks, match, blk, group, host_group, chain_group)
 
 
@@ -715,8 +738,9 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
             if err:
                 break
         gpu_s = time.perf_counter() - t_start
-        for r in reqs:
-            r.wait()
+        if not err:      # after a chain failure the peers may never post the matching receives
+            for r in reqs:
+                r.wait()
     except BaseException:
         # this rank's GPU side failed: report it now -- the chain thread may sit in a receive that its peers will never
         # answer (it is a daemon thread; the caller ends the ranks)
@@ -894,7 +918,8 @@ def _rank_main(rank, world, port, dist_backend, model_config, engine_kwargs, bac
         else:
             dist.init_process_group(dist_backend, rank=rank, world_size=world)
             host_group = None
-        chain_group = dist.new_group(backend='gloo')      # the block chain's own messages (its thread runs beside the GPU loop)
+        # the block chain's own messages (its thread runs beside the GPU loop); a receive whose peer failed times out
+        chain_group = dist.new_group(backend='gloo', timeout=chain_timeout())
         make = (backend_factory or _default_backend_factory)(model_config, engine_kwargs, rank)
         res_q.put(('ready', rank, None))
         while True:
@@ -1037,6 +1062,7 @@ class MultiGPUEngine3d:
 
     def close(self, kill=False):
         procs, self._procs = self._procs, None
+        self.__dict__.pop('_shm', None)      # the shared-memory copy of the last volume
         if not procs:
             return
         if not kill:
@@ -1059,13 +1085,16 @@ class MultiGPUEngine3d:
             self._start()
         payload = volume
         if isinstance(volume, np.ndarray):
-            # one copy, mapped by every rank; kept for the following axes of the same volume (the widget calls xy, xz, yz on
-            # one array: _volume_inference.py:336-348) instead of copying it into shared memory again per call
-            key = (id(volume), volume.shape, volume.dtype.str, volume.__array_interface__['data'][0])
-            if getattr(self, '_shm_key', None) != key:
-                self._shm = torch.from_numpy(np.ascontiguousarray(volume)).share_memory_()
-                self._shm_key = key
-            payload = self._shm
+            # one copy, mapped by every rank.  The shared-memory ALLOCATION is kept for the following calls with the same
+            # shape / dtype (the widget calls xy, xz, yz on one array: _volume_inference.py:336-348), the CONTENT is copied
+            # in on every call: identity of the caller's array proves nothing -- ids and buffer addresses are reused once
+            # an array is freed, and the same array may have been edited in place (round 3 keyed a cache on them and could
+            # segment the previous volume).  A memcpy costs what a content check would.
+            shm = self.__dict__.get('_shm')
+            if shm is None or tuple(shm.shape) != tuple(volume.shape) or shm.numpy().dtype != volume.dtype:
+                shm = self._shm = torch.empty(tuple(volume.shape), dtype=torch.from_numpy(np.empty(0, volume.dtype)).dtype).share_memory_()
+            np.copyto(shm.numpy(), volume)
+            payload = shm
         for q in self._cmd:
             q.put(('axis', payload, axis_name, self.ks, self._match_desc(volume.shape, axis_name)))
         return self._collect('done')[0]
@@ -1078,7 +1107,7 @@ class MultiGPUEngine3d:
             self._make = factory(self.model_config, self.engine_kwargs, local)
             if dist.get_backend(self.group) == 'nccl':
                 self._host_group = dist.new_group(backend='gloo')
-            self._chain_group = dist.new_group(backend='gloo')
+            self._chain_group = dist.new_group(backend='gloo', timeout=chain_timeout())
         axis = self.axes[axis_name]
         return stack_inference(volume.shape[axis], self._make(volume, axis), self.ks, self.group, self._host_group,
                                self._match_desc(volume.shape, axis_name), self._chain_group)

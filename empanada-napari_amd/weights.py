@@ -148,6 +148,17 @@ def model_spec(cfg=None):
     return bifpn_spec(cfg) if 'BiFPN' in arch else pdl_spec(cfg)
 
 
+def ins_projection_widths(cfg):
+    """Projected low-level channels of the INSTANCE decoder, per stage.  The reference derives them as
+    ``int(s * ins_ratio)`` (panoptic_deeplab.py: ``low_level_channels_project``, ``ins_ratio``); an export carries only the
+    resulting widths, and ``int(p * (a / p)) != a`` for some ``(a, p)`` -- so ``infer_cfg`` stores the widths it READ under
+    ``low_level_channels_project_ins`` and every consumer takes them from here instead of round-tripping through a float."""
+    explicit = cfg.get('low_level_channels_project_ins')
+    if explicit is not None:
+        return [int(v) for v in explicit]
+    return [int(s * cfg['ins_ratio']) for s in cfg['low_level_channels_project']]
+
+
 def pdl_spec(cfg=None):
     """Ordered layer list of QuantizablePanopticDeepLabPR for ``cfg``."""
     cfg = dict(MITONET_PDL_CFG, **(cfg or {}))
@@ -162,8 +173,7 @@ def pdl_spec(cfg=None):
                           cfg['low_level_channels_project'], cfg['aspp_channels'])
     if cfg['ins_decoder']:
         L += pdl_decoder_spec('instance_decoder', widths[-1], dec, llc,
-                              [int(s * cfg['ins_ratio']) for s in cfg['low_level_channels_project']],
-                              cfg['aspp_channels'])
+                              ins_projection_widths(cfg), cfg['aspp_channels'])
     L += pdl_head_spec('semantic_head', dec, ncls, out_std=0.8)
     L += pdl_head_spec('ins_center', dec, 1, out_std=0.25, bias_mean=-0.5)
     L += pdl_head_spec('ins_xy', dec, 2, out_std=3.0)
@@ -346,7 +356,9 @@ def infer_cfg(state_dict, module=None):
         cfg.update(num_classes=ncls, decoder_channels=dec, aspp_channels=None if aspp == dec else aspp, num_fc=num_fc,
                    low_level_stages=stages, low_level_channels_project=proj, ins_decoder=ins)
         if ins:
-            cfg['ins_ratio'] = shape('instance_decoder.project.0.0')[0] / proj[0]
+            # the widths as exported, stage by stage (ins_ratio is kept for display only: see ins_projection_widths)
+            cfg['low_level_channels_project_ins'] = [shape(f'instance_decoder.project.{i}.0')[0] for i in range(len(stages))]
+            cfg['ins_ratio'] = cfg['low_level_channels_project_ins'][0] / proj[0]
         if module is not None:
             rates = []
             for i in (1, 2, 3):

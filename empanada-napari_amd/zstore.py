@@ -400,6 +400,23 @@ class DirGroup:
         return f'<DirGroup {self.path} v{self.zarr_format} arrays={self.array_keys()}>'
 
 
+def _zarr_open_kwargs(version, mode, zarr_format):
+    """keyword arguments of ``zarr.open`` for the installed package: zarr-python 3 names the format ``zarr_format``,
+    zarr-python 2 ``zarr_version`` (and cannot create v3 stores outside its experimental API: a v3 request is dropped
+    there instead of raising a TypeError from the wrong keyword)."""
+    kw = {'mode': mode} if mode else {}
+    if zarr_format:
+        try:
+            major = int(str(version).split('.')[0])
+        except ValueError:
+            major = 3
+        if major >= 3:
+            kw['zarr_format'] = int(zarr_format)
+        elif int(zarr_format) == 2:
+            kw['zarr_version'] = 2
+    return kw
+
+
 def open_store(store_url, mode=None, zarr_format=None):
     """``zarr.open(store_url[, mode])`` of the reference (inference.py:58,113,404,464): the zarr package when it is
     installed, otherwise the directory-store reader / writer above.  ``mode``: 'w' create (delete what is there),
@@ -410,8 +427,7 @@ def open_store(store_url, mode=None, zarr_format=None):
     except ImportError:
         zarr = None
     if zarr is not None:
-        kw = {'zarr_format': zarr_format} if zarr_format else {}
-        return zarr.open(store_url, mode=mode, **kw) if mode else zarr.open(store_url, **kw)
+        return zarr.open(store_url, **_zarr_open_kwargs(getattr(zarr, '__version__', '3'), mode, zarr_format))
     url = str(store_url)
     if '://' in url and not url.startswith('file://'):
         raise NotImplementedError(f'{url}: only local directory stores without the zarr package')

@@ -228,6 +228,17 @@ EMP_API int emp_sepconvp_nhwc_f16(const void* d_in, int N, int H, int W, int C, 
                         int Cout, int act, void* d_out, int out_ld,
                         const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
                         void* stream);
+/* Round 4 -- the same block with the POINTWISE WEIGHTS as an fp16 hi + lo pair too (a third MFMA per product, w_lo * x_hi;
+ * Cout == 128 only): the 3x3 node blocks, the decoder's fusion conv and the centre head of PanopticBiFPNPR
+ * (models/quantization/panoptic_bifpn.py:147-161, decoders/bifpn.py:35-134), whose pointwise weight roundings were 65 %
+ * of the weight-side error of the centre heat-map (tools/error_budget.py --arch bifpn).  emp_sepconvp_ws_pack_pw writes
+ * 2*C*Cout fp16 (the hi fragments, then the lo fragments); every other argument as above. */
+EMP_API int emp_sepconvp_ws_pack_pw(const void* d_pw_w, int pw_ld, int C, int Cout, void* d_packed, void* stream);
+EMP_API int emp_sepconvp_ws_nhwc_f16(const void* d_in, int N, int H, int W, int C, int in_ld, int K,
+                        const void* d_dw_w, const void* d_pw_w, const float* d_bias,
+                        int Cout, int act, void* d_out, int out_ld,
+                        const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
+                        void* stream);
 
 /* ------------------------------------------------------------------------
  * 3. Instance post-processing (hot loop 2), one launch group per batch

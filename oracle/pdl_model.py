@@ -15,12 +15,12 @@ import torch.nn.functional as F
 RESNET50_LAYERS = (3, 4, 6, 3)
 
 
-def precise_block(pre, ins_decoder=True):
+def precise_block(pre, ins_decoder=True, bifpn=False):
     """Which separable blocks the HIP engine computes with an exact depthwise half (csrc/sepconv_precise.hip: fp32 taps,
     depthwise result carried as an fp16 hi + lo pair; pointwise weights fp16) -- the rule of pdl_net.hip's ``precise_layer``: by default the
     blocks the centre heat-map depends on (the fusion convs of the decoder that feeds ``ins_center`` and the
-    ``ins_center`` head); EMP_PRECISE_SEPCONV=2 every fused 5x5 block, 0 none.  ``pre`` is the block's parameter prefix
-    (``<pre>.sepconv.0`` / ``.1``).  Test infrastructure mirrors the switch so that A/B runs stay comparable."""
+    ``ins_center`` head); EMP_PRECISE_SEPCONV=2 every fused 5x5 block, 0 none, 6 the ``ins_xy`` head too.  ``pre`` is the
+    block's parameter prefix (``<pre>.sepconv.0`` / ``.1``).  Test infrastructure mirrors the switch so that A/B runs stay comparable."""
     mode = int(os.environ.get('EMP_PRECISE_SEPCONV', '1'))
     if mode <= 0:
         return False
@@ -32,7 +32,62 @@ def precise_block(pre, ins_decoder=True):
         return head
     if mode == 4:
         return fuse
+    if (mode == 6 or (mode == 1 and bifpn)) and pre.startswith('ins_xy.'):     # the offsets head: default on BiFPN networks
+        return True
     return head or fuse
+
+
+def precise_node(pre, ins_decoder=True, C=128, Cout=128):
+    """pdl_net.hip's ``precise_node``: the 3x3 separable node blocks of the BiFPN that feeds the centre / offset heads run
+    with the exact depthwise half by default (EMP_PRECISE_SEPCONV 1 / 6), those of both FPNs with 2 / 5, none otherwise --
+    where the kernel supports the shape (``sepconvp_supported``)."""
+    if not (C % 64 == 0 and 128 <= C <= 512 and Cout in (128, 256)):
+        return False
+    mode = int(os.environ.get('EMP_PRECISE_SEPCONV', '1'))
+    if mode in (2, 5):
+        return True
+    if mode not in (1, 6):
+        return False
+    return pre.startswith('instance_fpn.' if ins_decoder else 'semantic_fpn.')
+
+
+def wsplit_on():
+    """pdl_net.hip's ``wsplit_on`` for a BiFPN network: the weights of the precise 128-cout separable blocks' pointwise
+    convs and of the centre decoder's transposed convs are carried as fp16 hi + lo pairs (exact to ~2^-22)."""
+    return os.environ.get('EMP_PRECISE_WSPLIT', '1')[:1] != '0' and int(os.environ.get('EMP_PRECISE_SEPCONV', '1')) in (1, 2, 5, 6)
+
+
+def fsplit_on():
+    """pdl_net.hip's ``fsplit_on``: the fused maps of the precise FPN's nodes travel as fp16 hi + lo pairs"""
+    return wsplit_on() and os.environ.get('EMP_PRECISE_FSPLIT', '1')[:1] != '0'
+
+
+def engine_emu(P, cfg, weights=True, acts=True):
+    """``Fp16Emu`` configured like the HIP engine for this network: fp16 everywhere except where the engine carries hi + lo
+    pairs (BiFPN: ``wsplit_names`` weights, the centre FPN's fused maps)."""
+    emu = Fp16Emu(weights, acts, wsplit_names(P, cfg))
+    if 'BiFPN' in cfg.get('arch', '') and fsplit_on():
+        emu.split_acts_prefix = ('instance_fpn.' if cfg['ins_decoder'] else 'semantic_fpn.')
+    return emu
+
+
+def wsplit_names(P, cfg):
+    """the parameters of a BiFPN network that the engine carries as hi + lo pairs (``Fp16Emu(split_weights=...)``)"""
+    if 'BiFPN' not in cfg.get('arch', '') or not wsplit_on():
+        return set()
+    insd = bool(cfg['ins_decoder'])
+    dec = 'instance' if insd else 'semantic'
+    out = {k for k in P if k.startswith(f'{dec}_decoder.upsamplings.')}
+    for k, (w, _) in P.items():
+        if not k.endswith('.sepconv.1') or w.shape[0] != 128:
+            continue
+        pre = k[:-len('.sepconv.1')]
+        if '.after_combines.' in k:
+            if precise_node(k, insd, w.shape[1], w.shape[0]):
+                out.add(k)
+        elif precise_block(pre, insd, True) and not (pre.endswith('.head.0.0') and P[pre[:-len('.head.0.0')] + '.head.1'][0].shape[0] > 2):
+            out.add(k)
+    return out
 
 
 def _t(a):
@@ -50,6 +105,8 @@ class Fp16Emu:
     after the residual add + ReLU, under the block's name), ``bilinear:<decoder>``, ``pr.features``.
     ``split_weights``: parameter names whose weights the engine carries as an fp16 hi + lo pair (exact to
     ~2^-22 relative): rounded to that pair instead of to one fp16."""
+
+    split_acts_prefix = None      # activation sites '<prefix>...fuse<i>' are carried as hi + lo pairs (engine_emu)
 
     def __init__(self, weights=True, acts=True, split_weights=()):
         self.weights, self.acts, self.split_weights = weights, acts, set(split_weights)
@@ -81,6 +138,9 @@ class Fp16Emu:
         if site not in self.sites_a:
             self.sites_a.append(site)
         on = self.acts is True or (self.acts and site in self.acts)
+        if on and self.split_acts_prefix and site.startswith(self.split_acts_prefix) and '.fuse' in site:
+            hi = self.r16(x)
+            return hi + self.r16(x - hi)
         return self.r16(x) if on else x
 
 
@@ -176,9 +236,9 @@ def decoder_forward(P, pre, pyr, low_level_stages, rates, taps=None, ins_decoder
     return x
 
 
-def head_forward(P, pre, x, ins_decoder=True):
+def head_forward(P, pre, x, ins_decoder=True, bifpn=False):
     """heads.py:12-19."""
-    prec = precise_block(f'{pre}.head.0.0', ins_decoder) and P[f'{pre}.head.1'][0].shape[0] <= 2
+    prec = precise_block(f'{pre}.head.0.0', ins_decoder, bifpn) and P[f'{pre}.head.1'][0].shape[0] <= 2
     x = _conv(x, (P[f'{pre}.head.0.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=None if prec else True, w32=prec)
     x = _conv(x, P[f'{pre}.head.0.0.sepconv.1'], relu=True)      # fused head: this map stays fp32 on chip
     return _conv(x, P[f'{pre}.head.1'], w32=True)
@@ -290,19 +350,25 @@ def _fusion_weights(P, name, eps=1e-4):
     return w / (w.sum() + eps)
 
 
-def _sep3(P, pre, x):
-    """shared after_combine block: depthwise 3x3 + pointwise (+folded BN) + SiLU (bifpn.py:35,91)."""
-    x = _conv(x, (P[f'{pre}.after_combines.0.0.sepconv.0'][0], None), padding=1, groups=x.shape[1])
-    return _silu(_conv(x, P[f'{pre}.after_combines.0.0.sepconv.1']))
+def _sep3(P, pre, x, ins_decoder=True):
+    """shared after_combine block: depthwise 3x3 + pointwise (+folded BN) + SiLU (bifpn.py:35,91).  Format emulation: the
+    engine rounds the depthwise result to fp16 unless the node runs on sepconv_precise.hip (``precise_node``), and the
+    node's output once, after the SiLU."""
+    cout = P[f'{pre}.after_combines.0.0.sepconv.1'][0].shape[0]
+    prec = precise_node(pre, ins_decoder, x.shape[1], cout)
+    x = _conv(x, (P[f'{pre}.after_combines.0.0.sepconv.0'][0], None), padding=1, groups=x.shape[1],
+              site=None if prec else True, w32=prec)
+    return _round(f'{pre}.after_combines.0.0.sepconv.1', _silu(_conv(x, P[f'{pre}.after_combines.0.0.sepconv.1'])))
 
 
 def _resample(P, pre, i, x):
     k = f'{pre}.resamplings.{i}.conv.0'
-    return _conv(x, P[k]) if k in P else x          # Resample2d is the identity when nin == fpn_dim (blocks.py:62-67)
+    return _conv(x, P[k], site=True) if k in P else x          # Resample2d is the identity when nin == fpn_dim (blocks.py:62-67)
 
 
-def bifpn_layer(P, pre, feats, eps=1e-4):
-    """BiFPNLayer.forward (bifpn.py:147-156): feats = [P3..P7] -> [P3'..P7']."""
+def bifpn_layer(P, pre, feats, eps=1e-4, ins_decoder=True):
+    """BiFPNLayer.forward (bifpn.py:147-156): feats = [P3..P7] -> [P3'..P7'].  (Format emulation: the engine writes every
+    fused map -- the input of a node's separable conv -- to HBM in fp16: sites ``<pre>.<dir>.fuse<i>``.)"""
     # top-down over [P7, P6, P5, P4, P3]
     rev = feats[::-1]
     w = _fusion_weights(P, f'{pre}.top_down_fpn.weights')
@@ -310,8 +376,8 @@ def bifpn_layer(P, pre, feats, eps=1e-4):
     for i in range(4):
         hi = _resample(P, f'{pre}.top_down_fpn', i, rev[i + 1])
         up = F.interpolate(td[-1], scale_factor=2.0, mode='nearest')
-        fused = (w[i] * up + w[i + 1] * hi) / (w[i] + w[i + 1] + eps)
-        td.append(_sep3(P, f'{pre}.top_down_fpn', fused))
+        fused = _round(f'{pre}.top_down_fpn.fuse{i}', (w[i] * up + w[i + 1] * hi) / (w[i] + w[i + 1] + eps))
+        td.append(_sep3(P, f'{pre}.top_down_fpn', fused, ins_decoder))
     tdr = td[::-1]                                   # [P3', P4', P5', P6', P7]
     w = _fusion_weights(P, f'{pre}.bottom_up_fpn.weights')
     pyr = feats[1:]                                  # [P4, P5, P6, P7]
@@ -323,41 +389,51 @@ def bifpn_layer(P, pre, feats, eps=1e-4):
             fused = (w[i] * down + w[i + 1] * lo + w[i + 2] * tdr[i + 1]) / (w[i] + w[i + 1] + w[i + 2] + eps)
         else:
             fused = (w[i] * down + w[i + 1] * lo) / (w[i] + w[i + 1] + eps)
-        bu.append(_sep3(P, f'{pre}.bottom_up_fpn', fused))
+        bu.append(_sep3(P, f'{pre}.bottom_up_fpn', _round(f'{pre}.bottom_up_fpn.fuse{i}', fused), ins_decoder))
     return bu
 
 
-def bifpn_forward_decoder(P, dec, pyr345, p2f, n_layers, taps=None):
+def bifpn_forward_decoder(P, dec, pyr345, p2f, n_layers, taps=None, ins_decoder=True):
     """BiFPN.forward (bifpn.py:185-196) + BiFPNDecoder.forward (:226-236)."""
     fp = f'{dec}_fpn'
-    p6 = F.max_pool2d(_conv(pyr345[-1], P[f'{fp}.p6_resample.conv.0']), 3, stride=2, padding=1)
+    p6 = F.max_pool2d(_conv(pyr345[-1], P[f'{fp}.p6_resample.conv.0'], site=True), 3, stride=2, padding=1)
     p7 = F.max_pool2d(p6, 3, stride=2, padding=1)
     feats = list(pyr345) + [p6, p7]
     for li in range(n_layers):
-        feats = bifpn_layer(P, f'{fp}.bifpns.{li}', feats)
+        feats = bifpn_layer(P, f'{fp}.bifpns.{li}', feats, ins_decoder=ins_decoder)
         if taps is not None:
             taps[f'{fp}.layer{li}.P3'] = feats[0]
     seq = ([p2f] + feats)[::-1]                      # [P7, P6, P5, P4, P3, P2]
     x = seq[0]
     for i in range(5):
         w, b = P[f'{dec}_decoder.upsamplings.{i}.0']
-        x = F.relu(F.conv_transpose2d(x, _t(w), _t(b), stride=2))
+        wt = _t(w) if _EMU is None else _EMU.w(w)
+        x = _round(f'{dec}_decoder.upsamplings.{i}.0', F.relu(F.conv_transpose2d(x, wt, _t(b), stride=2)))
         x = torch.cat([x, seq[i + 1]], dim=1)
-    x = _conv(x, (P[f'{dec}_decoder.fusion.0.sepconv.0'][0], None), padding=2, groups=x.shape[1])
-    return _conv(x, P[f'{dec}_decoder.fusion.0.sepconv.1'], relu=True)
+    prec = precise_block(f'{dec}_decoder.fusion.0', ins_decoder)
+    x = _conv(x, (P[f'{dec}_decoder.fusion.0.sepconv.0'][0], None), padding=2, groups=x.shape[1], site=None if prec else True, w32=prec)
+    return _conv(x, P[f'{dec}_decoder.fusion.0.sepconv.1'], relu=True, site=True)
 
 
 @torch.no_grad()
-def bifpn_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None):
-    """QuantizablePanopticBiFPNPR.forward, eval (quantization/panoptic_bifpn.py:147-161)."""
+def bifpn_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None, emu=None):
+    """QuantizablePanopticBiFPNPR.forward, eval (quantization/panoptic_bifpn.py:147-161).  emu: as ``pdl_forward``."""
+    global _EMU
+    if emu is not None:
+        _EMU = emu.bind(P)
+        try:
+            return bifpn_forward(P, x, cfg, render_steps, interpolate_ins, taps, None)
+        finally:
+            _EMU = None
+    insd = bool(cfg['ins_decoder'])
     pyr = resnet50_forward(P, x, 32, taps)          # quantizable resnet50() default output_stride = 32
-    p2f = _conv(pyr[1], P['p2_resample.conv.0'])
+    p2f = _conv(pyr[1], P['p2_resample.conv.0'], site=True)
     nl = cfg['fpn_layers']
-    semantic_x = bifpn_forward_decoder(P, 'semantic', pyr[2:], p2f, nl, taps)
-    instance_x = bifpn_forward_decoder(P, 'instance', pyr[2:], p2f, nl, taps) if cfg['ins_decoder'] else semantic_x
-    sem = head_forward(P, 'semantic_head', semantic_x)
-    ctr = head_forward(P, 'ins_center', instance_x)
-    off = head_forward(P, 'ins_xy', instance_x)
+    semantic_x = bifpn_forward_decoder(P, 'semantic', pyr[2:], p2f, nl, taps, insd)
+    instance_x = bifpn_forward_decoder(P, 'instance', pyr[2:], p2f, nl, taps, insd) if insd else semantic_x
+    sem = head_forward(P, 'semantic_head', semantic_x, insd, True)
+    ctr = head_forward(P, 'ins_center', instance_x, insd, True)
+    off = head_forward(P, 'ins_xy', instance_x, insd, True)
     if taps is not None:
         taps.update(semantic_x=semantic_x, instance_x=instance_x, sem_coarse=sem)
     sem_logits = point_rend_forward(P, sem, semantic_x, render_steps, cfg['subdivision_num_points'], cfg['num_fc'], taps)
@@ -369,8 +445,7 @@ def bifpn_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None):
 
 def model_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None, emu=None):
     if 'BiFPN' in cfg.get('arch', ''):
-        assert emu is None, 'fp16 emulation is written for the Panoptic-DeepLab forward only'
-        return bifpn_forward(P, x, cfg, render_steps, interpolate_ins, taps)
+        return bifpn_forward(P, x, cfg, render_steps, interpolate_ins, taps, emu)
     return pdl_forward(P, x, cfg, render_steps, interpolate_ins, taps, emu)
 
 
@@ -434,17 +509,22 @@ def teacher_forced_layers(P, cfg, x, tap):
     yield from _tf_heads(P, semx, insx, tap, bool(cfg['ins_decoder']))
 
 
-def _tf_weights(P, name, fp32=False):
+def _tf_weights(P, name, fp32=False, split=False):
+    """the layer's weights as the engine holds them: fp16, fp32, or (split) an fp16 hi + lo pair"""
     w, b = P[name]
-    return (_t(w) if fp32 else Fp16Emu.r16(_t(w))), _t(b)
+    t = _t(w)
+    if split:
+        hi = Fp16Emu.r16(t)
+        return hi + Fp16Emu.r16(t - hi), _t(b)
+    return (t if fp32 else Fp16Emu.r16(t)), _t(b)
 
 
-def _tf_conv(P, xin, name, stride=1, padding=0, dilation=1, groups=1, fp32=False):
-    w, b = _tf_weights(P, name, fp32)
+def _tf_conv(P, xin, name, stride=1, padding=0, dilation=1, groups=1, fp32=False, split=False):
+    w, b = _tf_weights(P, name, fp32, split)
     return F.conv2d(xin, w, b if groups == 1 else None, stride, padding, dilation, groups)
 
 
-def _tf_sepconv(P, xin, pre, pad, precise):
+def _tf_sepconv(P, xin, pre, pad, precise, wsplit=False):
     """``pre``.sepconv.0 (depthwise) -> ``pre``.sepconv.1 (pointwise + folded BN) before the activation.  precise
     (sepconv_precise.hip): fp32 taps and the depthwise result carried as an fp16 hi + lo pair -- an exact depthwise half
     on the engine's fp16 input map -- with fp16 pointwise weights.  Otherwise (sepconv.hip, or the unfused dwconv + conv
@@ -452,7 +532,7 @@ def _tf_sepconv(P, xin, pre, pad, precise):
     dw = _tf_conv(P, xin, f'{pre}.sepconv.0', 1, pad, 1, xin.shape[1], fp32=precise)
     if not precise:
         dw = Fp16Emu.r16(dw)
-    return _tf_conv(P, dw, f'{pre}.sepconv.1')
+    return _tf_conv(P, dw, f'{pre}.sepconv.1', split=precise and wsplit and P[f'{pre}.sepconv.1'][0].shape[0] == 128)
 
 
 def _tf_encoder(P, cfg, x, tap):
@@ -482,14 +562,14 @@ def _tf_encoder(P, cfg, x, tap):
     return pyr
 
 
-def _tf_heads(P, semx, insx, tap, ins_decoder=True):
+def _tf_heads(P, semx, insx, tap, ins_decoder=True, wsplit=False, bifpn=False):
     """heads.py:12-19 on the engine's decoder outputs: 5x5 separable conv + ReLU + fp32 1x1.  The engine fuses the
     whole head into one launch when it has at most two output planes (the 256-channel map then never leaves the CU,
     fp32); a wider head (multi-class semantic) stores that map in fp16 as ``<head>.pw`` and runs the 1x1 from it."""
     for head, xin in (('semantic_head', semx), ('ins_center', insx), ('ins_xy', insx)):
         w, b = _tf_weights(P, f'{head}.head.1', fp32=True)
-        prec = precise_block(f'{head}.head.0.0', ins_decoder) and w.shape[0] <= 2
-        y = F.relu(_tf_sepconv(P, xin, f'{head}.head.0.0', 2, prec))
+        prec = precise_block(f'{head}.head.0.0', ins_decoder, bifpn) and w.shape[0] <= 2
+        y = F.relu(_tf_sepconv(P, xin, f'{head}.head.0.0', 2, prec, wsplit))
         if w.shape[0] > 2:
             yield head + '.pw', y, True
             y = tap(head + '.pw')
@@ -510,9 +590,18 @@ def teacher_forced_layers_bifpn(P, cfg, x, tap):
 
     def sep3(pre, fused_name):
         fz = tap(fused_name)
-        dw = r16(conv(fz, f'{pre}.after_combines.0.0.sepconv.0', 1, 1, 1, fz.shape[1]))
-        return _silu(conv(dw, f'{pre}.after_combines.0.0.sepconv.1'))
+        Fc = P[f'{pre}.after_combines.0.0.sepconv.0'][0].shape[0]
+        if fz.shape[1] == 2 * Fc:          # the engine's fused map as channels [hi | lo] (pdl_net.hip fsplit_on)
+            fz = fz[:, :Fc] + fz[:, Fc:]
+        cout = P[f'{pre}.after_combines.0.0.sepconv.1'][0].shape[0]
+        prec = precise_node(pre, bool(cfg['ins_decoder']), fz.shape[1], cout)
+        dw = _tf_conv(P, fz, f'{pre}.after_combines.0.0.sepconv.0', 1, 1, 1, fz.shape[1], fp32=prec)
+        if not prec:
+            dw = r16(dw)
+        return _silu(_tf_conv(P, dw, f'{pre}.after_combines.0.0.sepconv.1', split=prec and ws and cout == 128))
 
+    ws = wsplit_on()
+    cdec = 'instance' if cfg['ins_decoder'] else 'semantic'
     pyr = yield from _tf_encoder(P, cfg, x, tap)
     yield 'p2f', conv(tap(pyr[1]), 'p2_resample.conv.0'), True
     eps = 1e-4
@@ -565,11 +654,11 @@ def teacher_forced_layers_bifpn(P, cfg, x, tap):
         skips = [feat[3], feat[2], feat[1], feat[0], 'p2f']
         xn = feat[4]
         for i in range(5):
-            w, b = _tf_weights(P, f'{dp}.upsamplings.{i}.0')
+            w, b = _tf_weights(P, f'{dp}.upsamplings.{i}.0', split=ws and d == cdec)
             up = F.relu(F.conv_transpose2d(tap(xn), w, b, stride=2))     # cat{i-1} carries 2F channels, all of them inputs
             yield f'{dp}.cat{i}', torch.cat([up, tap(skips[i])], dim=1), True
             xn = f'{dp}.cat{i}'
-        yield f'{dp}.out', F.relu(_tf_sepconv(P, tap(xn), f'{dp}.fusion.0', 2, precise_block(f'{dp}.fusion.0', bool(cfg['ins_decoder'])))), True
+        yield f'{dp}.out', F.relu(_tf_sepconv(P, tap(xn), f'{dp}.fusion.0', 2, precise_block(f'{dp}.fusion.0', bool(cfg['ins_decoder'])), ws)), True
     semx = tap('semantic_decoder.out')
     insx = tap('instance_decoder.out') if cfg['ins_decoder'] else semx
-    yield from _tf_heads(P, semx, insx, tap, bool(cfg['ins_decoder']))
+    yield from _tf_heads(P, semx, insx, tap, bool(cfg['ins_decoder']), ws, True)

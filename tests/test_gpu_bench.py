@@ -1,0 +1,51 @@
+"""bench.py end to end on the GPU box: the JSON line's contract (roofline, cpu_baseline, parity), and the N > 1 form --
+two ranks time-sharing the one GPU over gloo (EMP_BENCH_SHARE_GPU=1: the builder's boxes have one GPU) -- which must
+also carry the `stack3d` block of the z-slab job (whatever `--gpus N` command the driver runs on an
+8-GPU node records the 3-D scaling too)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env=None, timeout=900):
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, env=e,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_one_gpu_line_carries_roofline_cpu_baseline_and_parity():
+    j = _bench(['--steps', '2', '--warmup', '1', '--batch', '4', '--size', '512', '--cpu-tiles', '1', '--stack3d', '0',
+                '--engine2d', '0', '--latency', '0'])
+    assert j['n_gpus'] == 1 and j['unit'] == 'tiles/s' and j['value'] > 0 and j['dtype'] == 'f16'
+    assert j['roofline']['bound'] == 'mfma' and j['cpu_baseline']['kind'] == 'port' and j['cpu_baseline']['value'] > 0
+    p = j['parity']
+    assert 'error' not in p, p
+    # the north star's gate on the float heat-maps, in rms, on the bench's own tile (tests/test_gpu_parity_fullsize.py
+    # holds the gates at BASELINE's tile size)
+    assert 0 < p['ctr_rms'] < 1e-3 and 0 < p['sem_rms'] < 1e-3, p
+    assert p['ctr_max'] < 1e-2 and p['sem_max'] < 1e-2 and 0 <= p['fg_flip_frac'] < 1e-2, p
+
+
+def test_two_ranks_sharing_the_gpu_emit_the_stack3d_block():
+    j = _bench(['--gpus', '2', '--steps', '1', '--warmup', '1', '--batch', '2', '--size', '256', '--slab-size', '512',
+                '--slab-depth', '6', '--engine2d', '0', '--latency', '0', '--no-cpu-baseline'],
+               env={'EMP_BENCH_SHARE_GPU': '1'})
+    assert j['n_gpus'] == 2 and j['config']['ranks_sharing_one_gpu'] == 2
+    s = j['stack3d']
+    assert s is not None and 'error' not in s, s
+    assert s['unit'] == 'voxels/s' and s['value'] > 0 and s['volume'] == [12, 512, 512] and s['ranks_sharing_one_gpu'] == 2
+    assert s['slab_pipeline']['ranks'] == 2 and len(s['slab_pipeline']['per_rank']) == 2
+    assert all(r['slices'] == 6 for r in s['slab_pipeline']['per_rank'])

@@ -192,3 +192,114 @@ def test_config3_512_cube_orthoplane_job_properties(engine, tmp_path):
         for s, r in zip(st, rn):
             want[s:s + r] = k
     np.testing.assert_array_equal(cvol.ravel(), want)
+
+
+def test_config4_slices_of_4096_squared(engine, monkeypatch):
+    """BASELINE configs[3] at its SLICE size (4096^2; the 4096-slice depth and the eight ranks are the driver's to run):
+    one slice per forward batch, 64 MiB probability maps under the recursive median, thousands of objects per matcher
+    step -- none of which a 1024^2 test touches.  Eight slices of a procedural volume:
+
+      * batch invariance: two slices per forward == the reference-style loop of single-slice calls of the 3-D engine;
+      * the xy job is repeatable, its panoptic stack is exactly the fill of its trackers, ids are unique and >= DIV + 1, every
+        instance passes the filters, runs are sorted, disjoint and inside the box (the properties of the 512^3 test);
+      * the sparse assignment solver (what the matcher runs) and the dense whole-matrix solve (scipy's algorithm as the
+        reference calls it) give identical trackers at this object count;
+      * one RCCL rank of the multi-GPU slab pipeline (block schedule) gives Engine3d's trackers."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from empanada_napari_amd import multigpu, synth
+    from empanada_napari_amd.inference import Engine3d
+    from empanada_napari_amd import weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    D, S = 8, 4096
+    pv = synth.ProceduralVolume((D, S, S), seed=7, cell=48)
+    vol = pv.block(0, 0, D, torch.device('cuda')).cpu().numpy()
+    assert vol.shape == (D, S, S) and vol.dtype == np.uint8
+    # the seeded network finds ~900 objects per 4096^2 slice; with the centre / semantic head biases lifted (as the 3-D
+    # tests of test_gpu_engine3d.py do) it finds thousands -- the regime of configs[3]'s matcher steps
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    for name, shift in (('ins_center.head.1', 0.75), ('semantic_head.head.1', 1.0), ('semantic_pr.point_head.predictor', 1.0)):
+        w, b = P[name]
+        P[name] = (w, b + np.float32(shift))
+    del engine
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.57571, 'std': 0.12765}}
+    kw = dict(label_divisor=DIV, median_kernel_size=3, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5, min_size=200,
+              min_extent=2)
+
+    # ---- batch invariance at this size ----
+    e3 = Engine3d(mc, batch_size=2, **kw)
+    a = [p.cpu() for p in e3.predict_slices(vol[:4], 0)]
+    e = e3.engine
+    b = []
+    for i in range(4):
+        r = e(e3.preprocessor(vol[i])['image'].unsqueeze(0), vol[i].shape, 1)
+        if r is not None:
+            b.append(r[0].cpu())
+    b += [s[0].cpu() for s in e.end(1)]
+    e.reset()
+    assert len(a) == len(b) == 4
+    for i, (p, q) in enumerate(zip(a, b)):
+        assert torch.equal(p, q), f'slice {i}: batched forward differs from the single-slice call'
+    per_slice = [int((torch.unique(p) > 0).sum()) for p in a]
+    print('objects per 4096^2 slice:', per_slice)
+    assert min(per_slice) > 2000, f'the test needs thousands of objects per slice, got {per_slice}'
+    del a, b, e3
+
+    # ---- the xy job: repeatable, stack == fill of the trackers, instance properties ----
+    e3 = Engine3d(mc, save_panoptic=True, **kw)
+    stack, trs = e3.infer_on_axis(vol, 'xy')
+    inst = trs[0].instances
+    stack2, trs2 = e3.infer_on_axis(vol, 'xy')
+    np.testing.assert_array_equal(stack, stack2)
+    assert list(inst) == list(trs2[0].instances) and len(inst) > 1000
+    ids = np.array(list(inst))
+    assert ids.min() >= DIV + 1 and len(np.unique(ids)) == len(ids)      # tracker order = first seen by the backward pass
+    want = np.zeros(vol.size, np.int32)
+    for k, o in inst.items():
+        st, rn = np.asarray(o['starts']), np.asarray(o['runs'])
+        assert int(rn.sum()) >= 200 and np.all(np.diff(st) > 0) and np.all(st[1:] >= (st + rn)[:-1])
+        z, y, x = np.unravel_index(np.concatenate([st, st + rn - 1]), vol.shape)
+        box = o['box']
+        assert z.min() >= box[0] and y.min() >= box[1] and x.min() >= box[2] and z.max() < box[3] and y.max() < box[4] and x.max() < box[5]
+        assert min(box[3] - box[0], box[4] - box[1], box[5] - box[2]) >= 2
+    # an independent fill (numpy): every run of every instance written once
+    st = np.concatenate([np.asarray(o['starts']) for o in inst.values()])
+    rn = np.concatenate([np.asarray(o['runs']) for o in inst.values()])
+    vals = np.repeat(np.array(list(inst), np.int32), [len(o['starts']) for o in inst.values()])
+    first = np.cumsum(rn) - rn
+    idx = np.repeat(st - first, rn) + np.arange(int(rn.sum()))
+    want[idx] = np.repeat(vals, rn)
+    np.testing.assert_array_equal(stack.ravel(), want)
+    del stack2, trs2, idx, want
+
+    def same(x, y):
+        assert [int(k) for k in x] == [int(k) for k in y]
+        for k in x:
+            assert tuple(int(v) for v in x[k]['box']) == tuple(int(v) for v in y[k]['box'])
+            np.testing.assert_array_equal(np.asarray(x[k]['starts']), np.asarray(y[k]['starts']))
+            np.testing.assert_array_equal(np.asarray(x[k]['runs']), np.asarray(y[k]['runs']))
+
+    # ---- sparse vs dense assignment at thousands of objects per step ----
+    monkeypatch.setenv('EMP_SM_FULL_LSA', '1')
+    _, trd = Engine3d(mc, **kw).infer_on_axis(vol, 'xy')
+    dense = trd[0].instances
+    monkeypatch.delenv('EMP_SM_FULL_LSA')
+    same(inst, dense)
+
+    # ---- one RCCL rank of the slab pipeline ----
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        monkeypatch.setattr(multigpu.MultiGPUEngine3d, 'MIN_WORLD', 1)
+        mg = multigpu.MultiGPUEngine3d(mc, **kw)
+        _, tm = mg.infer_on_axis(vol, 'xy')
+        same(tm[0].instances, inst)
+        _, tp = mg.infer_on_axis(pv, 'xy')        # the procedural description (each rank synthesises its own slab)
+        same(tp[0].instances, inst)
+    finally:
+        dist.destroy_process_group()

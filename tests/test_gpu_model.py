@@ -170,8 +170,9 @@ def test_bifpn_heads_match_reference_golden(golden_dir, tag, ncls, case):
         print(f'[{tag}{case}] {name}: max abs {err.max():.3e} (mean |ref| {scale:.3f}), rms rel {np.sqrt((err**2).mean())/scale:.3e}, '
               f'frac>1%*scale {np.mean(err > 0.05 * scale):.4f}')
         if name != 'sem_logits':
-            # relative to the map's mean magnitude; round 3 measures 1.2e-3 ... 1.8e-3 (centre) and 1.6e-3 ... 2.1e-3 (offsets)
-            assert np.sqrt((err ** 2).mean()) / scale < (2.3e-3 if name == 'ctr_hmp' else 2.8e-3)
+            # relative to the map's MEAN magnitude (stricter than its rms); round 4 measures 0.72e-3 ... 1.10e-3 (centre) and
+            # 0.96e-3 ... 1.16e-3 (offsets) -- round 3: 1.2 ... 1.8e-3 / 1.6 ... 2.1e-3; gates at 1.2 x the worst case
+            assert np.sqrt((err ** 2).mean()) / scale < (1.32e-3 if name == 'ctr_hmp' else 1.4e-3)
         else:
             # PointRend cell selection can differ on near-ties; the bulk must agree
             assert np.mean(err > 0.05 * scale) < 2e-2

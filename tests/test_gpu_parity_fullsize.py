@@ -202,6 +202,40 @@ def test_heads_vs_fp32_reference_forward(case):
     assert rep['off_rms'] < 1.5e-2 and rep['off_max'] < 8.5e-2, rep       # pixels; measured 1.20e-2 / 6.9e-2
 
 
+def test_final_semantic_map_is_gated(case):
+    """(B) for the map a user gets -- the semantic probability AFTER PointRend.  PointRend
+    re-predicts the 8192 most uncertain cells per step from the fine features; a cell picked on one side only differs by
+    (refined - interpolated), which is not a format error.  So: (1) the share of cells beyond 1e-3 and the plain rms are
+    bounded at 1.2 x what is measured (profiles/r04_parity_fullsize.json), and (2) on the cells that NEITHER side refined --
+    final logit == the twice bilinearly up-sampled coarse logit of that side -- the north star's 1e-3 holds in rms, as on
+    the coarse map they interpolate."""
+    import torch.nn.functional as F
+    o, r, t = case['out'], case['ref32'], case['taps32']
+
+    def untouched(final, coarse):
+        up = coarse
+        for _ in range(2):
+            up = F.interpolate(up, scale_factor=2.0, mode='bilinear', align_corners=False)
+        return (torch.as_tensor(final) - up).abs() < 1e-4
+
+    m_hip = untouched(o['sem_logits'], case['coarse'])
+    m_ref = untouched(r['sem_logits'], t['sem_coarse'])
+    both = (m_hip & m_ref).numpy()
+    e_prob = np.abs(_sig(o['sem_logits']) - _sig(r['sem_logits'].numpy()))
+    rep = dict(cells=int(e_prob.size), untouched_on_both_sides=float(both.mean()),
+               untouched_hip=float(m_hip.float().mean()), untouched_ref=float(m_ref.float().mean()),
+               prob_rms_untouched=float(np.sqrt((e_prob[both] ** 2).mean())), prob_max_untouched=float(e_prob[both].max()),
+               prob_frac_over_1e3_untouched=float((e_prob[both] > TOL).mean()),
+               prob_rms=float(np.sqrt((e_prob ** 2).mean())), prob_frac_over_1e3=float((e_prob > TOL).mean()),
+               selection_differs=float((m_hip != m_ref).float().mean()))
+    print('final semantic map @1024^2:', rep)
+    _report('final_semantic', rep)
+    assert rep['untouched_on_both_sides'] > 0.5, rep       # two steps x 8192 points and their 2x2 / 4x4 footprints
+    assert rep['prob_rms_untouched'] < TOL, rep            # the gate, where PointRend's selection does not interfere
+    assert rep['prob_max_untouched'] < 6.0e-3, rep         # max norm: the fp16 format, as on the coarse map (4.1e-3 x 1.2 + interpolation)
+    assert rep['prob_frac_over_1e3'] < 0.093 and rep['prob_rms'] < 0.022, rep      # 1.2 x measured (0.077 / 0.018)
+
+
 def _match_ids(a, b):
     """relabel the instances of ``a`` with the id of the instance of ``b`` they overlap most (0 stays 0)."""
     out = np.zeros_like(a)
@@ -253,7 +287,7 @@ def test_end_to_end_label_flips_vs_fp32_pipeline(case):
 def test_bifpn_512_tile_vs_fp32_forward(ncls):
     """PanopticBiFPNPR (MitoNet_v1_mini class; 4 outputs = BASELINE configs[4]) on one 512^2 tile against the fp32 oracle
     forward (pinned by tests/golden/bifpn_forward.npz): the same statement as (B) for the second network family -- rms inside
-    1e-3 of the head's scale, max reported.  Its encoder and heads are the kernels that (A) checks layer by layer."""
+    1e-3 of the head's scale ASSERTED (round 4), max bounded.  Its encoder and heads are the kernels that (A) checks layer by layer."""
     from empanada_napari_amd import synth, weights
     from empanada_napari_amd.engines import HipPanopticDeepLab
     from empanada_napari_amd.preprocess import normalize
@@ -271,7 +305,11 @@ def test_bifpn_512_tile_vs_fp32_forward(ncls):
         d = (out[k] - ref[k]).abs()
         scale = float(ref[k].pow(2).mean().sqrt())
         rep[k] = dict(max=float(d.max()), rms=float(d.pow(2).mean().sqrt()), scale_rms=scale)
-        assert rep[k]['rms'] < 2e-3 * max(1.0, scale), (k, rep[k])
+        # the north star's 1e-3, relative to the map's rms (these heads are unbounded: |ctr| rms ~8, |offsets| rms ~80 px).
+        # Round 4 measures 0.79e-3 / 0.63e-3 (centre, 1 / 4 classes) and 0.90e-3 / 0.78e-3 (offsets): precise nodes, hi + lo
+        # weight pairs and fused maps on the centre path (pdl_net.hip precise_node / wsplit_on / fsplit_on); round 3: 1.4e-3 / 1.6e-3
+        assert rep[k]['rms'] < TOL * max(1.0, scale), (k, rep[k])
+        assert rep[k]['max'] < 9e-3 * max(1.0, scale), (k, rep[k])
     if ncls == 1:
         pe = (torch.sigmoid(out['sem_logits']) - torch.sigmoid(ref['sem_logits'])).abs()
     else:

@@ -57,24 +57,35 @@ def _apply_act(y, act):
 
 
 def _ref64(x, dw, pw, b, Cc, act, ks=5, pw16=True):
-    """fp64 reference; pw16: pointwise weights rounded to fp16 as the kernel holds them (False: the all-fp32 truth)"""
+    """fp64 reference; pw16: pointwise weights rounded to fp16 as the kernel holds them (False: the all-fp32 truth;
+    'split': as the fp16 hi + lo pair of the weight-split form)"""
     xin = x[..., :Cc].double().permute(0, 3, 1, 2)
     d = F.conv2d(xin, dw.double()[:, None], padding=ks // 2, groups=Cc)
-    w = pw.to(torch.float16).double() if pw16 else pw.double()
+    if pw16 == 'split':
+        hi = pw.to(torch.float16)
+        w = hi.double() + (pw - hi.float()).to(torch.float16).double()
+    else:
+        w = pw.to(torch.float16).double() if pw16 else pw.double()
     return _apply_act(F.conv2d(d, w[:, :, None, None], b.double()), act)     # (N,Cout,H,W) fp64
 
 
-def _fused(x, dw, pw, b, case, head=None, ks=5):
+def _fused(x, dw, pw, b, case, head=None, ks=5, ws=False):
     from gpu_common import dev
     from empanada_napari_amd import _abi
     lib = _abi.load()
+    if ws:      # pointwise weights as an fp16 hi + lo pair (Cout == 128): same calls, the _ws_ entry points
+        class _L:
+            emp_sepconvp_pack_dw = lib.emp_sepconvp_pack_dw
+            emp_sepconvp_pack_pw = lib.emp_sepconvp_ws_pack_pw
+            emp_sepconvp_nhwc_f16 = lib.emp_sepconvp_ws_nhwc_f16
+        lib = _L
     N, H, W, Cc, in_ld, Cout, act = case
     xd = x.to(dev())
     dwu = dw.reshape(Cc, ks * ks).t().contiguous().float().to(dev())          # (ks*ks, C) fp32
     dwd = torch.empty_like(dwu)                                               # chunk-major [C/64][ks*ks][64]
     _abi.check(lib.emp_sepconvp_pack_dw(_abi.ptr(dwu), ks, Cc, _abi.ptr(dwd), _abi.stream_ptr(dev())), 'pack_dw')
     pwu = pw.contiguous().float().to(dev())
-    pwd = torch.empty((Cout, Cc), dtype=torch.float16, device=dev())          # fragment order
+    pwd = torch.empty(((2 if ws else 1) * Cout, Cc), dtype=torch.float16, device=dev())          # fragment order (ws: hi, then lo)
     _abi.check(lib.emp_sepconvp_pack_pw(_abi.ptr(pwu), Cc, Cc, Cout, _abi.ptr(pwd), _abi.stream_ptr(dev())), 'pack')
     bd = b.float().to(dev())
     if head is None:
@@ -202,3 +213,45 @@ def test_unsupported_shape_is_rejected():
     rc = lib.emp_sepconvp_nhwc_f16(_abi.ptr(x), 1, 8, 16, 64, 64, 5, _abi.ptr(w), _abi.ptr(p), None, 64, 1,
                                    _abi.ptr(o), 64, None, None, 0, None, _abi.stream_ptr(dev()))
     assert rc != 0 and b'unsupported' in lib.emp_last_error()
+
+
+WS_CASES = [c for c in CASES if c[5] == 128]
+WS_CASES3 = [c for c in CASES3 if c[5] == 128]
+
+
+@pytest.mark.parametrize('ks,case', [(5, c) for c in WS_CASES] + [(3, c) for c in WS_CASES3])
+def test_weight_split_form_is_the_correctly_rounded_result_with_hi_lo_weights(ks, case):
+    """Round 4 (emp_sepconvp_ws_*, Cout == 128: the BiFPN network's node / fusion / centre-head blocks): the pointwise
+    weights enter as an fp16 hi + lo pair, a third MFMA per product.  Against the fp64 reference with the SAME pair the
+    fp16 output is correctly rounded; against the all-fp32 truth it is closer than the fp16-weight form; launches repeat
+    bit for bit."""
+    x, dw, pw, b = _operands(case, ks)
+    y = _fused(x, dw, pw, b, case, ks=ks, ws=True)
+    _check_fp16_output(y, _ref64(x, dw, pw, b, case[3], case[6], ks, pw16='split'), f'{ks}x{ks} ws')
+    truth = _ref64(x, dw, pw, b, case[3], case[6], ks, pw16=False)
+    e_ws = (y.double().cpu().permute(0, 3, 1, 2) - truth).pow(2).mean().sqrt()
+    e_16 = (_fused(x, dw, pw, b, case, ks=ks).double().cpu().permute(0, 3, 1, 2) - truth).pow(2).mean().sqrt()
+    assert float(e_ws) < float(e_16), (float(e_ws), float(e_16))
+    assert torch.equal(y, _fused(x, dw, pw, b, case, ks=ks, ws=True))
+
+
+def test_weight_split_head_mode():
+    """the centre head of the BiFPN network: 5x5 block (128 -> 128, hi + lo weights) + fp32 1x1 head in one launch"""
+    case = (2, 24, 40, 128, 128, 128, 1)
+    x, dw, pw, b = _operands(case)
+    g = torch.Generator().manual_seed(5)
+    hw, hb = torch.randn((2, 128), generator=g) / np.sqrt(128), torch.randn((2,), generator=g) * 0.1
+    got = _fused(x, dw, pw, b, case, head=(hw, hb), ws=True).double().cpu()
+    y = _ref64(x, dw, pw, b, 128, 1, 5, pw16='split')
+    ref = F.conv2d(y, hw.double()[:, :, None, None], hb.double())
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 4e-6 * scale
+
+
+def test_weight_split_refuses_256_couts():
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    w = torch.zeros((256, 128), dtype=torch.float32, device=dev())
+    p = torch.zeros((512, 128), dtype=torch.float16, device=dev())
+    assert lib.emp_sepconvp_ws_pack_pw(_abi.ptr(w), 128, 128, 256, _abi.ptr(p), _abi.stream_ptr(dev())) != 0

@@ -38,10 +38,12 @@ PDL_KW = dict(encoder='resnet50', num_classes=1, stage4_stride=16, decoder_chann
               importance_sample_ratio=0.75, subdivision_steps=2, subdivision_num_points=8192)
 
 
-@pytest.mark.parametrize('variant', ['default', 'odd'])
+@pytest.mark.parametrize('variant', ['default', 'odd', 'ratio'])
 def test_panoptic_deeplab_export_is_loaded_without_arch(tmp_path, variant):
     from empanada_napari_amd import inference, weights
     kw = dict(PDL_KW)
+    if variant == 'ratio':    # int(22 * 0.7) = 15, but int(22 * (15 / 22)) = 14 -- the widths must be READ, not re-derived
+        kw.update(low_level_channels_project=[22], ins_ratio=0.7)
     if variant == 'odd':      # nothing of this is in a YAML: three classes, other widths / stages / rates / PointRend depth
         kw.update(num_classes=3, decoder_channels=128, aspp_channels=192, low_level_stages=[2, 1],
                   low_level_channels_project=[64, 32], atrous_rates=[3, 6, 9], stage4_stride=32, num_fc=2,
@@ -53,7 +55,8 @@ def test_panoptic_deeplab_export_is_loaded_without_arch(tmp_path, variant):
               'stage4_stride', 'ins_decoder', 'num_fc', 'subdivision_num_points'):
         assert cfg[k] == kw[k], (k, cfg[k], kw[k])
     assert (cfg['aspp_channels'] or cfg['decoder_channels']) == (kw['aspp_channels'] or kw['decoder_channels'])
-    assert cfg['ins_ratio'] == 0.5
+    assert variant == 'ratio' or cfg['ins_ratio'] == 0.5
+    assert weights.ins_projection_widths(cfg) == [int(s * kw['ins_ratio']) for s in kw['low_level_channels_project']]
     P = weights.fold_state_dict(sd, cfg)          # strict: every layer of the spec is found with the spec's shape
     assert len(P) == len(weights.model_spec(cfg))
     # and the folded parameters reproduce the export: oracle forward (pinned by tests/golden) == the scripted model

@@ -200,3 +200,74 @@ def test_rank_failure_is_reported(golden_dir):
     with pytest.raises(RuntimeError, match='rank'):
         eng.infer_on_axis(np.zeros((8, 64, 64), np.uint8), 'xy')
     assert eng._procs is None
+
+
+def test_shared_volume_follows_the_callers_array(monkeypatch):
+    """the shared-memory copy of a numpy volume that the spawned ranks map must hold what the caller
+    passes NOW -- not what an array with the same id / shape / buffer address held on an earlier call (a freed and
+    re-allocated volume of a per-file loop, or the same array edited in place).  The allocation is reused, the content
+    is copied on every call, and close() drops it."""
+    from empanada_napari_amd import multigpu
+    mc = {'model': 'unused.pth', 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.5, 'std': 0.1}}
+    eng = multigpu.MultiGPUEngine3d(mc, median_kernel_size=3, world_size=2, dist_backend='gloo')
+    sent = []
+
+    class Q:
+        def put(self, cmd):
+            sent.append(cmd)
+
+    eng._procs, eng._cmd = [], [Q()]
+    monkeypatch.setattr(eng, '_collect', lambda what: {0: None})
+    rng = np.random.default_rng(0)
+    storages = set()
+    for i in range(6):
+        v = rng.integers(0, 255, (5, 8, 8), dtype=np.uint8)      # freed at the next iteration: ids and addresses recur
+        eng._segs_spawn(v, 'xy')
+        np.testing.assert_array_equal(sent[-1][1].numpy(), v)
+        v[2] = 255 - v[2]                                        # the same array, edited in place
+        eng._segs_spawn(v, 'xz')
+        np.testing.assert_array_equal(sent[-1][1].numpy(), v)
+        assert sent[-1][1].is_shared()
+        storages.add(sent[-1][1].data_ptr())
+        del v
+    assert len(storages) == 1, 'the shared-memory allocation is kept across calls of one shape'
+    eng._segs_spawn(np.zeros((3, 8, 8), np.uint16), 'xy')        # another shape / dtype: a new allocation
+    assert sent[-1][1].numpy().dtype == np.uint16 and tuple(sent[-1][1].shape) == (3, 8, 8)
+    eng.close()
+    assert '_shm' not in eng.__dict__
+
+
+def _silent_peer_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import time
+    import __graft_entry__ as graft
+    graft.load_package()
+    from empanada_napari_amd import multigpu
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['EMP_MG_CHAIN_TIMEOUT'] = '2'
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cg = multigpu._default_chain_group(None)
+    assert multigpu._default_chain_group(None) is cg, 'one chain group per parent group, not one per call'
+    if rank == 0:
+        t0 = time.monotonic()
+        try:
+            multigpu._recv_pickled(1, cg)          # the peer "failed": it never sends
+            res = 'returned'
+        except Exception as e:                     # noqa: BLE001
+            res = 'raised after %.1f s: %s' % (time.monotonic() - t0, type(e).__name__)
+        open(out_path, 'w').write(res)
+    else:
+        time.sleep(6.0)
+    os._exit(0)      # no orderly teardown: rank 0's group is broken by design
+
+
+def test_chain_receive_times_out_instead_of_hanging(tmp_path):
+    """a block-chain receive whose peer never sends (it failed elsewhere) raises after
+    EMP_MG_CHAIN_TIMEOUT seconds -- the chain group is created with that timeout -- and the chain group is created once."""
+    out = str(tmp_path / 'res.txt')
+    mp.spawn(_silent_peer_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = open(out).read()
+    assert res.startswith('raised after'), res
+    assert float(res.split()[2]) < 5.5, res

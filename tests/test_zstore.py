@@ -217,3 +217,12 @@ def test_gzip_and_zlib_chunks_round_trip_and_other_codecs_are_refused(tmp_path):
         zstore.open_store(str(root), mode='r')
     with pytest.raises(NotImplementedError):
         zstore.open_store(str(tmp_path / 'v3z'), mode='w', zarr_format=3).create_array('x', shape=(4,), dtype=np.uint8, compressor='zlib')
+
+
+def test_zarr_open_kwargs_follow_the_installed_package():
+    """zarr-python 2 spells the format argument ``zarr_version``; 3 ``zarr_format``."""
+    from empanada_napari_amd import zstore
+    assert zstore._zarr_open_kwargs('3.0.8', 'w', 3) == {'mode': 'w', 'zarr_format': 3}
+    assert zstore._zarr_open_kwargs('2.18.3', 'w', 2) == {'mode': 'w', 'zarr_version': 2}
+    assert zstore._zarr_open_kwargs('2.18.3', None, 3) == {}          # zarr 2 cannot write v3: request dropped, no TypeError
+    assert zstore._zarr_open_kwargs('3.1.0', None, None) == {}

@@ -30,15 +30,17 @@ from oracle.pdl_model import Fp16Emu  # noqa: E402
 
 def heads(P, x, cfg, emu):
     taps = {}
-    o = pdl_model.pdl_forward(P, x, cfg, 2, False, taps, emu)
+    o = pdl_model.model_forward(P, x, cfg, 2, False, taps, emu)
     return {'ctr': o['ctr_hmp'], 'off': o['offsets'], 'sem_coarse': taps['sem_coarse'],
-            'prob': torch.sigmoid(o['sem_logits'])}
+            'prob': torch.sigmoid(o['sem_logits']) if o['sem_logits'].shape[1] == 1 else torch.softmax(o['sem_logits'], 1)}
 
 
 def errs(a, b):
     out = {}
     for k in ('ctr', 'off', 'sem_coarse', 'prob'):
         d = (a[k] - b[k]).abs()
+        if k in ('ctr', 'off'):
+            out[k + '_rms_rel'] = float(d.pow(2).mean().sqrt()) / max(1.0, float(b[k].pow(2).mean().sqrt()))
         out[k + '_max'] = float(d.max())
         out[k + '_rms'] = float(d.pow(2).mean().sqrt())
     # PointRend refines the 8192 most uncertain cells: probabilities away from selection flips
@@ -52,24 +54,30 @@ def main():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r02_error_budget.csv'))
     ap.add_argument('--sites', type=int, default=1, help='0: groups and mitigations only')
+    ap.add_argument('--arch', default='pdl', help="'pdl' (MitoNet class) or 'bifpn' (MitoNet_mini class, SURVEY row a5)")
+    ap.add_argument('--classes', type=int, default=1)
     args = ap.parse_args()
     torch.set_num_threads(min(os.cpu_count() or 1, 32))      # oneDNN convs stop scaling (and oversubscribe) beyond ~32 threads
-    cfg = dict(weights.MITONET_PDL_CFG)
-    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    if args.arch == 'bifpn':
+        cfg = dict(weights.MITONET_MINI_CFG, num_classes=args.classes)
+        P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
+    else:
+        cfg = dict(weights.MITONET_PDL_CFG)
+        P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
     img = synth.em_tiles(1, args.size, seed=5)
     x = torch.from_numpy(normalize(img, 0.57571, 0.12765))[:, None]
     t0 = time.time()
     ref = heads(P, x, cfg, None)
     print(f'fp32 forward {time.time() - t0:.1f} s; |ctr| rms {float(ref["ctr"].pow(2).mean().sqrt()):.3f} '
           f'|off| rms {float(ref["off"].pow(2).mean().sqrt()):.3f} |sem_coarse| rms {float(ref["sem_coarse"].pow(2).mean().sqrt()):.3f}')
-    probe = Fp16Emu(True, True)
+    probe = pdl_model.engine_emu(P, cfg)      # the engine's formats, hi + lo weight pairs and fused maps included
     full = heads(P, x, cfg, probe)
     rows = []
 
     def add(kind, site, emu):
         e = errs(heads(P, x, cfg, emu), ref)
         rows.append(dict(kind=kind, site=site, **e))
-        print(f'{kind:10s} {site:48s} ctr max {e["ctr_max"]:.2e} rms {e["ctr_rms"]:.2e} | off max {e["off_max"]:.2e} | '
+        print(f'{kind:10s} {site:60s} ctr rel {e["ctr_rms_rel"]:.2e} off rel {e["off_rms_rel"]:.2e} | ctr max {e["ctr_max"]:.2e} rms {e["ctr_rms"]:.2e} | off max {e["off_max"]:.2e} | '
               f'sem max {e["sem_coarse_max"]:.2e} rms {e["sem_coarse_rms"]:.2e} | prob max {e["prob_max"]:.2e} p99.9 {e["prob_p999"]:.2e}',
               flush=True)
         return e
