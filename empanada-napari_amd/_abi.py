@@ -33,6 +33,8 @@ PROTOTYPES = {
     'emp_pdl_destroy': (None, [vp]),
     'emp_pdl_set_param': (c_int, [vp, cp, vp, C.POINTER(c_i64), c_int, vp]),
     'emp_pdl_finalize': (c_int, [vp]),
+    'emp_pdl_set_precision': (c_int, [vp, c_int]),
+    'emp_pdl_precision': (c_int, [vp]),
     'emp_pdl_num_params': (c_int, [vp]),
     'emp_pdl_param_name': (cp, [vp, c_int]),
     'emp_pdl_reserve': (c_int, [vp, c_int, c_int, c_int]),
@@ -50,6 +52,8 @@ PROTOTYPES = {
     'emp_copy_d2d': (c_int, [vp, vp, sz, vp]),
     'emp_conv2d_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+    'emp_conv2d_nhwc_f32': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'emp_conv1x1_dual_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp,
                                   c_int, c_int, c_int, c_int, vp]),
     'emp_dwconv_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, vp, c_int, vp]),

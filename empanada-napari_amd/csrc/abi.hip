@@ -81,6 +81,22 @@ int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_l
   return launch_conv_igemm(p, variant, (hipStream_t)stream);
 }
 
+int emp_conv2d_nhwc_f32(const float* d_in, int N, int H, int W, int Cin, int in_ld, const float* d_w, const float* d_bias,
+                        const float* d_bias_n, const float* d_res, int res_ld, float* d_out, int out_ld, int Cout, int KH,
+                        int KW, int stride, int pad, int dil, int act, void* stream) {
+  EMP_REQUIRE(d_in && d_w && d_out, "conv2d_f32: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d_f32: bad geometry");
+  Conv32 p{};
+  p.in = d_in; p.in_ld = in_ld; p.w = d_w; p.bias = d_bias; p.bias_n = d_bias_n; p.res = d_res; p.res_ld = res_ld;
+  p.out = d_out; p.out_ld = out_ld;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  EMP_REQUIRE(p.Ho > 0 && p.Wo > 0 && out_ld >= Cout && (d_res == nullptr || res_ld >= Cout), "conv2d_f32: bad output geometry");
+  p.act = act;
+  return launch_conv32(p, (hipStream_t)stream);
+}
+
 int emp_conv1x1_dual_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_ld, const void* d_in2, int H2, int W2,
                               int Cin2, int in2_ld, int stride2, const void* d_w, const float* d_bias, void* d_out,
                               int out_ld, int Cout, int relu, int variant, void* stream) {

@@ -157,6 +157,34 @@ int launch_bilinear_ac_f32_nchw(const float* in, int NC, int h, int w, float* ou
 int launch_zero(void* p, size_t bytes, hipStream_t s);
 
 // ---------------------------------------------------------------------------
+// fp32 reference mode (ref32.hip): NHWC fp32 maps, fp32 weights [Cout][KH*KW][Cin16], exact fp32 MFMA
+// ---------------------------------------------------------------------------
+struct Conv32 {
+  const float* in; int in_ld;
+  const float* w; const float* bias; const float* bias_n;      // bias_n: (N, Cout) per-image bias or null
+  const float* res; int res_ld;
+  float* out; int out_ld;
+  int N, H, W, Cin, Cout, KH, KW, stride, pad, dil, Ho, Wo;
+  int act;          // 0 none, 1 ReLU, 2 SiLU
+  int ps_cout;      // > 0: k2s2 transposed-conv pixel-shuffle store, Cout == 4 * ps_cout
+};
+int launch_conv32(const Conv32& p, hipStream_t s);
+int launch_stem7x7_f32(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
+                       const float* w /*49x64*/, const float* b /*64*/, float* out, hipStream_t s);
+int launch_maxpool3x3s2_f32(const float* in, int N, int H, int W, int C, float* out, hipStream_t s);
+int launch_dwconv_f32(const float* in, int N, int H, int W, int C, int in_ld, const float* w /*[K*K][C]*/, int K, float* out,
+                      int out_ld, hipStream_t s);
+int launch_bilinear_ac_f32_nhwc(const float* in, int N, int h, int w, int C, int in_ld, float* out, int H, int W, int out_ld,
+                                hipStream_t s);
+int launch_avgpool_f32(const float* in, int N, int HW, int C, int in_ld, float* out, hipStream_t s);
+int launch_fuse_combine_f32(const float* a, const float* b, const float* c, float ca, float cb, float cc, int mode, int N,
+                            int H, int W, int C, float* out, hipStream_t s);
+int launch_head1x1_f32(const float* in, int N, int P, int K, int in_ld, const float* w, const float* b, int C, float* out,
+                       int64_t plane_size, const int32_t* scatter_idx, hipStream_t s);
+int launch_point_features_f32(const float* feat, int N, int fh, int fw, int C, int feat_ld, const float* coarse, int ncls,
+                              const int32_t* idx, int P, int H2, int W2, float* x0, float* x1, int ld, hipStream_t s);
+
+// ---------------------------------------------------------------------------
 // PointRend (pointrend.hip)
 // ---------------------------------------------------------------------------
 size_t topk_work_bytes(int N, int64_t plane);

@@ -14,10 +14,11 @@ namespace {
 // reference: encoders/resnet.py:164-167,219-221 (conv1+bn1+relu, BN folded)
 // One block = 16x16 output pixels; thread = 16 channels x 4 pixels.
 // ---------------------------------------------------------------------------
-template <typename T>
+// O = half_t (the fp16 engine) or float (the fp32 reference mode: same fp32 sums, stored unrounded)
+template <typename T, typename O = half_t>
 __global__ void __launch_bounds__(256) stem7x7_kernel(const T* __restrict__ img, float sub, float mul, int N,
                                                       int H, int W, int vh, int vw, const float* __restrict__ wgt,
-                                                      const float* __restrict__ bias, half_t* __restrict__ out,
+                                                      const float* __restrict__ bias, O* __restrict__ out,
                                                       int normalise) {
   constexpr int TO = 16, PI = TO * 2 + 5;  // 37
   __shared__ float patch[PI][PI + 1];
@@ -94,17 +95,26 @@ __global__ void __launch_bounds__(256) stem7x7_kernel(const T* __restrict__ img,
   for (int k = 0; k < 4; ++k) {
     int oy = oy0 + py[k], ox = ox0 + px[k];
     if (oy >= Ho || ox >= Wo) continue;
-    f16x8 o0, o1;
+    if constexpr (sizeof(O) == 4) {
+      float* dst = reinterpret_cast<float*>(out) + (((size_t)n * Ho + oy) * Wo + ox) * 64 + cg * 16;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float a = acc[k][c] + bv[c];
-      float d = acc[k][8 + c] + bv[8 + c];
-      o0[c] = (half_t)(a > 0.f ? a : 0.f);
-      o1[c] = (half_t)(d > 0.f ? d : 0.f);
+      for (int c = 0; c < 16; ++c) {
+        const float a = acc[k][c] + bv[c];
+        dst[c] = a > 0.f ? a : 0.f;
+      }
+    } else {
+      f16x8 o0, o1;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float a = acc[k][c] + bv[c];
+        float d = acc[k][8 + c] + bv[8 + c];
+        o0[c] = (half_t)(a > 0.f ? a : 0.f);
+        o1[c] = (half_t)(d > 0.f ? d : 0.f);
+      }
+      half_t* dst = reinterpret_cast<half_t*>(out) + (((size_t)n * Ho + oy) * Wo + ox) * 64 + cg * 16;
+      *reinterpret_cast<f16x8*>(dst) = o0;
+      *reinterpret_cast<f16x8*>(dst + 8) = o1;
     }
-    half_t* dst = out + (((size_t)n * Ho + oy) * Wo + ox) * 64 + cg * 16;
-    *reinterpret_cast<f16x8*>(dst) = o0;
-    *reinterpret_cast<f16x8*>(dst + 8) = o1;
   }
 }
 
@@ -611,6 +621,31 @@ int launch_stem7x7(const void* img, int dtype, float sub, float mul, int N, int 
     case EMP_IMG_U16:
       hipLaunchKernelGGL(stem7x7_kernel<uint16_t>, dim3(grid), dim3(256), 0, s, (const uint16_t*)img, sub, mul, N, H,
                          W, vh, vw, w, b, out, 1);
+      break;
+    default:
+      EMP_REQUIRE(false, "stem: unknown image dtype %d", dtype);
+  }
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_stem7x7_f32(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
+                       const float* w, const float* b, float* out, hipStream_t s) {
+  EMP_REQUIRE(H % 2 == 0 && W % 2 == 0, "stem: H, W must be even");
+  const int Ho = H / 2, Wo = W / 2;
+  const int grid = N * cdiv(Ho, 16) * cdiv(Wo, 16);
+  switch (dtype) {
+    case EMP_IMG_F32:
+      hipLaunchKernelGGL((stem7x7_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)img, sub, mul, N, H, W,
+                         vh, vw, w, b, out, 0);
+      break;
+    case EMP_IMG_U8:
+      hipLaunchKernelGGL((stem7x7_kernel<uint8_t, float>), dim3(grid), dim3(256), 0, s, (const uint8_t*)img, sub, mul, N, H,
+                         W, vh, vw, w, b, out, 1);
+      break;
+    case EMP_IMG_U16:
+      hipLaunchKernelGGL((stem7x7_kernel<uint16_t, float>), dim3(grid), dim3(256), 0, s, (const uint16_t*)img, sub, mul, N,
+                         H, W, vh, vw, w, b, out, 1);
       break;
     default:
       EMP_REQUIRE(false, "stem: unknown image dtype %d", dtype);

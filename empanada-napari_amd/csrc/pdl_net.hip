@@ -95,6 +95,12 @@ struct emp_pdl {
   // BiFPN nodes run fused once the map has this many 8 x 16 tiles (a tile per CU); EMP_SEPCONV_MIN_TILES for A/B runs
   int sepconv_min_tiles = [] { const char* e = getenv("EMP_SEPCONV_MIN_TILES"); return e ? atoi(e) : 256; }();
 
+  // fp32 reference mode (emp_pdl_set_precision / EMP_PRECISION=fp32; run32 below): fp32 weights, fp32 activation pool
+  int precision = [] { const char* e = getenv("EMP_PRECISION"); return (e && (!strcmp(e, "fp32") || !strcmp(e, "32"))) ? 1 : 0; }();
+  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; };
+  std::map<std::string, W32> w32;
+  std::map<std::string, std::pair<float*, size_t>> pool32;      // name -> (device buffer, floats)
+
   // device parameters
   std::map<std::string, DevConv> convs;
   std::map<std::string, float*> f32w;  // fp32 device blobs (stem, gemv, heads)
@@ -129,6 +135,7 @@ struct emp_pdl {
 
   ~emp_pdl() {
     for (void* p : owned) (void)hipFree(p);
+    for (auto& kv : pool32) (void)hipFree(kv.second.first);
     if (arena) (void)hipFree(arena);
     if (layer_log) fclose(layer_log);
     for (auto& e : prof_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1163,6 +1170,444 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
   return EMP_OK;
 }
 
+// ======================================================================================================================
+// fp32 reference mode (round 4).  The same layer schedule as run() -- panoptic_deeplab.py:194-250 / panoptic_bifpn.py:147-161
+// in eval -- with every map and weight in fp32 and no layer fusion: one generic exact-fp32 MFMA conv (ref32.hip), the
+// depthwise / pooling / resampling layers on the fp32 vector pipe.  The ASPP pooling branch still enters the projection
+// as a per-image bias (exact algebra, aspp.py:45-48,99-102).  Slow by design: the device-side fp32 comparator.
+// ======================================================================================================================
+struct T32 { float* p = nullptr; int N = 0, H = 0, W = 0, C = 0, ld = 0; };
+
+int buf32(emp_pdl* n, const std::string& key, size_t floats, float** out) {
+  auto it = n->pool32.find(key);
+  if (it == n->pool32.end() || it->second.second < floats) {
+    if (it != n->pool32.end()) { EMP_CHECK_HIP(hipFree(it->second.first)); n->pool32.erase(it); }
+    float* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, floats * sizeof(float) + 64);
+    if (e != hipSuccess) {
+      set_error("fp32 mode: hipMalloc(%zu bytes) for '%s' failed: %s", floats * sizeof(float), key.c_str(), hipGetErrorString(e));
+      return EMP_ERR_NOMEM;
+    }
+    EMP_CHECK_HIP(hipMemset(d, 0, floats * sizeof(float)));      // channel pads must read as zeros
+    n->pool32[key] = {d, floats};
+    *out = d;
+    return EMP_OK;
+  }
+  *out = it->second.first;
+  return EMP_OK;
+}
+
+int t32(emp_pdl* n, const std::string& key, int N, int H, int W, int C, T32* t) {
+  t->N = N; t->H = H; t->W = W; t->C = C; t->ld = C;
+  return buf32(n, key, (size_t)N * H * W * C, &t->p);
+}
+
+// OIHW / OIW fp32 -> [O][KH*KW][I16] fp32 (+ bias); cin_to: pad the input channels to this many (PointRend rows)
+int pack32(emp_pdl* n, const std::string& name, int cin_to = 0, const HostParam* src = nullptr) {
+  const HostParam& hp = src ? *src : n->params.at(name);
+  EMP_REQUIRE(hp.shape.size() == 4 || hp.shape.size() == 3, "%s: conv weight must be 3-d or 4-d", name.c_str());
+  emp_pdl::W32 w;
+  w.cout = (int)hp.shape[0];
+  w.cin = (int)hp.shape[1];
+  w.kh = hp.shape.size() == 4 ? (int)hp.shape[2] : 1;
+  w.kw = hp.shape.size() == 4 ? (int)hp.shape[3] : 1;
+  w.cin16 = cin_to ? cin_to : round_up(w.cin, 16);
+  EMP_REQUIRE(w.cin16 >= w.cin && w.cin16 % 16 == 0, "%s: bad channel padding", name.c_str());
+  const int kt = w.kh * w.kw;
+  std::vector<float> pk((size_t)w.cout * kt * w.cin16, 0.f);
+  for (int o = 0; o < w.cout; ++o)
+    for (int i = 0; i < w.cin; ++i)
+      for (int t = 0; t < kt; ++t) pk[((size_t)o * kt + t) * w.cin16 + i] = hp.w[((size_t)o * w.cin + i) * kt + t];
+  void* d;
+  int rc = dev_upload(n, pk.data(), pk.size() * sizeof(float), &d);
+  if (rc) return rc;
+  w.w = (float*)d;
+  rc = dev_upload(n, hp.b.data(), hp.b.size() * sizeof(float), &d);
+  if (rc) return rc;
+  w.b = (float*)d;
+  n->w32[name] = w;
+  return EMP_OK;
+}
+
+// depthwise (C,1,k,k) -> [k*k][C] fp32
+int pack32_dw(emp_pdl* n, const std::string& name, int cpad) {
+  const HostParam& hp = n->params.at(name);
+  const int C = (int)hp.shape[0], KK = (int)(hp.shape[2] * hp.shape[3]);
+  EMP_REQUIRE(cpad >= C, "%s: bad depthwise padding", name.c_str());
+  std::vector<float> pk((size_t)KK * cpad, 0.f);
+  for (int c = 0; c < C; ++c)
+    for (int t = 0; t < KK; ++t) pk[(size_t)t * cpad + c] = hp.w[(size_t)c * KK + t];
+  return upload_f32(n, name + ".dw32", pk);
+}
+
+// ConvTranspose2d(k=2,s=2) weight (Cin,Cout,2,2) -> 1x1 conv with 4*Cout outputs, fp32 (pack_convT)
+int pack32_convT(emp_pdl* n, const std::string& name) {
+  const HostParam& hp = n->params.at(name);
+  EMP_REQUIRE(hp.shape.size() == 4 && hp.shape[2] == 2 && hp.shape[3] == 2, "%s: expected (Cin,Cout,2,2)", name.c_str());
+  const int cin = (int)hp.shape[0], co = (int)hp.shape[1];
+  HostParam t;
+  t.shape = {4 * co, cin, 1, 1};
+  t.w.resize((size_t)4 * co * cin);
+  t.b.resize((size_t)4 * co);
+  for (int q = 0; q < 4; ++q)
+    for (int o = 0; o < co; ++o) {
+      t.b[(size_t)q * co + o] = hp.b[o];
+      for (int i = 0; i < cin; ++i) t.w[((size_t)q * co + o) * cin + i] = hp.w[(((size_t)i * co + o) * 2 + (q >> 1)) * 2 + (q & 1)];
+    }
+  return pack32(n, name, 0, &t);
+}
+
+#define RC32(x)          \
+  do {                   \
+    int _rc = (x);       \
+    if (_rc) return _rc; \
+  } while (0)
+
+int finalize32(emp_pdl* n) {
+  const emp_pdl_config& c = n->cfg;
+  for (int li = 1; li <= 4; ++li)
+    for (int b = 0; b < kLayers[li - 1]; ++b) {
+      const std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
+      RC32(pack32(n, p + ".conv1"));
+      RC32(pack32(n, p + ".conv2"));
+      RC32(pack32(n, p + ".conv3"));
+      if (b == 0) RC32(pack32(n, p + ".downsample.0"));
+    }
+  if (c.arch == 1) {
+    RC32(pack32(n, "p2_resample.conv.0"));
+    for (const auto& nm : n->param_names) {
+      const bool fpn = nm.find("_fpn.") != std::string::npos, dec = nm.find("_decoder.") != std::string::npos;
+      if (!fpn && !dec) continue;
+      if (nm.size() > 8 && nm.compare(nm.size() - 8, 8, ".weights") == 0) continue;      // fusew: host side (finalize)
+      if (nm.find(".sepconv.0") != std::string::npos) RC32(pack32_dw(n, nm, (int)n->params[nm].shape[0]));
+      else if (nm.find(".upsamplings.") != std::string::npos) RC32(pack32_convT(n, nm));
+      else RC32(pack32(n, nm));
+    }
+  } else {
+    const char* decs[2] = {"semantic_decoder", "instance_decoder"};
+    for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
+      const std::string p = decs[d];
+      for (int i = 0; i <= 3; ++i) RC32(pack32(n, p + ".aspp.convs." + std::to_string(i) + ".0"));
+      {   // projection: first 4A input channels -> conv; the pooled branch's A channels -> per-image bias (projpool.w)
+        const HostParam& hp = n->params[p + ".aspp.project.0"];
+        const int A = n->aspp_ch;
+        HostParam head;
+        head.shape = {A, 4 * A, 1, 1};
+        head.w.resize((size_t)A * 4 * A);
+        head.b = hp.b;
+        for (int o = 0; o < A; ++o)
+          for (int i = 0; i < 4 * A; ++i) head.w[(size_t)o * 4 * A + i] = hp.w[(size_t)o * 5 * A + i];
+        RC32(pack32(n, p + ".aspp.project.0", 0, &head));
+      }
+      int xch = n->aspp_ch;
+      for (int i = 0; i < c.n_stages; ++i) {
+        const int lp = d == 0 ? c.low_level_proj_sem[i] : c.low_level_proj_ins[i];
+        RC32(pack32(n, p + ".project." + std::to_string(i) + ".0"));
+        RC32(pack32_dw(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.0", round_up(xch + lp, 16)));
+        RC32(pack32(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1", round_up(xch + lp, 16)));
+        xch = n->dec_ch;
+      }
+    }
+  }
+  const char* heads[3] = {"semantic_head", "ins_center", "ins_xy"};
+  for (int k = 0; k < 3; ++k) {
+    const std::string p = heads[k];
+    RC32(pack32_dw(n, p + ".head.0.0.sepconv.0", n->dec_ch));
+    RC32(pack32(n, p + ".head.0.0.sepconv.1"));
+  }
+  const int ldp = round_up(n->dec_ch + n->ncls, 16);
+  for (int k = 0; k < c.num_fc; ++k) RC32(pack32(n, "semantic_pr.point_head.fc_layers." + std::to_string(k) + ".0", ldp));
+  {
+    const HostParam& hp = n->params["semantic_pr.point_head.predictor"];
+    const int K = (int)hp.shape[1];
+    std::vector<float> w((size_t)n->ncls * ldp, 0.f);
+    for (int o = 0; o < n->ncls; ++o)
+      for (int i = 0; i < K; ++i) w[(size_t)o * ldp + i] = hp.w[(size_t)o * K + i];
+    RC32(upload_f32(n, "pr.predictor.w32", w));
+  }
+  return EMP_OK;
+}
+
+// out[:, :, :, out_coff : out_coff + Cout) = act(conv(in[:, :, :, in_coff : in_coff + Cin16)) + bias (+ bias_n) (+ res))
+int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const T32& out, int out_coff, int stride, int pad,
+        int dil, int act, const T32* res, const float* bias_n, hipStream_t s, int ps_cout = 0) {
+  const emp_pdl::W32& w = n->w32.at(wname);
+  Conv32 p{};
+  p.in = in.p + in_coff; p.in_ld = in.ld;
+  p.w = w.w; p.bias = w.b; p.bias_n = bias_n;
+  p.res = res ? res->p : nullptr; p.res_ld = res ? res->ld : 0;
+  p.out = out.p + out_coff; p.out_ld = out.ld;
+  p.N = in.N; p.H = in.H; p.W = in.W; p.Cin = w.cin16; p.Cout = w.cout; p.KH = w.kh; p.KW = w.kw;
+  p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (in.H + 2 * pad - dil * (w.kh - 1) - 1) / stride + 1;
+  p.Wo = (in.W + 2 * pad - dil * (w.kw - 1) - 1) / stride + 1;
+  p.act = act; p.ps_cout = ps_cout;
+  const int up = ps_cout ? 2 : 1;
+  EMP_REQUIRE(p.Ho * up == out.H && p.Wo * up == out.W && in.N == out.N, "%s (fp32): output shape mismatch", wname.c_str());
+  EMP_REQUIRE(in_coff + w.cin16 <= in.ld && out_coff + (ps_cout ? ps_cout : w.cout) <= out.ld, "%s (fp32): channel slice out of range", wname.c_str());
+  n->flops += 2.0 * (double)p.N * p.Ho * p.Wo * w.cout * (double)(w.cin * w.kh * w.kw);
+  return launch_conv32(p, s);
+}
+
+int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw, int RS, int interp,
+          float* o_sem, float* o_ctr, float* o_off, hipStream_t s) {
+  const emp_pdl_config& c = n->cfg;
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0, "forward: H=%d W=%d must be positive multiples of 16", H, W);
+  EMP_REQUIRE(RS >= 1 && RS <= 6, "render_steps=%d out of range", RS);
+  EMP_REQUIRE(c.arch == 0 || (H % 128 == 0 && W % 128 == 0), "BiFPN forward: H=%d W=%d must be multiples of 128", H, W);
+  n->flops = 0.0;
+  std::map<std::string, T32> T;
+  auto mk = [&](const std::string& k, int H_, int W_, int C_) -> int { T32 t; int rc = t32(n, k, N, H_, W_, C_, &t); T[k] = t; return rc; };
+  auto A = [&](const std::string& k) -> T32& { return T.at(k); };
+  auto dw = [&](const T32& in, const std::string& wname, int K, const T32& out) -> int {
+    n->flops += 2.0 * K * K * (double)N * in.H * in.W * in.C;
+    return launch_dwconv_f32(in.p, N, in.H, in.W, in.C, in.ld, n->f32w.at(wname + ".dw32"), K, out.p, out.ld, s);
+  };
+  // ---- encoder ----
+  RC32(mk("stem", H / 2, W / 2, 64));
+  RC32(launch_stem7x7_f32(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("stem").p, s));
+  n->flops += 2.0 * N * (H / 2) * (W / 2) * 64.0 * 49.0;
+  RC32(mk("p1", H / 4, W / 4, 64));
+  RC32(launch_maxpool3x3s2_f32(A("stem").p, N, H / 2, W / 2, 64, A("p1").p, s));
+  std::string x = "p1", pyr[5];
+  pyr[0] = "p1";
+  for (int li = 1; li <= 4; ++li) {
+    int stride = li == 1 ? 1 : 2, dil = 1;
+    if (li == 4 && c.stage4_stride == 16) { stride = 1; dil = 2; }
+    for (int b = 0; b < kLayers[li - 1]; ++b) {
+      const int sb = b == 0 ? stride : 1, planes = kPlanes[li - 1];
+      const std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
+      const T32 xin = A(x);
+      const int ho = (xin.H - 1) / sb + 1, wo = (xin.W - 1) / sb + 1;
+      RC32(mk(p + ".c1", xin.H, xin.W, planes));
+      RC32(c32(n, p + ".conv1", xin, 0, A(p + ".c1"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+      RC32(mk(p + ".c2", ho, wo, planes));
+      RC32(c32(n, p + ".conv2", A(p + ".c1"), 0, A(p + ".c2"), 0, sb, dil, dil, 1, nullptr, nullptr, s));
+      const T32* idn = &A(x);
+      if (b == 0) {
+        RC32(mk(p + ".ds", ho, wo, planes * 4));
+        RC32(c32(n, p + ".downsample.0", xin, 0, A(p + ".ds"), 0, sb, 0, 1, 0, nullptr, nullptr, s));
+        idn = &A(p + ".ds");
+      }
+      RC32(mk(p, ho, wo, planes * 4));
+      RC32(c32(n, p + ".conv3", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, 1, idn, nullptr, s));
+      x = p;
+    }
+    pyr[li] = x;
+  }
+  std::string dec_out[2];
+  if (c.arch == 1) {
+    // ---- BiFPN decoders (bifpn.py:185-236) ----
+    const int F = c.fpn_dim;
+    const T32 p2 = A(pyr[1]);
+    RC32(mk("p2f", p2.H, p2.W, F));
+    RC32(c32(n, "p2_resample.conv.0", p2, 0, A("p2f"), 0, 1, 0, 1, 0, nullptr, nullptr, s));
+    const char* dn[2] = {"semantic", "instance"};
+    for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
+      const std::string fp = std::string(dn[d]) + "_fpn";
+      const T32 p5 = A(pyr[4]);
+      RC32(mk(fp + ".p6pre", p5.H, p5.W, F));
+      RC32(c32(n, fp + ".p6_resample.conv.0", p5, 0, A(fp + ".p6pre"), 0, 1, 0, 1, 0, nullptr, nullptr, s));
+      RC32(mk(fp + ".in.P6", p5.H / 2, p5.W / 2, F));
+      RC32(launch_maxpool3x3s2_f32(A(fp + ".p6pre").p, N, p5.H, p5.W, F, A(fp + ".in.P6").p, s));
+      RC32(mk(fp + ".in.P7", p5.H / 4, p5.W / 4, F));
+      RC32(launch_maxpool3x3s2_f32(A(fp + ".in.P6").p, N, p5.H / 2, p5.W / 2, F, A(fp + ".in.P7").p, s));
+      std::string feat[5] = {pyr[2], pyr[3], pyr[4], fp + ".in.P6", fp + ".in.P7"};
+      for (int li = 0; li < c.fpn_layers; ++li) {
+        const std::string L = fp + ".l" + std::to_string(li), pre = fp + ".bifpns." + std::to_string(li);
+        auto node = [&](const std::string& dirpre, const std::string& q, const float* a, const float* b2, const float* c3,
+                        float ca, float cb, float cc, int mode, int h_, int w_, const std::string& outname) -> int {
+          RC32(mk(q + ".fz", h_, w_, F));
+          RC32(launch_fuse_combine_f32(a, b2, c3, ca, cb, cc, mode, N, h_, w_, F, A(q + ".fz").p, s));
+          RC32(mk(q + ".dw", h_, w_, F));
+          RC32(dw(A(q + ".fz"), dirpre + ".after_combines.0.0.sepconv.0", 3, A(q + ".dw")));
+          RC32(mk(outname, h_, w_, F));
+          return c32(n, dirpre + ".after_combines.0.0.sepconv.1", A(q + ".dw"), 0, A(outname), 0, 1, 0, 1, 2, nullptr, nullptr, s);
+        };
+        auto resampled = [&](const std::string& rk, const std::string& src, const std::string& dst, std::string* name) -> int {
+          *name = src;
+          if (!n->w32.count(rk)) return EMP_OK;
+          const T32 in = A(src);
+          RC32(mk(dst, in.H, in.W, F));
+          *name = dst;
+          return c32(n, rk, in, 0, A(dst), 0, 1, 0, 1, 0, nullptr, nullptr, s);
+        };
+        {
+          const std::string dp = pre + ".top_down_fpn";
+          const float* w = n->fusew.at(dp + ".weights").data();
+          std::string td_prev = feat[4];
+          for (int i = 0; i < 4; ++i) {
+            const int lv = 3 - i;
+            const std::string q = L + ".P" + std::to_string(3 + lv);
+            std::string hi;
+            RC32(resampled(dp + ".resamplings." + std::to_string(i) + ".conv.0", feat[lv], q + ".rtd", &hi));
+            const float den = w[i] + w[i + 1] + 1e-4f;
+            const T32 hi_t = A(hi);
+            RC32(node(dp, q + ".tdn", A(td_prev).p, hi_t.p, nullptr, w[i] / den, w[i + 1] / den, 0.f, 0, hi_t.H, hi_t.W, q + ".td"));
+            td_prev = q + ".td";
+          }
+        }
+        {
+          const std::string dp = pre + ".bottom_up_fpn";
+          const float* w = n->fusew.at(dp + ".weights").data();
+          std::string bu_prev = L + ".P3.td", newfeat[5];
+          newfeat[0] = bu_prev;
+          for (int i = 0; i < 4; ++i) {
+            const int lv = i + 1;
+            const std::string q = L + ".P" + std::to_string(3 + lv);
+            std::string lo;
+            RC32(resampled(dp + ".resamplings." + std::to_string(i) + ".conv.0", feat[lv], q + ".rbu", &lo));
+            const T32 lo_t = A(lo);
+            if (i < 3) {
+              const float den = w[i] + w[i + 1] + w[i + 2] + 1e-4f;
+              RC32(node(dp, q + ".bun", A(bu_prev).p, lo_t.p, A(q + ".td").p, w[i] / den, w[i + 1] / den, w[i + 2] / den, 1, lo_t.H,
+                        lo_t.W, q + ".bu"));
+            } else {
+              const float den = w[i] + w[i + 1] + 1e-4f;
+              RC32(node(dp, q + ".bun", A(bu_prev).p, lo_t.p, nullptr, w[i] / den, w[i + 1] / den, 0.f, 1, lo_t.H, lo_t.W, q + ".bu"));
+            }
+            bu_prev = q + ".bu";
+            newfeat[lv] = bu_prev;
+          }
+          for (int lv = 0; lv < 5; ++lv) feat[lv] = newfeat[lv];
+        }
+      }
+      const std::string dp = std::string(dn[d]) + "_decoder";
+      const std::string skips[5] = {feat[3], feat[2], feat[1], feat[0], "p2f"};
+      std::string xx = feat[4];
+      for (int i = 0; i < 5; ++i) {
+        const T32 in = A(xx);
+        const std::string cn = dp + ".cat" + std::to_string(i);
+        RC32(mk(cn, in.H * 2, in.W * 2, 2 * F));
+        RC32(c32(n, dp + ".upsamplings." + std::to_string(i) + ".0", in, 0, A(cn), 0, 1, 0, 1, 1, nullptr, nullptr, s, F));
+        const T32 sk = A(skips[i]);
+        RC32(launch_bilinear_ac_f32_nhwc(sk.p, N, sk.H, sk.W, F, sk.ld, A(cn).p + F, sk.H, sk.W, 2 * F, s));      // same size: copy
+        xx = cn;
+      }
+      const T32 cat = A(xx);
+      RC32(mk(dp + ".dw", cat.H, cat.W, 2 * F));
+      RC32(dw(cat, dp + ".fusion.0.sepconv.0", 5, A(dp + ".dw")));
+      RC32(mk(dp + ".out", cat.H, cat.W, F));
+      RC32(c32(n, dp + ".fusion.0.sepconv.1", A(dp + ".dw"), 0, A(dp + ".out"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+      dec_out[d] = dp + ".out";
+    }
+  } else {
+    // ---- Panoptic-DeepLab decoders (decoders/panoptic_deeplab.py:68-80, aspp.py:96-102) ----
+    const T32 p5 = A(pyr[4]);
+    float* pooled;
+    RC32(buf32(n, "pooled", (size_t)N * p5.C, &pooled));
+    RC32(launch_avgpool_f32(p5.p, N, p5.H * p5.W, p5.C, p5.ld, pooled, s));
+    const char* decs[2] = {"semantic_decoder", "instance_decoder"};
+    for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
+      const std::string p = decs[d];
+      float *poolfeat, *bias_n;
+      RC32(buf32(n, p + ".poolfeat", (size_t)N * n->aspp_ch, &poolfeat));
+      RC32(buf32(n, p + ".bias_n", (size_t)N * n->aspp_ch, &bias_n));
+      RC32(launch_gemv(pooled, N, p5.C, n->f32w.at(p + ".pool.w"), nullptr, n->aspp_ch, 1, poolfeat, s));
+      RC32(launch_gemv(poolfeat, N, n->aspp_ch, n->f32w.at(p + ".projpool.w"), nullptr, n->aspp_ch, 0, bias_n, s));
+      RC32(mk(p + ".aspp.cat", p5.H, p5.W, 4 * n->aspp_ch));
+      RC32(c32(n, p + ".aspp.convs.0.0", p5, 0, A(p + ".aspp.cat"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+      for (int i = 1; i <= 3; ++i) {
+        const int r = c.atrous_rates[i - 1];
+        RC32(c32(n, p + ".aspp.convs." + std::to_string(i) + ".0", p5, 0, A(p + ".aspp.cat"), i * n->aspp_ch, 1, r, r, 1, nullptr, nullptr, s));
+      }
+      RC32(mk(p + ".aspp", p5.H, p5.W, n->aspp_ch));
+      RC32(c32(n, p + ".aspp.project.0", A(p + ".aspp.cat"), 0, A(p + ".aspp"), 0, 1, 0, 1, 1, nullptr, bias_n, s));
+      std::string xx = p + ".aspp";
+      int xch = n->aspp_ch;
+      for (int i = 0; i < c.n_stages; ++i) {
+        const T32 low = A(pyr[c.low_level_stages[i]]);
+        const int lp = d == 0 ? c.low_level_proj_sem[i] : c.low_level_proj_ins[i];
+        const int cpad = round_up(xch + lp, 16);
+        const std::string q = p + ".stage" + std::to_string(i);
+        RC32(mk(q + ".cat", low.H, low.W, cpad));
+        const T32 xa = A(xx);
+        RC32(launch_bilinear_ac_f32_nhwc(xa.p, N, xa.H, xa.W, xch, xa.ld, A(q + ".cat").p, low.H, low.W, cpad, s));
+        RC32(c32(n, p + ".project." + std::to_string(i) + ".0", low, 0, A(q + ".cat"), xch, 1, 0, 1, 1, nullptr, nullptr, s));
+        RC32(mk(q + ".dw", low.H, low.W, cpad));
+        RC32(dw(A(q + ".cat"), p + ".fuse." + std::to_string(i) + ".0.sepconv.0", 5, A(q + ".dw")));
+        RC32(mk(q + ".out", low.H, low.W, n->dec_ch));
+        RC32(c32(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1", A(q + ".dw"), 0, A(q + ".out"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+        xx = q + ".out";
+        xch = n->dec_ch;
+      }
+      dec_out[d] = xx;
+    }
+  }
+  if (!c.ins_decoder) dec_out[1] = dec_out[0];
+  const T32 semx = A(dec_out[0]), insx = A(dec_out[1]);
+  const int hq = semx.H, wq = semx.W;
+  EMP_REQUIRE(hq * 4 == H && wq * 4 == W, "the decoder output must be at 1/4 resolution (got %dx%d)", hq, wq);
+  // ---- heads (heads.py:12-19) ----
+  const char* heads[3] = {"semantic_head", "ins_center", "ins_xy"};
+  const int hc[3] = {n->ncls, 1, 2};
+  float* head_out[3];
+  for (int k = 0; k < 3; ++k) {
+    const std::string p = heads[k];
+    const T32& xin = k == 0 ? semx : insx;
+    RC32(mk(p + ".dw", hq, wq, n->dec_ch));
+    RC32(dw(xin, p + ".head.0.0.sepconv.0", 5, A(p + ".dw")));
+    RC32(mk(p + ".pw", hq, wq, n->dec_ch));
+    RC32(c32(n, p + ".head.0.0.sepconv.1", A(p + ".dw"), 0, A(p + ".pw"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+    float* dst;
+    RC32(buf32(n, p + ".out", (size_t)N * hc[k] * hq * wq, &dst));
+    if (k == 1 && !interp) dst = o_ctr;
+    if (k == 2 && !interp) dst = o_off;
+    head_out[k] = dst;
+    RC32(launch_head1x1_f32(A(p + ".pw").p, N, hq * wq, n->dec_ch, n->dec_ch, n->f32w.at(p + ".head.1.w"), n->f32w.at(p + ".head.1.b"),
+                            hc[k], dst, (int64_t)hq * wq, nullptr, s));
+    n->flops += 2.0 * (double)N * hq * wq * n->dec_ch * hc[k];
+  }
+  if (interp) {
+    RC32(launch_bilinear_ac_f32_nchw(head_out[1], N * 1, hq, wq, o_ctr, 4, s));
+    RC32(launch_bilinear_ac_f32_nchw(head_out[2], N * 2, hq, wq, o_off, 4, s));
+  }
+  // ---- PointRend subdivision (point_rend.py:241-269, eval) ----
+  const int P = c.subdivision_num_points;
+  const int ldp = round_up(n->dec_ch + n->ncls, 16);
+  const float* coarse = head_out[0];
+  const float* cur = coarse;
+  int hh = hq, ww = wq;
+  int64_t plane_max = (int64_t)hq * wq;
+  for (int st = 0; st < RS; ++st) plane_max *= 4;
+  float* fkeys;
+  RC32(buf32(n, "pr.keys", (size_t)N * plane_max, &fkeys));
+  float* ftopk;
+  const size_t topk_bytes = topk_work_bytes(N, plane_max);
+  RC32(buf32(n, "pr.topk", (topk_bytes + 3) / 4, &ftopk));
+  float* fidx;
+  RC32(buf32(n, "pr.idx", (size_t)N * P, &fidx));
+  T32 X[2];
+  for (int j = 0; j < 2; ++j) {
+    X[j].N = 1; X[j].H = 1; X[j].W = N * P; X[j].C = ldp; X[j].ld = ldp;
+    RC32(buf32(n, j ? "pr.x1" : "pr.x0", (size_t)N * P * ldp, &X[j].p));
+  }
+  for (int st = 0; st < RS; ++st) {
+    float* nxt = o_sem;
+    if (st + 1 < RS) RC32(buf32(n, "pr.sem" + std::to_string(st), (size_t)N * n->ncls * hh * ww * 4, &nxt));
+    RC32(launch_upsample2x_keys(cur, N, n->ncls, hh, ww, nxt, (uint32_t*)fkeys, s));
+    hh *= 2; ww *= 2;
+    const int64_t plane = (int64_t)hh * ww;
+    const int k = (int)(plane < P ? plane : P);
+    RC32(launch_topk_smallest((const uint32_t*)fkeys, N, plane, k, (char*)ftopk, topk_bytes, (int32_t*)fidx, s));
+    RC32(launch_point_features_f32(semx.p, N, hq, wq, n->dec_ch, semx.ld, coarse, n->ncls, (const int32_t*)fidx, k, hh, ww, X[0].p,
+                                   X[1].p, ldp, s));
+    T32 xa[2] = {X[0], X[1]};
+    xa[0].W = xa[1].W = N * k;
+    int curx = 0;
+    for (int f = 0; f < c.num_fc; ++f) {
+      RC32(c32(n, "semantic_pr.point_head.fc_layers." + std::to_string(f) + ".0", xa[curx], 0, xa[curx ^ 1], 0, 1, 0, 1, 1, nullptr,
+               nullptr, s));
+      curx ^= 1;
+    }
+    RC32(launch_head1x1_f32(xa[curx].p, N, k, ldp, ldp, n->f32w.at("pr.predictor.w32"), n->f32w.at("pr.predictor.b"), n->ncls, nxt,
+                            plane, (const int32_t*)fidx, s));
+    n->flops += 2.0 * (double)N * k * ldp * n->ncls;
+    cur = nxt;
+  }
+  return EMP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1413,12 +1858,23 @@ int emp_pdl_finalize(emp_pdl_t* n) {
     RC(upload_f32(n, "pr.predictor.w", w));
     RC(upload_f32(n, "pr.predictor.b", hp.b));
   }
+  if (n->precision == 1) RC(finalize32(n));      // fp32 reference mode: fp32 copies of every weight
   n->finalized = true;
   return EMP_OK;
 }
 
+int emp_pdl_set_precision(emp_pdl_t* net, int precision) {
+  EMP_REQUIRE(net, "set_precision: null network");
+  EMP_REQUIRE(precision == 0 || precision == 1, "set_precision: 0 = fp16 engine, 1 = fp32 reference mode (got %d)", precision);
+  EMP_REQUIRE(!net->finalized, "set_precision: call before emp_pdl_finalize");
+  net->precision = precision;
+  return EMP_OK;
+}
+int emp_pdl_precision(const emp_pdl_t* net) { return net ? net->precision : -1; }
+
 int emp_pdl_reserve(emp_pdl_t* net, int N, int H, int W) {
   EMP_REQUIRE(net, "reserve: null network");
+  if (net->precision == 1) return EMP_OK;      // the fp32 mode sizes its buffers on first use
   return plan(net, N, H, W, net->pRS > 2 ? net->pRS : 2, nullptr);
 }
 size_t emp_pdl_arena_bytes(const emp_pdl_t* net) { return net ? net->arena_used : 0; }
@@ -1432,6 +1888,9 @@ int emp_pdl_forward_padded(emp_pdl_t* net, const void* d_image, int image_dtype,
     set_error("forward: call emp_pdl_finalize first");
     return EMP_ERR_STATE;
   }
+  if (net->precision == 1)
+    return run32(net, d_image, image_dtype, sub, mul, N, H, W, vh, vw, render_steps, interpolate_ins, d_sem_logits, d_ctr_hmp,
+                 d_offsets, (hipStream_t)stream);
   if (H != net->pH || W != net->pW || render_steps != net->pRS || N > net->capN) {
     RC(plan(net, N, H, W, render_steps, (hipStream_t)stream));
   } else if (N != net->pN) {
@@ -1494,6 +1953,13 @@ int emp_pdl_tap(emp_pdl_t* net, const char* name, void** d_ptr, int64_t shape5[5
 
 int emp_pdl_tap_raw(emp_pdl_t* net, const char* name, void** d_ptr, int64_t* bytes) {
   EMP_REQUIRE(net && name && d_ptr && bytes, "tap_raw: null argument");
+  if (net->precision == 1) {      // fp32 mode: every buffer of the last forward by name (maps: NHWC fp32)
+    auto it32 = net->pool32.find(name);
+    EMP_REQUIRE(it32 != net->pool32.end(), "tap_raw: unknown fp32 buffer '%s'", name);
+    *d_ptr = it32->second.first;
+    *bytes = (int64_t)(it32->second.second * sizeof(float));
+    return EMP_OK;
+  }
   auto it = net->raw.find(name);
   EMP_REQUIRE(it != net->raw.end(), "tap_raw: unknown buffer '%s'", name);
   *d_ptr = net->arena + it->second.first;

@@ -53,7 +53,11 @@ class HipPanopticDeepLab:
     ``weights.fold_state_dict``.
     """
 
-    def __init__(self, state_dict, cfg=None, device=None, folded=False):
+    def __init__(self, state_dict, cfg=None, device=None, folded=False, precision=None):
+        """``precision``: None / 'fp16' -- the fp16 engine (the product and the bench); 'fp32' -- the fp32 REFERENCE MODE of
+        the library (csrc/ref32.hip: fp32 maps and weights, exact fp32 matrix pipe, no fusion; ~10x slower): the reference
+        computes this path in fp32 (engines.py:248-255), and in this mode the float heads are within 1e-3 of it in the
+        max norm.  None follows the environment variable EMP_PRECISION."""
         self.device = _require_gpu(device)
         bifpn = 'BiFPN' in (cfg or {}).get('arch', '')
         self.cfg = dict(weights.MITONET_MINI_CFG if bifpn else weights.MITONET_PDL_CFG, **(cfg or {}))
@@ -83,6 +87,11 @@ class HipPanopticDeepLab:
         self._h = C.c_void_p()
         torch.cuda.set_device(self.device)
         _abi.check(self.lib.emp_pdl_create(C.byref(c), C.byref(self._h)), 'emp_pdl_create')
+        if precision is not None:
+            if precision not in ('fp16', 'fp32'):
+                raise ValueError(f"precision must be 'fp16' or 'fp32', got {precision!r}")
+            _abi.check(self.lib.emp_pdl_set_precision(self._h, 1 if precision == 'fp32' else 0), 'emp_pdl_set_precision')
+        self.precision = 'fp32' if self.lib.emp_pdl_precision(self._h) == 1 else 'fp16'
         P = state_dict if folded else weights.fold_state_dict(state_dict, self.cfg)
         n = self.lib.emp_pdl_num_params(self._h)
         names = [self.lib.emp_pdl_param_name(self._h, i).decode() for i in range(n)]

@@ -88,6 +88,15 @@ EMP_API int emp_pdl_set_param(emp_pdl_t* net, const char* name, const float* h_w
                       const int64_t* shape, int ndim, const float* h_b);
 /* Packs fp16 weights on the device; fails if a parameter is missing. */
 EMP_API int emp_pdl_finalize(emp_pdl_t* net);
+/* Round 4 -- precision of the forward, chosen BEFORE emp_pdl_finalize: 0 (default) the fp16 engine; 1 the fp32 REFERENCE
+ * MODE (csrc/ref32.hip): every map and weight fp32, products on the exact fp32 matrix pipe (v_mfma_f32_32x32x2_f32), no
+ * layer fusion.  The reference runs this path in fp32 (empanada/inference/engines.py:248-255: the model in eval, no
+ * autocast); in this mode the float heads meet the north star's 1e-3 in the MAX norm (~1e-5 measured), at roughly a
+ * tenth of the fp16 engine's rate -- it is the device-side comparator, not the bench.  Same entry points and output
+ * tensors; emp_pdl_tap is not available (emp_pdl_tap_raw hands out every fp32 NHWC map of the last forward by name).
+ * The environment variable EMP_PRECISION=fp32 selects it for networks that do not call this. */
+EMP_API int emp_pdl_set_precision(emp_pdl_t* net, int precision);
+EMP_API int emp_pdl_precision(const emp_pdl_t* net);
 /* Number of parameters the network expects, and the name of the i-th one. */
 EMP_API int emp_pdl_num_params(const emp_pdl_t* net);
 EMP_API const char* emp_pdl_param_name(const emp_pdl_t* net, int i);
@@ -169,6 +178,16 @@ EMP_API int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, 
                         void* d_out, int out_ld, int Cout,
                         int KH, int KW, int stride, int pad, int dil, int relu,
                         int variant, void* stream);
+
+/* The convolution of the fp32 REFERENCE MODE (round 4, csrc/ref32.hip; emp_pdl_set_precision): NHWC fp32 maps, fp32
+ * weights (Cout, KH*KW, Cin) with Cin % 16 == 0 (pad with zero weights), every product on the exact fp32 matrix pipe
+ * (v_mfma_f32_32x32x2_f32).  replaces nn.Conv2d(+folded BatchNorm)(+ReLU / SiLU)(+skip add) exactly as the reference
+ * computes it (fp32, engines.py:248-255).  act: 0 none, 1 ReLU, 2 SiLU; other arguments as emp_conv2d_nhwc_f16. */
+EMP_API int emp_conv2d_nhwc_f32(const float* d_in, int N, int H, int W, int Cin, int in_ld,
+                        const float* d_w, const float* d_bias, const float* d_bias_n,
+                        const float* d_res, int res_ld,
+                        float* d_out, int out_ld, int Cout,
+                        int KH, int KW, int stride, int pad, int dil, int act, void* stream);
 
 /* out = act( in . W[:, :Cin] + in2(strided) . W[:, Cin:] + bias ): a 1x1 convolution whose reduction continues over a
  * second tensor sampled with stride2.  replaces the tail of a ResNet bottleneck with a projection shortcut,
