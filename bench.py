@@ -238,20 +238,42 @@ def stack3d_line(model, size, cfg=None, P=None, with_cpu=True):
     return res
 
 
+KERNEL_SOURCES = ('conv_igemm256.hip', 'conv_igemm.hip', 'pdl_net.hip', 'common.h')      # what the dominant kernel's traffic depends on
+
+
+def kernel_source_hash():
+    """sha256 over the sources that decide which launches the dominant kernel gets and what they fetch: a committed PMC
+    profile is quoted only while it still describes THIS code (the GPU box has no .git to ask)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, 'empanada-napari_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def traffic_from_profiles():
-    """HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes (tools/hbm_traffic.py): NOT measured in
-    this run -- the JSON names the file and the commit it was taken at."""
-    for name in ('r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+    """HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes (tools/hbm_traffic.py, separate --pmc runs
+    as the guide prescribes): NOT measured in this run -- the JSON names the file, the commit and the source hash it was
+    taken at, and a profile whose source hash differs from the tree's is NOT quoted (traffic: null, `traffic_note` says
+    stale) instead of sitting next to live numbers."""
+    cur = kernel_source_hash()
+    stale = None
+    for name in ('r04_hbm_traffic.json', 'r03_hbm_traffic.json', 'r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
         p = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(p):
             try:
                 tj = json.load(open(p))
                 k = tj['per_kernel']['conv_igemm256_kernel']
+                src = f'profiles/{name}' + (f" @ {tj['commit']}" if 'commit' in tj else '')
+                if tj.get('source_hash') != cur:
+                    stale = stale or f"{src} is stale (kernel sources changed since: {tj.get('source_hash')} != {cur})"
+                    continue
                 return ((k['fetch_corrected'] + k['write']) / k['launches_per_step'], tj['hbm_bytes_per_step'],
-                        f'profiles/{name}' + (f" @ {tj['commit']}" if 'commit' in tj else ''))
+                        src + f' (source hash {cur})')
             except Exception:
                 continue
-    return None, None, None
+    return None, None, stale or 'no committed PMC profile'
 
 
 def run_tiles(args, rank, local_rank, world, dist_on, dev):
@@ -314,6 +336,14 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
     dom_ms, dom_flops, dom_launches = model.profile_read()
     model.profile(False)
     flops_fwd = model.last_flops() * (B / mb)  # per step (last_flops is per forward call of mb tiles)
+    # the same K steps once more WITHOUT the HIP-event pairs around the dominant kernel's launches: what the
+    # instrumentation inside the timed region costs (reported, not the headline)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    torch.cuda.synchronize()
+    ms_plain = (time.perf_counter() - t1) * 1e3 / args.steps
     slab_block = None
     if dist_on and args.stack3d > 0:        # every rank takes part (SPMD); outside the timed region of `value`
         try:
@@ -348,7 +378,7 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
         'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(achieved / PEAK_F16_TFLOPS, 4), 'traffic': traffic,
                      'traffic_note': 'average HBM bytes per launch of this kernel (2*FETCH_SIZE + WRITE_SIZE, separate '
-                                     'rocprofv3 PMC passes); NOT measured in this run, taken from ' + str(traffic_src),
+                                     'rocprofv3 PMC passes); NOT measured in this run: ' + str(traffic_src),
                      'step_traffic_all_kernels': step_traffic,
                      'kernel': 'conv_igemm256_kernel<0, false> (256x256 implicit-GEMM tile: ASPP 3x3, layer3/4 convs, projection shortcuts; the <0, true> instantiation with the fused next conv is not counted)',
                      'launches_per_step': dom_launches / max(args.steps, 1),
@@ -358,6 +388,8 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
                      'forward_tflops': round(fwd_tflops, 2), 'forward_frac': round(fwd_tflops / PEAK_F16_TFLOPS, 4),
                      'flops_per_tile': round(flops_fwd / B / 1e9, 2), 'forward_ms_per_step': round(fwd_ms_per_step, 3)},
         'arena_gib': round(model.arena_bytes() / 2 ** 30, 2),
+        'ms_per_step_uninstrumented': round(ms_plain, 3),
+        'uninstrumented_note': 'the same steps on this rank without the HIP-event pairs around the dominant kernel (untimed extra pass)',
     }
     # ---- batch-1 latency (the reference API's contract, engines.py:300-325: one tile per call) ----
     try:

@@ -17,11 +17,18 @@ python3 $REPO/tools/hbm_traffic.py /tmp/pf /tmp/pw 4 $OUT/hbm_traffic.json > $OU
 # the bench line joins the per-launch HBM bytes from profiles/<round>_hbm_traffic.json: refresh it first (box-local copy)
 python3 - <<PY
 import json
-d=json.load(open('$OUT/hbm_traffic.json')); d['commit']='${EMP_COMMIT:-unknown}'; json.dump(d, open('$OUT/hbm_traffic.json','w'), indent=1)
+import sys; sys.path.insert(0, '$REPO')
+import bench
+d=json.load(open('$OUT/hbm_traffic.json')); d['commit']='${EMP_COMMIT:-unknown}'; d['source_hash']=bench.kernel_source_hash()
+json.dump(d, open('$OUT/hbm_traffic.json','w'), indent=1)
 PY
-cp $OUT/hbm_traffic.json $REPO/profiles/${EMP_ROUND:-r03}_hbm_traffic.json
+cp $OUT/hbm_traffic.json $REPO/profiles/${EMP_ROUND:-r04}_hbm_traffic.json
 python3 $REPO/bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench.json
 ls -la $OUT
 tail -3 $OUT/hbm_traffic.txt
 python3 -c "
-import json; d=json.load(open('$OUT/bench.json')); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['cpu_baseline']['value'])"
+import json; d=json.load(open('$OUT/bench.json')); print(d['value'], d['ms_per_step'], d['ms_per_step_uninstrumented'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline']['traffic'], d['cpu_baseline']['value'])"
+# BiFPN network (configs[0] / [4]): forward rate and per-layer table
+python3 $REPO/tools/bench_bifpn.py > $OUT/bifpn.txt 2>&1
+bash $REPO/tools/refresh_bifpn_profile.sh >> $OUT/bifpn.txt 2>&1
+tail -3 $OUT/bifpn.txt
