@@ -550,6 +550,32 @@ def block_slices(backend):
 
 
 _CHAIN_GROUPS = {}
+_GATHER_GROUPS = {}
+_CHAIN_EXEC = None
+
+
+def _chain_executor():
+    """ONE worker thread per process for the block chains: the chain job of an axis, then its gather to rank 0, then the
+    next axis' chain ... in submission order -- every rank submits the same sequence, so the messages of consecutive axes
+    on the chain / gather groups cannot interleave although an axis' backward pass may still run while the next axis'
+    GPU phase is under way (``defer``)."""
+    global _CHAIN_EXEC
+    if _CHAIN_EXEC is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _CHAIN_EXEC = ThreadPoolExecutor(max_workers=1, thread_name_prefix='emp-block-chain')
+    return _CHAIN_EXEC
+
+
+def _default_gather_group(group):
+    """a gloo group of its own for the per-block tracks' way to rank 0 when that gather is deferred behind the caller
+    (it must not share a group with the caller's halo / carry messages of the NEXT axis)"""
+    key = id(group) if group is not None else None
+    g = _GATHER_GROUPS.get(key)
+    if g is None:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        g = _GATHER_GROUPS[key] = dist.new_group(ranks=ranks, backend='gloo', timeout=chain_timeout())
+    return g
+
 
 
 def _default_chain_group(group):
@@ -563,15 +589,34 @@ def _default_chain_group(group):
     return g
 
 
-def stack_inference(n_slices, backend, ks, group=None, host_group=None, match=None, chain_group=None):
-    """the schedule the engine runs: block-interleaved when the slices are matched on the ranks, contiguous slabs otherwise"""
+class _Done:
+    """a finished result behind the Future interface ``stack_inference(defer=True)`` returns"""
+
+    def __init__(self, value):
+        self.value = value
+
+    def result(self, timeout=None):
+        return self.value
+
+    def done(self):
+        return True
+
+
+def stack_inference(n_slices, backend, ks, group=None, host_group=None, match=None, chain_group=None, defer=False):
+    """the schedule the engine runs: block-interleaved when the slices are matched on the ranks, contiguous slabs otherwise.
+    ``defer``: return when this rank's GPU phase is through -- a Future whose ``result()`` is what the call returns
+    otherwise (rank 0: the parts, elsewhere None): the rest of the forward chain, the backward chain, the tracking and the
+    gather to rank 0 finish on the chain thread, behind the caller (the next axis' GPU phase, in the ortho-plane job)."""
     blk = block_slices(backend) if match is not None else 0
     if blk <= 0:
-        return slab_stack_inference(n_slices, backend, ks, group, host_group, match)
+        res = slab_stack_inference(n_slices, backend, ks, group, host_group, match)
+        return _Done(res) if defer else res
     blk = min(blk, max(1, n_slices // dist.get_world_size(group)))      # a short stack: still a block for every rank
     if chain_group is None:          # the chain thread's messages must not share a group with this thread's
         chain_group = _default_chain_group(group)
-    return block_stack_inference(n_slices, backend, ks, match, blk, group, host_group, chain_group)
+    if defer and (host_group is None or host_group is group):
+        host_group = _default_gather_group(group)
+    return block_stack_inference(n_slices, backend, ks, match, blk, group, host_group, chain_group, defer)
 
 
 def block_bounds(n_slices, block, ks):
@@ -581,7 +626,7 @@ def block_bounds(n_slices, block, ks):
     return slab_bounds(n_slices, max(1, n_slices // b))
 
 
-def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_group=None, chain_group=None):
+def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_group=None, chain_group=None, defer=False):
     """SPMD body of one axis on one rank, BLOCK-INTERLEAVED: the stack is cut into blocks of about ``block`` slices (one
     forward batch) and rank r owns blocks r, r + W, r + 2W, ...  Same results as ``slab_stack_inference`` (one contiguous
     slab per rank = W blocks); what changes is WHEN things can run:
@@ -690,8 +735,7 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
             for e in pushed:
                 e.set()
 
-    th = threading.Thread(target=chain, name='emp-block-chain', daemon=True)
-    th.start()
+    th = _chain_executor().submit(chain)      # behind the previous axis' chain + gather, if those are still running
     reqs = []
     try:
         def forward(k):
@@ -750,23 +794,31 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
         raise
     for e in pushed:
         e.set()
-    th.join()
-    if err:
-        raise RuntimeError('block chain failed on rank %d:\n%s' % (rank, err[0]))
-    res = None
-    if mine:
-        ph = {key: sum(sm.phase_s[key] for sm in sms) for key in ('ghosts', 'forward', 'backward', 'track')}
-        res = {'blocks': [{'block': b, 'part': p} for b, p in zip(mine, parts)],
-               'host_s': sum(sm.host_s for sm in sms), 'tail_s': max(0.0, t_chain_end[0] - t_start - gpu_s), 'gpu_s': gpu_s,
-               'slices': sum(bounds[b][1] - bounds[b][0] for b in mine), 'phases': ph}
-    if rank != 0:
-        _send_blocks(res, 0, hg)
-        return None
-    gathered = [res] + [_recv_blocks(r, hg) for r in range(1, world)]
-    live = [g for g in gathered if g is not None]
-    by_block = {blk['block']: blk['part'] for g in live for blk in g['blocks']}
-    return {'parts': [by_block[b] for b in range(NB)], 'host_s': [g['host_s'] for g in live],
-            'timing': [{k: g[k] for k in ('host_s', 'tail_s', 'gpu_s', 'slices', 'phases')} for g in live]}
+
+    def finish():
+        """chain through, then the per-block tracks to rank 0 (host group); on the caller's thread, or -- ``defer`` -- as the
+        chain thread's next job"""
+        th.result()
+        if err:
+            raise RuntimeError('block chain failed on rank %d:\n%s' % (rank, err[0]))
+        res = None
+        if mine:
+            ph = {key: sum(sm.phase_s[key] for sm in sms) for key in ('ghosts', 'forward', 'backward', 'track')}
+            res = {'blocks': [{'block': b, 'part': p} for b, p in zip(mine, parts)],
+                   'host_s': sum(sm.host_s for sm in sms), 'tail_s': max(0.0, t_chain_end[0] - t_start - gpu_s), 'gpu_s': gpu_s,
+                   'slices': sum(bounds[b][1] - bounds[b][0] for b in mine), 'phases': ph}
+        if rank != 0:
+            _send_blocks(res, 0, hg)
+            return None
+        gathered = [res] + [_recv_blocks(r, hg) for r in range(1, world)]
+        live = [g for g in gathered if g is not None]
+        by_block = {blk['block']: blk['part'] for g in live for blk in g['blocks']}
+        return {'parts': [by_block[b] for b in range(NB)], 'host_s': [g['host_s'] for g in live],
+                'timing': [{k: g[k] for k in ('host_s', 'tail_s', 'gpu_s', 'slices', 'phases')} for g in live]}
+
+    if defer:
+        return _chain_executor().submit(finish)
+    return finish()
 
 
 def _send_blocks(res, dst, group):
@@ -1099,7 +1151,7 @@ class MultiGPUEngine3d:
             q.put(('axis', payload, axis_name, self.ks, self._match_desc(volume.shape, axis_name)))
         return self._collect('done')[0]
 
-    def _segs_spmd(self, volume, axis_name):
+    def _segs_spmd(self, volume, axis_name, defer=False):
         if self._make is None:
             rank = dist.get_rank(self.group)
             factory = self.backend_factory or _default_backend_factory
@@ -1108,9 +1160,19 @@ class MultiGPUEngine3d:
             if dist.get_backend(self.group) == 'nccl':
                 self._host_group = dist.new_group(backend='gloo')
             self._chain_group = dist.new_group(backend='gloo', timeout=chain_timeout())
+        prev = self.__dict__.pop('_spmd_pending', None)
+        if prev is not None and prev.done():
+            prev.result()          # a failure of the previous axis' deferred chain on THIS rank surfaces here at the latest
         axis = self.axes[axis_name]
         return stack_inference(volume.shape[axis], self._make(volume, axis), self.ks, self.group, self._host_group,
-                               self._match_desc(volume.shape, axis_name), self._chain_group)
+                               self._match_desc(volume.shape, axis_name), self._chain_group, defer=defer)
+
+    def wait(self):
+        """SPMD mode: joins this rank's deferred chain work (every rank calls it before the job's clock stops / before the
+        process group is torn down); re-raises what it raised"""
+        prev = self.__dict__.pop('_spmd_pending', None)
+        if prev is not None:
+            prev.result()
 
     def _match_desc(self, shape, axis_name):
         shape = tuple(int(v) for v in shape)
@@ -1120,21 +1182,33 @@ class MultiGPUEngine3d:
 
     def infer_on_axis(self, volume, axis_name):
         from . import sparse
-        segs = self._segs_spmd(volume, axis_name) if self.spmd else self._segs_spawn(volume, axis_name)
-        if segs is None:
-            return None, None
         shape = tuple(int(s) for s in volume.shape)
+        stack = self.create_panoptic_stack(axis_name, shape)
+        # SPMD ranks: the call returns when this rank's GPU phase is through; the backward chain, the tracking and the gather
+        # to rank 0 finish on the chain thread, behind the NEXT axis' GPU phase (patterns.py:102-134 ran them after the
+        # forward pass, in the caller).  EMP_MG_DEFER=0: synchronous, as round 3.
+        defer = self.spmd and stack is None and os.environ.get('EMP_MG_DEFER', '1') != '0'
+        segs = self._segs_spmd(volume, axis_name, defer) if self.spmd else self._segs_spawn(volume, axis_name)
+        if defer:
+            if dist.get_rank(self.group) != 0:
+                self._spmd_pending = segs          # joined by the next call / wait()
+                return None, None
+            segs_fut = segs
+        else:
+            if segs is None:
+                return None, None
+            segs_fut = _Done(segs)
         trackers = self.create_trackers(shape, axis_name)
         priv = self.create_trackers(shape, axis_name)
         min_size, min_extent = self.min_size, self.min_extent
-        stack = self.create_panoptic_stack(axis_name, shape)
-        self.last_host_s = list(segs['host_s'])      # every rank's matcher time
-        self.last_timing = list(segs['timing'])      # per rank: matcher time, its un-overlapped tail, GPU phase, slices
 
         def tail():
             # forward matching (patterns.py:279-350), backward matching and tracking (multigpu.py:240-252) ran per slab on
             # the ranks (SlabMatcher); what is left here is the concatenation of the per-slab tracks and the size filters
             import time
+            segs = segs_fut.result()
+            self.last_host_s = list(segs['host_s'])      # every rank's matcher time
+            self.last_timing = list(segs['timing'])      # per rank: matcher time, its un-overlapped tail, GPU phase, slices
             t0 = time.perf_counter()
             merged = merge_partial_trackers(segs['parts'], axis_name)
             for tr in priv:

@@ -271,3 +271,68 @@ def test_chain_receive_times_out_instead_of_hanging(tmp_path):
     res = open(out).read()
     assert res.startswith('raised after'), res
     assert float(res.split()[2]) < 5.5, res
+
+
+def _spmd_worker(rank, world, port, block, defer, out_path):
+    for d in (ROOT, os.path.join(ROOT, 'tests')):
+        if d not in sys.path:
+            sys.path.insert(0, d)
+    import pickle
+    import __graft_entry__ as graft
+    graft.load_package()
+    import mg_oracle_backend as mgb
+    import test_slab_matcher as tsm
+    from empanada_napari_amd import multigpu
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), EMP_MG_BLOCK=block, EMP_MG_DEFER=defer,
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    multigpu.MultiGPUEngine3d.MIN_WORLD = 1
+    mc = {'seed': 40, 'thing_list': tsm.THINGS, 'labels': tsm.LABELS, 'class_names': {1: 'a', 2: 'b', 3: 'c'},
+          'padding_factor': 16, 'norms': {'mean': 0.5, 'std': 0.1}}
+    eng = multigpu.MultiGPUEngine3d(mc, label_divisor=tsm.DIV, median_kernel_size=3, min_size=12, min_extent=2,
+                                    dist_backend='gloo', backend_factory=mgb.label_stack_backend_factory)
+    vol = np.zeros(tsm.SHAPE, np.uint8)
+    res = {}
+    held = []
+    for axis_name in ('xy', 'xz', 'yz'):          # back to back: an axis' backward chain runs behind the next axis' GPU loop
+        _, trackers = eng.infer_on_axis(vol, axis_name)
+        held.append((axis_name, trackers))
+    eng.wait()
+    if rank == 0:
+        for axis_name, trackers in held:
+            res[axis_name] = {tr.class_id: {int(k): (tuple(int(v) for v in o['box']), np.asarray(o['starts']), np.asarray(o['runs']))
+                                            for k, o in tr.instances.items()} for tr in trackers}
+        pickle.dump(res, open(out_path, 'wb'))
+    else:
+        assert all(t is None for _, t in held)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,block,defer', [(2, '2', '1'), (3, '3', '1'), (2, '2', '0'), (2, '0', '1')])
+def test_spmd_ranks_defer_the_backward_chain_behind_the_next_axis(tmp_path, world, block, defer):
+    """Under an SPMD launch (torchrun) ``infer_on_axis`` returns when a rank's GPU phase is through; the backward chain,
+    the tracking and the gather to rank 0 finish on the chain thread while the NEXT axis is already running (VERDICT r03
+    item 5b).  Three axes called back to back on gloo ranks, the trackers read only at the end: identical to the
+    sequential C++ matcher over the whole stack, per axis and class, size filters included; also with the deferral off
+    and with contiguous slabs (which do not defer)."""
+    import pickle
+    import test_slab_matcher as tsm
+    from empanada_napari_amd import sparse as ps
+    out = str(tmp_path / 'res.pkl')
+    mp.spawn(_spmd_worker, args=(world, _free_port(), block, defer, out), nprocs=world, join=True)
+    res = pickle.load(open(out, 'rb'))
+    for axis_name, axis in (('xy', 0), ('xz', 1), ('yz', 2)):
+        want = tsm._sequential(tsm._stack(tsm.SHAPE, axis, 40 + axis), axis_name, tsm.SHAPE)
+        for cid in tsm.LABELS:
+            ref = ps.InstanceTracker(cid, tsm.DIV, tsm.SHAPE, axis_name)
+            ref.instances = want[cid]
+            ref.finished = True
+            ps.remove_small_objects(ref, min_size=12)
+            ps.remove_pancakes(ref, min_span=2)
+            got = res[axis_name][cid]
+            assert len(ref.instances) > 0 and list(got) == [int(k) for k in ref.instances]
+            for k, (box, st, rn) in got.items():
+                assert box == tuple(int(v) for v in ref.instances[k]['box'])
+                np.testing.assert_array_equal(st, ref.instances[k]['starts'])
+                np.testing.assert_array_equal(rn, ref.instances[k]['runs'])

@@ -30,5 +30,5 @@ python3 -c "
 import json; d=json.load(open('$OUT/bench.json')); print(d['value'], d['ms_per_step'], d['ms_per_step_uninstrumented'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline']['traffic'], d['cpu_baseline']['value'])"
 # BiFPN network (configs[0] / [4]): forward rate and per-layer table
 python3 $REPO/tools/bench_bifpn.py > $OUT/bifpn.txt 2>&1
-bash $REPO/tools/refresh_bifpn_profile.sh >> $OUT/bifpn.txt 2>&1
+(cd $REPO && bash tools/refresh_bifpn_profile.sh) >> $OUT/bifpn.txt 2>&1
 tail -3 $OUT/bifpn.txt
