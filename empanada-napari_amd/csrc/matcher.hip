@@ -40,10 +40,74 @@ namespace {
 
 struct Pair { int a; int64_t inter; };        // overlap of a component with component `a` of the neighbouring slice
 
+// A vector of trivially copyable T with N inline slots (round 4).  An object is nearly always ONE component and overlaps one
+// or two targets, yet every object of every step owned two heap vectors: at thousands of objects per slice the allocator was
+// most of a matching step (17 k malloc / free pairs per 4096^2 step).  Heap storage only beyond N elements.
+template <typename T, int N>
+class SmallVec {
+ public:
+  SmallVec() = default;
+  SmallVec(size_t n, const T& v) { assign(n, v); }
+  SmallVec(const SmallVec& o) { copy_from(o); }
+  SmallVec(SmallVec&& o) noexcept { move_from(o); }
+  SmallVec& operator=(const SmallVec& o) { if (this != &o) { release(); copy_from(o); } return *this; }
+  SmallVec& operator=(SmallVec&& o) noexcept { if (this != &o) { release(); move_from(o); } return *this; }
+  ~SmallVec() { release(); }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  T* begin() { return data(); }
+  T* end() { return data() + n_; }
+  const T* begin() const { return data(); }
+  const T* end() const { return data() + n_; }
+  T& operator[](size_t i) { return data()[i]; }
+  const T& operator[](size_t i) const { return data()[i]; }
+  void clear() { n_ = 0; }
+  void reserve(size_t c) { if (c > cap_) grow(c); }
+  void push_back(const T& v) { if (n_ == cap_) grow(cap_ * 2); data()[n_++] = v; }
+  void assign(size_t n, const T& v) { n_ = 0; reserve(n); for (size_t i = 0; i < n; ++i) data()[i] = v; n_ = (uint32_t)n; }
+  template <typename It>
+  void append(It first, It last) {
+    const size_t k = (size_t)(last - first);
+    reserve(n_ + k);
+    T* d = data() + n_;
+    for (; first != last; ++first) *d++ = *first;
+    n_ += (uint32_t)k;
+  }
+  // std::vector's spelling, at the end only (what the matcher uses)
+  template <typename It>
+  void insert(const T* pos, It first, It last) { (void)pos; append(first, last); }
+
+ private:
+  T* data() { return heap_ ? heap_ : inl_; }
+  const T* data() const { return heap_ ? heap_ : inl_; }
+  void grow(size_t c) {
+    if (c < (size_t)cap_ * 2) c = (size_t)cap_ * 2;
+    T* h = static_cast<T*>(::operator new(c * sizeof(T)));
+    std::memcpy(h, data(), n_ * sizeof(T));
+    if (heap_) ::operator delete(heap_);
+    heap_ = h;
+    cap_ = (uint32_t)c;
+  }
+  void release() { if (heap_) ::operator delete(heap_); heap_ = nullptr; n_ = 0; cap_ = N; }
+  void copy_from(const SmallVec& o) {
+    heap_ = nullptr; cap_ = N; n_ = 0;
+    reserve(o.n_);
+    std::memcpy(data(), o.data(), o.n_ * sizeof(T));
+    n_ = o.n_;
+  }
+  void move_from(SmallVec& o) {
+    if (o.heap_) { heap_ = o.heap_; cap_ = o.cap_; n_ = o.n_; o.heap_ = nullptr; o.cap_ = N; o.n_ = 0; }
+    else { heap_ = nullptr; cap_ = N; n_ = o.n_; std::memcpy(inl_, o.inl_, o.n_ * sizeof(T)); o.n_ = 0; }
+  }
+  T* heap_ = nullptr;
+  uint32_t n_ = 0, cap_ = N;
+  T inl_[N];
+};
+
 struct FObj {
   int64_t label;
   int64_t box[4];
-  std::vector<int> members;                    // component indices of this slice
+  SmallVec<int, 2> members;                    // component indices of this slice
 };
 
 struct FSlice {
@@ -557,7 +621,7 @@ struct emp_stack_matcher {
   // col_ent[c] = (target index, intersection) of every target that intersects match object c, ascending target index
   int pending = -1, nt = 0, nm = 0;
   struct Ent { int t; int64_t inter; };
-  std::vector<std::vector<Ent>> col_ent;
+  std::vector<SmallVec<Ent, 2>> col_ent;
   std::vector<int64_t> ta, ma;                 // areas
   // the part of the assignment problem that needs a solver: rows / columns (ascending original indices) of the connected
   // components of the overlap graph that are not a single pair; `iou` is its dense block; the single pairs are applied
