@@ -575,9 +575,16 @@ class Engine3d:
             # per-axis transposition happens on the device: a yz stack is a stride-1 gather on the host
             # (tried: an xy stack's batches uploaded one by one behind the previous forward instead of the whole volume
             # first -- the pageable copies block the host between the forwards: 512^3 xy axis 0.118 -> 0.145 s)
-            on_dev = volume.nbytes <= (8 << 30)
+            # Round 4: up to EMP_VOLUME_ON_DEVICE_GIB (default 64: a 4096^3 uint8 volume next to the 30 GiB arena in 288 GB of
+            # HBM) the whole volume goes up once; beyond that its batches go up through two PINNED staging buffers on a side
+            # stream, one batch ahead, gathered by a helper thread (`_staged_batches`) -- round 3 fell back to pageable
+            # per-batch copies above 8 GiB, which block the host between the forwards.
+            on_dev = volume.nbytes <= int(float(os.environ.get('EMP_VOLUME_ON_DEVICE_GIB', '64')) * (1 << 30))
             moved = (torch.from_numpy(volume).to(eng.model.device) if on_dev else volume)
             moved = moved.movedim(axis, 0) if on_dev else np.moveaxis(volume, axis, 0)
+            staged = None if on_dev else self._staged_batches(moved, n, self.slice_batch(
+                (-(-moved.shape[1] // eng.padding_factor) * eng.padding_factor,
+                 -(-moved.shape[2] // eng.padding_factor) * eng.padding_factor)), eng.model.device)
             pf = eng.padding_factor
             vh, vw = moved.shape[1:]
             pad_to = (-(-vh // pf) * pf, -(-vw // pf) * pf)
@@ -590,10 +597,8 @@ class Engine3d:
         held = None           # post_stream mode: the group computed last, handed out after the next forward is enqueued
         for i0 in range(0, n, bs):
             if raw_path:
-                xb = (moved[i0:i0 + bs].contiguous() if on_dev else
-                      torch.from_numpy(np.ascontiguousarray(moved[i0:i0 + bs])))[:, None]
-                mo = eng.model(xb.to(eng.model.device, non_blocking=True), rs, interpolate_ins=not eng.coarse_boundaries,
-                               sub=float(sub), mul=float(mul), pad_to=pad_to)
+                xb = (moved[i0:i0 + bs].contiguous() if on_dev else next(staged))[:, None]
+                mo = eng.model(xb, rs, interpolate_ins=not eng.coarse_boundaries, sub=float(sub), mul=float(mul), pad_to=pad_to)
                 nb = xb.shape[0]
             else:
                 raws = [np.asarray(take(volume, i, axis)) for i in range(i0, min(n, i0 + bs))]
@@ -632,6 +637,50 @@ class Engine3d:
         if post_stream is not None:
             torch.cuda.current_stream().wait_stream(post_stream)
         eng.reset()
+
+    @staticmethod
+    def _staged_batches(moved, n, bs, dev):
+        """Device tensors of slices [i0, i0 + bs) of a HOST volume (axis already moved to the front) that is too large to
+        upload whole: a helper thread gathers batch k + 1 into one of two pinned buffers (a yz stack is a strided gather)
+        and enqueues its host-to-device copy on a side stream while the caller's stream runs the forward of batch k; the
+        consumer's stream waits for the copy's event only.  Yields exactly ceil(n / bs) tensors."""
+        import queue
+        import threading
+        shape = (bs,) + tuple(moved.shape[1:])
+        tdt = torch.from_numpy(np.empty(0, moved.dtype)).dtype
+        pinned = [torch.empty(shape, dtype=tdt).pin_memory() for _ in range(2)]
+        up = torch.cuda.Stream(device=dev)
+        free = queue.Queue()
+        ready = queue.Queue(maxsize=2)
+        for i in range(2):
+            free.put(i)
+
+        def producer():
+            try:
+                for i0 in range(0, n, bs):
+                    k = free.get()
+                    nb = min(bs, n - i0)
+                    np.copyto(pinned[k][:nb].numpy(), moved[i0:i0 + nb])      # contiguous or strided gather, host side
+                    with torch.cuda.stream(up):
+                        d = pinned[k][:nb].to(dev, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(up)
+                    ready.put((k, d, ev, None))
+            except BaseException as e:      # noqa: BLE001 -- handed to the consumer
+                ready.put((None, None, None, e))
+
+        th = threading.Thread(target=producer, name='emp-volume-stage', daemon=True)
+        th.start()
+        for _ in range(0, n, bs):
+            k, d, ev, err = ready.get()
+            if err is not None:
+                raise err
+            torch.cuda.current_stream(dev).wait_event(ev)
+            d.record_stream(torch.cuda.current_stream(dev))
+            ev.synchronize()          # the pinned buffer may be refilled once its copy has left the host
+            free.put(k)
+            yield d
+        th.join()
 
     def infer_on_axis(self, volume, axis_name):
         """:491-578 -> (stack, trackers)."""

@@ -559,3 +559,23 @@ def test_two_stream_axis_pipeline_equals_single_stream(model_config, monkeypatch
     for axis in ('xy', 'yz'):
         assert len(res['0'][axis]) > 0
         _same_instances(res['0'][axis], res['1'][axis])
+
+
+@pytest.mark.parametrize('axis_name', ['xy', 'yz'])
+def test_staged_host_volume_equals_whole_volume_upload(model_config, monkeypatch, axis_name):
+    """A volume larger than EMP_VOLUME_ON_DEVICE_GIB is not uploaded whole: its batches go up through two pinned staging
+    buffers on a side stream, one batch ahead (Engine3d._staged_batches).  Forced here with a limit
+    of 0: trackers and the panoptic stack equal the whole-volume-upload path bit for bit, uint8 and uint16."""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.inference import Engine3d
+    vol = synth.blob_volume(23, 40, 56, seed=12)
+    for v in (vol, vol.astype(np.uint16) * 257):
+        kw = dict(label_divisor=DIV, median_kernel_size=3, nms_kernel=3, confidence_thr=0.5, min_size=20, min_extent=2,
+                  save_panoptic=True, batch_size=5)
+        monkeypatch.delenv('EMP_VOLUME_ON_DEVICE_GIB', raising=False)
+        s0, t0 = Engine3d(model_config, **kw).infer_on_axis(v, axis_name)
+        monkeypatch.setenv('EMP_VOLUME_ON_DEVICE_GIB', '0')
+        s1, t1 = Engine3d(model_config, **kw).infer_on_axis(v, axis_name)
+        assert len(t0[0].instances) > 0
+        _same_instances(t0[0].instances, t1[0].instances)
+        np.testing.assert_array_equal(s0, s1)
