@@ -24,10 +24,16 @@ zarr-python 3 (the spelling at inference.py:100-103) writes:
                                           "codecs": [{"name": "bytes", "configuration": {"endian": "little"}}], "fill_value"}
     <store>/<array>/c/<i>/<j>/<k>        one C-order chunk
 
-Codecs: uncompressed chunks and the two the standard library can decode -- zlib / gzip (v2 ``compressor`` ids
-``zlib`` / ``gzip``; v3 codec ``gzip`` behind ``bytes``).  Blosc, zstd, lz4, sharding and transposes are refused loudly
-(no codec library in this image).  When the real ``zarr`` package is importable, ``open_store`` returns zarr's own
-objects instead.
+Codecs: uncompressed chunks; zlib / gzip from the standard library (v2 ``compressor`` ids ``zlib`` / ``gzip``; v3 codec
+``gzip`` behind ``bytes``); and -- round 4, through ``pyarrow``'s codecs when that package is importable (it is in this
+image; the zarr / numcodecs packages are not) -- what zarr-python writes BY DEFAULT: v3 ``zstd`` (``create_array`` of
+zarr-python 3, the reference's spelling at inference.py:100-103), v2 ``zstd`` / ``lz4`` (numcodecs: 4-byte length + raw LZ4
+block) and v2 ``blosc`` (``create_dataset`` of zarr-python 2, multigpu.py:202-205: Blosc(lz4, shuffle)): the Blosc-1 frame --
+16-byte header, block offsets, per-block split streams, byte shuffle -- is decoded here with lz4 / zstd / zlib inner
+codecs (blosclz, snappy and bit-shuffle are refused; restated from c-blosc's published frame format: no blosc library here
+to pin it against, tests build frames by hand from the same description).  New stores are written uncompressed or with
+gzip / zlib / zstd.  Sharding and transposes are refused loudly.  When the real ``zarr`` package is importable,
+``open_store`` returns zarr's own objects instead.
 
 Only what the reference's path touches is implemented: groups, n-d arrays, basic indexing with integers and
 unit-step slices (``array[z0:z1] = block``, ``array[...]``, ``array[i]``), ``shape / dtype / chunks / nchunks``.
@@ -43,6 +49,91 @@ import zlib
 import numpy as np
 
 __all__ = ['open_store', 'DirGroup', 'DirArray']
+
+
+def _arrow_codec(name):
+    try:
+        import pyarrow as pa
+    except ImportError as e:
+        raise NotImplementedError(f'{name}-compressed chunks need pyarrow (or the zarr package)') from e
+    if not pa.Codec.is_available(name):
+        raise NotImplementedError(f'this pyarrow build has no {name} codec')
+    return pa.Codec(name)
+
+
+def _decompress(codec, raw, nbytes):
+    """one chunk's bytes -> ``nbytes`` decoded bytes.  codec: None | 'gzip' | 'zlib' | 'zstd' | 'lz4' (numcodecs framing) |
+    'blosc' (Blosc-1 frame)."""
+    if codec is None:
+        return raw
+    if codec == 'gzip':
+        return gzip.decompress(raw)
+    if codec == 'zlib':
+        return zlib.decompress(raw)
+    if codec == 'zstd':
+        return _arrow_codec('zstd').decompress(raw, decompressed_size=nbytes, asbytes=True)
+    if codec == 'lz4':          # numcodecs.LZ4: little-endian uint32 decoded size, then one raw LZ4 block
+        n = int.from_bytes(raw[:4], 'little')
+        return _arrow_codec('lz4_raw').decompress(raw[4:], decompressed_size=n, asbytes=True)
+    if codec == 'blosc':
+        return blosc1_decode(raw)
+    raise NotImplementedError(f'codec {codec!r}')
+
+
+def _unshuffle(buf, typesize):
+    """inverse of Blosc's byte shuffle of one block: byte k of every element was stored together"""
+    n = len(buf) // typesize
+    body = np.frombuffer(buf, dtype=np.uint8, count=n * typesize).reshape(typesize, n).T
+    return body.tobytes() + bytes(buf[n * typesize:])
+
+
+def blosc1_decode(raw):
+    """A Blosc-1 frame (what numcodecs.Blosc / zarr-python 2 write) -> bytes.  Header (c-blosc README, "Blosc Header Format"):
+    version, versionlz, flags, typesize, nbytes (u32), blocksize (u32), cbytes (u32); flags: 0x1 byte shuffle, 0x2 memcpyed,
+    0x4 bit shuffle, 0x10 blocks not split, bits 5-7 the inner codec (0 blosclz, 1 lz4 / lz4hc, 2 snappy, 3 zlib, 4 zstd).
+    Then one int32 offset per block; a block is `typesize` streams (one when not split; the last, shorter block is never
+    split), each an int32 compressed size followed by that many bytes (size == stream length: stored raw)."""
+    raw = bytes(raw)
+    if len(raw) < 16:
+        raise ValueError('blosc: truncated header')
+    flags, typesize = raw[2], raw[3]
+    nbytes, blocksize, cbytes = (int.from_bytes(raw[i:i + 4], 'little') for i in (4, 8, 12))
+    if cbytes != len(raw):
+        raise ValueError(f'blosc: frame says {cbytes} bytes, chunk has {len(raw)}')
+    if flags & 0x2:
+        return raw[16:16 + nbytes]
+    if flags & 0x4:
+        raise NotImplementedError('blosc: bit-shuffled chunks need the zarr / numcodecs packages')
+    fmt = flags >> 5
+    inner = {1: 'lz4_raw', 3: 'zlib', 4: 'zstd'}.get(fmt)
+    if inner is None:
+        raise NotImplementedError(f'blosc: inner codec {fmt} (blosclz / snappy) needs the zarr / numcodecs packages')
+    dec = None if inner == 'zlib' else _arrow_codec(inner)
+    nblocks = -(-nbytes // blocksize) if nbytes else 0
+    out = []
+    for b in range(nblocks):
+        bsize = min(blocksize, nbytes - b * blocksize)
+        leftover = bsize < blocksize
+        nsplit = typesize if (not (flags & 0x10) and not leftover and typesize > 1 and bsize % typesize == 0) else 1
+        pos = int.from_bytes(raw[16 + 4 * b:20 + 4 * b], 'little', signed=True)
+        neblock = bsize // nsplit
+        parts = []
+        for _ in range(nsplit):
+            cs = int.from_bytes(raw[pos:pos + 4], 'little', signed=True)
+            pos += 4
+            data = raw[pos:pos + cs]
+            pos += cs
+            if cs == neblock:
+                parts.append(data)
+            elif inner == 'zlib':
+                parts.append(zlib.decompress(data))
+            else:
+                parts.append(dec.decompress(data, decompressed_size=neblock, asbytes=True))
+        blk = b''.join(parts)
+        if len(blk) != bsize:
+            raise ValueError(f'blosc: block {b} decoded to {len(blk)} bytes, expected {bsize}')
+        out.append(_unshuffle(blk, typesize) if (flags & 0x1) and typesize > 1 else blk)
+    return b''.join(out)
 
 
 def _write_json(path, obj):
@@ -77,11 +168,12 @@ class DirArray:
         comp = m.get('compressor')
         if comp is None:
             self.codec = None
-        elif comp.get('id') in ('zlib', 'gzip'):
+        elif comp.get('id') in ('zlib', 'gzip', 'zstd'):
             self.codec, self.level = comp['id'], int(comp.get('level', 1))
+        elif comp.get('id') in ('lz4', 'blosc'):      # read-only here (_write_chunk refuses)
+            self.codec, self.level = comp['id'], 0
         else:
-            raise NotImplementedError(f'{path}: compressor {comp} needs the zarr package (the standard library decodes '
-                                      f'zlib / gzip only)')
+            raise NotImplementedError(f'{path}: compressor {comp} needs the zarr package')
         if m.get('filters'):
             raise NotImplementedError(f'{path}: filtered chunks need the zarr package (filters={m.get("filters")})')
         if m.get('order', 'C') != 'C':
@@ -131,9 +223,11 @@ class DirArray:
         for c in codecs[1:]:
             if c.get('name') == 'gzip' and self.codec is None:
                 self.codec, self.level = 'gzip', int((c.get('configuration') or {}).get('level', 5))
+            elif c.get('name') == 'zstd' and self.codec is None:
+                conf_z = c.get('configuration') or {}      # (a frame checksum, if present, is verified by the decoder)
+                self.codec, self.level = 'zstd', int(conf_z.get('level', 0))
             else:
-                raise NotImplementedError(f'{path}: codec {c.get("name")} needs the zarr package (the standard library '
-                                          f'decodes gzip only)')
+                raise NotImplementedError(f'{path}: codec {c.get("name")} needs the zarr package')
         self.dtype = np.dtype(kind if kind in ('?', 'i1', 'u1') else endian + kind)
         fv = m.get('fill_value', 0)
         self.fill_value = 0 if fv is None else fv
@@ -154,8 +248,8 @@ class DirArray:
             raise ValueError(f'chunks {chunks} do not match shape {shape}')
         chunks = tuple(max(1, min(c, s)) if s > 0 else max(1, c) for c, s in zip(chunks, shape))
         dt = np.dtype(dtype)
-        if compressor not in (None, 'gzip', 'zlib'):
-            raise NotImplementedError(f'compressor {compressor!r}: None, "gzip" or "zlib"')
+        if compressor not in (None, 'gzip', 'zlib', 'zstd'):
+            raise NotImplementedError(f'compressor {compressor!r}: None, "gzip", "zlib" or "zstd"')
         if zarr_format == 2:
             _write_json(os.path.join(path, '.zarray'), {
                 'zarr_format': 2, 'shape': list(shape), 'chunks': list(chunks), 'dtype': dt.str,
@@ -171,6 +265,8 @@ class DirArray:
             codecs = [{'name': 'bytes', 'configuration': {'endian': 'little'}}]
             if compressor == 'gzip':
                 codecs.append({'name': 'gzip', 'configuration': {'level': 1}})
+            elif compressor == 'zstd':      # zarr-python 3's own default codec
+                codecs.append({'name': 'zstd', 'configuration': {'level': 0, 'checksum': False}})
             fv = bool(fill_value) if dt.kind == 'b' else (float(fill_value) if dt.kind == 'f' else int(fill_value))
             _write_json(os.path.join(path, 'zarr.json'), {
                 'zarr_format': 3, 'node_type': 'array', 'shape': list(shape), 'data_type': names[key],
@@ -212,7 +308,7 @@ class DirArray:
         else:
             with open(p, 'rb') as f:
                 raw = f.read()
-            a = np.frombuffer(gzip.decompress(raw) if self.codec == 'gzip' else zlib.decompress(raw), dtype=self.dtype)
+            a = np.frombuffer(_decompress(self.codec, raw, int(np.prod(self.chunks)) * self.dtype.itemsize), dtype=self.dtype)
         if a.size != int(np.prod(self.chunks)):
             raise ValueError(f'{p}: {a.size} items, expected a full chunk of {self.chunks}')
         return a.reshape(self.chunks)
@@ -228,8 +324,17 @@ class DirArray:
             block.tofile(tmp)
         else:
             data = block.tobytes()
+            if self.codec == 'gzip':
+                enc = gzip.compress(data, self.level, mtime=0)
+            elif self.codec == 'zlib':
+                enc = zlib.compress(data, self.level)
+            elif self.codec == 'zstd':
+                enc = _arrow_codec('zstd').compress(data, asbytes=True)
+            else:
+                raise NotImplementedError(f'{self.path}: writing {self.codec}-compressed chunks needs the zarr package (this '
+                                          f'module only READS lz4 / blosc chunks)')
             with open(tmp, 'wb') as f:
-                f.write(gzip.compress(data, self.level, mtime=0) if self.codec == 'gzip' else zlib.compress(data, self.level))
+                f.write(enc)
         os.replace(tmp, p)
 
     def _normalise(self, key):
