@@ -183,6 +183,43 @@ def _recv(t, src, group):
         dist.recv(t, src=src, group=group)
 
 
+class _Shift:
+    """a grouped neighbour exchange in flight: the send buffers it reads and, for a group that moves host tensors only, the
+    host copies of what it receives"""
+
+    def __init__(self, works, staged, keep):
+        self.works, self.staged, self.keep = list(works), staged, keep
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for dst, buf in self.staged:
+            dst.copy_(buf)
+        self.works, self.staged, self.keep = [], [], []
+
+
+def _ring_shift(sends, recvs, group):
+    """``sends`` [(tensor, dst)] and ``recvs`` [(tensor, src)] posted as ONE group (dist.batch_isend_irecv; RCCL: one
+    ncclGroupStart / End, executed by one kernel that serves all of its operations at once).  Stream-ordered RCCL
+    point-to-point calls issued one by one block each other when two ranks each have a send queued in front of the
+    receive the other side's send waits for; the operations of a group have no order among themselves, so ranks that all
+    post "first maps to the left, look-ahead from the right" at the same point of the program cannot."""
+    ops, staged, keep = [], [], []
+    for t, dst in sends:
+        buf = t.contiguous()
+        if _via_host(buf, group):
+            buf = buf.cpu()
+        keep.append(buf)
+        ops.append(dist.P2POp(dist.isend, buf, dst, group))
+    for t, src in recvs:
+        buf = t
+        if _via_host(t, group):
+            buf = torch.empty(t.shape, dtype=t.dtype)
+            staged.append((t, buf))
+        ops.append(dist.P2POp(dist.irecv, buf, src, group))
+    return _Shift(dist.batch_isend_irecv(ops) if ops else [], staged, keep)
+
+
 def _send_obj(obj, dst, group):
     dist.send_object_list([obj], dst=dst, group=group)
 
@@ -551,6 +588,7 @@ def block_slices(backend):
 
 _CHAIN_GROUPS = {}
 _GATHER_GROUPS = {}
+_CARRY_GROUPS = {}
 _CHAIN_EXEC = None
 
 
@@ -586,6 +624,24 @@ def _default_chain_group(group):
     if g is None:
         ranks = dist.get_process_group_ranks(group) if group is not None else None
         g = _CHAIN_GROUPS[key] = dist.new_group(ranks=ranks, backend='gloo', timeout=chain_timeout())
+    return g
+
+
+def _default_carry_group(group):
+    """a group of the tensor backend for the filtered carries alone.  The look-ahead maps travel as grouped ring shifts on
+    ``group``, the carries one by one down the ranks; on a communicator of their own the two kinds never have to agree on
+    ONE order per pair of ranks (with W = 2 both neighbours are the same rank, and a shift of round k + 1 is posted before
+    the carry of round k is received)."""
+    key = id(group) if group is not None else None
+    g = _CARRY_GROUPS.get(key)
+    if g is None:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        kw = {'timeout': chain_timeout()} if dist.get_backend(group) == 'gloo' else {}
+        g = _CARRY_GROUPS[key] = dist.new_group(ranks=ranks, backend=dist.get_backend(group), **kw)
+        if dist.get_backend(group) == 'nccl':
+            # a grouped point-to-point call must not be the first communication on a group unless every rank takes part
+            # in it (a rank without a block posts no shift): bring the communicator up here, where every rank is
+            dist.all_reduce(torch.zeros(1, device='cuda'), group=group)
     return g
 
 
@@ -626,6 +682,35 @@ def block_bounds(n_slices, block, ks):
     return slab_bounds(n_slices, max(1, n_slices // b))
 
 
+def ring_shift_plan(rank, world, n_blocks):
+    """The look-ahead traffic of the block-interleaved schedule as lock-step shifts of the ring of ranks.  Rank r owns
+    blocks r, r + W, ...; shift s is posted by every rank at the same point of its program -- right after the forward of
+    its block of round s (r + sW), or where that forward would be if the rank has no such block.  In shift s a rank
+    sends the first raw maps of its block of round s to the owner of the block before it (its left neighbour) and
+    receives what its right neighbour sends: the look-ahead of the block before the neighbour's, which is this rank's
+    block of round s -- or, on the last rank (whose right neighbour, rank 0, is a round ahead), of round s - 1.
+
+    -> per shift {'send': [(block whose first maps go out, destination rank)], 'recv': [(block whose look-ahead comes
+    in, source rank)]}; every send of a shift has its receive in the SAME shift of the destination, which is what lets
+    the operations of a shift be one RCCL group."""
+    W, NB = int(world), int(n_blocks)
+    if W <= 1:
+        return []
+    right = (rank + 1) % W
+    plan = []
+    s = 0
+    while True:
+        b, bR = rank + s * W, right + s * W
+        ent = {'send': [(b, (b - 1) % W)] if 0 < b < NB else [], 'recv': [(bR - 1, right)] if 0 < bR < NB else []}
+        if b >= NB and bR >= NB:
+            break
+        plan.append(ent)
+        s += 1
+    while plan and not plan[-1]['send'] and not plan[-1]['recv']:
+        plan.pop()
+    return plan
+
+
 def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_group=None, chain_group=None, defer=False):
     """SPMD body of one axis on one rank, BLOCK-INTERLEAVED: the stack is cut into blocks of about ``block`` slices (one
     forward batch) and rank r owns blocks r, r + W, r + 2W, ...  Same results as ``slab_stack_inference`` (one contiguous
@@ -642,10 +727,12 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
     GPU side of a round (block b of this rank; left / right = the owners of blocks b-1 / b+1, a ring): the forward of the
     NEXT round is enqueued first and its first raw maps go to the left neighbour at once -- the look-ahead a block's median
     waits for never waits for a forward that has not been started (the ring's wrap-around would otherwise idle the last
-    rank for a round); then look-ahead in, filtered carry in, median in place, carry out, voting / merge / run extraction,
-    push to the block's matcher.  Between two ranks a direction carries one kind of message (look-ahead leftwards, carry
-    rightwards; with W = 2 both kinds share a pair and alternate in the same order on both sides), so stream-ordered RCCL
-    point-to-point calls match without tags.
+    rank for a round); then filtered carry in, median in place, carry out, voting / merge / run extraction, push to the
+    block's matcher.  The look-ahead maps travel as lock-step shifts of the ring (``ring_shift_plan``: send left + receive
+    from the right as ONE RCCL group on ``group``, posted by every rank at the same point of its program), the carries one
+    by one down the ranks on a communicator of their own (``_default_carry_group``) where a pair of ranks sees them in one
+    order on both sides: no rank ever queues a send in front of the receive that its peer's send is waiting for, which is
+    what stream-ordered RCCL point-to-point calls need (gloo's buffered sends, the CPU tests' transport, would forgive it).
 
     -> on rank 0: {'parts': per-block partial trackers in block order, 'host_s', 'timing'}, elsewhere None."""
     import threading
@@ -659,6 +746,7 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
     mine = [b for b in range(NB) if owner(b) == rank]
     hg = host_group if host_group is not None else group
     cg = chain_group if chain_group is not None else hg
+    carry_group = _default_carry_group(group) if world > 1 and mid else group
     sms = [SlabMatcher(match['labels'], match['thing_list'], match['label_divisor'], match['iou_thr'], match['ioa_thr'],
                        match['width'], head=(b == 0)) for b in mine]
     pushed = [threading.Event() for _ in mine]
@@ -738,19 +826,40 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
     th = _chain_executor().submit(chain)      # behind the previous axis' chain + gather, if those are still running
     reqs = []
     try:
+        plan = ring_shift_plan(rank, world, NB) if mid else []
+        la = {}                                              # block -> the shift that brings its look-ahead
+
+        def shift(s):
+            """shift ``s`` of the ring (ring_shift_plan), posted by every rank right after the forward of its block of
+            round ``s``: that block's first raw maps to the owner of the block before it, and what the right neighbour
+            sends at this very point -- the look-ahead of the block before ITS block -- into that block's buffer"""
+            if s >= len(plan):
+                return
+            sends = [(fw[(b - rank) // world][0][:mid], dst) for b, dst in plan[s]['send']]
+            recvs = []
+            for b, src in plan[s]['recv']:
+                recvs.append((fw[(b - rank) // world][0][bounds[b][1] - bounds[b][0]:], src))
+            if sends or recvs:
+                sh = _ring_shift(sends, recvs, group)
+                reqs.append(sh)
+                for b, _ in plan[s]['recv']:
+                    la[b] = sh
+
         def forward(k):
             b = mine[k]
             lo, hi = bounds[b]
-            sem, stash = backend.forward(lo, hi, mid if b + 1 < NB else 0)
-            if mid and b > 0 and owner(b - 1) != rank:      # my first raw maps are the look-ahead of the block before
-                reqs.append(_isend(sem[:mid], owner(b - 1), group))
-            return sem, stash
+            fw[k] = backend.forward(lo, hi, mid if b + 1 < NB else 0)
+            shift(k)
 
-        fw = {0: forward(0)} if mine else {}
+        fw = {}
+        if mine:
+            forward(0)
         carry = None                                         # W = 1: the filtered tail of the block before, kept here
         for k, b in enumerate(mine):
             if k + 1 < len(mine):
-                fw[k + 1] = forward(k + 1)
+                forward(k + 1)
+            else:
+                shift(k + 1)       # no block of mine in the next round: the last rank may still be owed a look-ahead
             sem, stash = fw.pop(k)
             lo, hi = bounds[b]
             n_own = hi - lo
@@ -759,20 +868,20 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
                 if owner(b + 1) == rank:
                     sem[n_own:].copy_(fw[k + 1][0][:mid])
                 else:
-                    _recv(sem[n_own:], owner(b + 1), group)
+                    la.pop(b).wait()
             hist = None
             if mid and has_prev:
                 if owner(b - 1) == rank:
                     hist = carry
                 else:
                     hist = torch.empty_like(sem[:mid])
-                    _recv(hist, owner(b - 1), group)
+                    _recv(hist, owner(b - 1), carry_group)
             backend.median_inplace(sem, n_own, hist, mid if has_next else 0, b == 0, b == NB - 1, ks)
             if mid and has_next:
                 if owner(b + 1) == rank:
                     carry = sem[n_own - mid:n_own].clone()
                 else:
-                    reqs.append(_isend(sem[n_own - mid:n_own], owner(b + 1), group))
+                    reqs.append(_isend(sem[n_own - mid:n_own], owner(b + 1), carry_group))
             if hasattr(backend, 'runs_iter'):
                 for entries in backend.runs_iter(sem[:n_own], stash):
                     sms[k].push(entries)

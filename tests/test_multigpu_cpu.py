@@ -336,3 +336,34 @@ def test_spmd_ranks_defer_the_backward_chain_behind_the_next_axis(tmp_path, worl
                 assert box == tuple(int(v) for v in ref.instances[k]['box'])
                 np.testing.assert_array_equal(st, ref.instances[k]['starts'])
                 np.testing.assert_array_equal(rn, ref.instances[k]['runs'])
+
+
+def test_ring_shift_plan_is_lock_step():
+    """The look-ahead exchange of the block schedule as RCCL needs it (multigpu.ring_shift_plan): every send of shift s
+    has its receive in shift s of the destination -- so the operations of a shift can be ONE group, and no rank ever has
+    a send queued in front of the receive its peer's send waits for --, every block but the last gets its look-ahead
+    exactly once, from the block after it, into a buffer that exists when the shift is posted (the block of that round
+    or, on the last rank, of the round before), and no rank posts more shifts than it has rounds + 1."""
+    from empanada_napari_amd.multigpu import ring_shift_plan
+    assert ring_shift_plan(0, 1, 9) == []
+    for W in range(2, 9):
+        for NB in range(1, 40):
+            plans = [ring_shift_plan(r, W, NB) for r in range(W)]
+            served = []
+            for s in range(max(len(p) for p in plans)):
+                sends, recvs = {}, {}
+                for r, plan in enumerate(plans):
+                    if s >= len(plan):
+                        continue
+                    assert s <= len(range(r, NB, W))
+                    for b, dst in plan[s]['send']:
+                        assert b == r + s * W and dst == (b - 1) % W and (r, dst) not in sends
+                        sends[(r, dst)] = b
+                    for b, src in plan[s]['recv']:
+                        assert b % W == r and (b - r) // W in (s, s - 1) and src == (r + 1) % W
+                        recvs[(src, r)] = b
+                assert set(sends) == set(recvs)
+                for key, b in sends.items():
+                    assert recvs[key] == b - 1
+                    served.append(b - 1)
+            assert sorted(served) == list(range(NB - 1))
