@@ -18,6 +18,10 @@ workload `stack3d` (configs[3] in small): a procedural (hash-seeded, never store
 PER GPU of `--size`^2, xy stack inference with the recursive median through MultiGPUEngine3d's slab pipeline
 (RCCL neighbour halo + filtered carry) + matching / tracking on rank 0; value = voxels/s of the whole job.
 
+N > 1, workload `tiles`: after the tile measurement rank 0 runs the z-slab job (`--slab-depth` slices of `--slab-size`^2 per
+rank) as a bounded CHILD job on the same GPUs (`slab_job_child`, internal workload `slabjob`) and reports it as the
+`stack3d` block -- the headline line never depends on the only part of the bench with neighbour traffic between ranks.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -39,7 +43,7 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', choices=['tiles', 'stack3d'], default='tiles')
+    ap.add_argument('--workload', choices=['tiles', 'stack3d', 'slabjob'], default='tiles')
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--micro-batch', type=int, default=0, help='forward in chunks of this many tiles (0 = whole batch)')
@@ -52,6 +56,7 @@ def parse_args():
     ap.add_argument('--slab-size', type=int, default=4096, help='tiles workload, N > 1: slice side of the z-slab job of the `stack3d` block')
     ap.add_argument('--slab-depth', type=int, default=16, help='tiles workload, N > 1: slices per rank of that job')
     ap.add_argument('--ks', type=int, default=3, help='stack3d workload: median kernel size')
+    ap.add_argument('--slab-timeout', type=float, default=420.0, help='tiles workload, N > 1: bound (s) on the z-slab job, which runs as a child job of its own')
     return ap.parse_args()
 
 
@@ -345,11 +350,8 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
     torch.cuda.synchronize()
     ms_plain = (time.perf_counter() - t1) * 1e3 / args.steps
     slab_block = None
-    if dist_on and args.stack3d > 0:        # every rank takes part (SPMD); outside the timed region of `value`
-        try:
-            slab_block = slab_job_block(args, model, rank, world, dev)
-        except Exception as e:              # the headline line must not depend on the extra measurement
-            slab_block = {'error': f'{type(e).__name__}: {e}'}
+    if dist_on and args.stack3d > 0:        # outside the timed region of `value`, and outside this job altogether
+        slab_block = slab_job_child(args, rank, world)
     fwd_total_ms = sum(a.elapsed_time(b) for a, b in fwd_ms)
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * args.steps / dt
@@ -451,11 +453,69 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
     return res
 
 
+def slab_job_child(args, rank, world):
+    """N > 1: the 3-D half of BASELINE's metric (`slab_job_block`) as a CHILD job on the same GPUs, after the tile measurement:
+    rank 0 starts a second `torch.distributed.run` of this file (`--workload slabjob`, same N, a port of its own) while the
+    ranks of this job idle on the host (a gloo barrier: no kernel spins on a GPU meanwhile), and takes the child's JSON line
+    as the `stack3d` block.  The z-slab job is the only part of the bench with neighbour traffic between ranks; whatever
+    happens to it -- an exception on one rank, a peer that never answers -- ends with the child (killed as a process
+    group after `--slab-timeout` seconds) and an `error` entry, never with the headline line."""
+    import datetime
+    import signal
+    import socket
+    import subprocess
+    import torch.distributed as dist
+    wait_group = dist.new_group(backend='gloo', timeout=datetime.timedelta(seconds=args.slab_timeout + 300))
+    block = None
+    if rank == 0:
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        drop = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'GROUP_WORLD_SIZE', 'ROLE_RANK',
+                'ROLE_WORLD_SIZE', 'ROLE_NAME', 'MASTER_ADDR', 'MASTER_PORT', 'EMP_BENCH_FORCE_DIST')
+        env = {k: v for k, v in os.environ.items() if k not in drop and not k.startswith('TORCHELASTIC_')}
+        env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), '--gpus', str(world),
+               '--workload', 'slabjob', '--slab-size', str(args.slab_size), '--slab-depth', str(args.slab_depth),
+               '--ks', str(args.ks)]
+        try:
+            proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                    start_new_session=True)
+            try:
+                out, errtxt = proc.communicate(timeout=args.slab_timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)      # the launcher and its ranks: the group started here, nothing else
+                out, errtxt = proc.communicate()
+                block = {'error': f'z-slab child job killed after {args.slab_timeout:.0f} s'}
+            if block is None:
+                lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+                if proc.returncode == 0 and lines:
+                    block = json.loads(lines[-1])
+                else:
+                    block = {'error': f'z-slab child job exit {proc.returncode}: ' + errtxt.strip()[-400:]}
+        except Exception as e:      # noqa: BLE001 -- the headline line must not depend on the extra measurement
+            block = {'error': f'{type(e).__name__}: {e}'}
+    dist.barrier(group=wait_group)
+    return block
+
+
+def run_slabjob(args, rank, local_rank, world, dist_on, dev):
+    """the child job of `slab_job_child`: the bench model, then the z-slab job; rank 0 prints the block"""
+    from empanada_napari_amd import weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    model = HipPanopticDeepLab(P, cfg, device=dev, folded=True)
+    return slab_job_block(args, model, rank, world, dev)
+
+
 def slab_job_block(args, model, rank, world, dev):
     """N > 1: the 3-D half of BASELINE's metric on the SAME ranks, after the tile measurement and outside its timed region --
     configs[3] in small: a procedural uint8 volume of `--slab-depth` slices of `--slab-size`^2 PER RANK, xy stack inference
     through MultiGPUEngine3d on RCCL (z-slab / block-interleaved schedule, neighbour halo + filtered carry, slab-wise
-    matcher chained through the ranks).  Every rank calls it (SPMD); rank 0 returns the block.  Whatever `--gpus N`
+    matcher chained through the ranks).  Every rank calls it (SPMD, the ranks of `slab_job_child`'s child job); rank 0 returns the block.  Whatever `--gpus N`
     command the driver runs therefore records the 3-D scaling as well (weak: fixed slices per rank)."""
     import torch
     import torch.distributed as dist
@@ -666,7 +726,7 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
     graft.load_package()
-    run = run_tiles if args.workload == 'tiles' else run_stack3d
+    run = {'tiles': run_tiles, 'stack3d': run_stack3d, 'slabjob': run_slabjob}[args.workload]
     res = run(args, rank, local_rank, world, dist_on, dev)
     if rank == 0:
         print(json.dumps(res), flush=True)

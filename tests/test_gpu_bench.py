@@ -49,3 +49,13 @@ def test_two_ranks_sharing_the_gpu_emit_the_stack3d_block():
     assert s['unit'] == 'voxels/s' and s['value'] > 0 and s['volume'] == [12, 512, 512] and s['ranks_sharing_one_gpu'] == 2
     assert s['slab_pipeline']['ranks'] == 2 and len(s['slab_pipeline']['per_rank']) == 2
     assert all(r['slices'] == 6 for r in s['slab_pipeline']['per_rank'])
+
+
+def test_a_stuck_slab_job_costs_the_block_not_the_headline():
+    """the z-slab job runs as a child job with a bound (bench.slab_job_child): one that does not finish is killed and
+    leaves an `error` entry; the headline line of the N ranks is printed all the same"""
+    j = _bench(['--gpus', '2', '--steps', '1', '--warmup', '1', '--batch', '2', '--size', '256', '--slab-size', '512',
+                '--slab-depth', '6', '--engine2d', '0', '--latency', '0', '--no-cpu-baseline', '--slab-timeout', '1'],
+               env={'EMP_BENCH_SHARE_GPU': '1'})
+    assert j['n_gpus'] == 2 and j['value'] > 0
+    assert 'killed after' in j['stack3d']['error']
