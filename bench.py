@@ -456,7 +456,7 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
 def slab_job_child(args, rank, world):
     """N > 1: the 3-D half of BASELINE's metric (`slab_job_block`) as a CHILD job on the same GPUs, after the tile measurement:
     rank 0 starts a second `torch.distributed.run` of this file (`--workload slabjob`, same N, a port of its own) while the
-    ranks of this job idle on the host (a gloo barrier: no kernel spins on a GPU meanwhile), and takes the child's JSON line
+    ranks of this job idle on the host (a key of the rendezvous store: no kernel spins on a GPU meanwhile), and takes the child's JSON line
     as the `stack3d` block.  The z-slab job is the only part of the bench with neighbour traffic between ranks; whatever
     happens to it -- an exception on one rank, a peer that never answers -- ends with the child (killed as a process
     group after `--slab-timeout` seconds) and an `error` entry, never with the headline line."""
@@ -465,7 +465,8 @@ def slab_job_child(args, rank, world):
     import socket
     import subprocess
     import torch.distributed as dist
-    wait_group = dist.new_group(backend='gloo', timeout=datetime.timedelta(seconds=args.slab_timeout + 300))
+    store = dist.distributed_c10d._get_default_store()      # the ranks wait on the rendezvous store: no group, no kernel
+    key = 'emp_bench_slab_job_done'
     block = None
     if rank == 0:
         sk = socket.socket()
@@ -480,24 +481,49 @@ def slab_job_child(args, rank, world):
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), '--gpus', str(world),
                '--workload', 'slabjob', '--slab-size', str(args.slab_size), '--slab-depth', str(args.slab_depth),
                '--ks', str(args.ks)]
+        import tempfile
         try:
-            proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                    start_new_session=True)
-            try:
-                out, errtxt = proc.communicate(timeout=args.slab_timeout)
-            except subprocess.TimeoutExpired:
-                os.killpg(proc.pid, signal.SIGKILL)      # the launcher and its ranks: the group started here, nothing else
-                out, errtxt = proc.communicate()
-                block = {'error': f'z-slab child job killed after {args.slab_timeout:.0f} s'}
-            if block is None:
-                lines = [ln for ln in out.splitlines() if ln.startswith('{')]
-                if proc.returncode == 0 and lines:
-                    block = json.loads(lines[-1])
-                else:
-                    block = {'error': f'z-slab child job exit {proc.returncode}: ' + errtxt.strip()[-400:]}
+            # output into files, not pipes: a pipe reaches EOF only when EVERY descendant holding it is gone
+            with tempfile.TemporaryFile('w+') as fo, tempfile.TemporaryFile('w+') as fe:
+                proc = subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe, start_new_session=True)
+                print(f'bench.py: z-slab child job started (pid {proc.pid}, bound {args.slab_timeout:.0f} s)', file=sys.stderr, flush=True)
+                try:
+                    proc.wait(timeout=args.slab_timeout)
+                except subprocess.TimeoutExpired:
+                    block = {'error': f'z-slab child job killed after {args.slab_timeout:.0f} s'}
+                    started = []            # the launcher's descendants, by PID: the processes started here, nothing else
+                    try:
+                        import psutil
+                        started = psutil.Process(proc.pid).children(recursive=True)
+                    except Exception:       # noqa: BLE001
+                        pass
+                    try:
+                        os.killpg(proc.pid, signal.SIGKILL)
+                    except ProcessLookupError:
+                        pass
+                    for c in started:
+                        try:
+                            c.kill()
+                        except Exception:   # noqa: BLE001 -- already gone
+                            pass
+                    try:
+                        proc.wait(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        pass
+                if block is None:
+                    fo.seek(0)
+                    fe.seek(0)
+                    lines = [ln for ln in fo.read().splitlines() if ln.startswith('{')]
+                    if proc.returncode == 0 and lines:
+                        block = json.loads(lines[-1])
+                    else:
+                        block = {'error': f'z-slab child job exit {proc.returncode}: ' + fe.read().strip()[-400:]}
         except Exception as e:      # noqa: BLE001 -- the headline line must not depend on the extra measurement
             block = {'error': f'{type(e).__name__}: {e}'}
-    dist.barrier(group=wait_group)
+        print('bench.py: z-slab child job ' + ('failed: ' + block['error'][:200] if 'error' in block else 'done'), file=sys.stderr, flush=True)
+        store.set(key, '1')
+    else:
+        store.wait([key], datetime.timedelta(seconds=args.slab_timeout + 300))
     return block
 
 
