@@ -539,6 +539,8 @@ def slab_stack_inference(n_slices, backend, ks, group=None, host_group=None, mat
         if mid and has_prev:          # carry: filtered tail of the previous slab (ripples down the ranks)
             hist = torch.empty_like(sem[:mid])
             _recv(hist, rank - 1, group)
+        for r in reqs:
+            r.wait()                  # the median below overwrites the raw maps that send is reading
         backend.median_inplace(sem, n_own, hist, n_ahead, rank == 0, rank == aw - 1, ks)
         if mid and has_next:
             reqs.append(_isend(sem[n_own - mid:n_own], rank + 1, group))
@@ -828,6 +830,7 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
     try:
         plan = ring_shift_plan(rank, world, NB) if mid else []
         la = {}                                              # block -> the shift that brings its look-ahead
+        posted = {}                                          # round -> the shift that sends that block's first raw maps
 
         def shift(s):
             """shift ``s`` of the ring (ring_shift_plan), posted by every rank right after the forward of its block of
@@ -842,6 +845,7 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
             if sends or recvs:
                 sh = _ring_shift(sends, recvs, group)
                 reqs.append(sh)
+                posted[s] = sh
                 for b, _ in plan[s]['recv']:
                     la[b] = sh
 
@@ -869,6 +873,8 @@ def block_stack_inference(n_slices, backend, ks, match, block, group=None, host_
                     sem[n_own:].copy_(fw[k + 1][0][:mid])
                 else:
                     la.pop(b).wait()
+            if k in posted:
+                posted.pop(k).wait()      # the median below overwrites the maps that shift is sending
             hist = None
             if mid and has_prev:
                 if owner(b - 1) == rank:
