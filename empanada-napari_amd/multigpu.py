@@ -163,8 +163,9 @@ class _Sent:
         self.work, self.buf = work, buf
 
     def wait(self):
-        self.work.wait()
-        self.buf = None
+        if self.work is not None:
+            self.work.wait()
+        self.work = self.buf = None
 
 
 def _isend(t, dst, group):
