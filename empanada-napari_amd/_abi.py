@@ -21,6 +21,8 @@ class PdlConfig(C.Structure):
         ('low_level_proj_sem', c_i32 * 3), ('low_level_proj_ins', c_i32 * 3),
         ('atrous_rates', c_i32 * 3), ('ins_decoder', c_i32), ('num_fc', c_i32),
         ('subdivision_num_points', c_i32), ('arch', c_i32), ('fpn_dim', c_i32), ('fpn_layers', c_i32),
+        ('encoder', c_i32), ('rn_stem', c_i32), ('rn_widths', c_i32 * 4), ('rn_depths', c_i32 * 4),
+        ('rn_groups', c_i32 * 4), ('rn_strides', c_i32 * 4), ('rn_se', c_i32),
     ]
 
 
@@ -52,6 +54,8 @@ PROTOTYPES = {
     'emp_copy_d2d': (c_int, [vp, vp, sz, vp]),
     'emp_conv2d_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+    'emp_conv2d_grouped_nhwc_f32': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_int, c_int, c_int,
+                                            c_int, c_int, c_int, c_int, c_int, vp]),
     'emp_conv2d_nhwc_f32': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'emp_conv1x1_dual_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp,

@@ -34,7 +34,7 @@ using namespace emp;
 extern "C" {
 
 const char* emp_last_error(void) { return g_err; }
-int emp_abi_version(void) { return 1; }
+int emp_abi_version(void) { return 2; }      // 2: emp_pdl_config carries the encoder (RegNet) fields
 
 int emp_device_count(void) {
   int n = 0;
@@ -94,6 +94,24 @@ int emp_conv2d_nhwc_f32(const float* d_in, int N, int H, int W, int Cin, int in_
   p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   EMP_REQUIRE(p.Ho > 0 && p.Wo > 0 && out_ld >= Cout && (d_res == nullptr || res_ld >= Cout), "conv2d_f32: bad output geometry");
   p.act = act;
+  return launch_conv32(p, (hipStream_t)stream);
+}
+
+int emp_conv2d_grouped_nhwc_f32(const float* d_in, int N, int H, int W, int groups, int cin_g, int Cin16, int in_ld, const float* d_w,
+                                const float* d_bias, float* d_out, int out_ld, int cout_g, int KH, int KW, int stride, int pad,
+                                int dil, int act, void* stream) {
+  EMP_REQUIRE(d_in && d_w && d_out, "conv2d_grouped_f32: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0 && groups >= 1 && cout_g > 0,
+              "conv2d_grouped_f32: bad geometry");
+  Conv32 p{};
+  p.in = d_in; p.in_ld = in_ld; p.w = d_w; p.bias = d_bias; p.out = d_out; p.out_ld = out_ld;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin16; p.Cout = cout_g; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  EMP_REQUIRE(p.Ho > 0 && p.Wo > 0 && out_ld >= groups * cout_g, "conv2d_grouped_f32: bad output geometry");
+  p.act = act;
+  if (groups > 1) { p.groups = groups; p.cin_g = cin_g; }
+  else EMP_REQUIRE(cin_g == Cin16, "conv2d_grouped_f32: one group reads Cin16 channels");
   return launch_conv32(p, (hipStream_t)stream);
 }
 

@@ -192,21 +192,45 @@ void expect(emp_pdl* n, const std::string& name) {
   n->params[name] = HostParam();
 }
 
+// RegNet block (regnet.py:51-97): does block b (1-based) of stage si (1-based) carry a shortcut convolution?
+bool regnet_has_shortcut(const emp_pdl_config& c, int si, int b) {
+  if (b > 1) return false;
+  const int w_in = si == 1 ? c.rn_stem : c.rn_widths[si - 2];
+  return w_in != c.rn_widths[si - 1] || c.rn_strides[si - 1] > 1;
+}
+
 void build_param_list(emp_pdl* n) {
   const emp_pdl_config& c = n->cfg;
-  expect(n, "encoder.conv1");
-  for (int li = 1; li <= 4; ++li)
-    for (int b = 0; b < kLayers[li - 1]; ++b) {
-      std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
-      expect(n, p + ".conv1");
-      expect(n, p + ".conv2");
-      expect(n, p + ".conv3");
-      if (b == 0) expect(n, p + ".downsample.0");
-    }
+  if (c.encoder == 1) {
+    expect(n, "encoder.stem.cbr.0");
+    for (int si = 1; si <= 4; ++si)
+      for (int b = 1; b <= c.rn_depths[si - 1]; ++b) {
+        const std::string p = "encoder.stage" + std::to_string(si) + ".block" + std::to_string(b);
+        expect(n, p + ".bottleneck.a.0");
+        expect(n, p + ".bottleneck.b.0");
+        if (c.rn_se) {
+          expect(n, p + ".bottleneck.se.se.0");
+          expect(n, p + ".bottleneck.se.se.2");
+        }
+        expect(n, p + ".bottleneck.c.0");
+        if (regnet_has_shortcut(c, si, b)) expect(n, p + ".downsample.conv.0");
+      }
+  } else {
+    expect(n, "encoder.conv1");
+    for (int li = 1; li <= 4; ++li)
+      for (int b = 0; b < kLayers[li - 1]; ++b) {
+        std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
+        expect(n, p + ".conv1");
+        expect(n, p + ".conv2");
+        expect(n, p + ".conv3");
+        if (b == 0) expect(n, p + ".downsample.0");
+      }
+  }
   if (c.arch == 1) {
     expect(n, "p2_resample.conv.0");
     const int F = c.fpn_dim;
-    const int w0[5] = {512, 1024, 2048, F, F};
+    const bool rn = c.encoder == 1;
+    const int w0[5] = {rn ? c.rn_widths[1] : 512, rn ? c.rn_widths[2] : 1024, rn ? c.rn_widths[3] : 2048, F, F};
     const char* dn[2] = {"semantic", "instance"};
     for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
       std::string fp = std::string(dn[d]) + "_fpn";
@@ -1265,14 +1289,43 @@ int pack32_convT(emp_pdl* n, const std::string& name) {
 
 int finalize32(emp_pdl* n) {
   const emp_pdl_config& c = n->cfg;
-  for (int li = 1; li <= 4; ++li)
-    for (int b = 0; b < kLayers[li - 1]; ++b) {
-      const std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
-      RC32(pack32(n, p + ".conv1"));
-      RC32(pack32(n, p + ".conv2"));
-      RC32(pack32(n, p + ".conv3"));
-      if (b == 0) RC32(pack32(n, p + ".downsample.0"));
+  if (c.encoder == 1) {
+    {   // stem (W,1,3,3) -> [9][W] fp32
+      const HostParam& hp = n->params["encoder.stem.cbr.0"];
+      EMP_REQUIRE(hp.shape.size() == 4 && hp.shape[0] == c.rn_stem && hp.shape[1] == 1 && hp.shape[2] == 3 && hp.shape[3] == 3,
+                  "encoder.stem.cbr.0 must be (%d,1,3,3)", c.rn_stem);
+      std::vector<float> w((size_t)9 * c.rn_stem);
+      for (int o = 0; o < c.rn_stem; ++o)
+        for (int t = 0; t < 9; ++t) w[(size_t)t * c.rn_stem + o] = hp.w[(size_t)o * 9 + t];
+      RC32(upload_f32(n, "rn.stem.w", w));
+      RC32(upload_f32(n, "rn.stem.b", hp.b));
     }
+    for (int si = 1; si <= 4; ++si)
+      for (int b = 1; b <= c.rn_depths[si - 1]; ++b) {
+        const std::string p = "encoder.stage" + std::to_string(si) + ".block" + std::to_string(b);
+        const int w = c.rn_widths[si - 1], g = c.rn_groups[si - 1];
+        RC32(pack32(n, p + ".bottleneck.a.0"));
+        RC32(pack32(n, p + ".bottleneck.b.0"));      // (w, w / g, 3, 3): rows [o][tap][(w / g) padded to 16], group-major in o
+        const emp_pdl::W32& wb = n->w32.at(p + ".bottleneck.b.0");
+        EMP_REQUIRE(wb.cout == w && wb.cin * g == w && wb.kh == 3 && wb.kw == 3, "%s.bottleneck.b.0 must be (%d,%d,3,3)", p.c_str(), w,
+                    w / g);
+        if (c.rn_se) {
+          RC32(pack32(n, p + ".bottleneck.se.se.0"));
+          RC32(pack32(n, p + ".bottleneck.se.se.2"));
+        }
+        RC32(pack32(n, p + ".bottleneck.c.0"));
+        if (regnet_has_shortcut(c, si, b)) RC32(pack32(n, p + ".downsample.conv.0"));
+      }
+  } else {
+    for (int li = 1; li <= 4; ++li)
+      for (int b = 0; b < kLayers[li - 1]; ++b) {
+        const std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
+        RC32(pack32(n, p + ".conv1"));
+        RC32(pack32(n, p + ".conv2"));
+        RC32(pack32(n, p + ".conv3"));
+        if (b == 0) RC32(pack32(n, p + ".downsample.0"));
+      }
+  }
   if (c.arch == 1) {
     RC32(pack32(n, "p2_resample.conv.0"));
     for (const auto& nm : n->param_names) {
@@ -1330,21 +1383,28 @@ int finalize32(emp_pdl* n) {
 
 // out[:, :, :, out_coff : out_coff + Cout) = act(conv(in[:, :, :, in_coff : in_coff + Cin16)) + bias (+ bias_n) (+ res))
 int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const T32& out, int out_coff, int stride, int pad,
-        int dil, int act, const T32* res, const float* bias_n, hipStream_t s, int ps_cout = 0) {
+        int dil, int act, const T32* res, const float* bias_n, hipStream_t s, int ps_cout = 0, int groups = 1) {
   const emp_pdl::W32& w = n->w32.at(wname);
   Conv32 p{};
+  if (groups > 1) {      // grouped 3x3 of a RegNet block: w.cin is the group width, w.cout all output channels
+    EMP_REQUIRE(w.cout % groups == 0 && in_coff == 0 && out_coff == 0 && !res && !bias_n && !ps_cout, "%s (fp32): bad grouped call",
+                wname.c_str());
+    p.groups = groups;
+    p.cin_g = w.cin;
+  }
   p.in = in.p + in_coff; p.in_ld = in.ld;
   p.w = w.w; p.bias = w.b; p.bias_n = bias_n;
   p.res = res ? res->p : nullptr; p.res_ld = res ? res->ld : 0;
   p.out = out.p + out_coff; p.out_ld = out.ld;
-  p.N = in.N; p.H = in.H; p.W = in.W; p.Cin = w.cin16; p.Cout = w.cout; p.KH = w.kh; p.KW = w.kw;
+  p.N = in.N; p.H = in.H; p.W = in.W; p.Cin = w.cin16; p.Cout = w.cout / groups; p.KH = w.kh; p.KW = w.kw;
   p.stride = stride; p.pad = pad; p.dil = dil;
   p.Ho = (in.H + 2 * pad - dil * (w.kh - 1) - 1) / stride + 1;
   p.Wo = (in.W + 2 * pad - dil * (w.kw - 1) - 1) / stride + 1;
   p.act = act; p.ps_cout = ps_cout;
   const int up = ps_cout ? 2 : 1;
   EMP_REQUIRE(p.Ho * up == out.H && p.Wo * up == out.W && in.N == out.N, "%s (fp32): output shape mismatch", wname.c_str());
-  EMP_REQUIRE(in_coff + w.cin16 <= in.ld && out_coff + (ps_cout ? ps_cout : w.cout) <= out.ld, "%s (fp32): channel slice out of range", wname.c_str());
+  EMP_REQUIRE(in_coff + (groups - 1) * w.cin + w.cin16 <= in.ld && out_coff + (ps_cout ? ps_cout : w.cout) <= out.ld,
+              "%s (fp32): channel slice out of range (needs %d of a row of %d)", wname.c_str(), in_coff + (groups - 1) * w.cin + w.cin16, in.ld);
   n->flops += 2.0 * (double)p.N * p.Ho * p.Wo * w.cout * (double)(w.cin * w.kh * w.kw);
   return launch_conv32(p, s);
 }
@@ -1364,36 +1424,87 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
     return launch_dwconv_f32(in.p, N, in.H, in.W, in.C, in.ld, n->f32w.at(wname + ".dw32"), K, out.p, out.ld, s);
   };
   // ---- encoder ----
-  RC32(mk("stem", H / 2, W / 2, 64));
-  RC32(launch_stem7x7_f32(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("stem").p, s));
-  n->flops += 2.0 * N * (H / 2) * (W / 2) * 64.0 * 49.0;
-  RC32(mk("p1", H / 4, W / 4, 64));
-  RC32(launch_maxpool3x3s2_f32(A("stem").p, N, H / 2, W / 2, 64, A("p1").p, s));
-  std::string x = "p1", pyr[5];
-  pyr[0] = "p1";
-  for (int li = 1; li <= 4; ++li) {
-    int stride = li == 1 ? 1 : 2, dil = 1;
-    if (li == 4 && c.stage4_stride == 16) { stride = 1; dil = 2; }
-    for (int b = 0; b < kLayers[li - 1]; ++b) {
-      const int sb = b == 0 ? stride : 1, planes = kPlanes[li - 1];
-      const std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
-      const T32 xin = A(x);
-      const int ho = (xin.H - 1) / sb + 1, wo = (xin.W - 1) / sb + 1;
-      RC32(mk(p + ".c1", xin.H, xin.W, planes));
-      RC32(c32(n, p + ".conv1", xin, 0, A(p + ".c1"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
-      RC32(mk(p + ".c2", ho, wo, planes));
-      RC32(c32(n, p + ".conv2", A(p + ".c1"), 0, A(p + ".c2"), 0, sb, dil, dil, 1, nullptr, nullptr, s));
-      const T32* idn = &A(x);
-      if (b == 0) {
-        RC32(mk(p + ".ds", ho, wo, planes * 4));
-        RC32(c32(n, p + ".downsample.0", xin, 0, A(p + ".ds"), 0, sb, 0, 1, 0, nullptr, nullptr, s));
-        idn = &A(p + ".ds");
+  std::string x, pyr[5];
+  if (c.encoder == 1) {
+    // RegNet (regnet.py:160-166).  Its widths are multiples of 8, not of 16: every map gets a row of round_up(C, 16) + 16
+    // floats whose tail stays zero (buf32 clears a buffer when it allocates it and no kernel writes beyond C), so that a
+    // consumer reading its input channels padded to 16 -- from a group's first channel, in the grouped 3x3 -- stays
+    // inside the row and meets zeros (or the next group's finite values) under zero weights.
+    auto mkp = [&](const std::string& k, int H_, int W_, int C_) -> int {
+      T32 t;
+      t.N = N; t.H = H_; t.W = W_; t.C = C_; t.ld = round_up(C_, 16) + 16;
+      const int rc = buf32(n, k, (size_t)N * H_ * W_ * t.ld, &t.p);
+      T[k] = t;
+      return rc;
+    };
+    RC32(mkp("stem", H / 2, W / 2, c.rn_stem));
+    RC32(launch_stem3x3s2_f32(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("rn.stem.w"), n->f32w.at("rn.stem.b"), c.rn_stem,
+                              A("stem").p, A("stem").ld, s));
+    n->flops += 2.0 * N * (H / 2) * (W / 2) * (double)c.rn_stem * 9.0;
+    x = "stem";
+    pyr[0] = "stem";
+    for (int si = 1; si <= 4; ++si) {
+      const int w = c.rn_widths[si - 1], g = c.rn_groups[si - 1];
+      for (int b = 1; b <= c.rn_depths[si - 1]; ++b) {
+        const std::string p = "encoder.stage" + std::to_string(si) + ".block" + std::to_string(b);
+        const int sb = b == 1 ? c.rn_strides[si - 1] : 1;
+        const T32 xin = A(x);
+        const int ho = (xin.H - 1) / sb + 1, wo = (xin.W - 1) / sb + 1;
+        RC32(mkp(p + ".a", xin.H, xin.W, w));
+        RC32(c32(n, p + ".bottleneck.a.0", xin, 0, A(p + ".a"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+        RC32(mkp(p + ".b", ho, wo, w));
+        RC32(c32(n, p + ".bottleneck.b.0", A(p + ".a"), 0, A(p + ".b"), 0, sb, 1, 1, 1, nullptr, nullptr, s, 0, g));
+        if (c.rn_se) {      // per-pixel gate: x * sigmoid(W2 relu(W1 x)) (blocks.py:35-50: the pool is 1 x 1)
+          RC32(mkp(p + ".se1", ho, wo, w / 4));
+          RC32(c32(n, p + ".bottleneck.se.se.0", A(p + ".b"), 0, A(p + ".se1"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+          RC32(mkp(p + ".se2", ho, wo, w));
+          RC32(c32(n, p + ".bottleneck.se.se.2", A(p + ".se1"), 0, A(p + ".se2"), 0, 1, 0, 1, 0, nullptr, nullptr, s));
+          RC32(launch_gate_mul_f32(A(p + ".b").p, A(p + ".b").ld, A(p + ".se2").p, A(p + ".se2").ld, (int64_t)N * ho * wo, w, s));
+        }
+        const T32* idn = &A(x);
+        if (regnet_has_shortcut(c, si, b)) {
+          RC32(mkp(p + ".ds", ho, wo, w));
+          RC32(c32(n, p + ".downsample.conv.0", xin, 0, A(p + ".ds"), 0, sb, 0, 1, 0, nullptr, nullptr, s));
+          idn = &A(p + ".ds");
+        }
+        RC32(mkp(p, ho, wo, w));
+        RC32(c32(n, p + ".bottleneck.c.0", A(p + ".b"), 0, A(p), 0, 1, 0, 1, 1, idn, nullptr, s));
+        x = p;
       }
-      RC32(mk(p, ho, wo, planes * 4));
-      RC32(c32(n, p + ".conv3", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, 1, idn, nullptr, s));
-      x = p;
+      pyr[si] = x;
     }
-    pyr[li] = x;
+  } else {
+    RC32(mk("stem", H / 2, W / 2, 64));
+    RC32(launch_stem7x7_f32(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("stem").p, s));
+    n->flops += 2.0 * N * (H / 2) * (W / 2) * 64.0 * 49.0;
+    RC32(mk("p1", H / 4, W / 4, 64));
+    RC32(launch_maxpool3x3s2_f32(A("stem").p, N, H / 2, W / 2, 64, A("p1").p, s));
+    x = "p1";
+    pyr[0] = "p1";
+    for (int li = 1; li <= 4; ++li) {
+      int stride = li == 1 ? 1 : 2, dil = 1;
+      if (li == 4 && c.stage4_stride == 16) { stride = 1; dil = 2; }
+      for (int b = 0; b < kLayers[li - 1]; ++b) {
+        const int sb = b == 0 ? stride : 1, planes = kPlanes[li - 1];
+        const std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
+        const T32 xin = A(x);
+        const int ho = (xin.H - 1) / sb + 1, wo = (xin.W - 1) / sb + 1;
+        RC32(mk(p + ".c1", xin.H, xin.W, planes));
+        RC32(c32(n, p + ".conv1", xin, 0, A(p + ".c1"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+        RC32(mk(p + ".c2", ho, wo, planes));
+        RC32(c32(n, p + ".conv2", A(p + ".c1"), 0, A(p + ".c2"), 0, sb, dil, dil, 1, nullptr, nullptr, s));
+        const T32* idn = &A(x);
+        if (b == 0) {
+          RC32(mk(p + ".ds", ho, wo, planes * 4));
+          RC32(c32(n, p + ".downsample.0", xin, 0, A(p + ".ds"), 0, sb, 0, 1, 0, nullptr, nullptr, s));
+          idn = &A(p + ".ds");
+        }
+        RC32(mk(p, ho, wo, planes * 4));
+        RC32(c32(n, p + ".conv3", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, 1, idn, nullptr, s));
+        x = p;
+      }
+      pyr[li] = x;
+    }
   }
   std::string dec_out[2];
   if (c.arch == 1) {
@@ -1630,9 +1741,25 @@ int emp_pdl_create(const emp_pdl_config* cfg, emp_pdl_t** out) {
     EMP_REQUIRE(cfg->low_level_proj_sem[i] % 8 == 0 && (!cfg->ins_decoder || cfg->low_level_proj_ins[i] % 8 == 0),
                 "projected low-level channels must be multiples of 8");
   }
+  EMP_REQUIRE(cfg->encoder == 0 || cfg->encoder == 1, "encoder must be 0 (ResNet50) or 1 (RegNet)");
+  if (cfg->encoder == 1) {
+    EMP_REQUIRE(cfg->rn_stem > 0 && cfg->rn_stem % 4 == 0, "RegNet: stem width %d must be a positive multiple of 4", cfg->rn_stem);
+    for (int i = 0; i < 4; ++i) {
+      const int w = cfg->rn_widths[i], g = cfg->rn_groups[i];
+      EMP_REQUIRE(w > 0 && g > 0 && w % g == 0 && (w / g) % 4 == 0 && w % 8 == 0 && cfg->rn_depths[i] >= 1 &&
+                      (cfg->rn_strides[i] == 1 || cfg->rn_strides[i] == 2),
+                  "RegNet stage %d: width %d (multiple of 8), groups %d (group width a multiple of 4), depth %d, stride %d", i + 1, w, g,
+                  cfg->rn_depths[i], cfg->rn_strides[i]);
+    }
+    int os_ = 2;
+    for (int i = 0; i < 4; ++i) os_ *= cfg->rn_strides[i];
+    EMP_REQUIRE(cfg->rn_strides[0] == 2 && (os_ == 32 || os_ == 16) && (cfg->arch == 0 || os_ == 32),
+                "RegNet: stage 1 must be at stride 4 and the encoder's output stride 16 or 32 (BiFPN: 32)");
+  }
   emp_pdl* n = new (std::nothrow) emp_pdl();
   if (!n) return EMP_ERR_NOMEM;
   n->cfg = *cfg;
+  if (cfg->encoder == 1) n->precision = 1;      // RegNet encoders exist in the fp32 mode only (grouped conv32, ref32.hip)
   n->dec_ch = cfg->arch == 1 ? cfg->fpn_dim : cfg->decoder_channels;
   n->aspp_ch = cfg->aspp_channels > 0 ? cfg->aspp_channels : cfg->decoder_channels;
   n->ncls = cfg->num_classes;
@@ -1678,6 +1805,44 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       return EMP_ERR_STATE;
     }
   const emp_pdl_config& c = n->cfg;
+  if (c.encoder == 1) {
+    // RegNet: fp32 mode only -- none of the fp16 packs below; what run32 reads besides finalize32's conv weights:
+    if (c.arch == 1) {
+      for (const auto& nm : n->param_names)
+        if (nm.size() > 8 && nm.compare(nm.size() - 8, 8, ".weights") == 0) {
+          const HostParam& hp = n->params[nm];
+          EMP_REQUIRE(hp.w.size() == 5, "%s: expected 5 fusion weights", nm.c_str());
+          std::vector<float> w(5);
+          float sum = 0.f;
+          for (int i = 0; i < 5; ++i) { w[i] = hp.w[i] > 0.f ? hp.w[i] : 0.f; sum += w[i]; }
+          for (int i = 0; i < 5; ++i) w[i] = w[i] / (sum + 1e-4f);   // bifpn.py:52-55
+          n->fusew[nm] = w;
+        }
+    } else {
+      const char* decs[2] = {"semantic_decoder", "instance_decoder"};
+      for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
+        const std::string p = decs[d];
+        const int A = n->aspp_ch;
+        RC(upload_f32(n, p + ".pool.w", n->params[p + ".aspp.convs.4.aspp_pooling.1"].w));
+        const HostParam& hp = n->params[p + ".aspp.project.0"];
+        EMP_REQUIRE(hp.shape[0] == A && hp.shape[1] == 5 * A, "%s.aspp.project.0 must be (%d,%d,1,1)", p.c_str(), A, 5 * A);
+        std::vector<float> tail((size_t)A * A);
+        for (int o = 0; o < A; ++o)
+          for (int i = 0; i < A; ++i) tail[(size_t)o * A + i] = hp.w[(size_t)o * 5 * A + 4 * A + i];
+        RC(upload_f32(n, p + ".projpool.w", tail));
+      }
+    }
+    const char* heads32[3] = {"semantic_head", "ins_center", "ins_xy"};
+    for (int k = 0; k < 3; ++k) {
+      const std::string p = heads32[k];
+      RC(upload_f32(n, p + ".head.1.w", n->params[p + ".head.1"].w));
+      RC(upload_f32(n, p + ".head.1.b", n->params[p + ".head.1"].b));
+    }
+    RC(upload_f32(n, "pr.predictor.b", n->params["semantic_pr.point_head.predictor"].b));
+    RC(finalize32(n));
+    n->finalized = true;
+    return EMP_OK;
+  }
   // stem: (64,1,7,7) -> [49][64] fp32
   {
     const HostParam& hp = n->params["encoder.conv1"];
@@ -1867,6 +2032,7 @@ int emp_pdl_set_precision(emp_pdl_t* net, int precision) {
   EMP_REQUIRE(net, "set_precision: null network");
   EMP_REQUIRE(precision == 0 || precision == 1, "set_precision: 0 = fp16 engine, 1 = fp32 reference mode (got %d)", precision);
   EMP_REQUIRE(!net->finalized, "set_precision: call before emp_pdl_finalize");
+  EMP_REQUIRE(net->cfg.encoder == 0 || precision == 1, "set_precision: a RegNet network runs in the fp32 mode only");
   net->precision = precision;
   return EMP_OK;
 }

@@ -34,6 +34,10 @@ __global__ void __launch_bounds__(256) conv32_kernel(const Conv32 p) {
   __shared__ float Bs[R_BN][R_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * R_BM, n0 = blockIdx.y * R_BN;
+  // grouped convolution (RegNet's 3x3): blockIdx.z = group; Cout / Cin are PER GROUP, the group's input channels start
+  // at g * cin_g (Cin >= cin_g is its padding to 16: the extra channels meet zero weights), its outputs at g * Cout
+  const int g = blockIdx.z, gco = g * p.Cout;
+  const float* gin = p.in + (size_t)g * p.cin_g;
   const int HoWo = p.Ho * p.Wo;
   const int M = p.N * HoWo;
   const int K = p.KH * p.KW * p.Cin;
@@ -49,7 +53,7 @@ __global__ void __launch_bounds__(256) conv32_kernel(const Conv32 p) {
     aox = r - aoy * p.Wo;
   }
   const int bco = n0 + srow;
-  const float* brow = bco < p.Cout ? p.w + (size_t)bco * K : nullptr;
+  const float* brow = bco < p.Cout ? p.w + (size_t)(gco + bco) * K : nullptr;
   const int wrow = (wave & 1) * 32, wcol = (wave >> 1) * 32;
   f32x16 acc;
 #pragma unroll
@@ -61,7 +65,7 @@ __global__ void __launch_bounds__(256) conv32_kernel(const Conv32 p) {
     if (arow_ok) {
       const int iy = aoy * p.stride - p.pad + ky * p.dil, ix = aox * p.stride - p.pad + kx * p.dil;
       if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-        av = *reinterpret_cast<const float4*>(p.in + (((size_t)an * p.H + iy) * p.W + ix) * p.in_ld + c0 + skq);
+        av = *reinterpret_cast<const float4*>(gin + (((size_t)an * p.H + iy) * p.W + ix) * p.in_ld + c0 + skq);
     }
     if (brow) bv = *reinterpret_cast<const float4*>(brow + k0 + skq);
     __syncthreads();      // the previous step's fragment reads are done
@@ -76,8 +80,9 @@ __global__ void __launch_bounds__(256) conv32_kernel(const Conv32 p) {
     }
   }
   // epilogue: bias (+ per-image bias) (+ residual), activation, store (plain NHWC slice or k2s2 pixel shuffle)
-  const int co = n0 + wcol + (lane & 31);
-  if (co >= p.Cout) return;
+  const int col = n0 + wcol + (lane & 31);
+  if (col >= p.Cout) return;
+  const int co = gco + col;
   const float bias = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -85,7 +90,7 @@ __global__ void __launch_bounds__(256) conv32_kernel(const Conv32 p) {
     if (m >= M) continue;
     const int n = m / HoWo;
     float v = acc[i] + bias;
-    if (p.bias_n) v += p.bias_n[(size_t)n * p.Cout + co];
+    if (p.bias_n) v += p.bias_n[(size_t)n * p.Cout + co];      // (never with groups: launch_conv32)
     if (p.res) v += p.res[(size_t)m * p.res_ld + co];
     v = r_act<ACT>(v);
     size_t o;
@@ -312,15 +317,105 @@ __global__ void __launch_bounds__(256) point_features32_kernel(const float* __re
 
 }  // namespace
 
+// RegNet stem (regnet.py:38-49): 3x3 stride-2 conv of the single-channel image + folded BN + ReLU, normalisation and
+// factor_pad fused as in the 7x7 stem; thread = one output pixel x 4 channels, weights [9][C]
+template <typename T>
+__global__ void __launch_bounds__(256) stem3x3s2_32_kernel(const T* __restrict__ img, float sub, float mul, int normalise, int N,
+                                                           int H, int W, int vh, int vw, const float* __restrict__ w,
+                                                           const float* __restrict__ b, int C, float* __restrict__ out,
+                                                           int out_ld, int64_t total) {
+  const int CG = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % CG);
+    int64_t q = i / CG;
+    const int ox = (int)(q % Wo); q /= Wo;
+    const int oy = (int)(q % Ho);
+    const int n = (int)(q / Ho);
+    const T* src = img + (size_t)n * vh * vw;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        float v = 0.f;
+        if (iy >= 0 && iy < vh && ix >= 0 && ix < vw) {      // outside the valid image: zero AFTER normalisation
+          v = (float)src[(size_t)iy * vw + ix];
+          if (normalise) { v -= sub; v *= mul; }
+        }
+        const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)(ky * 3 + kx) * C + cg * 4);
+        acc.x = fmaf(v, wv.x, acc.x); acc.y = fmaf(v, wv.y, acc.y); acc.z = fmaf(v, wv.z, acc.z); acc.w = fmaf(v, wv.w, acc.w);
+      }
+    }
+    const float4 bv = *reinterpret_cast<const float4*>(b + cg * 4);
+    float4 o;
+    o.x = fmaxf(acc.x + bv.x, 0.f); o.y = fmaxf(acc.y + bv.y, 0.f); o.z = fmaxf(acc.z + bv.z, 0.f); o.w = fmaxf(acc.w + bv.w, 0.f);
+    *reinterpret_cast<float4*>(out + (((size_t)n * Ho + oy) * Wo + ox) * out_ld + cg * 4) = o;
+  }
+}
+
+// the reference's squeeze-excite gate (blocks.py:35-50; per pixel, its "pool" is 1 x 1): x *= sigmoid(g), in place
+__global__ void __launch_bounds__(256) gate_mul32_kernel(float* __restrict__ x, int x_ld, const float* __restrict__ g, int g_ld, int C,
+                                                         int64_t total) {
+  const int CG = C >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % CG);
+    const int64_t m = i / CG;
+    float4 xv = *reinterpret_cast<const float4*>(x + (size_t)m * x_ld + cg * 4);
+    const float4 gv = *reinterpret_cast<const float4*>(g + (size_t)m * g_ld + cg * 4);
+    xv.x *= 1.f / (1.f + expf(-gv.x)); xv.y *= 1.f / (1.f + expf(-gv.y));
+    xv.z *= 1.f / (1.f + expf(-gv.z)); xv.w *= 1.f / (1.f + expf(-gv.w));
+    *reinterpret_cast<float4*>(x + (size_t)m * x_ld + cg * 4) = xv;
+  }
+}
+
+int launch_stem3x3s2_f32(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw, const float* w,
+                         const float* b, int C, float* out, int out_ld, hipStream_t s) {
+  EMP_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && out_ld % 4 == 0 && out_ld >= C, "stem3x3: bad shape");
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
+  const dim3 grid(grid_for(total));
+  switch (dtype) {
+    case EMP_IMG_F32:
+      hipLaunchKernelGGL(stem3x3s2_32_kernel<float>, grid, dim3(256), 0, s, (const float*)img, sub, mul, 0, N, H, W, vh, vw, w, b, C,
+                         out, out_ld, total);
+      break;
+    case EMP_IMG_U8:
+      hipLaunchKernelGGL(stem3x3s2_32_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)img, sub, mul, 1, N, H, W, vh, vw, w, b,
+                         C, out, out_ld, total);
+      break;
+    case EMP_IMG_U16:
+      hipLaunchKernelGGL(stem3x3s2_32_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)img, sub, mul, 1, N, H, W, vh, vw, w, b,
+                         C, out, out_ld, total);
+      break;
+    default:
+      EMP_REQUIRE(false, "stem3x3: unknown image dtype %d", dtype);
+  }
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_gate_mul_f32(float* x, int x_ld, const float* g, int g_ld, int64_t rows, int C, hipStream_t s) {
+  EMP_REQUIRE(C % 4 == 0 && x_ld % 4 == 0 && g_ld % 4 == 0 && x_ld >= C && g_ld >= C, "gate_mul32: bad shape");
+  const int64_t total = rows * (C / 4);
+  hipLaunchKernelGGL(gate_mul32_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, x_ld, g, g_ld, C, total);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
 int launch_conv32(const Conv32& p, hipStream_t s) {
   EMP_REQUIRE(p.in && p.w && p.out, "conv32: null pointer");
   EMP_REQUIRE(p.Cin % R_BK == 0 && p.in_ld % 4 == 0 && p.in_ld >= p.Cin && ((uintptr_t)p.in % 16) == 0 && ((uintptr_t)p.w % 16) == 0,
               "conv32: Cin=%d must be a multiple of 16 (padded with zero weights), in_ld=%d a multiple of 4", p.Cin, p.in_ld);
   EMP_REQUIRE(p.ps_cout == 0 || (p.Cout == 4 * p.ps_cout && p.res == nullptr), "conv32: pixel-shuffle store needs Cout == 4 * ps_cout");
   EMP_REQUIRE(p.act >= 0 && p.act <= 2, "conv32: bad activation");
+  const int G = p.groups > 1 ? p.groups : 1;
+  EMP_REQUIRE(G == 1 || (p.bias_n == nullptr && p.ps_cout == 0 && p.cin_g > 0 && p.cin_g % 4 == 0 && p.cin_g <= p.Cin &&
+                         (G - 1) * p.cin_g + p.Cin <= p.in_ld && G < 65536),
+              "conv32: grouped form needs cin_g %% 4 == 0 and (G - 1) * cin_g + Cin <= in_ld (G=%d cin_g=%d Cin=%d in_ld=%d)", G, p.cin_g,
+              p.Cin, p.in_ld);
+  EMP_REQUIRE(G > 1 || p.cin_g == 0, "conv32: cin_g is the grouped form's channel step");
   const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
   EMP_REQUIRE(M > 0 && M < (1ll << 31), "conv32: bad problem size");
-  const dim3 grid((unsigned)((M + R_BM - 1) / R_BM), (unsigned)((p.Cout + R_BN - 1) / R_BN));
+  const dim3 grid((unsigned)((M + R_BM - 1) / R_BM), (unsigned)((p.Cout + R_BN - 1) / R_BN), (unsigned)G);
   if (p.act == 1) hipLaunchKernelGGL(conv32_kernel<1>, grid, dim3(256), 0, s, p);
   else if (p.act == 2) hipLaunchKernelGGL(conv32_kernel<2>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(conv32_kernel<0>, grid, dim3(256), 0, s, p);

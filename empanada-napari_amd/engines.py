@@ -84,6 +84,17 @@ class HipPanopticDeepLab:
         c.ins_decoder = int(bool(cfgd['ins_decoder']))
         c.num_fc = cfgd['num_fc']
         c.subdivision_num_points = cfgd['subdivision_num_points']
+        if weights.is_regnet(cfgd):
+            # RegNet encoders (encoders/regnet.py) exist in the library's fp32 mode only: grouped 3x3 convolutions and the
+            # per-pixel squeeze-excite gate on the generic fp32 kernels (csrc/ref32.hip), no fp16 engine behind them
+            if precision == 'fp16':
+                raise ValueError(f"encoder {cfgd['encoder']!r} runs with precision='fp32' only (the fp16 engine is built for resnet50)")
+            r = self.cfg['regnet'] = weights.regnet_cfg(cfgd)
+            c.encoder, c.rn_stem, c.rn_se = 1, r['w_stem'], int(r['use_se'])
+            for i, st in enumerate(weights.regnet_stage_strides(cfgd)):
+                c.rn_widths[i], c.rn_depths[i], c.rn_groups[i], c.rn_strides[i] = r['widths'][i], r['depths'][i], r['groups'][i], st
+        elif cfgd.get('encoder', 'resnet50') != 'resnet50':
+            raise NotImplementedError(f"encoder {cfgd['encoder']!r}: resnet50 and the RegNets are built")
         self._h = C.c_void_p()
         torch.cuda.set_device(self.device)
         _abi.check(self.lib.emp_pdl_create(C.byref(c), C.byref(self._h)), 'emp_pdl_create')

@@ -69,6 +69,93 @@ def resnet50_spec(prefix='encoder', in_channels=1):
     return layers
 
 
+# the two RegNets the reference can export (quantization/encoders/__init__.py; regnet.py:266-271,296-301):
+# (depth, w_0, w_a, w_m, group width, squeeze-excite)
+REGNET_PARAMS = {
+    'regnetx_6p4gf': (17, 184, 60.83, 2.07, 56, False),
+    'regnety_6p4gf': (25, 112, 33.22, 2.27, 72, True),
+}
+REGNET_STEM = 32      # RegNetConfig.w_stem, regnet.py:168
+
+
+def regnet_layout(depth, w_0, w_a, w_m, group_w, use_se, q=8):
+    """Stage widths / depths / groups of a RegNet from its generating parameters (regnet.py:191-260, after
+    arXiv:2003.13678 eqs 2-4): block widths on the line w_0 + j w_a, snapped to w_0 w_m^s, rounded to multiples of q and
+    grouped into stages; bottleneck ratio 1, so a width only has to be a multiple of its group width."""
+    u = w_0 + np.arange(depth) * w_a
+    s_ = np.round(np.log(u / w_0) / np.log(w_m))
+    w = (q * np.round(w_0 * np.power(w_m, s_) / q)).astype(int)
+    widths, depths = np.unique(w, return_counts=True)
+    if len(widths) != 4:
+        raise ValueError('RegNet parameters must give four stages')
+    out_w, groups = [], []
+    for wi in widths.tolist():
+        gw = min(int(group_w), int(wi))
+        wi = max(gw, int(gw * round(wi / gw)))
+        out_w.append(wi)
+        groups.append(wi // gw)
+    return dict(w_stem=REGNET_STEM, widths=out_w, depths=[int(d) for d in depths], groups=groups, use_se=bool(use_se))
+
+
+def is_regnet(cfg):
+    return str((cfg or {}).get('encoder', 'resnet50')).startswith('regnet')
+
+
+def regnet_cfg(cfg):
+    """the RegNet layout of ``cfg``: explicit (``cfg['regnet']``, what ``infer_cfg`` reads off an export) or derived from the
+    encoder's name"""
+    if cfg.get('regnet'):
+        return cfg['regnet']
+    name = cfg['encoder']
+    if name not in REGNET_PARAMS:
+        raise NotImplementedError(f'encoder {name!r}: only {sorted(REGNET_PARAMS)} and resnet50 are built')
+    return regnet_layout(*REGNET_PARAMS[name])
+
+
+def encoder_widths(cfg):
+    """``encoder.cfg.widths``: channels of pyramid levels 1..4 (resnet.py:207-208, regnet.py:244-245)"""
+    if is_regnet(cfg):
+        return list(regnet_cfg(cfg)['widths'])
+    return [p * 4 for p in RESNET_PLANES]
+
+
+def regnet_stage_strides(cfg):
+    """stride of each stage's first block: RegNetConfig.strides = [2, 2, 2, 2] (regnet.py:170).  ``stage4_stride`` does NOT
+    reach a RegNet built by name: the constructors hand ``output_stride`` to RegNetConfig (where it becomes an unused
+    attribute, regnet.py:262-271,296-301) and RegNet.__init__ keeps its default 32 -- a PanopticDeepLab on a RegNet runs
+    its ASPP at stride 32 whatever the YAML says.  An export built differently carries its strides in the scripted
+    convolutions; ``infer_cfg`` stores them under ``cfg['regnet']['strides']``."""
+    return list(regnet_cfg(cfg).get('strides', [2, 2, 2, 2]))
+
+
+def regnet_spec(cfg, prefix='encoder', in_channels=1):
+    """Layers of the RegNet encoder (encoders/regnet.py:38-160): 3x3 stride-2 stem, four stages of bottleneck blocks
+    a (1x1) -> b (grouped 3x3, strided in a stage's first block) -> [se] -> c (1x1, no activation) + shortcut (1x1
+    strided conv where shape changes), ReLU."""
+    r = regnet_cfg(cfg)
+    L = [_L(f'{prefix}.stem.cbr.0', (r['w_stem'], in_channels, 3, 3), bn=f'{prefix}.stem.cbr.1')]
+    w_in = r['w_stem']
+    strides = regnet_stage_strides(cfg)
+    for si, (w, d, g) in enumerate(zip(r['widths'], r['depths'], r['groups']), start=1):
+        for b in range(1, d + 1):
+            p = f'{prefix}.stage{si}.block{b}'
+            stride = strides[si - 1] if b == 1 else 1
+            L.append(_L(f'{p}.bottleneck.a.0', (w, w_in, 1, 1), bn=f'{p}.bottleneck.a.1'))
+            L.append(_L(f'{p}.bottleneck.b.0', (w, w // g, 3, 3), bn=f'{p}.bottleneck.b.1'))
+            if r['use_se']:
+                L.append(_L(f'{p}.bottleneck.se.se.0', (w // 4, w, 1, 1), bias=True))
+                L.append(_L(f'{p}.bottleneck.se.se.2', (w, w // 4, 1, 1), bias=True, gain=0.5, bias_mean=1.0))
+            L.append(_L(f'{p}.bottleneck.c.0', (w, w, 1, 1), bn=f'{p}.bottleneck.c.1', bn_gamma=0.35))
+            if w_in != w or stride > 1:
+                L.append(_L(f'{p}.downsample.conv.0', (w, w_in, 1, 1), bn=f'{p}.downsample.conv.1', bn_gamma=0.7))
+            w_in = w
+    return L
+
+
+def encoder_spec(cfg):
+    return regnet_spec(cfg) if is_regnet(cfg) else resnet50_spec()
+
+
 def pdl_decoder_spec(prefix, in_ch, dec_ch, low_level_channels, low_level_project, aspp_ch=None):
     """decoders/panoptic_deeplab.py:25-62 + decoders/aspp.py:51-94."""
     aspp_ch = aspp_ch or dec_ch
@@ -102,14 +189,15 @@ def bifpn_spec(cfg=None):
     state-dict prefixes under which a SHARED module appears (one conv block instance serves every
     level of a direction, bifpn.py:41-42,97-98)."""
     cfg = dict(MITONET_MINI_CFG, **(cfg or {}))
-    assert cfg['encoder'] == 'resnet50' and cfg['depthwise']
+    assert cfg['depthwise']
     F, ncls = cfg['fpn_dim'], cfg['num_classes']
-    L = resnet50_spec()
-    L.append(_L('p2_resample.conv.0', (F, 256, 1, 1), bn='p2_resample.conv.1'))
-    widths = [512, 1024, 2048, F, F]                      # P3..P7 inputs of the first BiFPN layer
+    ew = encoder_widths(cfg)
+    L = encoder_spec(cfg)
+    L.append(_L('p2_resample.conv.0', (F, ew[0], 1, 1), bn='p2_resample.conv.1'))
+    widths = ew[1:] + [F, F]                              # P3..P7 inputs of the first BiFPN layer
     for dec in (['semantic'] + (['instance'] if cfg['ins_decoder'] else [])):
         fp = f'{dec}_fpn'
-        L.append(_L(f'{fp}.p6_resample.conv.0', (F, 2048, 1, 1), bn=f'{fp}.p6_resample.conv.1'))
+        L.append(_L(f'{fp}.p6_resample.conv.0', (F, ew[3], 1, 1), bn=f'{fp}.p6_resample.conv.1'))
         for li in range(cfg['fpn_layers']):
             nins = widths if li == 0 else [F] * 5
             td_nins = nins[::-1][1:]                        # P6, P5, P4, P3
@@ -162,13 +250,12 @@ def ins_projection_widths(cfg):
 def pdl_spec(cfg=None):
     """Ordered layer list of QuantizablePanopticDeepLabPR for ``cfg``."""
     cfg = dict(MITONET_PDL_CFG, **(cfg or {}))
-    assert cfg['encoder'] == 'resnet50', 'only the resnet50 encoder is built so far'
-    widths = [p * 4 for p in RESNET_PLANES]  # cfg.widths, resnet.py:207-208
+    widths = encoder_widths(cfg)
     stages = cfg['low_level_stages']
     llc = [widths[s - 1] for s in stages]
     dec = cfg['decoder_channels']
     ncls = cfg['num_classes']
-    L = resnet50_spec()
+    L = encoder_spec(cfg)
     L += pdl_decoder_spec('semantic_decoder', widths[-1], dec, llc,
                           cfg['low_level_channels_project'], cfg['aspp_channels'])
     if cfg['ins_decoder']:
@@ -319,12 +406,32 @@ def infer_cfg(state_dict, module=None):
                 return tuple(int(d) for d in state_dict[name + suf].shape)
         return None
 
-    if shape('encoder.conv1') is None or shape('encoder.layer1.0.conv3') is None:
+    enc = {}
+    if shape('encoder.stem.cbr.0') is not None:      # RegNet (encoders/regnet.py:38-160)
+        widths, depths, groups = [], [], []
+        for si in (1, 2, 3, 4):
+            blocks = {k.split('.')[2] for k in keys if k.startswith(f'encoder.stage{si}.')}
+            if not blocks or shape(f'encoder.stage{si}.block1.bottleneck.b.0') is None:
+                raise NotImplementedError(f'RegNet export without stage {si}: only four-stage RegNets are built')
+            w, gw = shape(f'encoder.stage{si}.block1.bottleneck.b.0')[:2]
+            widths.append(w)
+            depths.append(len(blocks))
+            groups.append(w // gw)
+        layout = dict(w_stem=shape('encoder.stem.cbr.0')[0], widths=widths, depths=depths, groups=groups,
+                      use_se=any('.bottleneck.se.' in k for k in keys))
+        name = next((n for n, prm in REGNET_PARAMS.items() if regnet_layout(*prm) == layout), 'regnet')
+        enc = dict(encoder=name, regnet=layout)
+        if module is not None:      # the strides as exported (regnet.py:141-142 can set the last one to 1)
+            st = [_conv_attr(_child(module, f'encoder.stage{si}.block1.bottleneck.b'), 'stride') for si in (1, 2, 3, 4)]
+            if all(v is not None for v in st) and [int(v[0]) for v in st] != [2, 2, 2, 2]:
+                enc['regnet'] = dict(layout, strides=[int(v[0]) for v in st])
+    elif shape('encoder.conv1') is None or shape('encoder.layer1.0.conv3') is None:
         stem = [k for k in keys if k.startswith('encoder.')][:3]
-        raise NotImplementedError(f'only ResNet encoders are built (RegNet exports are not supported yet); encoder keys: {stem}')
-    nblocks = tuple(len({k.split('.')[2] for k in keys if k.startswith(f'encoder.layer{li}.')}) for li in (1, 2, 3, 4))
-    if nblocks != RESNET50_LAYERS or shape('encoder.layer1.0.conv3')[0] != 256:
-        raise NotImplementedError(f'only the resnet50 encoder is built; this export has blocks {nblocks}')
+        raise NotImplementedError(f'only ResNet50 and RegNet encoders are built; encoder keys: {stem}')
+    else:
+        nblocks = tuple(len({k.split('.')[2] for k in keys if k.startswith(f'encoder.layer{li}.')}) for li in (1, 2, 3, 4))
+        if nblocks != RESNET50_LAYERS or shape('encoder.layer1.0.conv3')[0] != 256:
+            raise NotImplementedError(f'only the resnet50 encoder is built; this export has blocks {nblocks}')
     ncls = shape('semantic_head.head.1')[0]
     num_fc = len({k.split('.')[3] for k in keys if k.startswith('semantic_pr.point_head.fc_layers.')})
     npts = None
@@ -335,7 +442,7 @@ def infer_cfg(state_dict, module=None):
         except Exception:
             npts = None
     if any(k.startswith('semantic_fpn.') for k in keys):
-        cfg = dict(MITONET_MINI_CFG)
+        cfg = dict(MITONET_MINI_CFG, **enc)
         cfg.update(num_classes=ncls, fpn_dim=shape('p2_resample.conv.0')[0], num_fc=num_fc,
                    fpn_layers=len({k.split('.')[2] for k in keys if k.startswith('semantic_fpn.bifpns.')}),
                    ins_decoder=any(k.startswith('instance_fpn.') for k in keys),
@@ -343,8 +450,8 @@ def infer_cfg(state_dict, module=None):
         if not cfg['depthwise']:
             raise NotImplementedError('BiFPN exports without depthwise-separable node convolutions are not built')
     else:
-        cfg = dict(MITONET_PDL_CFG)
-        widths = [p * 4 for p in RESNET_PLANES]
+        cfg = dict(MITONET_PDL_CFG, **enc)
+        widths = encoder_widths(cfg)
         stages, proj = [], []
         while shape(f'semantic_decoder.project.{len(stages)}.0') is not None:
             lp, cin = shape(f'semantic_decoder.project.{len(stages)}.0')[:2]
@@ -370,6 +477,7 @@ def infer_cfg(state_dict, module=None):
             d4 = _conv_attr(_child(module, 'encoder.layer4.0.conv2'), 'dilation')
             if d4 is not None:
                 cfg['stage4_stride'] = 16 if int(d4[0]) == 2 else 32
+
     if npts:
         cfg['subdivision_num_points'] = npts
     return cfg

@@ -75,6 +75,19 @@ typedef struct {
   int32_t arch;                   /* 0 PanopticDeepLabPR (MitoNet_v1), 1 PanopticBiFPNPR (MitoNet_v1_mini)  */
   int32_t fpn_dim;                /* BiFPN width (128)                                 */
   int32_t fpn_layers;             /* BiFPN depth (3)                                   */
+  /* Round 4 -- the encoder.  0: ResNet50 (encoders/resnet.py:143-215).  1: a four-stage RegNet
+   * (encoders/regnet.py:38-160; quantization/encoders/__init__.py exports regnetx_6p4gf and regnety_6p4gf): 3x3
+   * stride-2 stem of rn_stem channels, stage i = rn_depths[i] bottleneck blocks of width rn_widths[i] with
+   * rn_groups[i] groups in the 3x3, the first block of a stage at stride rn_strides[i], rn_se != 0 with the reference's
+   * per-pixel squeeze-excite gate (blocks.py:35-50).  RegNet networks run in the fp32 mode only (emp_pdl_precision
+   * reports 1; emp_pdl_set_precision(net, 0) is refused). */
+  int32_t encoder;
+  int32_t rn_stem;
+  int32_t rn_widths[4];
+  int32_t rn_depths[4];
+  int32_t rn_groups[4];
+  int32_t rn_strides[4];
+  int32_t rn_se;
 } emp_pdl_config;
 
 EMP_API int emp_pdl_create(const emp_pdl_config* cfg, emp_pdl_t** out);
@@ -187,6 +200,15 @@ EMP_API int emp_conv2d_nhwc_f32(const float* d_in, int N, int H, int W, int Cin,
                         const float* d_w, const float* d_bias, const float* d_bias_n,
                         const float* d_res, int res_ld,
                         float* d_out, int out_ld, int Cout,
+                        int KH, int KW, int stride, int pad, int dil, int act, void* stream);
+
+/* The same convolution with `groups` groups (nn.Conv2d(groups=g), the 3x3 of a RegNet bottleneck:
+ * empanada/models/encoders/regnet.py:51-77 via blocks.py:134-153): group g reads input channels [g * cin_g, g * cin_g +
+ * Cin16) -- Cin16 = cin_g padded to a multiple of 16, the padding meeting zero weights, so a row of the input must hold
+ * (groups - 1) * cin_g + Cin16 floats -- and writes output channels [g * cout_g, (g + 1) * cout_g); weights
+ * (groups * cout_g, KH*KW, Cin16), bias (groups * cout_g). */
+EMP_API int emp_conv2d_grouped_nhwc_f32(const float* d_in, int N, int H, int W, int groups, int cin_g, int Cin16, int in_ld,
+                        const float* d_w, const float* d_bias, float* d_out, int out_ld, int cout_g,
                         int KH, int KW, int stride, int pad, int dil, int act, void* stream);
 
 /* out = act( in . W[:, :Cin] + in2(strided) . W[:, Cin:] + bias ): a 1x1 convolution whose reduction continues over a

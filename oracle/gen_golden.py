@@ -119,6 +119,54 @@ def gen_bifpn():
     save('bifpn_forward', **out)
 
 
+def gen_regnet():
+    """RegNet encoders (the two the reference can export, quantization/encoders/__init__.py): PanopticBiFPNPR on
+    regnety_6p4gf (grouped 3x3 + the per-pixel squeeze-excite gate, encoder at stride 32) and PanopticDeepLabPR on
+    regnetx_6p4gf (whose stage 4 stays at stride 2: ``stage4_stride`` never reaches a RegNet built by name, see
+    weights.regnet_stage_strides)."""
+    from empanada.models.quantization.panoptic_bifpn import QuantizablePanopticBiFPNPR
+    from empanada.models.quantization.panoptic_deeplab import QuantizablePanopticDeepLabPR
+    out = {}
+    specs = (('y', QuantizablePanopticBiFPNPR, dict(weights.MITONET_MINI_CFG, encoder='regnety_6p4gf', num_classes=2), 11,
+              {'a': (np.stack([synth.blob_image(128, 128, seed=1), synth.em_tiles(1, 128, seed=2)[0]]), 2, False),
+               'b': (np.stack([synth.blob_image(128, 256, seed=3)]), 2, True)}),
+             ('x', QuantizablePanopticDeepLabPR, dict(weights.MITONET_PDL_CFG, encoder='regnetx_6p4gf'), 12,
+              {'a': (np.stack([synth.blob_image(64, 64, seed=1), synth.blob_image(64, 64, seed=2)]), 2, False),
+               'b': (np.stack([synth.blob_image(96, 160, seed=7)]), 3, True)}))
+    for tag, cls, cfg, seed, cases in specs:
+        sd = weights.seeded_state_dict(cfg, seed=seed)
+        m = cls(quantize=False, **{k: v for k, v in cfg.items() if k != 'arch'})
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        m.eval()
+        with torch.no_grad():
+            for k, (img, rs, interp) in cases.items():
+                o = m(torch.from_numpy(norm_image(img))[:, None], rs, interp)
+                out[f'{tag}{k}_image'] = img
+                out[f'{tag}{k}_render_steps'] = np.int64(rs)
+                out[f'{tag}{k}_interpolate_ins'] = np.int64(interp)
+                for name in ('sem_logits', 'ctr_hmp', 'offsets'):
+                    out[f'{tag}{k}_{name}'] = o[name].numpy().astype(np.float32)
+            x = torch.from_numpy(norm_image(cases['a'][0]))[:, None]
+            pyr = m.encoder(x)
+            for i, f in enumerate(pyr):          # the pyramid itself: per-level mean |x| and a strided sample
+                out[f'{tag}_pyr{i}_shape'] = np.array(f.shape, np.int64)
+                out[f'{tag}_pyr{i}_absmean'] = np.float64(f.abs().mean().item())
+                out[f'{tag}_pyr{i}_sample'] = f[:, ::7, ::3, ::3].numpy().astype(np.float32)
+            ref = m(x, 2, False)
+            m.fuse_model()
+            fo = m(x, 2, False)
+            assert all(torch.allclose(ref[n], fo[n], atol=5e-4, rtol=1e-4) for n in ref)
+            fsd = {k: v.numpy() for k, v in m.state_dict().items()}
+            A = weights.fold_state_dict(sd, cfg)
+            B = weights.fold_state_dict(fsd, cfg)
+            for n in A:
+                assert np.allclose(A[n][0], B[n][0], atol=1e-6, rtol=1e-5) and np.allclose(A[n][1], B[n][1], atol=1e-5, rtol=1e-4), n
+            # the export's key layout with the shapes behind it: weights.infer_cfg reads the architecture from exactly this
+            out[f'{tag}_fused_keys'] = np.array(sorted(fsd.keys()))
+            out[f'{tag}_fused_shapes'] = np.array([','.join(str(d) for d in fsd[k].shape) for k in sorted(fsd.keys())])
+    save('regnet_forward', **out)
+
+
 # ----------------------------------------------------------------------------
 # B. post-processing on synthetic head tensors
 # ----------------------------------------------------------------------------
@@ -478,5 +526,7 @@ def gen_tiles():
     save('tiles', **out)
 
 
+if __name__ == '__main__' and 'regnet' in (sys.argv[1:] or ['regnet']):
+    gen_regnet()
 if __name__ == '__main__' and 'tiles' in (sys.argv[1:] or ['tiles']):
     gen_tiles()

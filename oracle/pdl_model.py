@@ -196,6 +196,45 @@ def resnet50_forward(P, x, output_stride=16, taps=None):
     return pyr  # [p1, p2, p3, p4, p5]
 
 
+def regnet_forward(P, x, layout, taps=None):
+    """encoders/regnet.py:160-166 (RegNet.forward) with Stem (:38-49), BottleneckBlock (:79-97) and Bottleneck
+    (:51-77); BN folded.  ``layout``: w_stem / widths / depths / groups / use_se [/ strides] (weights.regnet_cfg); the
+    stride of each stage's first block is 2 (RegNetConfig.strides, regnet.py:170) -- the model's ``stage4_stride`` never
+    reaches a RegNet built by name (weights.regnet_stage_strides).  The squeeze-excite
+    gate pools over a 1 x 1 window (blocks.py:38: nn.AvgPool2d((1, 1)) -- the identity), so it is a per-PIXEL gate
+    x * sigmoid(W2 relu(W1 x)): restated as the reference computes it, not as the paper defines it."""
+    x = _conv(x, P['encoder.stem.cbr.0'], stride=2, padding=1, relu=True)
+    pyr = [x]
+    if taps is not None:
+        taps['stem'] = x
+    strides = layout.get('strides', [2, 2, 2, 2])
+    for si, (d, g) in enumerate(zip(layout['depths'], layout['groups']), start=1):
+        for b in range(1, d + 1):
+            pre = f'encoder.stage{si}.block{b}'
+            s = strides[si - 1] if b == 1 else 1
+            out = _conv(x, P[f'{pre}.bottleneck.a.0'], relu=True)
+            out = _conv(out, P[f'{pre}.bottleneck.b.0'], stride=s, padding=1, groups=g, relu=True)
+            if layout['use_se']:
+                gate = _conv(out, P[f'{pre}.bottleneck.se.se.0'], relu=True)
+                out = out * torch.sigmoid(_conv(gate, P[f'{pre}.bottleneck.se.se.2']))
+            out = _conv(out, P[f'{pre}.bottleneck.c.0'])
+            short = _conv(x, P[f'{pre}.downsample.conv.0'], stride=s) if f'{pre}.downsample.conv.0' in P else x
+            x = F.relu(short + out)
+            if taps is not None:
+                taps[pre] = x
+        pyr.append(x)
+    return pyr  # [stem, stage1, stage2, stage3, stage4]
+
+
+def encoder_forward(P, x, cfg, output_stride, taps=None):
+    """the pyramid of ``cfg``'s encoder: index 0 is never read by a decoder, 1..4 are the stage outputs"""
+    if str(cfg.get('encoder', 'resnet50')).startswith('regnet'):
+        if _EMU is not None:
+            raise NotImplementedError('RegNet encoders run in the fp32 mode only: there is no fp16 engine to emulate')
+        return regnet_forward(P, x, cfg['regnet'], taps)
+    return resnet50_forward(P, x, output_stride, taps)
+
+
 def aspp_forward(P, pre, x, rates, taps=None):
     """decoders/aspp.py:96-102 (+ ASPPPooling.forward :45-48)."""
     res = [_conv(x, P[f'{pre}.convs.0.0'], relu=True, site=True)]
@@ -319,7 +358,7 @@ def pdl_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None, emu=
             return pdl_forward(P, x, cfg, render_steps, interpolate_ins, taps, None)
         finally:
             _EMU = None
-    pyr = resnet50_forward(P, x, cfg['stage4_stride'], taps)
+    pyr = encoder_forward(P, x, cfg, cfg['stage4_stride'], taps)
     stages, rates = cfg['low_level_stages'], cfg['atrous_rates']
     insd = bool(cfg['ins_decoder'])
     semantic_x = decoder_forward(P, 'semantic_decoder', pyr, stages, rates, taps, insd)
@@ -426,7 +465,7 @@ def bifpn_forward(P, x, cfg, render_steps=2, interpolate_ins=True, taps=None, em
         finally:
             _EMU = None
     insd = bool(cfg['ins_decoder'])
-    pyr = resnet50_forward(P, x, 32, taps)          # quantizable resnet50() default output_stride = 32
+    pyr = encoder_forward(P, x, cfg, 32, taps)          # the BiFPN models build their encoder at its default output stride 32
     p2f = _conv(pyr[1], P['p2_resample.conv.0'], site=True)
     nl = cfg['fpn_layers']
     semantic_x = bifpn_forward_decoder(P, 'semantic', pyr[2:], p2f, nl, taps, insd)

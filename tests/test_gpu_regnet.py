@@ -1,0 +1,131 @@
+"""RegNet encoders on the device (reference: empanada/models/encoders/regnet.py:38-316).  They run in
+the library's fp32 mode (csrc/ref32.hip): the grouped 3x3 on the exact fp32 matrix pipe (one workgroup column per group),
+the reference's per-pixel squeeze-excite gate, the 3x3 stride-2 stem with the normalisation fused.  Checked against the
+reference's own outputs (tests/golden/regnet_forward.npz: PanopticBiFPNPR / regnety_6p4gf and PanopticDeepLabPR /
+regnetx_6p4gf) and, at a larger size, against the oracle's fp32 forward in the max norm."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+GROUPED = [
+    # N, H, W, groups, group width in, group width out, stride, act
+    (2, 20, 28, 3, 56, 56, 1, 1),       # regnetx stage 1: the group width is not a multiple of 16 (padded to 64)
+    (1, 17, 33, 2, 72, 72, 2, 1),       # regnety stage 1, strided, odd sizes
+    (1, 8, 8, 29, 56, 56, 1, 0),        # regnetx stage 4: 29 groups
+    (2, 12, 12, 4, 16, 80, 1, 2),       # more outputs than one 64-column tile per group
+]
+
+
+@pytest.mark.parametrize('case', GROUPED)
+def test_grouped_conv32_equals_torch(case):
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    N, H, W, G, ci, co, stride, act = case
+    g = torch.Generator().manual_seed(sum(case))
+    C = G * ci
+    x = torch.randn((N, H, W, C), generator=g)
+    w = torch.randn((G * co, ci, 3, 3), generator=g) / np.sqrt(ci * 9)
+    b = torch.randn((G * co,), generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride, 1, 1, G)
+    ref = torch.relu(ref) if act == 1 else ref * torch.sigmoid(ref) if act == 2 else ref
+    ci16 = -(-ci // 16) * 16
+    ld = -(-C // 16) * 16 + 16
+    xp = torch.zeros((N, H, W, ld))
+    xp[..., :C] = x
+    wp = torch.zeros((G * co, 9, ci16))
+    wp[..., :ci] = w.permute(0, 2, 3, 1).reshape(G * co, 9, ci)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.full((N, Ho, Wo, G * co + 4), 7.0, device=dev())
+    xd, wd, bd = xp.to(dev()), wp.to(dev()), b.to(dev())
+    _abi.check(lib.emp_conv2d_grouped_nhwc_f32(_abi.ptr(xd), N, H, W, G, ci, ci16, ld, _abi.ptr(wd), _abi.ptr(bd), _abi.ptr(out),
+                                               G * co + 4, co, 3, 3, stride, 1, 1, act, _abi.stream_ptr(dev())), 'grouped conv32')
+    torch.cuda.synchronize()
+    got = out[..., :G * co].cpu().permute(0, 3, 1, 2).double()
+    assert torch.all(out[..., G * co:] == 7.0)
+    assert float((got - ref).abs().max()) < 4e-6 * float(ref.abs().max()) * np.sqrt(ci * 9 / 64.0 + 1.0)
+    # a row too short for the last group's padded read is refused, not read past
+    assert lib.emp_conv2d_grouped_nhwc_f32(_abi.ptr(xd), N, H, W, G, ci, ci16, (G - 1) * ci + ci16 - 4, _abi.ptr(wd), _abi.ptr(bd),
+                                           _abi.ptr(out), G * co + 4, co, 3, 3, stride, 1, 1, act, _abi.stream_ptr(dev())) != 0 or ci16 == ci
+
+
+def _model(tag):
+    from test_regnet import regnet_model
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    cfg, P = regnet_model(tag)
+    return cfg, P, HipPanopticDeepLab(P, cfg, folded=True)
+
+
+@pytest.mark.parametrize('tag', ['y', 'x'])
+def test_regnet_forward_matches_the_reference_goldens(golden_dir, tag):
+    from empanada_napari_amd.preprocess import normalize
+    g = np.load(os.path.join(golden_dir, 'regnet_forward.npz'))
+    cfg, P, model = _model(tag)
+    assert model.precision == 'fp32'          # chosen by the library: there is no fp16 engine behind a RegNet
+    for case in 'ab':
+        img = g[f'{tag}{case}_image']
+        rs, interp = int(g[f'{tag}{case}_render_steps']), bool(g[f'{tag}{case}_interpolate_ins'])
+        x = torch.from_numpy(normalize(img, 0.57571, 0.12765))[:, None]
+        out = model(x.cuda(), rs, interp)
+        for name in ('ctr_hmp', 'offsets'):
+            ref = g[f'{tag}{case}_{name}']
+            got = out[name].cpu().numpy()
+            assert got.shape == ref.shape
+            scale = max(1.0, float(np.sqrt((ref.astype(np.float64) ** 2).mean())))
+            assert float(np.abs(got - ref).max()) < 2e-4 * scale, (tag, case, name, float(np.abs(got - ref).max()), scale)
+        ref = g[f'{tag}{case}_sem_logits']
+        got = out['sem_logits'].cpu().numpy()
+        assert got.shape == ref.shape
+        # PointRend refines the most uncertain cells: two fp32 forwards pick the same ones up to near-ties of the uncertainty
+        assert float((np.abs(got - ref) > 1e-3 * max(1.0, float(np.abs(ref).max()))).mean()) < 2e-3
+        # raw uint8 in, normalisation inside the 3x3 stem
+        raw = model(torch.from_numpy(img)[:, None].cuda(), rs, interp, sub=0.57571 * 255, mul=1.0 / (0.12765 * 255))
+        for name in ('ctr_hmp', 'offsets'):
+            assert float((raw[name] - out[name]).abs().max()) < 1e-3 * max(1.0, float(out[name].abs().max()))
+
+
+@pytest.mark.parametrize('tag,size', [('y', 256), ('x', 224)])
+def test_regnet_heads_within_1e3_of_the_fp32_oracle(tag, size):
+    """the north star's gate in the max norm, at a size with ragged tiles (224 = 7 x 32: stage 4 is 7 x 7)"""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg, P, model = _model(tag)
+    img = synth.em_tiles(2, size, seed=5)
+    x = torch.from_numpy(normalize(img, 0.57571, 0.12765))[:, None]
+    out = {k: v.cpu().numpy() for k, v in model(x.cuda(), 2, False).items()}
+    taps = {}
+    ref = pdl_model.model_forward(P, x, cfg, 2, False, taps)
+    for k in ('ctr_hmp', 'offsets'):
+        scale = max(1.0, float(ref[k].pow(2).mean().sqrt()))
+        assert float(np.abs(out[k] - ref[k].numpy()).max()) / scale < 1e-4, k
+    ncls = cfg['num_classes']
+    coarse = model.tap_raw('semantic_head.out', (2, ncls, size // 4, size // 4)).cpu()
+    if ncls == 1:
+        e = (torch.sigmoid(coarse) - torch.sigmoid(taps['sem_coarse'])).abs()
+    else:
+        e = (torch.softmax(coarse, 1) - torch.softmax(taps['sem_coarse'], 1)).abs()
+    assert float(e.max()) < 1e-4
+    # the last encoder map itself
+    name = 'encoder.stage4.block%d' % cfg['regnet']['depths'][3]
+    w4 = cfg['regnet']['widths'][3]
+    h4 = -(-size // 32)
+    ld = -(-w4 // 16) * 16 + 16
+    p5 = model.tap_raw(name, (2, h4, h4, ld)).cpu()
+    want = pdl_model.regnet_forward(P, x, cfg['regnet'])[4].permute(0, 2, 3, 1)
+    assert float((p5[..., :w4] - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+    assert float(p5[..., w4:].abs().max()) == 0.0          # the row tails other kernels rely on stay zero
+
+
+def test_regnet_refuses_the_fp16_engine():
+    from test_regnet import regnet_model
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    cfg, P = regnet_model('x')
+    with pytest.raises(ValueError):
+        HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
