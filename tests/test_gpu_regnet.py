@@ -129,3 +129,20 @@ def test_regnet_refuses_the_fp16_engine():
     cfg, P = regnet_model('x')
     with pytest.raises(ValueError):
         HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
+
+
+def test_regnet_pdl_at_a_size_the_stride_does_not_divide():
+    """PanopticDeepLab pads to multiples of 16 (configs/*.yaml: padding_factor) while a RegNet's last stage sits at stride
+    32: 80 x 112 gives a 3 x 4 stage-4 map (3x3 stride-2 pad-1 conv and 1x1 stride-2 shortcut both round up), which the
+    decoder resamples to the stride-4 map's 20 x 28 -- same as the reference's convolution arithmetic (the oracle's)"""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model
+    cfg, P, model = _model('x')
+    img = synth.em_tiles(1, 112, seed=9)[:, :80]
+    x = torch.from_numpy(normalize(img, 0.57571, 0.12765))[:, None]
+    out = {k: v.cpu() for k, v in model(x.cuda(), 2, True).items()}
+    ref = pdl_model.model_forward(P, x, cfg, 2, True)
+    for k in ('ctr_hmp', 'offsets'):
+        assert out[k].shape == ref[k].shape == (1, 1 if k == 'ctr_hmp' else 2, 80, 112)
+        assert float((out[k] - ref[k]).abs().max()) < 1e-4 * max(1.0, float(ref[k].pow(2).mean().sqrt())), k

@@ -113,8 +113,39 @@ def test_url_resolves_to_the_torch_hub_cache(tmp_path, monkeypatch):
     assert inference.resolve_model_file(url) == str(tmp_path / 'MitoNet_v1.pth')
 
 
-def test_regnet_export_is_refused_with_a_clear_message():
+@pytest.mark.parametrize('arch,encoder', [('PanopticBiFPNPR', 'regnety_6p4gf'), ('PanopticDeepLabPR', 'regnetx_6p4gf'),
+                                          ('PanopticDeepLabPR', 'regnety_6p4gf')])
+def test_regnet_export_is_loaded_without_arch(tmp_path, arch, encoder):
+    """the reference's other exportable encoders (quantization/encoders/__init__.py): widths, depths, group width and the
+    squeeze-excite gate are read off the export; the oracle forward on the folded parameters == the scripted model"""
+    from empanada_napari_amd import inference, weights
+    if arch == 'PanopticBiFPNPR':
+        kw = dict(encoder=encoder, num_classes=3, fpn_dim=128, fpn_layers=2, ins_decoder=True, depthwise=True, num_fc=3,
+                  train_num_points=1024, oversample_ratio=3, importance_sample_ratio=0.75, subdivision_steps=2,
+                  subdivision_num_points=2048)
+        size = 128
+    else:
+        kw = dict(PDL_KW, encoder=encoder)
+        size = 64
+    model, path = _export(arch, tmp_path, **kw)
+    sd, cfg = inference.load_model_spec({'model': path})
+    assert cfg['arch'] == arch and cfg['encoder'] == encoder
+    assert cfg['regnet'] == weights.regnet_layout(*weights.REGNET_PARAMS[encoder])
+    assert weights.regnet_stage_strides(cfg) == [2, 2, 2, 2]      # stage4_stride never reaches a RegNet built by name
+    P = weights.fold_state_dict(sd, cfg)
+    assert len(P) == len(weights.model_spec(cfg))
+    from oracle import pdl_model
+    torch.manual_seed(1)
+    x = torch.randn(1, 1, size, size)
+    with torch.no_grad():
+        want = torch.jit.load(path)(x, 2, False)
+    got = pdl_model.model_forward(P, x, cfg, 2, False)
+    for k in ('sem_logits', 'ctr_hmp', 'offsets'):
+        assert torch.allclose(got[k], want[k], rtol=1e-4, atol=1e-5), k
+
+
+def test_unknown_encoder_is_refused_with_a_clear_message():
     from empanada_napari_amd import weights
-    sd = {'encoder.stem.conv.weight': np.zeros((32, 1, 3, 3), np.float32), 'semantic_head.head.1.weight': np.zeros((1, 256, 1, 1), np.float32)}
-    with pytest.raises(NotImplementedError, match='RegNet'):
+    sd = {'encoder.features.0.weight': np.zeros((32, 1, 3, 3), np.float32), 'semantic_head.head.1.weight': np.zeros((1, 256, 1, 1), np.float32)}
+    with pytest.raises(NotImplementedError, match='ResNet50 and RegNet'):
         weights.infer_cfg(sd)
