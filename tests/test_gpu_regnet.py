@@ -146,3 +146,40 @@ def test_regnet_pdl_at_a_size_the_stride_does_not_divide():
     for k in ('ctr_hmp', 'offsets'):
         assert out[k].shape == ref[k].shape == (1, 1 if k == 'ctr_hmp' else 2, 80, 112)
         assert float((out[k] - ref[k]).abs().max()) < 1e-4 * max(1.0, float(ref[k].pow(2).mean().sqrt())), k
+
+
+def test_regnet_state_dict_through_the_public_engines():
+    """a RegNet model handed to the engines the way the widgets do (model_config['model'] = the unfused state dict: the
+    architecture is inferred, the fp32 mode chosen): Engine2d label map == the oracle's post-processing of the oracle's
+    fp32 forward up to near-ties; Engine3d runs a small stack through the same model"""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.inference import Engine2d, Engine3d
+    from oracle import pdl_model, postprocess as opp, sparse as osp
+    cfg0 = dict(weights.MITONET_PDL_CFG, encoder='regnetx_6p4gf')
+    sd = weights.seeded_state_dict(cfg0, seed=12)
+    for name, shift in (('ins_center.head.1', 0.75), ('semantic_head.head.1', 1.5), ('semantic_pr.point_head.predictor', 1.5)):
+        sd[name + '.bias'] = sd[name + '.bias'] + np.float32(shift)
+    mc = {'model': sd, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.57571, 'std': 0.12765}}
+    eng = Engine2d(mc, label_divisor=1000, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5)
+    assert eng.engine.model.precision == 'fp32' and eng.engine.model.cfg['encoder'] == 'regnetx_6p4gf'
+    img = synth.em_tiles(1, 256, seed=21)[0][:200, :232]
+    got = eng.infer(img)
+    assert got.shape == img.shape and got.dtype == np.int32
+    cfg = dict(eng.engine.model.cfg)
+    P = weights.fold_state_dict(sd, cfg)
+    x = eng.preprocessor(img)['image'].unsqueeze(0)
+    assert x.ndim == 4
+    xp = torch.nn.functional.pad(x, (0, 240 - 232, 0, 208 - 200))
+    r = {k: v.numpy() for k, v in pdl_model.model_forward(P, xp, cfg, 2, False).items()}
+    r['sem'] = opp.logits_to_prob(r['sem_logits'])
+    oeng = opp.RenderEngine(lambda *_: r, [1], label_divisor=1000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                            coarse_boundaries=True)
+    want = oeng.postprocess(r['sem'], oeng.cells(r['ctr_hmp'], r['offsets'], 1))[0][:200, :232]
+    want = osp.force_connected_pan(want.astype(np.int32).copy(), [1], 1000)
+    assert len(np.unique(want)) > 5
+    assert float(((got > 0) != (want > 0)).mean()) < 1e-3 and abs(len(np.unique(got)) - len(np.unique(want))) <= 2
+    vol = synth.blob_volume(6, 64, 96, seed=4)
+    e3 = Engine3d(dict(mc, model=eng.engine.model), label_divisor=1000, median_kernel_size=3, confidence_thr=0.5)
+    stack, trackers = e3.infer_on_axis(vol, 'xy')
+    assert len(trackers) == 1 and trackers[0].class_id == 1
