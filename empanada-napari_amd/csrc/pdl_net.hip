@@ -16,6 +16,7 @@
 //  * the unused first semantic_head call of _encode_decode (:107) is skipped.
 #include <string.h>
 
+#include <array>
 #include <map>
 #include <memory>
 #include <string>
@@ -100,6 +101,7 @@ struct emp_pdl {
   struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; };
   std::map<std::string, W32> w32;
   std::map<std::string, std::pair<float*, size_t>> pool32;      // name -> (device buffer, floats)
+  std::map<std::string, std::array<int, 4>> geom32;             // zero-tailed RegNet maps: the geometry a buffer was last cleared for
 
   // device parameters
   std::map<std::string, DevConv> convs;
@@ -1433,9 +1435,19 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
     auto mkp = [&](const std::string& k, int H_, int W_, int C_) -> int {
       T32 t;
       t.N = N; t.H = H_; t.W = W_; t.C = C_; t.ld = round_up(C_, 16) + 16;
+      const size_t had = n->pool32.count(k) ? n->pool32[k].second : 0;
       const int rc = buf32(n, k, (size_t)N * H_ * W_ * t.ld, &t.p);
+      if (rc) return rc;
+      // a buffer kept from a forward of another shape holds that forward's values where this one's row tails are
+      const std::array<int, 4> geo = {N, H_, W_, t.ld};
+      auto gi = n->geom32.find(k);
+      if (gi == n->geom32.end() || gi->second != geo) {
+        if (had >= (size_t)N * H_ * W_ * t.ld && gi != n->geom32.end())
+          EMP_CHECK_HIP(hipMemsetAsync(t.p, 0, (size_t)N * H_ * W_ * t.ld * sizeof(float), s));
+        n->geom32[k] = geo;
+      }
       T[k] = t;
-      return rc;
+      return EMP_OK;
     };
     RC32(mkp("stem", H / 2, W / 2, c.rn_stem));
     RC32(launch_stem3x3s2_f32(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("rn.stem.w"), n->f32w.at("rn.stem.b"), c.rn_stem,

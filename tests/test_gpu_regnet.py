@@ -183,3 +183,23 @@ def test_regnet_state_dict_through_the_public_engines():
     e3 = Engine3d(dict(mc, model=eng.engine.model), label_divisor=1000, median_kernel_size=3, confidence_thr=0.5)
     stack, trackers = e3.infer_on_axis(vol, 'xy')
     assert len(trackers) == 1 and trackers[0].class_id == 1
+
+
+def test_regnet_buffers_are_clean_after_a_forward_of_another_shape():
+    """RegNet maps live in rows whose tails (channels padded to 16, plus the grouped conv's read-ahead) must read as
+    zeros; a buffer kept from a larger forward is cleared when the geometry changes -- same bits as a fresh network"""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.preprocess import normalize
+    cfg, P, model = _model('x')
+    big = torch.from_numpy(normalize(synth.em_tiles(2, 192, seed=1), 0.57571, 0.12765))[:, None].cuda()
+    small = torch.from_numpy(normalize(synth.em_tiles(1, 128, seed=2), 0.57571, 0.12765))[:, None].cuda()
+    model(big, 2, False)
+    got = {k: v.clone() for k, v in model(small, 2, False).items()}
+    w1 = cfg['regnet']['widths'][0]
+    ld = -(-w1 // 16) * 16 + 16
+    a = model.tap_raw('encoder.stage1.block1.a', (1, 64, 64, ld))
+    assert float(a[..., w1:].abs().max()) == 0.0 and float(a[..., :w1].abs().max()) > 0.0
+    _, _, fresh = _model('x')
+    want = fresh(small, 2, False)
+    for k in got:
+        assert torch.equal(got[k], want[k]), k
