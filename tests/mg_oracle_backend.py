@@ -68,10 +68,28 @@ class LabelStackBackend:
         self.entries = tsm._stack(shape, axis, seed)
 
     def forward(self, lo, hi, n_ahead):
-        return torch.zeros((hi - lo + n_ahead, 1, 4, 4)), (lo, hi)
+        # every "probability map" carries its slice index; the rows the exchange has to fill start out as NaN
+        sem = torch.full((hi - lo + n_ahead, 1, 4, 4), float('nan'))
+        sem[:hi - lo] = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1, 1)
+        return sem, (lo, hi)
 
     def median_inplace(self, sem, n_own, hist, n_ahead, first, last, ks):
-        pass
+        """no filtering -- but a full check of what the halo / carry exchange delivered (slab and block schedules alike):
+        the look-ahead rows are the RAW first maps of the slices right behind the block, the carry is the FILTERED tail of
+        the slices right before it (a filtered map is marked + 0.5), each exactly once and in order"""
+        mid = (ks - 1) // 2
+        lo = int(sem[0, 0, 0, 0])
+        assert torch.equal(sem[:n_own, 0, 0, 0], torch.arange(lo, lo + n_own, dtype=torch.float32)), 'own rows disturbed'
+        assert first == (lo == 0) and (hist is None) == (first or mid == 0), (first, lo, hist is None)
+        assert n_ahead == (0 if last else mid)
+        if n_ahead:
+            want = torch.arange(lo + n_own, lo + n_own + n_ahead, dtype=torch.float32)
+            assert torch.equal(sem[n_own:, 0, 0, 0], want), ('look-ahead', lo, n_own, sem[n_own:, 0, 0, 0].tolist())
+            assert bool((sem[n_own:] == want.view(-1, 1, 1, 1)).all())
+        if hist is not None:
+            want = torch.arange(lo - mid, lo, dtype=torch.float32) + 0.5
+            assert torch.equal(hist[:, 0, 0, 0], want), ('carry', lo, hist[:, 0, 0, 0].tolist())
+        sem[:n_own] += 0.5
 
     def runs(self, sem, stash):
         lo, hi = stash

@@ -139,8 +139,9 @@ def test_public_multigpu_engine_spawns_its_ranks(golden_dir, world, ks, block, m
     assert eng._procs is None
 
 
-@pytest.mark.parametrize('world,block', [(2, '0'), (2, '2'), (2, '4'), (3, '0'), (3, '2'), (3, '4'), (1, '3'), (4, '1')])
-def test_public_multigpu_engine_multiclass_slab_matching(world, block, monkeypatch):
+@pytest.mark.parametrize('world,block,ks', [(2, '0', 3), (2, '2', 3), (2, '4', 5), (3, '0', 5), (3, '2', 3), (3, '4', 7), (1, '3', 3), (4, '1', 3),
+                                            (4, '2', 5), (2, '1', 7)])
+def test_public_multigpu_engine_multiclass_slab_matching(world, block, ks, monkeypatch):
     """Several classes through the public API on gloo (BASELINE configs[4]'s class structure: two instance classes and a
     semantic one): every rank matches and tracks its own slab (multigpu.SlabMatcher) -- ghost slices, forward state down
     the ranks, backward state up, partial trackers to the caller -- and the result equals the sequential C++ matcher over
@@ -155,7 +156,8 @@ def test_public_multigpu_engine_multiclass_slab_matching(world, block, monkeypat
     shape = tsm.SHAPE
     mc = {'seed': 40, 'thing_list': tsm.THINGS, 'labels': tsm.LABELS, 'class_names': {1: 'a', 2: 'b', 3: 'c'},
           'padding_factor': 16, 'norms': {'mean': 0.5, 'std': 0.1}}
-    eng = multigpu.MultiGPUEngine3d(mc, label_divisor=tsm.DIV, median_kernel_size=3, min_size=12, min_extent=2,
+    # the stand-in backend checks every look-ahead / carry map the exchange delivers (mg_oracle_backend.LabelStackBackend)
+    eng = multigpu.MultiGPUEngine3d(mc, label_divisor=tsm.DIV, median_kernel_size=ks, min_size=12, min_extent=2,
                                     world_size=world, dist_backend='gloo', backend_factory=mgb.label_stack_backend_factory)
     try:
         vol = np.zeros(shape, np.uint8)
