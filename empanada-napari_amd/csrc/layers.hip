@@ -602,6 +602,60 @@ inline int grid_for(int64_t total, int per_block = 256, int cap = 256 * 16) {
   return (int)g;
 }
 
+// RegNet stem for the fp16 engine (regnet.py:38-49): 3x3 stride-2 conv of the single-channel image + folded BN + ReLU in
+// fp32 (the arithmetic of ref32.hip's stem3x3s2_32_kernel), stored as fp16; thread = one output pixel x 8 channels
+template <typename T>
+__global__ void __launch_bounds__(256) stem3x3s2_f16_kernel(const T* __restrict__ img, float sub, float mul, int normalise, int N,
+                                                            int H, int W, int vh, int vw, const float* __restrict__ w,
+                                                            const float* __restrict__ b, int C, half_t* __restrict__ out,
+                                                            int out_ld, int64_t total) {
+  const int CG = C >> 3, Ho = H >> 1, Wo = W >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % CG);
+    int64_t q = i / CG;
+    const int ox = (int)(q % Wo); q /= Wo;
+    const int oy = (int)(q % Ho);
+    const int n = (int)(q / Ho);
+    const T* src = img + (size_t)n * vh * vw;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * 2 - 1 + kx;
+        float v = 0.f;
+        if (iy >= 0 && iy < vh && ix >= 0 && ix < vw) {
+          v = (float)src[(size_t)iy * vw + ix];
+          if (normalise) { v -= sub; v *= mul; }
+        }
+        const float* wp = w + (size_t)(ky * 3 + kx) * C + cg * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wp[c], acc[c]);
+      }
+    }
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = (half_t)fmaxf(acc[c] + b[cg * 8 + c], 0.f);
+    *reinterpret_cast<f16x8*>(out + (((size_t)n * Ho + oy) * Wo + ox) * out_ld + cg * 8) = o;
+  }
+}
+
+// the reference's per-pixel squeeze-excite gate (blocks.py:35-50) on fp16 maps: x = fp16(x * sigmoid(g)), fp32 inside
+__global__ void __launch_bounds__(256) gate_mul_f16_kernel(half_t* __restrict__ x, int x_ld, const half_t* __restrict__ g,
+                                                           int g_ld, int C, int64_t total) {
+  const int CG = C >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % CG);
+    const int64_t m = i / CG;
+    f16x8 xv = *reinterpret_cast<const f16x8*>(x + (size_t)m * x_ld + cg * 8);
+    const f16x8 gv = *reinterpret_cast<const f16x8*>(g + (size_t)m * g_ld + cg * 8);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xv[c] = (half_t)((float)xv[c] * (1.f / (1.f + expf(-(float)gv[c]))));
+    *reinterpret_cast<f16x8*>(x + (size_t)m * x_ld + cg * 8) = xv;
+  }
+}
+
 }  // namespace
 
 int launch_stem7x7(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
@@ -650,6 +704,39 @@ int launch_stem7x7_f32(const void* img, int dtype, float sub, float mul, int N, 
     default:
       EMP_REQUIRE(false, "stem: unknown image dtype %d", dtype);
   }
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_stem3x3s2_f16(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw, const float* w,
+                         const float* b, int C, half_t* out, int out_ld, hipStream_t s) {
+  EMP_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 8 == 0 && out_ld % 8 == 0 && out_ld >= C, "stem3x3 (fp16): bad shape");
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+  const dim3 grid(grid_for(total));
+  switch (dtype) {
+    case EMP_IMG_F32:
+      hipLaunchKernelGGL(stem3x3s2_f16_kernel<float>, grid, dim3(256), 0, s, (const float*)img, sub, mul, 0, N, H, W, vh, vw, w, b, C,
+                         out, out_ld, total);
+      break;
+    case EMP_IMG_U8:
+      hipLaunchKernelGGL(stem3x3s2_f16_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)img, sub, mul, 1, N, H, W, vh, vw, w,
+                         b, C, out, out_ld, total);
+      break;
+    case EMP_IMG_U16:
+      hipLaunchKernelGGL(stem3x3s2_f16_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)img, sub, mul, 1, N, H, W, vh, vw, w,
+                         b, C, out, out_ld, total);
+      break;
+    default:
+      EMP_REQUIRE(false, "stem3x3 (fp16): unknown image dtype %d", dtype);
+  }
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+int launch_gate_mul_f16(half_t* x, int x_ld, const half_t* g, int g_ld, int64_t rows, int C, hipStream_t s) {
+  EMP_REQUIRE(C % 8 == 0 && x_ld % 8 == 0 && g_ld % 8 == 0 && x_ld >= C && g_ld >= C, "gate_mul (fp16): bad shape");
+  const int64_t total = rows * (C / 8);
+  hipLaunchKernelGGL(gate_mul_f16_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, x_ld, g, g_ld, C, total);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }

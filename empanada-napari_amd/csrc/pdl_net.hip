@@ -350,6 +350,22 @@ int pack_conv3_ds(emp_pdl* n, const std::string& block) {
   return EMP_OK;
 }
 
+int upload_f32(emp_pdl* n, const std::string& key, const std::vector<float>& v);
+
+// RegNet stem (W,1,3,3) -> [9][W] fp32 (both precisions compute it in fp32)
+int upload_regnet_stem(emp_pdl* n) {
+  const emp_pdl_config& c = n->cfg;
+  const HostParam& hp = n->params["encoder.stem.cbr.0"];
+  EMP_REQUIRE(hp.shape.size() == 4 && hp.shape[0] == c.rn_stem && hp.shape[1] == 1 && hp.shape[2] == 3 && hp.shape[3] == 3,
+              "encoder.stem.cbr.0 must be (%d,1,3,3)", c.rn_stem);
+  std::vector<float> w((size_t)9 * c.rn_stem);
+  for (int o = 0; o < c.rn_stem; ++o)
+    for (int t = 0; t < 9; ++t) w[(size_t)t * c.rn_stem + o] = hp.w[(size_t)o * 9 + t];
+  int rc = upload_f32(n, "rn.stem.w", w);
+  if (rc) return rc;
+  return upload_f32(n, "rn.stem.b", hp.b);
+}
+
 // fragment-ordered copy of a pointwise weight for the fused separable conv (sepconv.hip), when its shape qualifies
 int pack_sepconv_pw(emp_pdl* n, const std::string& name) {
   const DevConv& dc = n->convs.at(name);
@@ -509,10 +525,36 @@ int plan(emp_pdl* n, int N, int H, int W, int RS, hipStream_t stream) {
   n->raw.clear();
   Planner pl;
   add_raw(n, pl, "zero", 2048);
+  int ph[5], pw[5];
+  if (c.encoder == 1) {
+    // RegNet: widths are multiples of 8, the kernels read channels in slabs of 64 -- every map gets rows of
+    // round_up(C, 64) channels (the input of the grouped 3x3 64 more: its last group's padded slab starts at channel
+    // (G - 1) * group width); the tails are zeroed with the arena below and never written
+    int h = H / 2, w = W / 2;
+    add_act(n, pl, "stem", N, h, w, c.rn_stem, round_up(c.rn_stem, 64));
+    ph[0] = h; pw[0] = w;
+    for (int si = 1; si <= 4; ++si) {
+      const int cw = c.rn_widths[si - 1], ld = round_up(cw, 64);
+      for (int b = 1; b <= c.rn_depths[si - 1]; ++b) {
+        const int sb = b == 1 ? c.rn_strides[si - 1] : 1;
+        const std::string p = "encoder.stage" + std::to_string(si) + ".block" + std::to_string(b);
+        add_act(n, pl, p + ".a", N, h, w, cw, ld + 64);
+        const int ho = (h - 1) / sb + 1, wo = (w - 1) / sb + 1;
+        add_act(n, pl, p + ".b", N, ho, wo, cw, ld);
+        if (c.rn_se) {
+          add_act(n, pl, p + ".se1", N, ho, wo, round_up(cw / 4, 8), round_up(cw / 4, 64));
+          add_act(n, pl, p + ".se2", N, ho, wo, cw, ld);
+        }
+        if (regnet_has_shortcut(c, si, b)) add_act(n, pl, p + ".ds", N, ho, wo, cw, ld);
+        add_act(n, pl, p, N, ho, wo, cw, ld);
+        h = ho; w = wo;
+      }
+      ph[si] = h; pw[si] = w;
+    }
+  } else {
   add_act(n, pl, "stem", N, H / 2, W / 2, 64);
   add_act(n, pl, "p1", N, H / 4, W / 4, 64);
   int h = H / 4, w = W / 4, inpl = 64;
-  int ph[5], pw[5];
   ph[0] = h; pw[0] = w;
   for (int li = 1; li <= 4; ++li) {
     int stride = li == 1 ? 1 : 2;
@@ -531,6 +573,7 @@ int plan(emp_pdl* n, int N, int H, int W, int RS, hipStream_t stream) {
     ph[li] = h; pw[li] = w;
   }
   (void)inpl;
+  }
   int hq = 0, wq = 0;
   if (c.arch == 0) {
     const int h5 = ph[4], w5 = pw[4];
@@ -767,70 +810,106 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
   };
 
   // ---- encoder ----
-  if (n->fuse_stem) {
-    // conv1 + bn1 + relu + maxpool in one launch on the matrix pipe; the half-resolution map is never written
-    RC(launch_stem_pool(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("p1").p, s));
-  } else {
-    RC(launch_stem7x7(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("stem").p, s));
-    RC(launch_maxpool3x3s2(A("stem").p, N, H / 2, W / 2, 64, A("p1").p, s));
-  }
-  n->flops += 2.0 * N * (H / 2) * (W / 2) * 64.0 * 49.0;
-  std::string xname = "p1";
-  std::string pyr[5];
-  pyr[0] = "p1";
-  bool c1_done = false;      // the coming block's conv1 was computed by the previous block's last launch
+  std::string xname, pyr[5];
   bool proj_done[8] = {false, false, false, false, false, false, false, false};   // decoder projections written by the encoder
-  for (int li = 1; li <= 4; ++li) {
-    int stride = li == 1 ? 1 : 2, dil = 1;
-    if (li == 4 && c.stage4_stride == 16) { stride = 1; dil = 2; }
-    for (int b = 0; b < kLayers[li - 1]; ++b) {
-      const int sb = b == 0 ? stride : 1;
-      std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
-      if (!c1_done) {
-        // first block of a stage whose input the decoders project too: one conv, three destinations (see create)
-        int pi = -1;
-        if (b == 0 && c.arch == 0)
-          for (int i = 0; i < c.n_stages; ++i)
-            if (c.low_level_stages[i] == li - 1 && n->convs.count(p + ".conv1+project." + std::to_string(i))) pi = i;
-        if (pi >= 0) {
-          const int xch = pi == 0 ? n->aspp_ch : n->dec_ch;      // where the projected channels sit in the concat buffers
-          const Act& cb1 = A("semantic_decoder.stage" + std::to_string(pi) + ".cat");
-          const Act& cb2 = A("instance_decoder.stage" + std::to_string(pi) + ".cat");
-          const int c1 = n->convs.at(p + ".conv1").cout;
-          RC(conv(n, p + ".conv1+project." + std::to_string(pi), A(xname), 0, A(p + ".c1"), 0, 1, 0, 1, true, nullptr, nullptr, s,
-                  0, nullptr, 1, &cb1, xch, c1, nullptr, nullptr, nullptr, &cb2, xch, c1 + c.low_level_proj_sem[pi]));
-          proj_done[pi] = true;
-        } else {
-          RC(conv(n, p + ".conv1", A(xname), 0, A(p + ".c1"), 0, 1, 0, 1, true, nullptr, nullptr, s));
+  if (c.encoder == 1) {
+    // RegNet (regnet.py:160-166) on the generic conv: a (1x1) -> b (grouped 3x3: one launch per group on its channel
+    // slice) -> [per-pixel squeeze-excite gate] -> c (1x1) + shortcut, ReLU
+    const Act& st = A("stem");
+    RC(launch_stem3x3s2_f16(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("rn.stem.w"), n->f32w.at("rn.stem.b"), c.rn_stem, st.p,
+                            st.ld, s));
+    n->flops += 2.0 * N * (H / 2) * (W / 2) * (double)c.rn_stem * 9.0;
+    xname = "stem";
+    pyr[0] = "stem";
+    for (int si = 1; si <= 4; ++si) {
+      const int cw = c.rn_widths[si - 1], g = c.rn_groups[si - 1], gw = cw / g;
+      for (int b = 1; b <= c.rn_depths[si - 1]; ++b) {
+        const std::string p = "encoder.stage" + std::to_string(si) + ".block" + std::to_string(b);
+        const int sb = b == 1 ? c.rn_strides[si - 1] : 1;
+        RC(conv(n, p + ".bottleneck.a.0", A(xname), 0, A(p + ".a"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+        for (int gi = 0; gi < g; ++gi)
+          RC(conv(n, p + ".bottleneck.b.0#" + std::to_string(gi), A(p + ".a"), gi * gw, A(p + ".b"), gi * gw, sb, 1, 1, 1, nullptr,
+                  nullptr, s));
+        if (c.rn_se) {
+          RC(conv(n, p + ".bottleneck.se.se.0#pad", A(p + ".b"), 0, A(p + ".se1"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+          RC(conv(n, p + ".bottleneck.se.se.2", A(p + ".se1"), 0, A(p + ".se2"), 0, 1, 0, 1, 0, nullptr, nullptr, s));
+          const Act& xb = A(p + ".b");
+          RC(launch_gate_mul_f16(xb.p, xb.ld, A(p + ".se2").p, A(p + ".se2").ld, (int64_t)N * xb.H * xb.W, cw, s));
         }
+        const Act* idn = &A(xname);
+        if (regnet_has_shortcut(c, si, b)) {
+          RC(conv(n, p + ".downsample.conv.0", A(xname), 0, A(p + ".ds"), 0, sb, 0, 1, 0, nullptr, nullptr, s));
+          idn = &A(p + ".ds");
+        }
+        RC(conv(n, p + ".bottleneck.c.0", A(p + ".b"), 0, A(p), 0, 1, 0, 1, 1, idn, nullptr, s));
+        xname = p;
       }
-      c1_done = false;
-      RC(conv(n, p + ".conv2", A(p + ".c1"), 0, A(p + ".c2"), 0, sb, dil, dil, true, nullptr, nullptr, s));
-      // the conv1 of the block that follows (same layer, or the first block of the next one): a candidate for the
-      // back-to-back fusion into this block's last launch (ConvParams::next_*; conv() decides)
-      std::string nxt;
-      if (b + 1 < kLayers[li - 1]) nxt = "encoder.layer" + std::to_string(li) + "." + std::to_string(b + 1);
-      else if (li < 4) nxt = "encoder.layer" + std::to_string(li + 1) + ".0";
-      const std::string nxt_w = nxt + ".conv1";
-      const bool has_next = !nxt.empty() && n->convs.count(nxt_w);
-      const Act* idn = &A(xname);
-      if (b == 0 && n->fuse_ds) {
-        // relu(bn3(conv3(c2)) + bn(downsample(x))) as ONE GEMM whose K runs over c2's channels and then over x's
-        // (sampled with the block's stride): the shortcut map is neither written nor read back
-        RC(conv(n, p + ".conv3+ds", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, true, nullptr, nullptr, s, 0, &A(xname), sb, nullptr, 0, 0,
+      pyr[si] = xname;
+    }
+  } else {
+    if (n->fuse_stem) {
+      // conv1 + bn1 + relu + maxpool in one launch on the matrix pipe; the half-resolution map is never written
+      RC(launch_stem_pool(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("p1").p, s));
+    } else {
+      RC(launch_stem7x7(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("stem").p, s));
+      RC(launch_maxpool3x3s2(A("stem").p, N, H / 2, W / 2, 64, A("p1").p, s));
+    }
+    n->flops += 2.0 * N * (H / 2) * (W / 2) * 64.0 * 49.0;
+    xname = "p1";
+    pyr[0] = "p1";
+    bool c1_done = false;      // the coming block's conv1 was computed by the previous block's last launch
+    for (int li = 1; li <= 4; ++li) {
+      int stride = li == 1 ? 1 : 2, dil = 1;
+      if (li == 4 && c.stage4_stride == 16) { stride = 1; dil = 2; }
+      for (int b = 0; b < kLayers[li - 1]; ++b) {
+        const int sb = b == 0 ? stride : 1;
+        std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
+        if (!c1_done) {
+          // first block of a stage whose input the decoders project too: one conv, three destinations (see create)
+          int pi = -1;
+          if (b == 0 && c.arch == 0)
+            for (int i = 0; i < c.n_stages; ++i)
+              if (c.low_level_stages[i] == li - 1 && n->convs.count(p + ".conv1+project." + std::to_string(i))) pi = i;
+          if (pi >= 0) {
+            const int xch = pi == 0 ? n->aspp_ch : n->dec_ch;      // where the projected channels sit in the concat buffers
+            const Act& cb1 = A("semantic_decoder.stage" + std::to_string(pi) + ".cat");
+            const Act& cb2 = A("instance_decoder.stage" + std::to_string(pi) + ".cat");
+            const int c1 = n->convs.at(p + ".conv1").cout;
+            RC(conv(n, p + ".conv1+project." + std::to_string(pi), A(xname), 0, A(p + ".c1"), 0, 1, 0, 1, true, nullptr, nullptr, s,
+                    0, nullptr, 1, &cb1, xch, c1, nullptr, nullptr, nullptr, &cb2, xch, c1 + c.low_level_proj_sem[pi]));
+            proj_done[pi] = true;
+          } else {
+            RC(conv(n, p + ".conv1", A(xname), 0, A(p + ".c1"), 0, 1, 0, 1, true, nullptr, nullptr, s));
+          }
+        }
+        c1_done = false;
+        RC(conv(n, p + ".conv2", A(p + ".c1"), 0, A(p + ".c2"), 0, sb, dil, dil, true, nullptr, nullptr, s));
+        // the conv1 of the block that follows (same layer, or the first block of the next one): a candidate for the
+        // back-to-back fusion into this block's last launch (ConvParams::next_*; conv() decides)
+        std::string nxt;
+        if (b + 1 < kLayers[li - 1]) nxt = "encoder.layer" + std::to_string(li) + "." + std::to_string(b + 1);
+        else if (li < 4) nxt = "encoder.layer" + std::to_string(li + 1) + ".0";
+        const std::string nxt_w = nxt + ".conv1";
+        const bool has_next = !nxt.empty() && n->convs.count(nxt_w);
+        const Act* idn = &A(xname);
+        if (b == 0 && n->fuse_ds) {
+          // relu(bn3(conv3(c2)) + bn(downsample(x))) as ONE GEMM whose K runs over c2's channels and then over x's
+          // (sampled with the block's stride): the shortcut map is neither written nor read back
+          RC(conv(n, p + ".conv3+ds", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, true, nullptr, nullptr, s, 0, &A(xname), sb, nullptr, 0, 0,
+                  has_next ? &nxt_w : nullptr, has_next ? &A(nxt + ".c1") : nullptr, &c1_done));
+          xname = p;
+          continue;
+        }
+        if (b == 0) {
+          RC(conv(n, p + ".downsample.0", A(xname), 0, A(p + ".ds"), 0, sb, 0, 1, false, nullptr, nullptr, s));
+          idn = &A(p + ".ds");
+        }
+        RC(conv(n, p + ".conv3", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, true, idn, nullptr, s, 0, nullptr, 1, nullptr, 0, 0,
                 has_next ? &nxt_w : nullptr, has_next ? &A(nxt + ".c1") : nullptr, &c1_done));
         xname = p;
-        continue;
       }
-      if (b == 0) {
-        RC(conv(n, p + ".downsample.0", A(xname), 0, A(p + ".ds"), 0, sb, 0, 1, false, nullptr, nullptr, s));
-        idn = &A(p + ".ds");
-      }
-      RC(conv(n, p + ".conv3", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, true, idn, nullptr, s, 0, nullptr, 1, nullptr, 0, 0,
-              has_next ? &nxt_w : nullptr, has_next ? &A(nxt + ".c1") : nullptr, &c1_done));
-      xname = p;
+      pyr[li] = xname;
     }
-    pyr[li] = xname;
   }
   std::string dec_out[2];
   if (c.arch == 1) {
@@ -1292,16 +1371,7 @@ int pack32_convT(emp_pdl* n, const std::string& name) {
 int finalize32(emp_pdl* n) {
   const emp_pdl_config& c = n->cfg;
   if (c.encoder == 1) {
-    {   // stem (W,1,3,3) -> [9][W] fp32
-      const HostParam& hp = n->params["encoder.stem.cbr.0"];
-      EMP_REQUIRE(hp.shape.size() == 4 && hp.shape[0] == c.rn_stem && hp.shape[1] == 1 && hp.shape[2] == 3 && hp.shape[3] == 3,
-                  "encoder.stem.cbr.0 must be (%d,1,3,3)", c.rn_stem);
-      std::vector<float> w((size_t)9 * c.rn_stem);
-      for (int o = 0; o < c.rn_stem; ++o)
-        for (int t = 0; t < 9; ++t) w[(size_t)t * c.rn_stem + o] = hp.w[(size_t)o * 9 + t];
-      RC32(upload_f32(n, "rn.stem.w", w));
-      RC32(upload_f32(n, "rn.stem.b", hp.b));
-    }
+    RC32(upload_regnet_stem(n));
     for (int si = 1; si <= 4; ++si)
       for (int b = 1; b <= c.rn_depths[si - 1]; ++b) {
         const std::string p = "encoder.stage" + std::to_string(si) + ".block" + std::to_string(b);
@@ -1771,7 +1841,10 @@ int emp_pdl_create(const emp_pdl_config* cfg, emp_pdl_t** out) {
   emp_pdl* n = new (std::nothrow) emp_pdl();
   if (!n) return EMP_ERR_NOMEM;
   n->cfg = *cfg;
-  if (cfg->encoder == 1) n->precision = 1;      // RegNet encoders exist in the fp32 mode only (grouped conv32, ref32.hip)
+  if (cfg->encoder == 1) {      // RegNet: the fp32 mode unless emp_pdl_set_precision(net, 0) / EMP_PRECISION=fp16 ask for the fp16 engine
+    const char* e = getenv("EMP_PRECISION");
+    n->precision = (e && (!strcmp(e, "fp16") || !strcmp(e, "16"))) ? 0 : 1;
+  }
   n->dec_ch = cfg->arch == 1 ? cfg->fpn_dim : cfg->decoder_channels;
   n->aspp_ch = cfg->aspp_channels > 0 ? cfg->aspp_channels : cfg->decoder_channels;
   n->ncls = cfg->num_classes;
@@ -1817,8 +1890,8 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       return EMP_ERR_STATE;
     }
   const emp_pdl_config& c = n->cfg;
-  if (c.encoder == 1) {
-    // RegNet: fp32 mode only -- none of the fp16 packs below; what run32 reads besides finalize32's conv weights:
+  if (c.encoder == 1 && n->precision == 1) {
+    // RegNet in the fp32 mode: none of the fp16 packs below; what run32 reads besides finalize32's conv weights:
     if (c.arch == 1) {
       for (const auto& nm : n->param_names)
         if (nm.size() > 8 && nm.compare(nm.size() - 8, 8, ".weights") == 0) {
@@ -1855,6 +1928,52 @@ int emp_pdl_finalize(emp_pdl_t* n) {
     n->finalized = true;
     return EMP_OK;
   }
+  if (c.encoder == 1) {
+    // RegNet on the fp16 engine (regnet.py:38-160): every layer on the generic implicit-GEMM conv (conv_igemm.hip); the
+    // grouped 3x3 as one launch per group on a channel slice (group width 56 / 72 -> K padded to 64 / 128 with zero
+    // weights, Cout = the group width); the squeeze convolution's width (w / 4) padded to a multiple of 8 with zero rows
+    RC(upload_regnet_stem(n));
+    for (int si = 1; si <= 4; ++si)
+      for (int b = 1; b <= c.rn_depths[si - 1]; ++b) {
+        const std::string p = "encoder.stage" + std::to_string(si) + ".block" + std::to_string(b);
+        const int w = c.rn_widths[si - 1], g = c.rn_groups[si - 1], gw = w / g;
+        RC(pack_conv(n, p + ".bottleneck.a.0"));
+        {
+          const HostParam& hb = n->params.at(p + ".bottleneck.b.0");
+          EMP_REQUIRE(hb.shape.size() == 4 && hb.shape[0] == w && hb.shape[1] == gw && hb.shape[2] == 3 && hb.shape[3] == 3 && gw % 8 == 0,
+                      "%s.bottleneck.b.0 must be (%d,%d,3,3) with a group width that is a multiple of 8", p.c_str(), w, gw);
+          for (int gi = 0; gi < g; ++gi) {
+            HostParam t;
+            t.shape = {gw, gw, 3, 3};
+            t.w.assign(hb.w.begin() + (size_t)gi * gw * gw * 9, hb.w.begin() + (size_t)(gi + 1) * gw * gw * 9);
+            t.b.assign(hb.b.begin() + (size_t)gi * gw, hb.b.begin() + (size_t)(gi + 1) * gw);
+            const std::string tn = p + ".bottleneck.b.0#" + std::to_string(gi);
+            n->params[tn] = t;
+            const int rc = pack_conv(n, tn);
+            n->params.erase(tn);
+            if (rc) return rc;
+          }
+        }
+        if (c.rn_se) {
+          const HostParam& h0 = n->params.at(p + ".bottleneck.se.se.0");
+          const int ns = (int)h0.shape[0], ns8 = round_up(ns, 8);
+          HostParam t;      // zero rows + zero bias for the padded squeeze channels: relu(0) = 0 meets zero input weights
+          t.shape = {ns8, h0.shape[1], 1, 1};
+          t.w.assign((size_t)ns8 * h0.shape[1], 0.f);
+          std::copy(h0.w.begin(), h0.w.end(), t.w.begin());
+          t.b.assign((size_t)ns8, 0.f);
+          std::copy(h0.b.begin(), h0.b.end(), t.b.begin());
+          const std::string tn = p + ".bottleneck.se.se.0#pad";
+          n->params[tn] = t;
+          int rc = pack_conv(n, tn);
+          n->params.erase(tn);
+          if (rc) return rc;
+          RC(pack_conv(n, p + ".bottleneck.se.se.2"));
+        }
+        RC(pack_conv(n, p + ".bottleneck.c.0"));
+        if (regnet_has_shortcut(c, si, b)) RC(pack_conv(n, p + ".downsample.conv.0"));
+      }
+  } else {
   // stem: (64,1,7,7) -> [49][64] fp32
   {
     const HostParam& hp = n->params["encoder.conv1"];
@@ -1877,6 +1996,7 @@ int emp_pdl_finalize(emp_pdl_t* n) {
         RC(pack_conv3_ds(n, p));
       }
     }
+  }
   if (c.arch == 1) {
     const int F = c.fpn_dim;
     RC(pack_conv(n, "p2_resample.conv.0"));
@@ -2044,7 +2164,6 @@ int emp_pdl_set_precision(emp_pdl_t* net, int precision) {
   EMP_REQUIRE(net, "set_precision: null network");
   EMP_REQUIRE(precision == 0 || precision == 1, "set_precision: 0 = fp16 engine, 1 = fp32 reference mode (got %d)", precision);
   EMP_REQUIRE(!net->finalized, "set_precision: call before emp_pdl_finalize");
-  EMP_REQUIRE(net->cfg.encoder == 0 || precision == 1, "set_precision: a RegNet network runs in the fp32 mode only");
   net->precision = precision;
   return EMP_OK;
 }

@@ -57,7 +57,8 @@ class HipPanopticDeepLab:
         """``precision``: None / 'fp16' -- the fp16 engine (the product and the bench); 'fp32' -- the fp32 REFERENCE MODE of
         the library (csrc/ref32.hip: fp32 maps and weights, exact fp32 matrix pipe, no fusion; ~10x slower): the reference
         computes this path in fp32 (engines.py:248-255), and in this mode the float heads are within 1e-3 of it in the
-        max norm.  None follows the environment variable EMP_PRECISION."""
+        max norm.  None follows the environment variable EMP_PRECISION, else the library's default for the encoder: the
+        fp16 engine for ResNet50, the fp32 mode for a RegNet (which 'fp16' moves onto the fp16 engine's generic kernels)."""
         self.device = _require_gpu(device)
         bifpn = 'BiFPN' in (cfg or {}).get('arch', '')
         self.cfg = dict(weights.MITONET_MINI_CFG if bifpn else weights.MITONET_PDL_CFG, **(cfg or {}))
@@ -85,10 +86,9 @@ class HipPanopticDeepLab:
         c.num_fc = cfgd['num_fc']
         c.subdivision_num_points = cfgd['subdivision_num_points']
         if weights.is_regnet(cfgd):
-            # RegNet encoders (encoders/regnet.py) exist in the library's fp32 mode only: grouped 3x3 convolutions and the
-            # per-pixel squeeze-excite gate on the generic fp32 kernels (csrc/ref32.hip), no fp16 engine behind them
-            if precision == 'fp16':
-                raise ValueError(f"encoder {cfgd['encoder']!r} runs with precision='fp32' only (the fp16 engine is built for resnet50)")
+            # RegNet encoders (encoders/regnet.py): the library runs them in its fp32 mode unless precision='fp16' asks for
+            # the fp16 engine (generic implicit-GEMM convs, the grouped 3x3 one launch per group; no layer fusion, and no
+            # parity gate at the north star's 1e-3: tests/test_gpu_regnet.py states what it measures)
             r = self.cfg['regnet'] = weights.regnet_cfg(cfgd)
             c.encoder, c.rn_stem, c.rn_se = 1, r['w_stem'], int(r['use_se'])
             for i, st in enumerate(weights.regnet_stage_strides(cfgd)):

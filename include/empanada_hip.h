@@ -79,8 +79,10 @@ typedef struct {
    * (encoders/regnet.py:38-160; quantization/encoders/__init__.py exports regnetx_6p4gf and regnety_6p4gf): 3x3
    * stride-2 stem of rn_stem channels, stage i = rn_depths[i] bottleneck blocks of width rn_widths[i] with
    * rn_groups[i] groups in the 3x3, the first block of a stage at stride rn_strides[i], rn_se != 0 with the reference's
-   * per-pixel squeeze-excite gate (blocks.py:35-50).  RegNet networks run in the fp32 mode only (emp_pdl_precision
-   * reports 1; emp_pdl_set_precision(net, 0) is refused). */
+   * per-pixel squeeze-excite gate (blocks.py:35-50).  A RegNet network starts in the fp32 mode (emp_pdl_precision
+   * reports 1: heads within 1e-4 of the reference's fp32 forward); emp_pdl_set_precision(net, 0) or EMP_PRECISION=fp16
+   * put it on the fp16 engine -- generic implicit-GEMM convolutions, the grouped 3x3 one launch per group, 4-5x the
+   * rate, heads within ~0.6e-3 .. 1.4e-3 (rms) of the fp32 forward. */
   int32_t encoder;
   int32_t rn_stem;
   int32_t rn_widths[4];

@@ -123,12 +123,49 @@ def test_regnet_heads_within_1e3_of_the_fp32_oracle(tag, size):
     assert float(p5[..., w4:].abs().max()) == 0.0          # the row tails other kernels rely on stay zero
 
 
-def test_regnet_refuses_the_fp16_engine():
-    from test_regnet import regnet_model
+@pytest.mark.parametrize('tag,size', [('x', 256), ('y', 256)])
+def test_regnet_on_the_fp16_engine(tag, size):
+    """precision='fp16': the RegNet encoder on the fp16 engine's generic convolutions (one launch per group for the 3x3).
+    Against the fp32 forward its heads carry the fp16 engine's usual storage error; gated at 1.3x what was measured (the
+    fp32 mode, the default for a RegNet, is the one that meets 1e-3 in the max norm)"""
+    from empanada_napari_amd import synth
     from empanada_napari_amd.engines import HipPanopticDeepLab
-    cfg, P = regnet_model('x')
-    with pytest.raises(ValueError):
-        HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
+    from empanada_napari_amd.preprocess import normalize
+    from test_regnet import regnet_model
+    from oracle import pdl_model
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg, P = regnet_model(tag)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
+    assert model.precision == 'fp16'
+    img = synth.em_tiles(2, size, seed=5)
+    x = torch.from_numpy(normalize(img, 0.57571, 0.12765))[:, None]
+    out = {k: v.cpu() for k, v in model(x.cuda(), 2, False).items()}
+    ref = pdl_model.model_forward(P, x, cfg, 2, False)
+    rep = {}
+    for k in ('ctr_hmp', 'offsets'):
+        scale = max(1.0, float(ref[k].pow(2).mean().sqrt()))
+        d = (out[k] - ref[k]).abs()
+        rep[k] = (float(d.pow(2).mean().sqrt()) / scale, float(d.max()) / scale)
+    print('fp16 RegNet', tag, rep)
+    assert rep['ctr_hmp'][0] < GATE[tag][0] and rep['offsets'][0] < GATE[tag][1], rep
+    # the last encoder map against the oracle's, and its zero row tail
+    w4 = cfg['regnet']['widths'][3]
+    p5 = model.tap('encoder.stage4.block%d' % cfg['regnet']['depths'][3]).float().cpu()
+    want = pdl_model.regnet_forward(P, x, cfg['regnet'])[4].permute(0, 2, 3, 1)
+    assert p5.shape == want.shape
+    assert float((p5 - want).pow(2).mean().sqrt()) < 4e-3 * float(want.pow(2).mean().sqrt())
+    # batch invariance: one image alone == the same image in the batch, bit for bit
+    one = model(x[:1].cuda(), 2, False)
+    for k in ('ctr_hmp', 'offsets'):
+        assert torch.equal(one[k].cpu(), out[k][:1]), k
+    # raw uint8 in
+    raw = model(torch.from_numpy(img)[:, None].cuda(), 2, False, sub=0.57571 * 255, mul=1.0 / (0.12765 * 255))
+    assert float((raw['ctr_hmp'].cpu() - out['ctr_hmp']).abs().max()) < 2e-2
+
+
+# ctr rms, offsets rms relative to the map's scale: 1.3 x the measured 0.58e-3 / 0.73e-3 (PDL-PR on regnetx) and 1.38e-3 / 0.84e-3
+# (BiFPN-PR on regnety, no precise separable nodes on this path)
+GATE = {'x': (0.75e-3, 0.95e-3), 'y': (1.8e-3, 1.1e-3)}
 
 
 def test_regnet_pdl_at_a_size_the_stride_does_not_divide():
