@@ -164,7 +164,7 @@ def test_regnet_on_the_fp16_engine(tag, size):
 
 
 # ctr rms, offsets rms relative to the map's scale: 1.3 x the measured 0.58e-3 / 0.73e-3 (PDL-PR on regnetx) and 1.38e-3 / 0.84e-3
-# (BiFPN-PR on regnety, no precise separable nodes on this path)
+# (BiFPN-PR on regnety)
 GATE = {'x': (0.75e-3, 0.95e-3), 'y': (1.8e-3, 1.1e-3)}
 
 
