@@ -112,7 +112,8 @@ int launch_stem7x7(const void* img, int dtype, float sub, float mul, int N, int 
 int launch_maxpool3x3s2(const half_t* in, int N, int H, int W, int C, half_t* out, hipStream_t s);
 int launch_stem3x3s2_f16(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
                          const float* w /*[9][C]*/, const float* b, int C, half_t* out, int out_ld, hipStream_t s);
-int launch_gate_mul_f16(half_t* x, int x_ld, const half_t* g, int g_ld, int64_t rows, int C, hipStream_t s);
+int launch_gate_mul_f16(const half_t* x, int x_ld, half_t* g /* in: gate logits, out: x * sigmoid(g) */, int g_ld, int64_t rows, int C,
+                        hipStream_t s);
 // conv1 + bn1 + relu + maxpool on MFMA in one launch (stem.hip): img -> (N,H/4,W/4,64)
 int launch_stem_pool(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
                      const float* w, const float* b, half_t* out, hipStream_t s);

@@ -641,18 +641,19 @@ __global__ void __launch_bounds__(256) stem3x3s2_f16_kernel(const T* __restrict_
   }
 }
 
-// the reference's per-pixel squeeze-excite gate (blocks.py:35-50) on fp16 maps: x = fp16(x * sigmoid(g)), fp32 inside
-__global__ void __launch_bounds__(256) gate_mul_f16_kernel(half_t* __restrict__ x, int x_ld, const half_t* __restrict__ g,
+// the reference's per-pixel squeeze-excite gate (blocks.py:35-50) on fp16 maps: g = fp16(x * sigmoid(g)), fp32 inside.
+// The gated map replaces the GATE, not x: the block's pre-gate map stays intact (teacher-forced layer checks read it)
+__global__ void __launch_bounds__(256) gate_mul_f16_kernel(const half_t* __restrict__ x, int x_ld, half_t* __restrict__ g,
                                                            int g_ld, int C, int64_t total) {
   const int CG = C >> 3;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int cg = (int)(i % CG);
     const int64_t m = i / CG;
-    f16x8 xv = *reinterpret_cast<const f16x8*>(x + (size_t)m * x_ld + cg * 8);
-    const f16x8 gv = *reinterpret_cast<const f16x8*>(g + (size_t)m * g_ld + cg * 8);
+    const f16x8 xv = *reinterpret_cast<const f16x8*>(x + (size_t)m * x_ld + cg * 8);
+    f16x8 gv = *reinterpret_cast<const f16x8*>(g + (size_t)m * g_ld + cg * 8);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) xv[c] = (half_t)((float)xv[c] * (1.f / (1.f + expf(-(float)gv[c]))));
-    *reinterpret_cast<f16x8*>(x + (size_t)m * x_ld + cg * 8) = xv;
+    for (int c = 0; c < 8; ++c) gv[c] = (half_t)((float)xv[c] * (1.f / (1.f + expf(-(float)gv[c]))));
+    *reinterpret_cast<f16x8*>(g + (size_t)m * g_ld + cg * 8) = gv;
   }
 }
 
@@ -733,7 +734,7 @@ int launch_stem3x3s2_f16(const void* img, int dtype, float sub, float mul, int N
   return EMP_OK;
 }
 
-int launch_gate_mul_f16(half_t* x, int x_ld, const half_t* g, int g_ld, int64_t rows, int C, hipStream_t s) {
+int launch_gate_mul_f16(const half_t* x, int x_ld, half_t* g, int g_ld, int64_t rows, int C, hipStream_t s) {
   EMP_REQUIRE(C % 8 == 0 && x_ld % 8 == 0 && g_ld % 8 == 0 && x_ld >= C && g_ld >= C, "gate_mul (fp16): bad shape");
   const int64_t total = rows * (C / 8);
   hipLaunchKernelGGL(gate_mul_f16_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, x_ld, g, g_ld, C, total);

@@ -833,7 +833,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
         if (c.rn_se) {
           RC(conv(n, p + ".bottleneck.se.se.0#pad", A(p + ".b"), 0, A(p + ".se1"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
           RC(conv(n, p + ".bottleneck.se.se.2", A(p + ".se1"), 0, A(p + ".se2"), 0, 1, 0, 1, 0, nullptr, nullptr, s));
-          const Act& xb = A(p + ".b");
+          const Act& xb = A(p + ".b");      // the gated map lands in .se2 (the gate's own buffer); .b keeps the pre-gate map
           RC(launch_gate_mul_f16(xb.p, xb.ld, A(p + ".se2").p, A(p + ".se2").ld, (int64_t)N * xb.H * xb.W, cw, s));
         }
         const Act* idn = &A(xname);
@@ -841,7 +841,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
           RC(conv(n, p + ".downsample.conv.0", A(xname), 0, A(p + ".ds"), 0, sb, 0, 1, 0, nullptr, nullptr, s));
           idn = &A(p + ".ds");
         }
-        RC(conv(n, p + ".bottleneck.c.0", A(p + ".b"), 0, A(p), 0, 1, 0, 1, 1, idn, nullptr, s));
+        RC(conv(n, p + ".bottleneck.c.0", A(p + (c.rn_se ? ".se2" : ".b")), 0, A(p), 0, 1, 0, 1, 1, idn, nullptr, s));
         xname = p;
       }
       pyr[si] = xname;

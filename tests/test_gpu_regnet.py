@@ -240,3 +240,73 @@ def test_regnet_buffers_are_clean_after_a_forward_of_another_shape():
     want = fresh(small, 2, False)
     for k in got:
         assert torch.equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize('tag', ['x', 'y'])
+def test_regnet_fp16_layers_teacher_forced(tag):
+    """Every layer of the RegNet encoder on the fp16 engine, fed the ENGINE'S OWN input map (teacher forcing): the
+    reference's arithmetic (regnet.py:51-97, blocks.py:35-50) in fp32 on those inputs with the weights as the engine
+    stores them (fp16), rounded once to fp16, equals the engine's output map to one fp16 ulp (+1e-4 of the map's scale: a
+    sum added in another order can land on the other side of a rounding boundary) -- layer by layer, so no error of one
+    layer can hide behind the next: a (1x1), b (grouped 3x3, per-group launches on channel slices) [+ the per-pixel gate],
+    the shortcut, c (1x1 + shortcut + ReLU)."""
+    import torch.nn.functional as F
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    from test_regnet import regnet_model
+    cfg, P = regnet_model(tag)
+    r = cfg['regnet']
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
+    size = 128 if tag == 'y' else 96
+    x = torch.from_numpy(normalize(synth.em_tiles(2, size, seed=8), 0.57571, 0.12765))[:, None]
+    model(x.cuda(), 2, False)
+    tap = lambda name: model.tap(name).float().cpu().permute(0, 3, 1, 2).contiguous()
+    w16 = lambda name: (torch.from_numpy(P[name][0]).half().float(), torch.from_numpy(P[name][1]))
+    r16 = lambda t: t.half().float()
+
+    def check(name, got, want):
+        d = (got - want).abs()
+        rms = float(want.pow(2).mean().sqrt())
+        ulp = torch.maximum(want.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10
+        excess = float((d - ulp - 1e-4 * max(1.0, rms)).max())
+        assert excess <= 0, f'{name}: off by more than one fp16 ulp (max |d| {float(d.max()):.3e}, rms {rms:.3f})'
+
+    w, b = P['encoder.stem.cbr.0']
+    check('stem', tap('stem'), r16(F.relu(F.conv2d(x, torch.from_numpy(w), torch.from_numpy(b), 2, 1))))      # fp32 weights
+    xin_name, n_checked = 'stem', 1
+    for si, (d, g) in enumerate(zip(r['depths'], r['groups']), start=1):
+        for bi in range(1, d + 1):
+            p = f'encoder.stage{si}.block{bi}'
+            s = 2 if bi == 1 else 1
+            xin = tap(xin_name)
+            wa, ba = w16(f'{p}.bottleneck.a.0')
+            check(p + '.a', tap(p + '.a'), r16(F.relu(F.conv2d(xin, wa, ba))))
+            wb, bb = w16(f'{p}.bottleneck.b.0')
+            check(p + '.b', tap(p + '.b'), r16(F.relu(F.conv2d(tap(p + '.a'), wb, bb, s, 1, 1, g))))
+            bname = p + '.b'
+            if r['use_se']:      # the gated map is written over the gate (.se2); .b keeps the pre-gate map
+                w0, b0 = w16(f'{p}.bottleneck.se.se.0')
+                w2, b2 = w16(f'{p}.bottleneck.se.se.2')
+                ns = w0.shape[0]
+                check(p + '.se1', tap(p + '.se1')[:, :ns], r16(F.relu(F.conv2d(tap(p + '.b'), w0, b0))))
+                assert tap(p + '.se1').shape[1] == -(-ns // 8) * 8 and not bool(tap(p + '.se1')[:, ns:].any())      # the squeeze width's padding to 8
+                # (the gate logits themselves are gone -- overwritten by the gated map: two steps in one check)
+                gate = r16(F.conv2d(tap(p + '.se1')[:, :ns], w2, b2))
+                want = r16(tap(p + '.b') * torch.sigmoid(gate))
+                dg = (tap(p + '.se2') - want).abs()
+                # one ulp of the gate logit moves sigmoid by <= 2^-12 relative: two ulps of the product
+                assert float((dg - 2 * torch.maximum(want.abs(), torch.tensor(2.0 ** -14)) * 2.0 ** -10 - 1e-4).max()) <= 0, p
+                bname = p + '.se2'
+            wc, bc = w16(f'{p}.bottleneck.c.0')
+            if f'{p}.downsample.conv.0' in P:
+                wd, bd = w16(f'{p}.downsample.conv.0')
+                short = r16(F.conv2d(xin, wd, bd, s))
+                check(p + '.ds', tap(p + '.ds'), short)
+                short = tap(p + '.ds')
+            else:
+                short = xin
+            check(p, tap(p), r16(F.relu(F.conv2d(tap(bname), wc, bc) + short)))
+            xin_name = p
+            n_checked += 4
+    assert n_checked > 60
