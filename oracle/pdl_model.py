@@ -230,7 +230,8 @@ def encoder_forward(P, x, cfg, output_stride, taps=None):
     """the pyramid of ``cfg``'s encoder: index 0 is never read by a decoder, 1..4 are the stage outputs"""
     if str(cfg.get('encoder', 'resnet50')).startswith('regnet'):
         if _EMU is not None:
-            raise NotImplementedError('RegNet encoders run in the fp32 mode only: there is no fp16 engine to emulate')
+            raise NotImplementedError('no format emulation of the fp16 engine exists for RegNet encoders (their fp16 layers are checked '
+                                      'teacher-forced, tests/test_gpu_regnet.py)')
         return regnet_forward(P, x, cfg['regnet'], taps)
     return resnet50_forward(P, x, output_stride, taps)
 

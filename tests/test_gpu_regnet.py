@@ -1,8 +1,10 @@
-"""RegNet encoders on the device (reference: empanada/models/encoders/regnet.py:38-316).  They run in
-the library's fp32 mode (csrc/ref32.hip): the grouped 3x3 on the exact fp32 matrix pipe (one workgroup column per group),
-the reference's per-pixel squeeze-excite gate, the 3x3 stride-2 stem with the normalisation fused.  Checked against the
-reference's own outputs (tests/golden/regnet_forward.npz: PanopticBiFPNPR / regnety_6p4gf and PanopticDeepLabPR /
-regnetx_6p4gf) and, at a larger size, against the oracle's fp32 forward in the max norm."""
+"""RegNet encoders on the device (reference: empanada/models/encoders/regnet.py:38-316).  By default
+they run in the library's fp32 mode (csrc/ref32.hip): the grouped 3x3 on the exact fp32 matrix pipe (one workgroup column
+per group), the reference's per-pixel squeeze-excite gate, the 3x3 stride-2 stem with the normalisation fused -- checked
+against the reference's own outputs (tests/golden/regnet_forward.npz: PanopticBiFPNPR / regnety_6p4gf and
+PanopticDeepLabPR / regnetx_6p4gf) and, at a larger size, against the oracle's fp32 forward in the max norm.  On request
+(precision='fp16') they run on the fp16 engine's generic convolutions: every layer teacher-forced to one fp16 ulp, the heads
+against the fp32 forward at what they measure."""
 import os
 
 import numpy as np
@@ -66,7 +68,7 @@ def test_regnet_forward_matches_the_reference_goldens(golden_dir, tag):
     from empanada_napari_amd.preprocess import normalize
     g = np.load(os.path.join(golden_dir, 'regnet_forward.npz'))
     cfg, P, model = _model(tag)
-    assert model.precision == 'fp32'          # chosen by the library: there is no fp16 engine behind a RegNet
+    assert model.precision == 'fp32'          # the library's default for a RegNet (precision='fp16' is opt-in)
     for case in 'ab':
         img = g[f'{tag}{case}_image']
         rs, interp = int(g[f'{tag}{case}_render_steps']), bool(g[f'{tag}{case}_interpolate_ins'])
