@@ -1107,6 +1107,51 @@ def _instance_runs(instances):
     return starts, lens, vals, order
 
 
+_DL = {'slabs': None, 'pool': None}
+_DL_SLAB = 32 << 20      # bytes per staging slab
+_DL_MIN = 64 << 20       # below this one plain copy is as fast
+
+
+@torch.no_grad()
+def download(dvol, host):
+    """``host.copy_(dvol)`` for a large contiguous device tensor and a contiguous pageable host tensor of the same shape,
+    as a pipeline: the device -> pinned copy of slab k + 1 runs while host threads move slab k from its pinned buffer
+    into the caller's array (a pageable destination makes the runtime stage the whole copy through one bounce buffer on
+    one thread: 537 MB in 33-39 ms against 23 ms this way, MI355X box).  Four pinned slabs of 32 MB and the copier
+    threads are kept for the process."""
+    nbytes = dvol.numel() * dvol.element_size()
+    if nbytes < _DL_MIN or not dvol.is_cuda or dvol.dim() < 1 or not (dvol.is_contiguous() and host.is_contiguous()):
+        host.copy_(dvol)
+        return host
+    if _DL['slabs'] is None:
+        _DL['slabs'] = [torch.empty(_DL_SLAB, dtype=torch.uint8, pin_memory=True) for _ in range(4)]
+        _DL['pool'] = ThreadPoolExecutor(max_workers=4, thread_name_prefix='emp-download')
+    slabs, pool = _DL['slabs'], _DL['pool']
+    src = dvol.reshape(-1).view(torch.uint8)
+    dst = host.reshape(-1).view(torch.uint8).numpy()
+    side = torch.cuda.Stream(dvol.device)
+    side.wait_stream(torch.cuda.current_stream(dvol.device))
+    pending = [None] * len(slabs)
+
+    def drain(b, o, n, ev):
+        ev.synchronize()
+        dst[o:o + n] = slabs[b][:n].numpy()
+
+    with torch.cuda.stream(side):
+        for k, o in enumerate(range(0, nbytes, _DL_SLAB)):
+            b, n = k % len(slabs), min(_DL_SLAB, nbytes - o)
+            if pending[b] is not None:
+                pending[b].result()
+            slabs[b][:n].copy_(src[o:o + n], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            pending[b] = pool.submit(drain, b, o, n, ev)
+    for f in pending:
+        if f is not None:
+            f.result()
+    return host
+
+
 @torch.no_grad()
 def fill_volume(volume, instances, device=None, fresh=False):
     """Fills ``volume`` (numpy array or cuda tensor) in place with the instances' ids; where instances overlap the
@@ -1128,7 +1173,7 @@ def fill_volume(volume, instances, device=None, fresh=False):
     assert dvol.is_contiguous()
     _fill_device(dvol, starts, lens, vals, order)
     if is_np:
-        host.copy_(dvol)       # one device -> host copy straight into the caller's array
+        download(dvol, host)   # device -> host straight into the caller's array (pipelined through pinned slabs when large)
     return volume
 
 

@@ -214,3 +214,24 @@ def test_fill_holes_in_segmentation_matches_oracle():
     osp.fill_holes_in_segmentation(b, vol.shape, [1], 1000, [1])
     _same(a.instances, b.instances)
     assert sum(int(v['runs'].sum()) for v in a.instances.values()) > int((vol > 0).sum())
+
+
+def test_pipelined_download_equals_a_plain_copy():
+    """sparse.download: a dense result volume goes back through pinned slabs with host threads emptying them behind the
+    copies -- same bytes as ``host.copy_(dvol)``, for sizes around the slab boundaries, a dtype of every width the fill
+    writes, and a small tensor (plain path)"""
+    import torch
+    from empanada_napari_amd import sparse
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    for shape, dt in (((96, 512, 512), torch.int32), ((65, 1000, 1037), torch.uint8), ((33, 511, 513), torch.int64), ((4, 8, 8), torch.int32)):
+        d = torch.randint(0, 250, shape, generator=g, device=dev).to(dt)
+        host = torch.empty(shape, dtype=dt)
+        out = sparse.download(d, host)
+        assert out is host and torch.equal(host, d.cpu())
+    # twice in a row: the pinned slabs are reused
+    d = torch.randint(0, 1 << 30, (80, 512, 512), generator=g, device=dev, dtype=torch.int32)
+    a, b = torch.empty(d.shape, dtype=d.dtype), torch.empty(d.shape, dtype=d.dtype)
+    sparse.download(d, a)
+    sparse.download(d + 1, b)
+    assert torch.equal(a + 1, b)
