@@ -1201,7 +1201,7 @@ def chunked_fill(array, instances, slab_depth=None, device=None):
             s = np.maximum(starts[sel], lo) - lo
             e = np.minimum(ends[sel], hi) - lo
             _fill_device(block, s, e - s, vals[sel], order[sel])
-        array[z0:z1] = block.cpu().numpy().view(dt)
+        array[z0:z1] = download(block, torch.empty(block.shape, dtype=tdt)).numpy().view(dt)
     return array
 
 
