@@ -1118,7 +1118,8 @@ def download(dvol, host):
     as a pipeline: the device -> pinned copy of slab k + 1 runs while host threads move slab k from its pinned buffer
     into the caller's array (a pageable destination makes the runtime stage the whole copy through one bounce buffer on
     one thread: 537 MB in 33-39 ms against 23 ms this way, MI355X box).  Four pinned slabs of 32 MB and the copier
-    threads are kept for the process."""
+    threads are kept for the process.  [The other direction needs none of this: a pageable 134 MB volume goes UP in 2.4 ms
+    (56 GB/s) as one plain copy; the same pipeline mirrored took 4.5 ms and was removed.]"""
     nbytes = dvol.numel() * dvol.element_size()
     if nbytes < _DL_MIN or not dvol.is_cuda or dvol.dim() < 1 or not (dvol.is_contiguous() and host.is_contiguous()):
         host.copy_(dvol)

@@ -235,3 +235,4 @@ def test_pipelined_download_equals_a_plain_copy():
     sparse.download(d, a)
     sparse.download(d + 1, b)
     assert torch.equal(a + 1, b)
+
