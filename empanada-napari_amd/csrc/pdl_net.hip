@@ -528,8 +528,8 @@ int plan(emp_pdl* n, int N, int H, int W, int RS, hipStream_t stream) {
   int ph[5], pw[5];
   if (c.encoder == 1) {
     // RegNet: widths are multiples of 8, the kernels read channels in slabs of 64 -- every map gets rows of
-    // round_up(C, 64) channels (the input of the grouped 3x3 64 more: its last group's padded slab starts at channel
-    // (G - 1) * group width); the tails are zeroed with the arena below and never written
+    // round_up(C, 64) channels (the input and the output of the grouped 3x3 64 more: its last group's padded slab starts
+    // at channel (G - 1) * group width); the tails are zeroed with the arena below and only ever written with zeros
     int h = H / 2, w = W / 2;
     add_act(n, pl, "stem", N, h, w, c.rn_stem, round_up(c.rn_stem, 64));
     ph[0] = h; pw[0] = w;
@@ -540,7 +540,7 @@ int plan(emp_pdl* n, int N, int H, int W, int RS, hipStream_t stream) {
         const std::string p = "encoder.stage" + std::to_string(si) + ".block" + std::to_string(b);
         add_act(n, pl, p + ".a", N, h, w, cw, ld + 64);
         const int ho = (h - 1) / sb + 1, wo = (w - 1) / sb + 1;
-        add_act(n, pl, p + ".b", N, ho, wo, cw, ld);
+        add_act(n, pl, p + ".b", N, ho, wo, cw, ld + 64);
         if (c.rn_se) {
           add_act(n, pl, p + ".se1", N, ho, wo, round_up(cw / 4, 8), round_up(cw / 4, 64));
           add_act(n, pl, p + ".se2", N, ho, wo, cw, ld);
@@ -1942,11 +1942,18 @@ int emp_pdl_finalize(emp_pdl_t* n) {
           const HostParam& hb = n->params.at(p + ".bottleneck.b.0");
           EMP_REQUIRE(hb.shape.size() == 4 && hb.shape[0] == w && hb.shape[1] == gw && hb.shape[2] == 3 && hb.shape[3] == 3 && gw % 8 == 0,
                       "%s.bottleneck.b.0 must be (%d,%d,3,3) with a group width that is a multiple of 8", p.c_str(), w, gw);
+          // a group's couts padded to its K padding (56 -> 64, 72 -> 128) with zero rows and zero bias: a 64 -> 64 / 128 -> 128
+          // 3x3 is what the register-weight kernels take (conv3x3c64.hip, ~1 PFLOP/s on ResNet layer1's conv2).  The zeros
+          // a group writes past its width land on the first channels of the NEXT group -- whose launch follows on the
+          // same stream and overwrites them -- or, for the last group, on the row's zero tail
+          const int gwp = round_up(gw, 64);
           for (int gi = 0; gi < g; ++gi) {
             HostParam t;
-            t.shape = {gw, gw, 3, 3};
-            t.w.assign(hb.w.begin() + (size_t)gi * gw * gw * 9, hb.w.begin() + (size_t)(gi + 1) * gw * gw * 9);
-            t.b.assign(hb.b.begin() + (size_t)gi * gw, hb.b.begin() + (size_t)(gi + 1) * gw);
+            t.shape = {gwp, gw, 3, 3};
+            t.w.assign((size_t)gwp * gw * 9, 0.f);
+            std::copy(hb.w.begin() + (size_t)gi * gw * gw * 9, hb.w.begin() + (size_t)(gi + 1) * gw * gw * 9, t.w.begin());
+            t.b.assign((size_t)gwp, 0.f);
+            std::copy(hb.b.begin() + (size_t)gi * gw, hb.b.begin() + (size_t)(gi + 1) * gw, t.b.begin());
             const std::string tn = p + ".bottleneck.b.0#" + std::to_string(gi);
             n->params[tn] = t;
             const int rc = pack_conv(n, tn);
