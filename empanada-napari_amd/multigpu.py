@@ -37,7 +37,6 @@ and kept for the following axes -- unless the caller already runs SPMD (``torchr
 initialised process group, as ``bench.py --workload stack3d`` does): then every rank calls
 ``infer_on_axis`` and rank 0 gets the result.
 """
-import math
 import os
 import socket
 import traceback

@@ -11,7 +11,6 @@ calls (matcher.py:213, consensus.py:2).  Dict schema is the reference's:
 ``{label: {'box', 'starts', 'runs'}}`` over row-major raveled indices.
 """
 import ctypes as C
-import math
 import os
 from concurrent.futures import ThreadPoolExecutor
 from itertools import combinations
