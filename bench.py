@@ -637,7 +637,8 @@ def run_stack3d(args, rank, local_rank, world, dist_on, dev):
         n_ranks = ranks_one_gpu
     elif dist_on:
         multigpu.MultiGPUEngine3d.MIN_WORLD = 1
-        eng = multigpu.MultiGPUEngine3d(mc, **kw)
+        shared = dist.get_backend() != 'nccl'      # EMP_BENCH_SHARE_GPU: all ranks on this one device, gloo transport
+        eng = multigpu.MultiGPUEngine3d(mc, devices=[dev.index] * world if shared else None, **kw)
         job = lambda: eng.infer_on_axis(vol, 'xy')
     else:
         e3 = Engine3d(mc, device=dev, **kw)
@@ -701,18 +702,20 @@ def run_stack3d(args, rank, local_rank, world, dist_on, dev):
                         'gpu_ms_per_slice = rank 0 GPU phase / its own slices'}
     if ranks_one_gpu > 1:
         eng.close()
+    shared_spmd = dist_on and dist.get_backend() != 'nccl'      # EMP_BENCH_SHARE_GPU: the ranks time-share ONE device over gloo
+    gpus = 1 if shared_spmd else world
     return {'metric': 'voxels/sec, 3-D stack (xy) z-slab inference', 'value': round(vox / sec, 1), 'unit': 'voxels/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': 1, 'ms_per_step': round(sec * 1e3, 2),
+            'n_gpus': gpus, 'steps': args.steps, 'warmup': 1, 'ms_per_step': round(sec * 1e3, 2),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': f'procedural uint8 volume {D}x{S}x{S} ({args.depth} slices per GPU), xy stack inference, '
                                    f'recursive median ks={args.ks}, z-slabs over {world} GPU(s), neighbour halo + filtered '
                                    f'carry over RCCL, slab-wise C++ matcher + tracker on every rank (forward / backward '
                                    f'state chained through the ranks), per-slab tracks to rank 0',
-                       'rccl_ranks': world if dist_on else 0, 'tracked_objects': nobj,
-                       'ranks_sharing_one_gpu': ranks_one_gpu if ranks_one_gpu > 1 else 0,
+                       'rccl_ranks': world if dist_on and not shared_spmd else 0, 'tracked_objects': nobj,
+                       'ranks_sharing_one_gpu': ranks_one_gpu if ranks_one_gpu > 1 else (world if shared_spmd else 0),
                        'parallelism': f'z-slab x{n_ranks}'},
-            'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F16_TFLOPS * world, 'unit': 'TFLOP/s',
-                         'frac': round(tf / (PEAK_F16_TFLOPS * world), 4), 'traffic': None,
+            'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': PEAK_F16_TFLOPS * gpus, 'unit': 'TFLOP/s',
+                         'frac': round(tf / (PEAK_F16_TFLOPS * gpus), 4), 'traffic': None,
                          'note': 'whole-job rate: forward FLOPs of every slice / wall time of the job over all ranks (median, '
                                  'voting, merge, run extraction and the host matcher included in the time); kernel-level '
                                  'roofline: the tiles workload', 'forward_flops': flops},
