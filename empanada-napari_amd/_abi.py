@@ -122,6 +122,7 @@ PROTOTYPES = {
     'emp_rle_fill_ordered': (c_int, [vp, vp, vp, vp, c_i64, vp, c_i64, c_int, vp, vp]),
     'emp_rle_pair_intersections': (c_int, [vp, vp, vp, vp, c_i64, vp]),
     'emp_ranges_vote': (c_int, [vp, c_i64, c_int, vp, C.POINTER(c_i64)]),
+    'emp_gather_segments_i64': (c_int, [vp, vp, vp, vp, vp, vp, c_i64, vp, vp]),
     'emp_panoptic_merge': (c_int, [vp, vp, c_int, c_int, c_int, c_int, c_f32, C.POINTER(c_i32), c_int, c_i64, c_i64,
                                    c_i64, c_int, vp, vp, vp]),
 }

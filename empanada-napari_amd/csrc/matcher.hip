@@ -1597,4 +1597,33 @@ int emp_sm_slice_object_runs(const emp_stack_matcher* h, int64_t idx, int64_t k,
   return EMP_OK;
 }
 
+
+// Segment gather for the rank-0 merge of per-slab partial trackers (multigpu.merge_partial_trackers): output segment j =
+// n = cnt[j] runs copied from source array src_id[j] at offset src_off[j] to out + out_off[j], for the starts and the run
+// lengths alike -- contiguous memcpys on worker threads instead of one numpy slice + concatenate per object and slab.
+int emp_gather_segments_i64(const int64_t* const* h_src_a, const int64_t* const* h_src_b, const int32_t* h_src_id,
+                            const int64_t* h_src_off, const int64_t* h_cnt, const int64_t* h_out_off, int64_t n_seg,
+                            int64_t* h_out_a, int64_t* h_out_b) {
+  EMP_REQUIRE(n_seg >= 0 && (n_seg == 0 || (h_src_a && h_src_b && h_src_id && h_src_off && h_cnt && h_out_off && h_out_a && h_out_b)),
+              "gather_segments: null pointer");
+  // memory-bound (and the destination is freshly allocated: first-touch page faults): more threads than the matcher's
+  // default, contiguous ranges of segments per thread so that every thread writes its own stretch of the output
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)std::max(sm_threads(), 8), (int64_t)(hw > 0 ? hw : 8), n_seg / 64 + 1}));
+  auto work = [&](int t) {
+    const int64_t j0 = n_seg * t / T, j1 = n_seg * (t + 1) / T;
+    for (int64_t j = j0; j < j1; ++j) {
+      const int64_t n = h_cnt[j];
+      if (n <= 0) continue;
+      std::memcpy(h_out_a + h_out_off[j], h_src_a[h_src_id[j]] + h_src_off[j], (size_t)n * sizeof(int64_t));
+      std::memcpy(h_out_b + h_out_off[j], h_src_b[h_src_id[j]] + h_src_off[j], (size_t)n * sizeof(int64_t));
+    }
+  };
+  if (T == 1) { work(0); return EMP_OK; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+  for (auto& x : th) x.join();
+  return EMP_OK;
+}
+
 }  // extern "C"

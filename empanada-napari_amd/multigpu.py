@@ -463,39 +463,91 @@ class SlabMatcher:
         return self.track(lo, axis_name, shape3d)
 
 
+def _flat_part(p):
+    """a part's class entry as flat arrays (labels, boxes (n,6), counts, starts, runs): the packed form as it is, or an
+    instances dict flattened in its own order"""
+    if not isinstance(p, dict):
+        labels, boxes, counts, starts, runs = p
+        return (np.asarray(labels, np.int64), np.asarray(boxes, np.int64).reshape(-1, 6), np.asarray(counts, np.int64),
+                np.asarray(starts, np.int64), np.asarray(runs, np.int64))
+    labels = np.fromiter((int(k) for k in p), np.int64, len(p))
+    boxes = np.array([a['box'] for a in p.values()], np.int64).reshape(-1, 6)
+    counts = np.fromiter((len(a['starts']) for a in p.values()), np.int64, len(p))
+    cat = lambda key: (np.concatenate([np.asarray(a[key], np.int64) for a in p.values()]) if len(p) else np.zeros(0, np.int64))
+    return labels, boxes, counts, cat('starts'), cat('runs')
+
+
 def merge_partial_trackers(parts, axis_name):
     """Per-slab partial trackers (rank order) -> one instances dict per class, as ONE tracker fed downwards over the whole
     stack would hold it (tracker.py:61-123): labels in first-seen order walking from the last slab to the first; xy / xz
     runs concatenated in that order (a slab's runs are final); yz runs -- re-encoded per object by ``finish()`` from ALL
-    its voxels (tracker.py:111-120) -- joined across slabs: the slabs cut the x axis, so a run can continue in the next."""
-    from . import sparse
+    its voxels (tracker.py:111-120) -- joined across slabs: the slabs cut the x axis, so a run can continue in the next.
+
+    Flat arithmetic: a part is (labels, boxes, counts, starts, runs) with an object's runs contiguous; the merge is a
+    segment table (part, offset, count per object and slab) sorted by (first-seen rank of the label, walk order) and ONE
+    threaded gather of all runs into label-major order (``emp_gather_segments_i64``: contiguous memcpys); the result dict
+    holds views into the two gathered arrays.  At 4096^2 a block of 8 slices carries ~4 300 objects and 1.6 M runs: the
+    per-object Python loop this replaces cost 2-5 ms per SLICE on rank 0 -- serial, proportional to the whole stack, the
+    one cost of the multi-GPU job no rank count hides."""
+    import ctypes as C
+    from . import _abi
     classes = list(parts[0].keys()) if parts else []
     out = {}
     for c in classes:
+        flat = [_flat_part(part[c]) for part in reversed(parts)]          # walk order: last slab first
+        seg_label = np.concatenate([f[0] for f in flat]) if flat else np.zeros(0, np.int64)
+        if len(seg_label) == 0:
+            out[c] = {}
+            continue
+        seg_box = np.concatenate([f[1] for f in flat])
+        seg_cnt = np.concatenate([f[2] for f in flat])
+        seg_src = np.concatenate([np.full(len(f[0]), i, np.int32) for i, f in enumerate(flat)])
+        seg_off = np.concatenate([np.concatenate([[0], np.cumsum(f[2])[:-1]]) if len(f[2]) else np.zeros(0, np.int64) for f in flat])
+        # label -> rank of its first appearance in walk order
+        uniq, first, inv = np.unique(seg_label, return_index=True, return_inverse=True)
+        rank_of_uniq = np.empty(len(uniq), np.int64)
+        rank_of_uniq[np.argsort(first, kind='stable')] = np.arange(len(uniq))
+        seg_rank = rank_of_uniq[inv]
+        order = np.argsort(seg_rank, kind='stable')                       # segments label-major, walk order inside a label
+        cnt_o = np.ascontiguousarray(seg_cnt[order])
+        off_o = np.ascontiguousarray(seg_off[order].astype(np.int64))
+        src_o = np.ascontiguousarray(seg_src[order])
+        out_off = np.concatenate([[0], np.cumsum(cnt_o)]).astype(np.int64)
+        n_runs = int(out_off[-1])
+        st, rn = np.empty(n_runs, np.int64), np.empty(n_runs, np.int64)
+        keep = [(np.ascontiguousarray(f[3]), np.ascontiguousarray(f[4])) for f in flat]
+        pa = (C.c_void_p * len(keep))(*[k[0].ctypes.data for k in keep])
+        pb = (C.c_void_p * len(keep))(*[k[1].ctypes.data for k in keep])
+        _abi.check(_abi.load().emp_gather_segments_i64(pa, pb, src_o.ctypes.data_as(C.c_void_p), off_o.ctypes.data_as(C.c_void_p),
+                                                       cnt_o.ctypes.data_as(C.c_void_p), out_off.ctypes.data_as(C.c_void_p), len(order),
+                                                       st.ctypes.data_as(C.c_void_p), rn.ctypes.data_as(C.c_void_p)),
+                   'emp_gather_segments_i64')
+        # per label: run range, merged box
+        lab_sorted = seg_rank[order]
+        lab_edges = np.concatenate([[0], np.flatnonzero(lab_sorted[1:] != lab_sorted[:-1]) + 1, [len(order)]])
+        run_lo, run_hi = out_off[lab_edges[:-1]], out_off[lab_edges[1:]]
+        box_o = seg_box[order]
+        box_min = np.minimum.reduceat(box_o[:, :3], lab_edges[:-1], axis=0)
+        box_max = np.maximum.reduceat(box_o[:, 3:], lab_edges[:-1], axis=0)
+        labels_out = uniq[np.argsort(rank_of_uniq)]                          # labels in first-seen order
+        if axis_name == 'yz' and len(flat) > 1:
+            # per object: runs sorted by start, touching runs of neighbouring slabs joined
+            obj_of_run = np.repeat(np.arange(len(labels_out)), run_hi - run_lo)
+            o2 = np.lexsort((st, obj_of_run))
+            st, rn, obj_of_run = st[o2], rn[o2], obj_of_run[o2]
+            new = np.ones(len(st), bool)
+            if len(st) > 1:
+                new[1:] = (obj_of_run[1:] != obj_of_run[:-1]) | (st[1:] != st[:-1] + rn[:-1])
+            heads = np.flatnonzero(new)
+            ends = st + rn
+            last = np.concatenate([heads[1:], [len(st)]]) - 1
+            st, rn = st[heads], ends[last] - st[heads]
+            cnt_obj = np.bincount(obj_of_run[heads], minlength=len(labels_out))
+            run_hi = np.cumsum(cnt_obj)
+            run_lo = run_hi - cnt_obj
         acc = {}
-        for part in reversed(parts):
-            inst = part[c] if isinstance(part[c], dict) else sparse.unpack_instances(part[c])
-            for label, a in inst.items():
-                d = acc.get(label)
-                if d is None:
-                    acc[label] = {'box': tuple(int(v) for v in a['box']), 'starts': [a['starts']], 'runs': [a['runs']]}
-                else:
-                    d['box'] = sparse.merge_boxes(tuple(int(v) for v in a['box']), d['box'])
-                    d['starts'].append(a['starts'])
-                    d['runs'].append(a['runs'])
-        for label, d in acc.items():
-            if len(d['starts']) == 1:
-                d['starts'], d['runs'] = d['starts'][0], d['runs'][0]
-            elif axis_name == 'yz':
-                st, rn = np.concatenate(d['starts']), np.concatenate(d['runs'])
-                order = np.argsort(st, kind='stable')
-                st, rn = st[order], rn[order]
-                brk = np.flatnonzero(st[1:] != st[:-1] + rn[:-1]) + 1      # slabs are disjoint: runs touch or leave a gap
-                edges = np.concatenate([[0], brk, [len(st)]])
-                ends = st + rn
-                d['starts'], d['runs'] = st[edges[:-1]], ends[edges[1:] - 1] - st[edges[:-1]]
-            else:
-                d['starts'], d['runs'] = np.concatenate(d['starts']), np.concatenate(d['runs'])
+        for k, (lab, lo, hi) in enumerate(zip(labels_out.tolist(), run_lo.tolist(), run_hi.tolist())):
+            acc[lab] = {'box': tuple(box_min[k].tolist() + box_max[k].tolist()), 'starts': st[lo:hi], 'runs': rn[lo:hi]}
         out[c] = acc
     return out
 

@@ -401,6 +401,13 @@ EMP_API int emp_rle_pair_intersections(const int64_t* h_starts, const int64_t* h
 /* HOST: k-of-n vote over (n,2) ranges -> maximal ranges covered >= thr times (thr 1 = union).
  * replaces vote_by_ranges / rle_voting / join_ranges, array_utils.py:461-699. */
 EMP_API int emp_ranges_vote(const int64_t* h_ranges, int64_t n, int thr, int64_t* h_out, int64_t* n_out);
+/* HOST: copies n_seg segments of two parallel int64 arrays (run starts, run lengths): segment j = h_cnt[j] elements of
+ * source array h_src_id[j] from element h_src_off[j] on, to h_out_* + h_out_off[j]; worker threads.  The concatenation of
+ * the per-slab partial trackers into one tracker on rank 0 (empanada_napari/multigpu.py:240-252 builds that tracker by
+ * feeding every slice to InstanceTracker.update in one process, tracker.py:61-100). */
+EMP_API int emp_gather_segments_i64(const int64_t* const* h_src_a, const int64_t* const* h_src_b, const int32_t* h_src_id,
+                            const int64_t* h_src_off, const int64_t* h_cnt, const int64_t* h_out_off, int64_t n_seg,
+                            int64_t* h_out_a, int64_t* h_out_b);
 
 /* ------------------------------------------------------------------------
  * 5. HOST: slice-to-slice matching + instance tracking of ONE class over a
