@@ -139,9 +139,9 @@ def test_public_multigpu_engine_spawns_its_ranks(golden_dir, world, ks, block, m
     assert eng._procs is None
 
 
-@pytest.mark.parametrize('world,block,ks', [(2, '0', 3), (2, '2', 3), (2, '4', 5), (3, '0', 5), (3, '2', 3), (3, '4', 7), (1, '3', 3), (4, '1', 3),
-                                            (4, '2', 5), (2, '1', 7)])
-def test_public_multigpu_engine_multiclass_slab_matching(world, block, ks, monkeypatch):
+@pytest.mark.parametrize('world,block,ks,shm_min', [(2, '0', 3, None), (2, '2', 3, '0'), (2, '4', 5, None), (3, '0', 5, '0'), (3, '2', 3, None),
+                                                    (3, '4', 7, '0'), (1, '3', 3, None), (4, '1', 3, '0'), (4, '2', 5, None), (2, '1', 7, None)])
+def test_public_multigpu_engine_multiclass_slab_matching(world, block, ks, shm_min, monkeypatch):
     """Several classes through the public API on gloo (BASELINE configs[4]'s class structure: two instance classes and a
     semantic one): every rank matches and tracks its own slab (multigpu.SlabMatcher) -- ghost slices, forward state down
     the ranks, backward state up, partial trackers to the caller -- and the result equals the sequential C++ matcher over
@@ -152,6 +152,9 @@ def test_public_multigpu_engine_multiclass_slab_matching(world, block, ks, monke
     from empanada_napari_amd import multigpu
     from empanada_napari_amd import sparse as ps
     monkeypatch.setenv('EMP_MG_BLOCK', block)      # '0': contiguous slabs; else blocks of that many slices, interleaved over the ranks
+    if shm_min is not None:      # every run list, however short, reaches rank 0 as a file in /dev/shm (multigpu.ranks_share_host)
+        monkeypatch.setenv('EMP_MG_SHM_MIN', shm_min)
+    shm_before = set(os.listdir('/dev/shm')) if os.path.isdir('/dev/shm') else set()
     monkeypatch.setattr(multigpu.MultiGPUEngine3d, 'MIN_WORLD', 1)      # one rank: every neighbour of a block is the rank itself
     shape = tsm.SHAPE
     mc = {'seed': 40, 'thing_list': tsm.THINGS, 'labels': tsm.LABELS, 'class_names': {1: 'a', 2: 'b', 3: 'c'},
@@ -180,6 +183,8 @@ def test_public_multigpu_engine_multiclass_slab_matching(world, block, ks, monke
             assert len(eng.last_host_s) == world
     finally:
         eng.close()
+    if os.path.isdir('/dev/shm'):      # every file handed over was unlinked by the receiver
+        assert not [f for f in set(os.listdir('/dev/shm')) - shm_before if f.startswith('emp_mg_')]
 
 
 def test_public_multigpu_engine_errors():
@@ -369,3 +374,42 @@ def test_ring_shift_plan_is_lock_step():
                     assert recvs[key] == b - 1
                     served.append(b - 1)
             assert sorted(served) == list(range(NB - 1))
+
+
+def _shm_part_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as graft
+    graft.load_package()
+    from empanada_napari_amd import multigpu
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), EMP_MG_SHM_MIN='0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    shared = multigpu.ranks_share_host(None)
+    rng = np.random.default_rng(3)
+    n = 5000
+    part = {1: (np.arange(3, dtype=np.int64), np.zeros((3, 6), np.int64), np.array([n - 7, 0, 7], np.int64),
+                rng.integers(0, 1 << 40, n).astype(np.int64), rng.integers(1, 99, n).astype(np.int64)),
+            2: (np.zeros(0, np.int64), np.zeros((0, 6), np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int64))}
+    if rank == 1:
+        multigpu._send_part({'part': part, 'host_s': 0.5}, 0, None, shared)
+        assert not multigpu._SHM_PENDING
+    else:
+        got = multigpu._recv_part(1, None)
+        ok = shared and isinstance(got['part'][1][3].base, np.memmap) or isinstance(got['part'][1][3], np.memmap)
+        same = all(np.array_equal(np.asarray(a), b) for c in part for a, b in zip(got['part'][c], part[c]))
+        left = [f for f in os.listdir('/dev/shm') if f.startswith('emp_mg_')] if os.path.isdir('/dev/shm') else []
+        with open(out_path, 'w') as f:
+            f.write(f'{int(shared)} {int(bool(ok))} {int(same)} {len(left)} {got["host_s"]}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_lists_travel_through_shared_memory_between_ranks_of_one_host(tmp_path):
+    """multigpu._send_part / _recv_part with ``ranks_share_host``: the run lists arrive as a mapping of a /dev/shm file that
+    is already unlinked (nothing is left behind), bit for bit; small tables still travel through the group"""
+    if not os.path.isdir('/dev/shm'):
+        pytest.skip('no /dev/shm')
+    out = str(tmp_path / 'res.txt')
+    mp.spawn(_shm_part_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    shared, mapped, same, left, host_s = open(out).read().split()
+    assert (shared, mapped, same, left, host_s) == ('1', '1', '1', '0', '0.5')
