@@ -1106,7 +1106,7 @@ def _instance_runs(instances):
     return starts, lens, vals, order
 
 
-_DL = {'slabs': None, 'pool': None}
+_DL = {'slabs': None, 'pool': None, 'lock': __import__('threading').Lock()}      # one download at a time: the slabs are shared
 _DL_SLAB = 32 << 20      # bytes per staging slab
 _DL_MIN = 64 << 20       # below this one plain copy is as fast
 
@@ -1123,32 +1123,38 @@ def download(dvol, host):
     if nbytes < _DL_MIN or not dvol.is_cuda or dvol.dim() < 1 or not (dvol.is_contiguous() and host.is_contiguous()):
         host.copy_(dvol)
         return host
-    if _DL['slabs'] is None:
-        _DL['slabs'] = [torch.empty(_DL_SLAB, dtype=torch.uint8, pin_memory=True) for _ in range(4)]
-        _DL['pool'] = ThreadPoolExecutor(max_workers=4, thread_name_prefix='emp-download')
-    slabs, pool = _DL['slabs'], _DL['pool']
-    src = dvol.reshape(-1).view(torch.uint8)
-    dst = host.reshape(-1).view(torch.uint8).numpy()
-    side = torch.cuda.Stream(dvol.device)
-    side.wait_stream(torch.cuda.current_stream(dvol.device))
-    pending = [None] * len(slabs)
+    with _DL['lock']:
+        if _DL['slabs'] is None:
+            _DL['slabs'] = [torch.empty(_DL_SLAB, dtype=torch.uint8, pin_memory=True) for _ in range(4)]
+            _DL['pool'] = ThreadPoolExecutor(max_workers=4, thread_name_prefix='emp-download')
+        slabs, pool = _DL['slabs'], _DL['pool']
+        src = dvol.reshape(-1).view(torch.uint8)
+        dst = host.reshape(-1).view(torch.uint8).numpy()
+        side = torch.cuda.Stream(dvol.device)
+        side.wait_stream(torch.cuda.current_stream(dvol.device))
+        pending = [None] * len(slabs)
 
-    def drain(b, o, n, ev):
-        ev.synchronize()
-        dst[o:o + n] = slabs[b][:n].numpy()
+        def drain(b, o, n, ev):
+            ev.synchronize()
+            dst[o:o + n] = slabs[b][:n].numpy()
 
-    with torch.cuda.stream(side):
-        for k, o in enumerate(range(0, nbytes, _DL_SLAB)):
-            b, n = k % len(slabs), min(_DL_SLAB, nbytes - o)
-            if pending[b] is not None:
-                pending[b].result()
-            slabs[b][:n].copy_(src[o:o + n], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(side)
-            pending[b] = pool.submit(drain, b, o, n, ev)
-    for f in pending:
-        if f is not None:
-            f.result()
+        try:
+            with torch.cuda.stream(side):
+                for k, o in enumerate(range(0, nbytes, _DL_SLAB)):
+                    b, n = k % len(slabs), min(_DL_SLAB, nbytes - o)
+                    if pending[b] is not None:
+                        pending[b].result()
+                    slabs[b][:n].copy_(src[o:o + n], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    pending[b] = pool.submit(drain, b, o, n, ev)
+        finally:
+            for f in pending:      # also after an error: no copier may still be reading a slab when the lock is released
+                if f is not None:
+                    f.exception()
+        for f in pending:
+            if f is not None:
+                f.result()
     return host
 
 
