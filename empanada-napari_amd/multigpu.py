@@ -558,7 +558,7 @@ def _flat_part(p):
     return labels, boxes, counts, cat('starts'), cat('runs')
 
 
-def merge_partial_trackers(parts, axis_name):
+def merge_partial_trackers(parts, axis_name, min_size=None, min_extent=None):
     """Per-slab partial trackers (rank order) -> one instances dict per class, as ONE tracker fed downwards over the whole
     stack would hold it (tracker.py:61-123): labels in first-seen order walking from the last slab to the first; xy / xz
     runs concatenated in that order (a slab's runs are final); yz runs -- re-encoded per object by ``finish()`` from ALL
@@ -569,7 +569,11 @@ def merge_partial_trackers(parts, axis_name):
     threaded gather of all runs into label-major order (``emp_gather_segments_i64``: contiguous memcpys); the result dict
     holds views into the two gathered arrays.  At 4096^2 a block of 8 slices carries ~4 300 objects and 1.6 M runs: the
     per-object Python loop this replaces cost 2-5 ms per SLICE on rank 0 -- serial, proportional to the whole stack, the
-    one cost of the multi-GPU job no rank count hides."""
+    one cost of the multi-GPU job no rank count hides.
+
+    ``min_size`` / ``min_extent``: the size filters the caller would apply next (filters.py: remove_small_objects drops an
+    object whose runs sum to less than ``min_size`` voxels, remove_pancakes one whose box is thinner than ``min_extent``
+    along any axis) applied HERE, on the flat arrays, so that no dict entry is built for an object that is dropped."""
     import ctypes as C
     from . import _abi
     classes = list(parts[0].keys()) if parts else []
@@ -626,9 +630,16 @@ def merge_partial_trackers(parts, axis_name):
             cnt_obj = np.bincount(obj_of_run[heads], minlength=len(labels_out))
             run_hi = np.cumsum(cnt_obj)
             run_lo = run_hi - cnt_obj
+        keep = np.ones(len(labels_out), bool)
+        if min_size is not None:
+            csum = np.concatenate([[0], np.cumsum(rn)])
+            keep &= (csum[run_hi] - csum[run_lo]) >= min_size
+        if min_extent is not None:
+            keep &= (box_max - box_min).min(axis=1) >= min_extent
         acc = {}
-        for k, (lab, lo, hi) in enumerate(zip(labels_out.tolist(), run_lo.tolist(), run_hi.tolist())):
-            acc[lab] = {'box': tuple(box_min[k].tolist() + box_max[k].tolist()), 'starts': st[lo:hi], 'runs': rn[lo:hi]}
+        for k in np.flatnonzero(keep).tolist():
+            lo, hi = int(run_lo[k]), int(run_hi[k])
+            acc[int(labels_out[k])] = {'box': tuple(box_min[k].tolist() + box_max[k].tolist()), 'starts': st[lo:hi], 'runs': rn[lo:hi]}
         out[c] = acc
     return out
 
@@ -1462,13 +1473,11 @@ class MultiGPUEngine3d:
             self.last_host_s = list(segs['host_s'])      # every rank's matcher time
             self.last_timing = list(segs['timing'])      # per rank: matcher time, its un-overlapped tail, GPU phase, slices
             t0 = time.perf_counter()
-            merged = merge_partial_trackers(segs['parts'], axis_name)
+            # (the size filters of multigpu.py:254-256 -- remove_small_objects, remove_pancakes -- inside the merge)
+            merged = merge_partial_trackers(segs['parts'], axis_name, min_size=min_size, min_extent=min_extent)
             for tr in priv:
                 tr.instances = merged[tr.class_id]
                 tr.finished = True
-            for tr in priv:
-                sparse.remove_small_objects(tr, min_size=min_size)
-                sparse.remove_pancakes(tr, min_span=min_extent)
             for tr, pv in zip(trackers, priv):
                 tr.__dict__['_instances'] = pv.instances
                 tr.finished = True
