@@ -119,6 +119,7 @@ class HipPanopticDeepLab:
         _abi.check(self.lib.emp_pdl_finalize(self._h), 'emp_pdl_finalize')
         self._dummy = torch.zeros(1, device=self.device)
         self.num_classes = cfgd['num_classes']
+        self.forward_calls = 0      # forward calls through __call__ (bench.py reports it; profile tools cross-check it)
 
     # --- the reference's model contract (engines.py:34,41,250) ---
     def eval(self):
@@ -161,6 +162,7 @@ class HipPanopticDeepLab:
         ``sub``/``mul`` are the normalisation constants).  ``pad_to=(Hp,Wp)``: run at that padded size with the
         reference's ``factor_pad`` (zeros after normalisation) fused into the stem.  Returns the reference's dict."""
         assert image.ndim == 4 and image.size(1) == 1, 'expected (N,1,H,W)'
+        self.forward_calls += 1
         if image.device != self.device:
             image = image.to(self.device, non_blocking=True)
         image = image.contiguous()

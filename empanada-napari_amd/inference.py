@@ -581,8 +581,23 @@ class Engine3d:
             # HBM) the whole volume goes up once; beyond that its batches go up through two PINNED staging buffers on a side
             # stream, one batch ahead, gathered by a helper thread (`_staged_batches`) -- round 3 fell back to pageable
             # per-batch copies above 8 GiB, which block the host between the forwards.
-            on_dev = volume.nbytes <= int(float(os.environ.get('EMP_VOLUME_ON_DEVICE_GIB', '64')) * (1 << 30))
-            moved = (torch.from_numpy(volume).to(eng.model.device) if on_dev else volume)
+            # The threshold is also bounded by what the device has FREE (40 % of it: the network's arena for this slice
+            # size may not be reserved yet, and ranks may time-share the GPU), and an upload that still runs out of memory
+            # falls back to the staged path.
+            limit = int(float(os.environ.get('EMP_VOLUME_ON_DEVICE_GIB', '64')) * (1 << 30))
+            try:
+                limit = min(limit, int(0.4 * torch.cuda.mem_get_info(eng.model.device)[0]))
+            except Exception:       # noqa: BLE001 -- no such query on this runtime: the configured threshold alone
+                pass
+            on_dev = volume.nbytes <= limit
+            if on_dev:
+                try:
+                    moved = torch.from_numpy(volume).to(eng.model.device)
+                except torch.OutOfMemoryError:
+                    torch.cuda.empty_cache()
+                    on_dev = False
+            if not on_dev:
+                moved = volume
             moved = moved.movedim(axis, 0) if on_dev else np.moveaxis(volume, axis, 0)
             staged = None if on_dev else self._staged_batches(moved, n, self.slice_batch(
                 (-(-moved.shape[1] // eng.padding_factor) * eng.padding_factor,
@@ -656,11 +671,14 @@ class Engine3d:
         ready = queue.Queue(maxsize=2)
         for i in range(2):
             free.put(i)
+        STOP = -1           # pushed into `free` when the consumer stops early: the producer leaves instead of blocking
 
         def producer():
             try:
                 for i0 in range(0, n, bs):
                     k = free.get()
+                    if k == STOP:
+                        return
                     nb = min(bs, n - i0)
                     np.copyto(pinned[k][:nb].numpy(), moved[i0:i0 + nb])      # contiguous or strided gather, host side
                     with torch.cuda.stream(up):
@@ -673,16 +691,26 @@ class Engine3d:
 
         th = threading.Thread(target=producer, name='emp-volume-stage', daemon=True)
         th.start()
-        for _ in range(0, n, bs):
-            k, d, ev, err = ready.get()
-            if err is not None:
-                raise err
-            torch.cuda.current_stream(dev).wait_event(ev)
-            d.record_stream(torch.cuda.current_stream(dev))
-            ev.synchronize()          # the pinned buffer may be refilled once its copy has left the host
-            free.put(k)
-            yield d
-        th.join()
+        try:
+            for _ in range(0, n, bs):
+                k, d, ev, err = ready.get()
+                if err is not None:
+                    raise err
+                torch.cuda.current_stream(dev).wait_event(ev)
+                d.record_stream(torch.cuda.current_stream(dev))
+                ev.synchronize()          # the pinned buffer may be refilled once its copy has left the host
+                free.put(k)
+                yield d
+        finally:
+            # also reached when the consumer stops early (an exception in a forward, the generator closed: GeneratorExit):
+            # the producer must not stay blocked in free.get() holding two pinned buffers and a stream
+            free.put(STOP)
+            while th.is_alive():
+                try:
+                    ready.get(timeout=0.05)      # a producer blocked in ready.put() gets its slot
+                except queue.Empty:
+                    pass
+            th.join()
 
     def infer_on_axis(self, volume, axis_name):
         """:491-578 -> (stack, trackers)."""

@@ -291,12 +291,42 @@ def ranks_share_host(group):
     ranks at once and mapped by rank 0, instead of one after the other through the group's sockets (gloo over loopback:
     2.3 GB/s measured; at 4096^2 the tracks are 3.3 MB per slice -- 11.8 GB for the seven other ranks of a 4096-slice job).
     COLLECTIVE on first use per group (every rank calls it at the same point); cached."""
-    key = id(group) if group is not None else None
+    # keyed by the group's MEMBERSHIP (an id() alone can be reused by another group once this one is destroyed; two groups
+    # over the same global ranks share the answer)
+    try:
+        key = tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD))
+    except Exception:       # noqa: BLE001
+        key = (id(group), dist.get_world_size(group))
     if key not in _SHM_SAME_HOST:
         mine = _host_id() if (os.environ.get('EMP_MG_SHM', '1') != '0' and os.path.isdir(_SHM_DIR)) else None
         ids = [None] * dist.get_world_size(group)
         dist.all_gather_object(ids, mine, group=group)
-        _SHM_SAME_HOST[key] = mine is not None and all(i == mine for i in ids)
+        same = mine is not None and all(i == mine for i in ids)
+        # hostname + boot id do not prove a shared tmpfs (pods on one node: same ids, private /dev/shm mounts): the first
+        # rank of the group writes a token file, every rank says whether it sees it (ADVICE r04).  Collective as well --
+        # every rank reaches it, whatever `same` says on it (the ids were all-gathered: `same` agrees on all ranks).
+        if same:
+            import uuid
+            tok = [None]
+            first = dist.get_rank(group) == 0
+            if first:
+                tok[0] = os.path.join(_SHM_DIR, 'emp_mg_probe_%d_%s' % (os.getpid(), uuid.uuid4().hex))
+                try:
+                    with open(tok[0], 'w') as f:
+                        f.write('1')
+                except OSError:
+                    tok[0] = None
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(tok, src=src, group=group)
+            seen = [None] * dist.get_world_size(group)
+            dist.all_gather_object(seen, bool(tok[0]) and os.path.exists(tok[0]), group=group)
+            same = all(seen)
+            if first and tok[0]:
+                try:
+                    os.unlink(tok[0])
+                except OSError:
+                    pass
+        _SHM_SAME_HOST[key] = same
     return _SHM_SAME_HOST[key]
 
 
@@ -1306,7 +1336,9 @@ class MultiGPUEngine3d:
         if devices is not None:       # rank -> device index (default: rank r on cuda:r)
             self.engine_kwargs['devices'] = list(devices)
         from .inference import _open_zarr
-        self.zarr_store = _open_zarr(store_url, mode='w') if store_url is not None else None
+        # mode 'w' deletes what is there: under an SPMD launch only rank 0 -- the one rank that writes the stack -- opens it
+        opens = store_url is not None and (not self.spmd or dist.get_rank(group) == 0)
+        self.zarr_store = _open_zarr(store_url, mode='w') if opens else None
         self._procs = None
         self._make = None
         self._host_group = None
@@ -1423,9 +1455,14 @@ class MultiGPUEngine3d:
             if dist.get_backend(self.group) == 'nccl':
                 self._host_group = dist.new_group(backend='gloo')
             self._chain_group = dist.new_group(backend='gloo', timeout=chain_timeout())
-        prev = self.__dict__.pop('_spmd_pending', None)
-        if prev is not None and prev.done():
-            prev.result()          # a failure of the previous axis' deferred chain on THIS rank surfaces here at the latest
+        # every deferred future of the earlier axes is kept until it has been joined: the finished ones here (a failure of an
+        # earlier axis' deferred chain on THIS rank is re-raised on this rank, at the next call at the latest), the
+        # running ones stay in the list for the next call / wait() -- none is dropped
+        pending = self.__dict__.get('_spmd_pending') or []
+        self._spmd_pending = [f for f in pending if not f.done()]
+        for f in pending:
+            if f.done():
+                f.result()
         axis = self.axes[axis_name]
         return stack_inference(volume.shape[axis], self._make(volume, axis), self.ks, self.group, self._host_group,
                                self._match_desc(volume.shape, axis_name), self._chain_group, defer=defer)
@@ -1433,9 +1470,15 @@ class MultiGPUEngine3d:
     def wait(self):
         """SPMD mode: joins this rank's deferred chain work (every rank calls it before the job's clock stops / before the
         process group is torn down); re-raises what it raised"""
-        prev = self.__dict__.pop('_spmd_pending', None)
-        if prev is not None:
-            prev.result()
+        pending = self.__dict__.pop('_spmd_pending', None) or []
+        first = None
+        for f in pending:           # join ALL of them, then re-raise the earliest failure
+            try:
+                f.result()
+            except BaseException as e:      # noqa: BLE001
+                first = first or e
+        if first is not None:
+            raise first
 
     def _match_desc(self, shape, axis_name):
         shape = tuple(int(v) for v in shape)
@@ -1446,21 +1489,24 @@ class MultiGPUEngine3d:
     def infer_on_axis(self, volume, axis_name):
         from . import sparse
         shape = tuple(int(s) for s in volume.shape)
-        stack = self.create_panoptic_stack(axis_name, shape)
         # SPMD ranks: the call returns when this rank's GPU phase is through; the backward chain, the tracking and the gather
         # to rank 0 finish on the chain thread, behind the NEXT axis' GPU phase (patterns.py:102-134 ran them after the
-        # forward pass, in the caller).  EMP_MG_DEFER=0: synchronous, as round 3.
-        defer = self.spmd and stack is None and os.environ.get('EMP_MG_DEFER', '1') != '0'
+        # forward pass, in the caller).  EMP_MG_DEFER=0: synchronous, as round 3.  Whether a dense stack is wanted follows
+        # from the engine's settings alone, so every rank decides alike WITHOUT creating it: the stack (a zarr dataset
+        # made with overwrite=True, or a volume-sized array) is created on rank 0 only, after inference, as the reference
+        # does (multigpu.py:198-212) -- W ranks creating the same dataset raced its delete / create
+        defer = self.spmd and not self.save_panoptic and os.environ.get('EMP_MG_DEFER', '1') != '0'
         segs = self._segs_spmd(volume, axis_name, defer) if self.spmd else self._segs_spawn(volume, axis_name)
         if defer:
             if dist.get_rank(self.group) != 0:
-                self._spmd_pending = segs          # joined by the next call / wait()
+                self._spmd_pending.append(segs)    # joined by a later call / wait()
                 return None, None
             segs_fut = segs
         else:
             if segs is None:
                 return None, None
             segs_fut = _Done(segs)
+        stack = self.create_panoptic_stack(axis_name, shape)
         trackers = self.create_trackers(shape, axis_name)
         priv = self.create_trackers(shape, axis_name)
         min_size, min_extent = self.min_size, self.min_extent

@@ -28,8 +28,12 @@ def _bench(args, env=None, timeout=900):
 
 def test_one_gpu_line_carries_roofline_cpu_baseline_and_parity():
     j = _bench(['--steps', '2', '--warmup', '1', '--batch', '4', '--size', '512', '--cpu-tiles', '1', '--stack3d', '0',
-                '--engine2d', '0', '--latency', '0'])
+                '--engine2d', '0', '--latency', '0', '--fp32-mode', '2'])
     assert j['n_gpus'] == 1 and j['unit'] == 'tiles/s' and j['value'] > 0 and j['dtype'] == 'f16'
+    f = j['fp32_mode']       # the rate of the tolerance-compliant mode rides on the same line
+    assert 'error' not in f, f
+    assert f['batch'] == 2 and 0 < f['tiles_per_s'] < j['value'] and 0 < f['frac_of_157TF'] < 1
+    assert j['forward_steps_bench_loop'] == 1 + 2 * 2 and j['forward_calls_total'] >= j['forward_steps_bench_loop']
     assert j['roofline']['bound'] == 'mfma' and j['cpu_baseline']['kind'] == 'port' and j['cpu_baseline']['value'] > 0
     p = j['parity']
     assert 'error' not in p, p
@@ -59,3 +63,32 @@ def test_a_stuck_slab_job_costs_the_block_not_the_headline():
                env={'EMP_BENCH_SHARE_GPU': '1'})
     assert j['n_gpus'] == 2 and j['value'] > 0
     assert 'killed after' in j['stack3d']['error']
+
+
+def test_profile_tools_read_the_step_count_off_the_trace(tmp_path):
+    """the same command tools/refresh_profiles.sh profiles, under rocprofv3 --kernel-trace, at BASELINE's batch: the
+    steps tools/step_breakdown.py finds in the trace are the forward calls bench.py says it made, the dominant kernel is
+    launched 29 times per step, and the kernel time of a step fits in the step (round 4's committed
+    per-step figures were 1.77x high)"""
+    import shutil
+    if shutil.which('rocprofv3') is None:
+        pytest.skip('rocprofv3 not on PATH')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import step_breakdown as sb
+    e = dict(os.environ, TMPDIR=str(tmp_path))
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    d = str(tmp_path / 'ks')
+    r = subprocess.run(['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'ks', '--', sys.executable,
+                        os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--stack3d', '0',
+                        '--engine2d', '0', '--latency', '0', '--fp32-mode', '0'],
+                       capture_output=True, text=True, env=e, cwd=str(tmp_path), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    steps, rows, total_us = sb.breakdown(d)
+    assert steps == j['forward_steps_bench_loop'] == j['forward_calls_total'] == 5
+    dom = [(c, us) for k, c, us, _ in rows if k.startswith('conv_igemm256_kernel<0, false>')][0]
+    assert dom[0] == 29 == j['roofline']['launches_per_step']
+    assert total_us / 1e3 < 1.05 * j['ms_per_step'], (total_us, j['ms_per_step'])
+    # the HIP-event figure of the line and the trace agree on the dominant kernel's time per step
+    assert abs(dom[1] / 1e3 - j['roofline']['kernel_ms_per_step']) < 0.08 * j['roofline']['kernel_ms_per_step']

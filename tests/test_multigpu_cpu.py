@@ -413,3 +413,71 @@ def test_run_lists_travel_through_shared_memory_between_ranks_of_one_host(tmp_pa
     mp.spawn(_shm_part_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     shared, mapped, same, left, host_s = open(out).read().split()
     assert (shared, mapped, same, left, host_s) == ('1', '1', '1', '0', '0.5')
+
+
+def test_wait_joins_every_deferred_axis_and_reraises_the_first_failure():
+    """a deferred chain of an EARLIER axis that failed on this rank must not be dropped when a later axis'
+    future replaces it: every future is kept until joined; wait() joins all of them and re-raises the earliest failure"""
+    from concurrent.futures import Future
+    from empanada_napari_amd import multigpu
+    eng = multigpu.MultiGPUEngine3d.__new__(multigpu.MultiGPUEngine3d)
+    a, b, c = Future(), Future(), Future()
+    a.set_result(1)
+    b.set_exception(RuntimeError('axis xz: chain failed'))
+    c.set_exception(ValueError('axis yz: later'))
+    eng._spmd_pending = [a, b, c]
+    with pytest.raises(RuntimeError, match='axis xz'):
+        eng.wait()
+    assert not eng.__dict__.get('_spmd_pending')
+    eng.wait()      # nothing left: no error twice
+
+
+def _spmd_store_worker(rank, world, port, store, out_path):
+    for d in (ROOT, os.path.join(ROOT, 'tests')):
+        if d not in sys.path:
+            sys.path.insert(0, d)
+    import __graft_entry__ as graft
+    graft.load_package()
+    import mg_oracle_backend as mgb
+    import test_slab_matcher as tsm
+    from empanada_napari_amd import multigpu, sparse as ps
+    from oracle import sparse as osp
+
+    def host_fill(volume, trackers):      # the product fills on the GPU (no CPU fallback); this test is about WHO fills
+        for tr in trackers:
+            osp.numpy_fill_instances(volume, tr.instances)
+    ps.fill_panoptic_volume = host_fill
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), EMP_MG_BLOCK='2', LOCAL_RANK=str(rank))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    multigpu.MultiGPUEngine3d.MIN_WORLD = 1
+    mc = {'seed': 40, 'thing_list': tsm.THINGS, 'labels': tsm.LABELS, 'class_names': {1: 'a', 2: 'b', 3: 'c'},
+          'padding_factor': 16, 'norms': {'mean': 0.5, 'std': 0.1}}
+    eng = multigpu.MultiGPUEngine3d(mc, label_divisor=tsm.DIV, median_kernel_size=3, min_size=12, min_extent=2,
+                                    dist_backend='gloo', backend_factory=mgb.label_stack_backend_factory,
+                                    store_url=store, save_panoptic=True, chunk_size=(8, 8, 8))
+    created = []
+    make = eng.create_panoptic_stack
+    eng.create_panoptic_stack = lambda *a: (created.append(a[0]), make(*a))[1]
+    vol = np.zeros(tsm.SHAPE, np.uint8)
+    stack, trackers = eng.infer_on_axis(vol, 'xy')
+    eng.wait()
+    if rank == 0:
+        assert created == ['xy'] and eng.zarr_store is not None
+        want = np.zeros(tsm.SHAPE, np.int32)
+        ps.fill_panoptic_volume(want, trackers)
+        assert want.any()
+        np.testing.assert_array_equal(np.asarray(stack[...]), want)
+        open(out_path, 'w').write('ok')
+    else:
+        # a non-zero rank neither opens (mode 'w' deletes) nor creates the dataset, and allocates no volume-sized array
+        assert created == [] and eng.zarr_store is None and stack is None and trackers is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_spmd_ranks_leave_the_panoptic_store_to_rank_0(tmp_path):
+    """with save_panoptic and a store, every SPMD rank used to run create_dataset(overwrite=True) on the same
+    array; now only rank 0 touches the store, after inference (the reference: multigpu.py:198-212 on the main process)"""
+    out = str(tmp_path / 'ok.txt')
+    mp.spawn(_spmd_store_worker, args=(2, _free_port(), str(tmp_path / 'pan.zarr'), out), nprocs=2, join=True)
+    assert open(out).read() == 'ok'
