@@ -153,11 +153,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'cu_partition.txt'))
     ap.add_argument('--skip-model', action='store_true')
+    ap.add_argument('--only-model', action='store_true')
     a = ap.parse_args()
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
     B = 32
     say(f'# CU-partition probe, batch {B} x 1024^2 shapes, {torch.cuda.get_device_name(0)}')
+    if a.only_model:
+        full = masked_stream(0, 32, dev)
+        s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        return whole_forward(a, dev, full, s1, s2, {}, {})
     mfma = [Conv('merged ASPP 3x3 d4 2048->512', B, 64, 64, 2048, 512, 3, 1, 4, 4, 64, dev),
             Conv('layer4 conv2 3x3 d2 512->512', B, 64, 64, 512, 512, 3, 1, 2, 2, 64, dev),
             Conv('layer4.x.conv3 512->2048 (write-bound)', B, 64, 64, 512, 2048, 1, 1, 0, 1, 64, dev),
@@ -216,9 +221,13 @@ def main():
                 f'-> {1.0 / (ta0 / pa + tb0 / pb):4.2f} of serial time')
     if a.skip_model:
         return finish(a)
+    del mfma, hbm
+    whole_forward(a, dev, full, s1, s2, sa, sb)
+
+
+def whole_forward(a, dev, full, s1, s2, sa, sb):
     # ---- (d) the whole forward ----
     say('\n(d) whole forward (PanopticDeepLabPR / resnet50, 1024^2 uint8 tiles): one engine of 32 vs two engines of 16 on two streams')
-    del mfma, hbm
     torch.cuda.empty_cache()
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
@@ -262,10 +271,52 @@ def main():
     same = all(torch.equal(torch.cat([o[0][i], o[1][i]]), ref[i]) for i in range(3))
     say(f'  two engines of 16, two unmasked streams:                     {ms:7.3f} ms per 32 tiles = {32e3 / ms:7.1f} tiles/s   outputs == batch-32 run: {same}')
     for c in (16, 12, 8):
+        if c not in sa:
+            continue
         ms, o = run([(ma, sa[c], ta_), (mb, sb[c], tb_)], 8)
         same = all(torch.equal(torch.cat([o[0][i], o[1][i]]), ref[i]) for i in range(3))
         say(f'  two engines of 16, masked streams {(32 - c) * 8:3d} + {c * 8:3d} CUs (whole forward each): {ms:7.3f} ms per 32 tiles = {32e3 / ms:7.1f} tiles/s   outputs == batch-32 run: {same}')
-    # three / four engines of 8 tiles on unmasked streams: more launches in flight, smaller tails
+    # (e) the same two engines on two unmasked streams with a CONTROLLED offset: the second stream starts d ms after the
+    # first and both then run their forwards back to back; which kernels meet depends on d (encoder of one half-batch next
+    # to the decoder of the other, ...).  A flat curve = no schedule of whole half-batch forwards beats the average above.
+    say('\n(e) two engines of 16 on two unmasked streams, the second delayed by d ms (spin kernel), 6 forwards each:')
+    outs = [[torch.empty((16, 1, 1024, 1024), dtype=torch.float32, device=dev),
+             torch.empty((16, 1, 256, 256), dtype=torch.float32, device=dev),
+             torch.empty((16, 2, 256, 256), dtype=torch.float32, device=dev)] for _ in range(2)]
+    clk = 100e6      # torch.cuda._sleep counts cycles of a ~100 MHz-class counter on ROCm? calibrate instead
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.cuda._sleep(10_000_000)
+    e1.record()
+    torch.cuda.synchronize()
+    per_ms = 10_000_000 / e0.elapsed_time(e1)
+    for d in (0.0, 1.5, 3.0, 4.5, 6.0, 7.5, 9.0, 10.5, 12.0):
+        n = 6
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(s2):
+            if d > 0:
+                torch.cuda._sleep(int(d * per_ms))
+        for _ in range(n):
+            with torch.cuda.stream(s1):
+                ma(ta_, 2, interpolate_ins=False, sub=float(sub), mul=float(mul), out=outs[0])
+            with torch.cuda.stream(s2):
+                mb(tb_, 2, interpolate_ins=False, sub=float(sub), mul=float(mul), out=outs[1])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        say(f'  d = {d:5.1f} ms: {ms:7.2f} ms for {n} x 32 tiles -> {(ms - d) / n:7.3f} ms per 32 tiles net of the delay ({32e3 * n / (ms - d):7.1f} tiles/s)')
+    # (f) four engines of 8 tiles on four unmasked streams: more launches in flight, smaller tails
+    del ma, mb
+    torch.cuda.empty_cache()
+    ms4 = [HipPanopticDeepLab(P, cfg, device=dev, folded=True) for _ in range(4)]
+    for m in ms4:
+        m.reserve(8, 1024, 1024)
+    st4 = [torch.cuda.Stream(dev) for _ in range(4)]
+    ms, o = run([(m, full, tiles[8 * i:8 * i + 8]) for i, m in enumerate(ms4)], 8)
+    say(f'\n(f) four engines of 8, ONE stream (serial):                    {ms:7.3f} ms per 32 tiles = {32e3 / ms:7.1f} tiles/s')
+    ms, o = run([(m, st4[i], tiles[8 * i:8 * i + 8]) for i, m in enumerate(ms4)], 8)
+    same = all(torch.equal(torch.cat([o[k][i] for k in range(4)]), ref[i]) for i in range(3))
+    say(f'    four engines of 8, four unmasked streams:                  {ms:7.3f} ms per 32 tiles = {32e3 / ms:7.1f} tiles/s   outputs == batch-32 run: {same}')
     finish(a)
 
 
