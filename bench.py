@@ -184,6 +184,43 @@ def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3):
     return res
 
 
+def fine_boundaries_block(model, tiles, sub, mul, batch=4, steps=5):
+    """The widget's `fine_boundaries` option (reference: _volume_inference.py:39,183 -> coarse_boundaries=False): the
+    instance heads interpolated to the image size and every pixel voted against every centre at step 1
+    (postprocess.py:78-169) -- the reference's most expensive post-processing case (11.5 s per 1024^2 tile on CPU,
+    BASELINE.md section 2).  Same network and tiles as `value`, outside its timed region; tests/test_gpu_fine_boundaries.py
+    holds the parity test at >= 1 500 centres per tile (profiles/r05_fine_boundaries.json)."""
+    import torch
+    from empanada_napari_amd.engines import PanopticDeepLabRenderEngine, logits_to_prob
+    eng = PanopticDeepLabRenderEngine(model, thing_list=[1], label_divisor=100000, nms_threshold=0.1, nms_kernel=3,
+                                      confidence_thr=0.5, padding_factor=16, coarse_boundaries=False)
+    x = tiles[:batch]
+
+    def step():
+        o = model(x, 2, interpolate_ins=True, sub=float(sub), mul=float(mul))
+        sem = logits_to_prob(o['sem_logits'])
+        cells, _, num, kmax = eng.instance_cells_int(o['ctr_hmp'], o['offsets'], 1)
+        return eng.panoptic_merge_int(sem, cells, kmax), o, num
+
+    _, o, num = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        eng.instance_cells_int(o['ctr_hmp'], o['offsets'], 1)
+    e1.record()
+    torch.cuda.synchronize()
+    return {'ms_per_tile': round(dt * 1e3 / batch, 3), 'tiles_per_s': round(batch / dt, 1),
+            'voting_ms_per_tile': round(e0.elapsed_time(e1) / steps / batch, 4), 'batch': batch,
+            'centres_per_tile': [int(v) for v in num.cpu().tolist()],
+            'note': 'coarse_boundaries=False: forward with interpolate_ins=True + NMS / nearest-centre voting at 1024^2 + merge'}
+
+
 def cpu_stack_baseline(cfg, P, vol, n_slices=12):
     """The oracle's restatement of the reference's per-axis control flow (3-D engine with the recursive median, dense ->
     RLE, matcher, tracker) on the first ``n_slices`` xy slices of the same volume."""
@@ -497,6 +534,12 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
             res['fp32_mode'] = fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=min(args.fp32_mode, B))
         except Exception as e:      # noqa: BLE001 -- the headline line must not depend on the extra measurement
             res['fp32_mode'] = {'error': f'{type(e).__name__}: {e}'}
+    if world == 1 and args.latency:
+        try:
+            res['fine_boundaries'] = fine_boundaries_block(model, tiles, sub, mul, batch=min(4, B))
+            res['fine_boundaries_ms_per_tile'] = res['fine_boundaries']['ms_per_tile']
+        except Exception as e:      # noqa: BLE001
+            res['fine_boundaries'] = {'error': f'{type(e).__name__}: {e}'}
     res['forward_calls_total'] = model.forward_calls
     # the 3-D half of the headline metric, outside the timed region of `value` (rank 0, one GPU)
     res['stack3d'] = slab_block

@@ -58,6 +58,8 @@ PROTOTYPES = {
                                             c_int, c_int, c_int, c_int, c_int, vp]),
     'emp_conv2d_nhwc_f32': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+    'emp_conv2d_nhwc_f16x3': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,
+                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
     'emp_conv1x1_dual_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp,
                                   c_int, c_int, c_int, c_int, vp]),
     'emp_dwconv_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, vp, c_int, vp]),

@@ -97,6 +97,24 @@ int emp_conv2d_nhwc_f32(const float* d_in, int N, int H, int W, int Cin, int in_
   return launch_conv32(p, (hipStream_t)stream);
 }
 
+int emp_conv2d_nhwc_f16x3(const float* d_in, int N, int H, int W, int Cin, int in_ld, const float* d_w, const float* d_bias,
+                          const float* d_bias_n, const float* d_res, int res_ld, float* d_out, int out_ld, int Cout, int KH,
+                          int KW, int stride, int pad, int dil, int act, int groups, int cin_g, void* stream) {
+  EMP_REQUIRE(d_in && d_w && d_out, "conv2d_f16x3: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0 && groups >= 1, "conv2d_f16x3: bad geometry");
+  Conv32 p{};
+  p.in = d_in; p.in_ld = in_ld; p.w = d_w; p.bias = d_bias; p.bias_n = d_bias_n; p.res = d_res; p.res_ld = res_ld;
+  p.out = d_out; p.out_ld = out_ld;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  EMP_REQUIRE(p.Ho > 0 && p.Wo > 0 && out_ld >= groups * Cout && (d_res == nullptr || res_ld >= Cout), "conv2d_f16x3: bad output geometry");
+  p.act = act;
+  p.x3 = 1;
+  if (groups > 1) { p.groups = groups; p.cin_g = cin_g; }
+  return launch_conv32(p, (hipStream_t)stream);
+}
+
 int emp_conv2d_grouped_nhwc_f32(const float* d_in, int N, int H, int W, int groups, int cin_g, int Cin16, int in_ld, const float* d_w,
                                 const float* d_bias, float* d_out, int out_ld, int cout_g, int KH, int KW, int stride, int pad,
                                 int dil, int act, void* stream) {

@@ -97,7 +97,15 @@ struct emp_pdl {
   int sepconv_min_tiles = [] { const char* e = getenv("EMP_SEPCONV_MIN_TILES"); return e ? atoi(e) : 256; }();
 
   // fp32 reference mode (emp_pdl_set_precision / EMP_PRECISION=fp32; run32 below): fp32 weights, fp32 activation pool
-  int precision = [] { const char* e = getenv("EMP_PRECISION"); return (e && (!strcmp(e, "fp32") || !strcmp(e, "32"))) ? 1 : 0; }();
+  // precision 2 = the fp16x3 mode (round 5): the fp32 mode's graph, maps and weights, its convolutions on the fp16 matrix
+  // pipe with split operands (conv16x3.hip: three MFMAs per product into an fp32 accumulator)
+  int precision = [] {
+    const char* e = getenv("EMP_PRECISION");
+    if (e && (!strcmp(e, "fp32") || !strcmp(e, "32"))) return 1;
+    if (e && (!strcmp(e, "fp16x3") || !strcmp(e, "x3"))) return 2;
+    return 0;
+  }();
+  bool fp32_graph() const { return precision != 0; }
   struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; };
   std::map<std::string, W32> w32;
   std::map<std::string, std::pair<float*, size_t>> pool32;      // name -> (device buffer, floats)
@@ -1473,6 +1481,7 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
   p.Ho = (in.H + 2 * pad - dil * (w.kh - 1) - 1) / stride + 1;
   p.Wo = (in.W + 2 * pad - dil * (w.kw - 1) - 1) / stride + 1;
   p.act = act; p.ps_cout = ps_cout;
+  p.x3 = n->precision == 2;
   const int up = ps_cout ? 2 : 1;
   EMP_REQUIRE(p.Ho * up == out.H && p.Wo * up == out.W && in.N == out.N, "%s (fp32): output shape mismatch", wname.c_str());
   EMP_REQUIRE(in_coff + (groups - 1) * w.cin + w.cin16 <= in.ld && out_coff + (ps_cout ? ps_cout : w.cout) <= out.ld,
@@ -1843,7 +1852,7 @@ int emp_pdl_create(const emp_pdl_config* cfg, emp_pdl_t** out) {
   n->cfg = *cfg;
   if (cfg->encoder == 1) {      // RegNet: the fp32 mode unless emp_pdl_set_precision(net, 0) / EMP_PRECISION=fp16 ask for the fp16 engine
     const char* e = getenv("EMP_PRECISION");
-    n->precision = (e && (!strcmp(e, "fp16") || !strcmp(e, "16"))) ? 0 : 1;
+    n->precision = (e && (!strcmp(e, "fp16") || !strcmp(e, "16"))) ? 0 : (e && (!strcmp(e, "fp16x3") || !strcmp(e, "x3"))) ? 2 : 1;
   }
   n->dec_ch = cfg->arch == 1 ? cfg->fpn_dim : cfg->decoder_channels;
   n->aspp_ch = cfg->aspp_channels > 0 ? cfg->aspp_channels : cfg->decoder_channels;
@@ -1890,7 +1899,7 @@ int emp_pdl_finalize(emp_pdl_t* n) {
       return EMP_ERR_STATE;
     }
   const emp_pdl_config& c = n->cfg;
-  if (c.encoder == 1 && n->precision == 1) {
+  if (c.encoder == 1 && n->fp32_graph()) {
     // RegNet in the fp32 mode: none of the fp16 packs below; what run32 reads besides finalize32's conv weights:
     if (c.arch == 1) {
       for (const auto& nm : n->param_names)
@@ -2162,14 +2171,14 @@ int emp_pdl_finalize(emp_pdl_t* n) {
     RC(upload_f32(n, "pr.predictor.w", w));
     RC(upload_f32(n, "pr.predictor.b", hp.b));
   }
-  if (n->precision == 1) RC(finalize32(n));      // fp32 reference mode: fp32 copies of every weight
+  if (n->fp32_graph()) RC(finalize32(n));      // fp32 reference mode: fp32 copies of every weight
   n->finalized = true;
   return EMP_OK;
 }
 
 int emp_pdl_set_precision(emp_pdl_t* net, int precision) {
   EMP_REQUIRE(net, "set_precision: null network");
-  EMP_REQUIRE(precision == 0 || precision == 1, "set_precision: 0 = fp16 engine, 1 = fp32 reference mode (got %d)", precision);
+  EMP_REQUIRE(precision >= 0 && precision <= 2, "set_precision: 0 = fp16 engine, 1 = fp32 reference mode, 2 = fp16x3 mode (got %d)", precision);
   EMP_REQUIRE(!net->finalized, "set_precision: call before emp_pdl_finalize");
   net->precision = precision;
   return EMP_OK;
@@ -2178,7 +2187,7 @@ int emp_pdl_precision(const emp_pdl_t* net) { return net ? net->precision : -1; 
 
 int emp_pdl_reserve(emp_pdl_t* net, int N, int H, int W) {
   EMP_REQUIRE(net, "reserve: null network");
-  if (net->precision == 1) return EMP_OK;      // the fp32 mode sizes its buffers on first use
+  if (net->fp32_graph()) return EMP_OK;      // the fp32 / fp16x3 modes size its buffers on first use
   return plan(net, N, H, W, net->pRS > 2 ? net->pRS : 2, nullptr);
 }
 size_t emp_pdl_arena_bytes(const emp_pdl_t* net) { return net ? net->arena_used : 0; }
@@ -2192,7 +2201,7 @@ int emp_pdl_forward_padded(emp_pdl_t* net, const void* d_image, int image_dtype,
     set_error("forward: call emp_pdl_finalize first");
     return EMP_ERR_STATE;
   }
-  if (net->precision == 1)
+  if (net->fp32_graph())
     return run32(net, d_image, image_dtype, sub, mul, N, H, W, vh, vw, render_steps, interpolate_ins, d_sem_logits, d_ctr_hmp,
                  d_offsets, (hipStream_t)stream);
   if (H != net->pH || W != net->pW || render_steps != net->pRS || N > net->capN) {
@@ -2257,7 +2266,7 @@ int emp_pdl_tap(emp_pdl_t* net, const char* name, void** d_ptr, int64_t shape5[5
 
 int emp_pdl_tap_raw(emp_pdl_t* net, const char* name, void** d_ptr, int64_t* bytes) {
   EMP_REQUIRE(net && name && d_ptr && bytes, "tap_raw: null argument");
-  if (net->precision == 1) {      // fp32 mode: every buffer of the last forward by name (maps: NHWC fp32)
+  if (net->fp32_graph()) {      // fp32 / fp16x3 mode: every buffer of the last forward by name (maps: NHWC fp32)
     auto it32 = net->pool32.find(name);
     EMP_REQUIRE(it32 != net->pool32.end(), "tap_raw: unknown fp32 buffer '%s'", name);
     *d_ptr = it32->second.first;

@@ -236,6 +236,12 @@ __global__ void __launch_bounds__(256) group_pixels_kernel(const float* __restri
     lx = (float)(x * step) + off[hw + i];
   }
   float best = (K > 20) ? 1e5f : INFINITY;
+  // squared-distance screen (round 5; exact): sqrt is monotone, so a centre whose fp32 sum s = fma(dx,dx,fl(dy*dy)) is
+  // strictly greater than the sum behind the running best cannot have a smaller rounded distance -- it is skipped without
+  // the correctly rounded sqrt (most of this loop at K ~ 1 700-4 500 centres per 1024^2 tile, the fine-boundary case).  A
+  // sum that is not greater goes through the reference's comparison of the rounded distances unchanged (two sums may round
+  // to one distance: the first centre keeps the pixel).  1e10f = (1e5f)^2 exactly; NaN sums take the exact path.
+  float best_s = (K > 20) ? 1e10f : INFINITY;
   int id = 0;
   const int32_t* cn = centers + (size_t)n * max_centers * 2;
   for (int k0 = 0; k0 < K; k0 += CTR_TILE) {
@@ -250,9 +256,11 @@ __global__ void __launch_bounds__(256) group_pixels_kernel(const float* __restri
       for (int t = 0; t < kn; ++t) {
         const float dy = cy[t] - ly, dx = cx[t] - lx;
         const float dy2 = dy * dy;  // rounded on its own: this file is built with -ffp-contract=off
-        const float d = __builtin_sqrtf(__builtin_fmaf(dx, dx, dy2));  // correctly rounded sqrt (build flag)
+        const float s = __builtin_fmaf(dx, dx, dy2);
+        if (s > best_s) continue;
+        const float d = __builtin_sqrtf(s);  // correctly rounded sqrt (build flag)
         const bool first = (K <= 20) && (k0 + t == 0);  // argmin always yields an index
-        if (d < best || first) { best = d; id = k0 + t + 1; }
+        if (d < best || first) { best = d; best_s = s; id = k0 + t + 1; }
       }
     }
   }

@@ -53,11 +53,15 @@ class HipPanopticDeepLab:
     ``weights.fold_state_dict``.
     """
 
+    PRECISIONS = ('fp16', 'fp32', 'fp16x3')      # emp_pdl_set_precision's 0 / 1 / 2
+
     def __init__(self, state_dict, cfg=None, device=None, folded=False, precision=None):
         """``precision``: None / 'fp16' -- the fp16 engine (the product and the bench); 'fp32' -- the fp32 REFERENCE MODE of
         the library (csrc/ref32.hip: fp32 maps and weights, exact fp32 matrix pipe, no fusion; ~10x slower): the reference
         computes this path in fp32 (engines.py:248-255), and in this mode the float heads are within 1e-3 of it in the
-        max norm.  None follows the environment variable EMP_PRECISION, else the library's default for the encoder: the
+        max norm.  'fp16x3' (round 5) -- the fp32 mode's graph with every convolution on the FP16 matrix pipe, operands
+        split into fp16 pairs and three MFMAs per product into an fp32 accumulator (csrc/conv16x3.hip): the same 1e-3 in the
+        max norm at several times the fp32 mode's rate -- the tolerance-compliant mode to use for throughput.  None follows the environment variable EMP_PRECISION, else the library's default for the encoder: the
         fp16 engine for ResNet50, the fp32 mode for a RegNet (which 'fp16' moves onto the fp16 engine's generic kernels)."""
         self.device = _require_gpu(device)
         bifpn = 'BiFPN' in (cfg or {}).get('arch', '')
@@ -99,10 +103,10 @@ class HipPanopticDeepLab:
         torch.cuda.set_device(self.device)
         _abi.check(self.lib.emp_pdl_create(C.byref(c), C.byref(self._h)), 'emp_pdl_create')
         if precision is not None:
-            if precision not in ('fp16', 'fp32'):
-                raise ValueError(f"precision must be 'fp16' or 'fp32', got {precision!r}")
-            _abi.check(self.lib.emp_pdl_set_precision(self._h, 1 if precision == 'fp32' else 0), 'emp_pdl_set_precision')
-        self.precision = 'fp32' if self.lib.emp_pdl_precision(self._h) == 1 else 'fp16'
+            if precision not in self.PRECISIONS:
+                raise ValueError(f"precision must be one of {self.PRECISIONS}, got {precision!r}")
+            _abi.check(self.lib.emp_pdl_set_precision(self._h, self.PRECISIONS.index(precision)), 'emp_pdl_set_precision')
+        self.precision = self.PRECISIONS[self.lib.emp_pdl_precision(self._h)]
         P = state_dict if folded else weights.fold_state_dict(state_dict, self.cfg)
         n = self.lib.emp_pdl_num_params(self._h)
         names = [self.lib.emp_pdl_param_name(self._h, i).decode() for i in range(n)]

@@ -204,6 +204,19 @@ EMP_API int emp_conv2d_nhwc_f32(const float* d_in, int N, int H, int W, int Cin,
                         float* d_out, int out_ld, int Cout,
                         int KH, int KW, int stride, int pad, int dil, int act, void* stream);
 
+/* The same convolution in the `fp16x3` precision mode (round 5, csrc/conv16x3.hip; emp_pdl_set_precision(net, 2)): the
+ * same fp32 operands, every operand split into an fp16 pair x = hi + lo on its way into LDS and every product computed as
+ * w_lo.x_hi + w_hi.x_lo + w_hi.x_hi on the FP16 matrix pipe into an fp32 accumulator -- the reference's fp32 result
+ * (engines.py:248-255) to ~2^-22 relative per term at three fp16 MFMAs per product instead of sixteen fp16-MFMA times on
+ * the fp32 pipe.  groups > 1: Cout and Cin are per group (Cin = cin_g padded to 16), as emp_conv2d_grouped_nhwc_f32;
+ * groups == 1: cin_g = 0.  Values must fit fp16's range. */
+EMP_API int emp_conv2d_nhwc_f16x3(const float* d_in, int N, int H, int W, int Cin, int in_ld,
+                        const float* d_w, const float* d_bias, const float* d_bias_n,
+                        const float* d_res, int res_ld,
+                        float* d_out, int out_ld, int Cout,
+                        int KH, int KW, int stride, int pad, int dil, int act,
+                        int groups, int cin_g, void* stream);
+
 /* The same convolution with `groups` groups (nn.Conv2d(groups=g), the 3x3 of a RegNet bottleneck:
  * empanada/models/encoders/regnet.py:51-77 via blocks.py:134-153): group g reads input channels [g * cin_g, g * cin_g +
  * Cin16) -- Cin16 = cin_g padded to a multiple of 16, the padding meeting zero weights, so a row of the input must hold

@@ -1,0 +1,116 @@
+"""The fine-boundary path at BASELINE's tile size: ``coarse_boundaries=False`` -- the widget's
+``fine_boundaries`` option (_volume_inference.py:39,183) -- makes the model interpolate the centre / offset heads to the
+image size (``interpolate_ins=True``) and votes every pixel against every centre at step 1
+(empanada/inference/postprocess.py:78-169): K ~ 1 700 centres x 1 M pixels, the reference's most expensive post-processing
+case (11.5 s on CPU).  The goldens pin it at 64^2-160^2; here at 1024^2 with >= 1 500 centres per tile:
+HIP label map == the oracle's post-processing on the engine's own heads, batch == per image, and the voting kernel is timed."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, 'gpurun_out', 'fine_boundaries.json')
+
+
+@pytest.fixture(scope='module')
+def fine():
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab, PanopticDeepLabRenderEngine
+    from empanada_napari_amd.preprocess import normalize_params
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    # the seeded network's centre head stays below the NMS threshold on most of a tile: lift the head biases (as elsewhere)
+    # far enough that a tile carries well over 1 500 centres
+    for name, shift in (('ins_center.head.1', 1.6), ('semantic_head.head.1', 1.5), ('semantic_pr.point_head.predictor', 1.5)):
+        w, b = P[name]
+        P[name] = (w, b + np.float32(shift))
+    model = HipPanopticDeepLab(P, cfg, folded=True)
+    eng = PanopticDeepLabRenderEngine(model, [1], label_divisor=100000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                                      padding_factor=16, coarse_boundaries=False)
+    tiles = torch.from_numpy(synth.em_tiles(3, 1024, seed=515))[:, None].cuda()
+    sub, mul = normalize_params(0.57571, 0.12765, 255)
+    out = model(tiles, 2, interpolate_ins=True, sub=float(sub), mul=float(mul))
+    out = {k: v.clone() for k, v in out.items()}
+    return dict(model=model, eng=eng, tiles=tiles, sub=float(sub), mul=float(mul), out=out)
+
+
+def test_fine_boundary_label_maps_equal_the_oracle_at_1024(fine):
+    from empanada_napari_amd.engines import logits_to_prob
+    from oracle import postprocess as opp
+    eng, out = fine['eng'], fine['out']
+    assert out['ctr_hmp'].shape[-2:] == (1024, 1024) and out['offsets'].shape[-2:] == (1024, 1024)
+    sem = logits_to_prob(out['sem_logits'])
+    cells, centers, num, kmax = eng.instance_cells_int(out['ctr_hmp'], out['offsets'], 1)
+    pan = eng.panoptic_merge_int(sem, cells, kmax).cpu().numpy()
+    num = num.cpu().numpy()
+    print('centres per tile:', num.tolist())
+    assert num.min() >= 1500, num          # the regime the goldens never reach (they stop at 160^2)
+    # batch == per image, through the single-image API of the reference (engines.py:300-325)
+    for i in range(fine['tiles'].shape[0]):
+        one = eng.call_raw(fine['tiles'][i:i + 1], fine['sub'], fine['mul']).cpu().numpy()[0]
+        assert np.array_equal(one, pan[i]), f'tile {i}: batched != per image ({int((one != pan[i]).sum())} pixels)'
+    # the oracle's post-processing (reference arithmetic: NMS on the full-size heat-map, chunked nearest-centre voting with
+    # its 1e5 start and first-wins ties, merge) on the engine's own head tensors: bit-exact.  Tile 0 (the oracle's voting
+    # loop is K passes over a 1 M-pixel map: ~20 s per tile)
+    o = {k: v[:1].cpu().numpy() for k, v in out.items()}
+    o['sem'] = opp.logits_to_prob(o['sem_logits'])
+    oeng = opp.RenderEngine(lambda *_: o, [1], label_divisor=100000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                            coarse_boundaries=False)
+    t0 = time.perf_counter()
+    ocells = oeng.cells(o['ctr_hmp'], o['offsets'], 1)
+    want = oeng.postprocess(o['sem'], ocells)[0]
+    cpu_s = time.perf_counter() - t0
+    assert int(ocells.max()) == int(num[0])
+    assert np.array_equal(cells[0].cpu().numpy(), ocells.reshape(1024, 1024).astype(np.int32)), \
+        f'{int((cells[0].cpu().numpy() != ocells.reshape(1024, 1024)).sum())} cells differ'
+    near_thr = np.abs(o['sem'][0, 0] - 0.5) < 1e-6
+    assert np.all((pan[0] == want) | near_thr), f'{int((pan[0] != want).sum())} label mismatches'
+    assert len(np.unique(want)) - 1 >= 1000
+    _save(dict(centres_per_tile=num.tolist(), oracle_postprocess_s_per_tile=round(cpu_s, 2)))
+
+
+def test_fine_boundary_voting_is_timed(fine):
+    """time of the voting launch group (NMS + centre list + group_pixels) and of the whole fine-boundary post-processing
+    per 1024^2 tile at >= 1 500 centres; bench.py carries the same figure as `fine_boundaries_ms_per_tile`"""
+    from empanada_napari_amd.engines import logits_to_prob
+    eng, out = fine['eng'], fine['out']
+    sem = logits_to_prob(out['sem_logits'])
+    n = out['ctr_hmp'].shape[0]
+
+    def post():
+        cells, _, _, kmax = eng.instance_cells_int(out['ctr_hmp'], out['offsets'], 1)
+        return eng.panoptic_merge_int(sem, cells, kmax)
+
+    post()
+    torch.cuda.synchronize()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    for _ in range(5):
+        cells, _, _, kmax = eng.instance_cells_int(out['ctr_hmp'], out['offsets'], 1)
+    e1.record()
+    for _ in range(5):
+        post()
+    e2.record()
+    torch.cuda.synchronize()
+    vote_ms, post_ms = e0.elapsed_time(e1) / 5 / n, e1.elapsed_time(e2) / 5 / n
+    print(f'fine boundaries @1024^2, {kmax} centres max: voting {vote_ms:.3f} ms per tile, voting + merge {post_ms:.3f} ms per tile')
+    _save(dict(voting_ms_per_tile=round(vote_ms, 4), voting_and_merge_ms_per_tile=round(post_ms, 4), max_centres=int(kmax)))
+    assert post_ms < 50.0          # the reference's CPU figure for this case is 11.5 s per tile
+
+
+def _save(d):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    cur = {}
+    if os.path.exists(REPORT):
+        try:
+            cur = json.load(open(REPORT))
+        except Exception:
+            cur = {}
+    cur.update(d)
+    json.dump(cur, open(REPORT, 'w'), indent=1, sort_keys=True)

@@ -1,0 +1,209 @@
+"""The `fp16x3` precision mode (round 5): the fp32 reference mode's graph with every convolution on
+the FP16 matrix pipe -- operands split into fp16 pairs x = hi + lo, three MFMAs per product into an fp32 accumulator
+(csrc/conv16x3.hip).  The reference computes this path in fp32 (empanada/inference/engines.py:248-255); the north star
+asks for the float heat-maps within 1e-3 of it.  Here: the kernel against torch's fp32 convolution, the whole forward
+against the fp32 oracle (one tile, the anchor) and against the library's fp32 mode over 8 tiles x 3 weight seeds at
+BASELINE's tile size -- in the MAX norm -- and the rate, which must be what makes the mode worth having."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPORT = os.path.join(ROOT, 'gpurun_out', 'fp16x3.json')
+
+
+def _save(key, val):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    d = {}
+    if os.path.exists(REPORT):
+        try:
+            d = json.load(open(REPORT))
+        except Exception:
+            d = {}
+    d[key] = val
+    json.dump(d, open(REPORT, 'w'), indent=1, sort_keys=True)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, act, res
+    (2, 20, 28, 64, 64, 1, 1, 0, 1, 1, False),       # BN = 64 tile
+    (1, 33, 17, 48, 96, 3, 1, 1, 1, 1, True),        # K = 9 x 48: a 32-step straddles two taps; ragged tiles; residual
+    (2, 16, 16, 32, 40, 3, 2, 1, 1, 0, False),       # stride 2, Cout not a multiple of 16
+    (1, 24, 24, 64, 128, 3, 1, 4, 4, 2, False),      # dilation 4, SiLU, BN = 128
+    (3, 8, 8, 256, 16, 1, 1, 0, 1, 0, False),
+    (1, 40, 40, 16, 200, 1, 1, 0, 1, 1, False),      # K = 16: one half-filled step; two cout tiles, the second ragged
+    (2, 12, 12, 80, 130, 3, 1, 2, 2, 1, True),       # K = 720 = 22.5 steps
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv16x3_equals_torch_fp32(case):
+    """against an fp64 convolution of the same fp32 operands: the error of the split (2^-22 per operand) and of the fp32
+    accumulation in another order -- the same bound the fp32 mode's exact conv is held to (test_gpu_fp32_mode.py), x 4"""
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    N, H, W, Cin, Cout, k, stride, pad, dil, act, res = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn((N, H, W, Cin), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn((Cout,), generator=g)
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    r = torch.randn((N, Ho, Wo, Cout), generator=g) if res else None
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride, pad, dil)
+    if res:
+        ref = ref + r.permute(0, 3, 1, 2).double()
+    if act == 1:
+        ref = torch.relu(ref)
+    elif act == 2:
+        ref = ref * torch.sigmoid(ref)
+    xd, bd = x.to(dev()), b.to(dev())
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin).contiguous().to(dev())
+    rd = r.to(dev()) if res else None
+    out = torch.full((N, Ho, Wo, Cout + 8), 7.0, device=dev())       # a channel slice of a wider buffer
+    _abi.check(lib.emp_conv2d_nhwc_f16x3(_abi.ptr(xd), N, H, W, Cin, Cin, _abi.ptr(wd), _abi.ptr(bd), None,
+                                         _abi.ptr(rd) if res else None, Cout, _abi.ptr(out), Cout + 8, Cout, k, k, stride, pad,
+                                         dil, act, 1, 0, _abi.stream_ptr(dev())), 'conv16x3')
+    torch.cuda.synchronize()
+    got = out[..., :Cout].cpu().permute(0, 3, 1, 2).double()
+    assert torch.all(out[..., Cout:] == 7.0), 'wrote outside its channel slice'
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert err < 8e-6 * scale * np.sqrt(Cin * k * k / 64.0 + 1.0), err
+    # and it is NOT the plain fp16 product: rounding the operands to fp16 once would leave ~3e-4 of the scale
+    x16, w16 = x.half().double(), w.half().double()
+    plain = F.conv2d(x16.permute(0, 3, 1, 2), w16, b.double(), stride, pad, dil)
+    if not res and act == 0:
+        assert float((plain - ref).abs().max()) > 20 * err
+
+
+def test_conv16x3_grouped_equals_the_fp32_grouped_conv():
+    """RegNet's grouped 3x3 (blockIdx.z = group): against the fp32 mode's grouped convolution on the same operands"""
+    from gpu_common import dev
+    from empanada_napari_amd import _abi
+    lib = _abi.load()
+    N, H, W, G, cin_g, cout_g = 2, 14, 18, 3, 24, 24
+    cin16 = 32
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((N, H, W, (G - 1) * cin_g + cin16), generator=g).to(dev())
+    w = torch.zeros((G * cout_g, 9, cin16))
+    w[:, :, :cin_g] = torch.randn((G * cout_g, 9, cin_g), generator=g) / np.sqrt(9 * cin_g)
+    w = w.to(dev())
+    b = torch.randn((G * cout_g,), generator=g).to(dev())
+    a = torch.zeros((N, H, W, G * cout_g), device=dev())
+    c = torch.zeros_like(a)
+    _abi.check(lib.emp_conv2d_grouped_nhwc_f32(_abi.ptr(x), N, H, W, G, cin_g, cin16, x.shape[-1], _abi.ptr(w), _abi.ptr(b),
+                                               _abi.ptr(a), G * cout_g, cout_g, 3, 3, 1, 1, 1, 1, _abi.stream_ptr(dev())), 'g32')
+    _abi.check(lib.emp_conv2d_nhwc_f16x3(_abi.ptr(x), N, H, W, cin16, x.shape[-1], _abi.ptr(w), _abi.ptr(b), None, None, 0,
+                                         _abi.ptr(c), G * cout_g, cout_g, 3, 3, 1, 1, 1, 1, G, cin_g, _abi.stream_ptr(dev())), 'gx3')
+    torch.cuda.synchronize()
+    assert float(a.abs().max()) > 0.5
+    assert float((a - c).abs().max()) < 1e-5 * float(a.abs().max())
+
+
+def _sig(x):
+    return 1.0 / (1.0 + np.exp(-np.asarray(x, np.float64)))
+
+
+def test_fp16x3_forward_vs_the_fp32_oracle_at_1024():
+    """the anchor: one 1024^2 tile through precision='fp16x3' against the oracle's fp32 forward (pinned by the reference
+    goldens): centre heat-map, offsets, semantic probability within 1e-3 in the MAX norm"""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    for name, shift in (('ins_center.head.1', 0.75), ('semantic_head.head.1', 1.0), ('semantic_pr.point_head.predictor', 1.0)):
+        w, b = P[name]
+        P[name] = (w, b + np.float32(shift))
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16x3')
+    assert model.precision == 'fp16x3'
+    img = synth.em_tiles(1, 1024, seed=2024)
+    x = torch.from_numpy(normalize(img, 0.57571, 0.12765))[:, None]
+    out = {k: v.cpu().numpy() for k, v in model(x.cuda(), 2, False).items()}
+    coarse = model.tap_raw('semantic_head.out', (1, 1, 256, 256)).cpu().numpy()
+    taps = {}
+    ref = pdl_model.pdl_forward(P, x, cfg, 2, False, taps)
+    rep = {}
+    for k in ('ctr_hmp', 'offsets'):
+        d = np.abs(out[k] - ref[k].numpy())
+        scale = max(1.0, float(ref[k].pow(2).mean().sqrt()))
+        rep[k + '_max'] = float(d.max()) / scale
+        assert rep[k + '_max'] < TOL, (k, rep)
+    rep['sem_coarse_prob_max'] = float(np.abs(_sig(coarse) - _sig(taps['sem_coarse'].numpy())).max())
+    assert rep['sem_coarse_prob_max'] < TOL, rep
+    pe = np.abs(_sig(out['sem_logits']) - _sig(ref['sem_logits'].numpy()))
+    rep['final_prob_frac_over_1e3'] = float((pe > TOL).mean())
+    assert rep['final_prob_frac_over_1e3'] < 2e-3, rep      # PointRend picks differ only at near-ties of the uncertainty
+    print('fp16x3 @1024^2 vs fp32 oracle:', rep)
+    _save('vs_oracle_1024', rep)
+
+
+@pytest.mark.parametrize('family', ['pdl', 'bifpn1', 'bifpn4'])
+def test_fp16x3_gate_holds_in_the_max_norm_over_tiles_and_seeds(family):
+    """8 tiles x 3 weight seeds against the library's fp32 mode (itself within 1e-4 of the oracle: test_gpu_fp32_mode.py):
+    every sample within 1e-3 in the MAX norm -- the statement the fp16 engine cannot make (test_gpu_parity_stats.py)"""
+    import test_gpu_parity_stats as ps
+    from empanada_napari_amd import weights
+    if family == 'pdl':
+        cfg, size, seeds, ncls = dict(weights.MITONET_PDL_CFG), 1024, (0, 1, 2), 1
+    else:
+        ncls = int(family[-1])
+        cfg, size, seeds = dict(weights.MITONET_MINI_CFG, num_classes=ncls), 512, (3, 4, 5)
+    rows = []
+    for seed in seeds:
+        rs = ps._pair(cfg, ps._params(cfg, seed, True), size, 2024 + 100 * seed, ncls, precisions=('fp16x3', 'fp32'))
+        for i, r in enumerate(rs):
+            r.update(weight_seed=seed, tile=i)
+        rows += rs
+    s = ps._summary(rows)
+    print(f'fp16x3 vs fp32 mode, {family}:', json.dumps(s))
+    _save(f'vs_fp32_mode_{family}', {'summary': s})
+    assert s['ctr_max']['worst'] < TOL and s['sem_max']['worst'] < TOL and s['off_max']['worst'] < TOL, s
+
+
+def test_fp16x3_rate():
+    """the mode exists to be fast: forward + voting + merge of 8 x 1024^2 tiles, against the fp32 mode on the same tiles"""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab, PanopticDeepLabRenderEngine, logits_to_prob
+    from empanada_napari_amd.preprocess import normalize_params
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    tiles = torch.from_numpy(synth.em_tiles(8, 1024, seed=1234))[:, None].cuda()
+    sub, mul = normalize_params(0.57571, 0.12765, 255)
+    rate = {}
+    for prec in ('fp16x3', 'fp32'):
+        m = HipPanopticDeepLab(P, cfg, folded=True, precision=prec)
+        eng = PanopticDeepLabRenderEngine(m, [1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                                          padding_factor=16, coarse_boundaries=True)
+
+        def step():
+            o = m(tiles, 2, interpolate_ins=False, sub=float(sub), mul=float(mul))
+            sem = logits_to_prob(o['sem_logits'])
+            cells, _, _, kmax = eng.instance_cells_int(o['ctr_hmp'], o['offsets'], 1)
+            return eng.panoptic_merge_int(sem, cells, kmax)
+
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        rate[prec] = {'tiles_per_s': round(8 / dt, 1), 'ms_per_step': round(dt * 1e3, 2), 'tflops_fp32_equivalent': round(m.last_flops() / dt / 1e12, 1)}
+        del m, eng
+        torch.cuda.empty_cache()
+    print('rates:', rate)
+    _save('rate_batch8_1024', rate)
+    assert rate['fp16x3']['tiles_per_s'] > 1.5 * rate['fp32']['tiles_per_s'], rate
