@@ -174,9 +174,11 @@ struct Conv32 {
   int groups;       // > 1: grouped convolution -- Cout and Cin are PER GROUP (Cin padded to 16), weights [G * Cout][KH*KW][Cin]
   int cin_g;        // grouped: real input channels per group (the channel step from one group to the next); else 0
   int x3;           // 1: the fp16x3 mode -- the same convolution on the fp16 matrix pipe with split operands (conv16x3.hip)
+  const uint32_t* wpair;      // x3 only, optional: the weights already split, one uint32 = fp16 hi | fp16 lo << 16, layout of `w`
 };
 int launch_conv32(const Conv32& p, hipStream_t s);
 int launch_conv16x3(const Conv32& p, hipStream_t s);      // called by launch_conv32 when p.x3 (its checks have run)
+int launch_split_pairs(const float* w, uint32_t* out, int64_t n, hipStream_t s);
 int launch_stem3x3s2_f32(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
                          const float* w /*[9][C]*/, const float* b, int C, float* out, int out_ld, hipStream_t s);
 int launch_gate_mul_f32(float* x, int x_ld, const float* g, int g_ld, int64_t rows, int C, hipStream_t s);

@@ -106,7 +106,7 @@ struct emp_pdl {
     return 0;
   }();
   bool fp32_graph() const { return precision != 0; }
-  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; };
+  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; };
   std::map<std::string, W32> w32;
   std::map<std::string, std::pair<float*, size_t>> pool32;      // name -> (device buffer, floats)
   std::map<std::string, std::array<int, 4>> geom32;             // zero-tailed RegNet maps: the geometry a buffer was last cleared for
@@ -1458,6 +1458,20 @@ int finalize32(emp_pdl* n) {
       for (int i = 0; i < K; ++i) w[(size_t)o * ldp + i] = hp.w[(size_t)o * K + i];
     RC32(upload_f32(n, "pr.predictor.w32", w));
   }
+  if (n->precision == 2) {
+    // fp16x3 mode: every convolution weight once more as fp16 pairs (hi | lo << 16, the fp32 blob's layout), so that the
+    // kernel's weight staging is a lane permutation instead of five vector operations per element (conv16x3.hip)
+    for (auto& kv : n->w32) {
+      emp_pdl::W32& w = kv.second;
+      const int64_t cnt = (int64_t)w.cout * w.kh * w.kw * w.cin16;
+      void* d = nullptr;
+      EMP_CHECK_HIP(hipMalloc(&d, (size_t)(cnt > 0 ? cnt : 4) * sizeof(uint32_t)));
+      n->owned.push_back(d);
+      w.wp = (uint32_t*)d;
+      RC32(launch_split_pairs(w.w, w.wp, cnt, nullptr));
+    }
+    EMP_CHECK_HIP(hipStreamSynchronize(nullptr));
+  }
   return EMP_OK;
 }
 
@@ -1482,6 +1496,7 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
   p.Wo = (in.W + 2 * pad - dil * (w.kw - 1) - 1) / stride + 1;
   p.act = act; p.ps_cout = ps_cout;
   p.x3 = n->precision == 2;
+  p.wpair = p.x3 ? w.wp : nullptr;
   const int up = ps_cout ? 2 : 1;
   EMP_REQUIRE(p.Ho * up == out.H && p.Wo * up == out.W && in.N == out.N, "%s (fp32): output shape mismatch", wname.c_str());
   EMP_REQUIRE(in_coff + (groups - 1) * w.cin + w.cin16 <= in.ld && out_coff + (ps_cout ? ps_cout : w.cout) <= out.ld,
