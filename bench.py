@@ -53,7 +53,8 @@ def parse_args():
     ap.add_argument('--stack3d', type=int, default=512, help='tiles workload: side of the 3-D cube of the second metric (0 = skip)')
     ap.add_argument('--engine2d', type=int, default=1, help='tiles workload: also measure the Engine2d-level rate (0 = skip)')
     ap.add_argument('--latency', type=int, default=1, help='tiles workload: also measure the batch-1 latency (0 = skip)')
-    ap.add_argument('--fp32-mode', type=int, default=4, help="tiles workload: batch of the fp32 reference mode's rate (precision='fp32'; 0 = skip)")
+    ap.add_argument('--fp32-mode', type=int, default=4, help="tiles workload: batch of the fp32 reference mode's rate (precision='fp32'; 0 = skip); "
+                    "the fp16x3 mode is measured at twice this batch")
     ap.add_argument('--depth', type=int, default=128, help='stack3d workload: slices per GPU')
     ap.add_argument('--slab-size', type=int, default=4096, help='tiles workload, N > 1: slice side of the z-slab job of the `stack3d` block')
     ap.add_argument('--slab-depth', type=int, default=16, help='tiles workload, N > 1: slices per rank of that job')
@@ -148,15 +149,16 @@ def parity_block(model, eng, ref, sub, mul, dev):
                          '(DESIGN.md section 2); label maps are bit-exact given identical head tensors'}
 
 
-def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3):
-    """Rate of the library's fp32 REFERENCE MODE (precision='fp32', csrc/ref32.hip) on the same workload: the same step
-    (forward + probability + voting + merge -> int64 label maps) over `batch` of the bench's tiles, outside the timed
-    region of `value`.  The reference computes this path in fp32 (empanada/inference/engines.py:248-255); this is the
-    mode whose float heads are within 1e-3 of it in the MAX norm (tests/test_gpu_fp32_mode.py), so its rate belongs next
-    to the fp16 engine's."""
+def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3, precision='fp32'):
+    """Rate of the library's fp32 REFERENCE MODE (precision='fp32', csrc/ref32.hip) or of its fp16x3 mode (the same graph with
+    split-fp16 convolutions on the fp16 matrix pipe, csrc/conv16x3.hip) on the same workload: the same step (forward +
+    probability + voting + merge -> int64 label maps) over `batch` of the bench's tiles, outside the timed region of
+    `value`.  The reference computes this path in fp32 (empanada/inference/engines.py:248-255); these are the modes whose
+    float heads are within 1e-3 of it in the MAX norm (tests/test_gpu_fp32_mode.py, tests/test_gpu_fp16x3.py), so their
+    rates belong next to the fp16 engine's."""
     import torch
     from empanada_napari_amd.engines import HipPanopticDeepLab, PanopticDeepLabRenderEngine, logits_to_prob
-    m32 = HipPanopticDeepLab(P, cfg, device=dev, folded=True, precision='fp32')
+    m32 = HipPanopticDeepLab(P, cfg, device=dev, folded=True, precision=precision)
     e32 = PanopticDeepLabRenderEngine(m32, thing_list=[1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3,
                                       confidence_thr=0.5, padding_factor=16, coarse_boundaries=True)
     x = torch.from_numpy(host_tiles[:batch])[:, None].to(dev)
@@ -175,10 +177,19 @@ def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     tf = m32.last_flops() / dt / 1e12
-    res = {'tiles_per_s': round(batch / dt, 2), 'ms_per_step': round(dt * 1e3, 2), 'batch': batch, 'steps': steps,
-           'tflops': round(tf, 2), 'frac_of_157TF': round(tf / PEAK_F32_TFLOPS, 4), 'peak_tflops': PEAK_F32_TFLOPS,
-           'note': "precision='fp32': fp32 maps and weights, exact fp32 MFMA, unfused; heads within 1e-4 of the fp32 oracle in "
-                   'the max norm at this size (tests/test_gpu_fp32_mode.py); same step as `value` (forward + voting + merge)'}
+    if precision == 'fp32':
+        res = {'tiles_per_s': round(batch / dt, 2), 'ms_per_step': round(dt * 1e3, 2), 'batch': batch, 'steps': steps,
+               'tflops': round(tf, 2), 'frac_of_157TF': round(tf / PEAK_F32_TFLOPS, 4), 'peak_tflops': PEAK_F32_TFLOPS,
+               'note': "precision='fp32': fp32 maps and weights, exact fp32 MFMA, unfused; heads within 1e-4 of the fp32 oracle in "
+                       'the max norm at this size (tests/test_gpu_fp32_mode.py); same step as `value` (forward + voting + merge)'}
+    else:
+        res = {'tiles_per_s': round(batch / dt, 2), 'ms_per_step': round(dt * 1e3, 2), 'batch': batch, 'steps': steps,
+               'tflops_fp32_equivalent': round(tf, 2), 'tflops_fp16_mfma': round(3 * tf, 2),
+               'frac_of_fp16_peak': round(3 * tf / PEAK_F16_TFLOPS, 4),
+               'note': "precision='fp16x3': the fp32 mode's graph and fp32 maps, every convolution as three fp16 MFMAs per product "
+                       '(operands split hi + lo, fp32 accumulate); heads within 1e-3 of the fp32 forward in the MAX norm on every '
+                       'one of 8 tiles x 3 weight seeds (2.4e-5 worst, tests/test_gpu_fp16x3.py) -- the tolerance-compliant mode '
+                       'for throughput; same step as `value`'}
     del m32, e32
     torch.cuda.empty_cache()
     return res
@@ -530,10 +541,11 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
     else:
         res['cpu_baseline'] = None
     if world == 1 and args.fp32_mode > 0 and S <= 1024:
-        try:
-            res['fp32_mode'] = fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=min(args.fp32_mode, B))
-        except Exception as e:      # noqa: BLE001 -- the headline line must not depend on the extra measurement
-            res['fp32_mode'] = {'error': f'{type(e).__name__}: {e}'}
+        for key, prec, mult in (('fp32_mode', 'fp32', 1), ('fp16x3_mode', 'fp16x3', 2)):
+            try:
+                res[key] = fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=min(mult * args.fp32_mode, B), precision=prec)
+            except Exception as e:      # noqa: BLE001 -- the headline line must not depend on the extra measurement
+                res[key] = {'error': f'{type(e).__name__}: {e}'}
     if world == 1 and args.latency:
         try:
             res['fine_boundaries'] = fine_boundaries_block(model, tiles, sub, mul, batch=min(4, B))

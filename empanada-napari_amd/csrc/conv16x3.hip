@@ -68,18 +68,20 @@ __device__ __forceinline__ void pair_store(const float4 (&r)[4], half_t* hi, hal
   *reinterpret_cast<uint4*>(lo + 8) = l[1];
 }
 
-template <int ACT, int BM, int BN, bool WPAIR>
-__global__ void __launch_bounds__(256, 2) conv16x3_kernel(const Conv32 p) {
+template <int ACT, int BM, int BN, bool WPAIR, bool DB>
+__global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 p) {
   constexpr int WC = BN / 64;          // waves along the couts (64 couts each)
   constexpr int WP = 4 / WC;           // waves along the pixels
   constexpr int NJ = BM / WP / 16;     // 16-pixel fragments per wave
   constexpr int XC = BM / 128;         // 16-channel chunks of the pixel tile per thread and step (BM rows x 2 chunks / 256)
   // two LDS buffers: step k computes from buffer k % 2 while the operands of step k + 1 (loaded during step k - 1) are split
   // into the other one and the loads of step k + 2 are in flight -- one barrier per step, two steps of latency cover
-  __shared__ __attribute__((aligned(16))) half_t Xh[2][BM * X_LD];
-  __shared__ __attribute__((aligned(16))) half_t Xl[2][BM * X_LD];
-  __shared__ __attribute__((aligned(16))) half_t Wh[2][BN * X_LD];
-  __shared__ __attribute__((aligned(16))) half_t Wl[2][BN * X_LD];
+  // DB = false (short K: the launch is its prologue and epilogue): one buffer, two barriers per step, three workgroups per CU
+  constexpr int NB = DB ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) half_t Xh[NB][BM * X_LD];
+  __shared__ __attribute__((aligned(16))) half_t Xl[NB][BM * X_LD];
+  __shared__ __attribute__((aligned(16))) half_t Wh[NB][BN * X_LD];
+  __shared__ __attribute__((aligned(16))) half_t Wl[NB][BN * X_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   // grouped convolution (RegNet's 3x3): blockIdx.z = group, as conv32_kernel (ref32.hip)
@@ -149,14 +151,23 @@ __global__ void __launch_bounds__(256, 2) conv16x3_kernel(const Conv32 p) {
   };
   const int fr = lane & 15, fk = (lane >> 4) * 8;
   gload(0);
-  stage(0);
-  if (X_BK < K) gload(X_BK);
+  if (DB) {
+    stage(0);
+    if (X_BK < K) gload(X_BK);
+  }
   int b = 0;
-  for (int k0 = 0; k0 < K; k0 += X_BK, b ^= 1) {
-    __syncthreads();      // buffer b is complete; nobody reads buffer b ^ 1 (step k - 1) any more
-    if (k0 + X_BK < K) {
-      stage(b ^ 1);                                   // the registers hold step k + 1
-      if (k0 + 2 * X_BK < K) gload(k0 + 2 * X_BK);    // in flight behind this step's and the next step's MFMAs
+  for (int k0 = 0; k0 < K; k0 += X_BK, b ^= (DB ? 1 : 0)) {
+    if (DB) {
+      __syncthreads();      // buffer b is complete; nobody reads buffer b ^ 1 (step k - 1) any more
+      if (k0 + X_BK < K) {
+        stage(b ^ 1);                                   // the registers hold step k + 1
+        if (k0 + 2 * X_BK < K) gload(k0 + 2 * X_BK);    // in flight behind this step's and the next step's MFMAs
+      }
+    } else {
+      __syncthreads();      // the previous step's fragment reads are done
+      stage(0);
+      __syncthreads();
+      if (k0 + X_BK < K) gload(k0 + X_BK);
     }
     // the wave's weight fragments stay in registers for the step (32 VGPRs); the pixel fragments stream through
     f16x8 wh[4], wl[4];
@@ -248,11 +259,11 @@ __global__ void __launch_bounds__(256, 2) conv16x3_kernel(const Conv32 p) {
   }
 }
 
-template <int BM, int BN, bool WPAIR>
+template <int BM, int BN, bool WPAIR, bool DB>
 int launch_tile(const Conv32& p, dim3 grid, hipStream_t s) {
-  if (p.act == 1) hipLaunchKernelGGL((conv16x3_kernel<1, BM, BN, WPAIR>), grid, dim3(256), 0, s, p);
-  else if (p.act == 2) hipLaunchKernelGGL((conv16x3_kernel<2, BM, BN, WPAIR>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((conv16x3_kernel<0, BM, BN, WPAIR>), grid, dim3(256), 0, s, p);
+  if (p.act == 1) hipLaunchKernelGGL((conv16x3_kernel<1, BM, BN, WPAIR, DB>), grid, dim3(256), 0, s, p);
+  else if (p.act == 2) hipLaunchKernelGGL((conv16x3_kernel<2, BM, BN, WPAIR, DB>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((conv16x3_kernel<0, BM, BN, WPAIR, DB>), grid, dim3(256), 0, s, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
@@ -266,7 +277,10 @@ int launch_pair(const Conv32& p, hipStream_t s) {
   // (a 256-pixel tile -- half the weight tile's trips through LDS per product -- measured 1.4-2.4x SLOWER on every shape of
   // the network at batch 8: one workgroup per CU leaves nothing to run behind a barrier; profiles/r05_conv16x3.txt)
   const dim3 grid((unsigned)((M + 127) / 128), nt, (unsigned)G);
-  return bn == 128 ? launch_tile<128, 128, WPAIR>(p, grid, s) : launch_tile<128, 64, WPAIR>(p, grid, s);
+  const int kdb = [] { const char* e = getenv("EMP_X3_KDB"); return e ? atoi(e) : 1024; }();     // K from which the two-buffer pipeline runs (measured: profiles/r05_conv16x3.txt)
+  const bool db = p.KH * p.KW * p.Cin >= kdb;
+  if (db) return bn == 128 ? launch_tile<128, 128, WPAIR, true>(p, grid, s) : launch_tile<128, 64, WPAIR, true>(p, grid, s);
+  return bn == 128 ? launch_tile<128, 128, WPAIR, false>(p, grid, s) : launch_tile<128, 64, WPAIR, false>(p, grid, s);
 }
 
 __global__ void __launch_bounds__(256) split_pairs_kernel(const float* __restrict__ w, uint32_t* __restrict__ out, int64_t n) {

@@ -33,6 +33,9 @@ def test_one_gpu_line_carries_roofline_cpu_baseline_and_parity():
     f = j['fp32_mode']       # the rate of the tolerance-compliant mode rides on the same line
     assert 'error' not in f, f
     assert f['batch'] == 2 and 0 < f['tiles_per_s'] < j['value'] and 0 < f['frac_of_157TF'] < 1
+    x = j['fp16x3_mode']      # ... and the rate of the fast tolerance-compliant mode (item 4)
+    assert 'error' not in x, x
+    assert x['batch'] == 4 and x['tiles_per_s'] > f['tiles_per_s'] and 0 < x['frac_of_fp16_peak'] < 1
     assert j['forward_steps_bench_loop'] == 1 + 2 * 2 and j['forward_calls_total'] >= j['forward_steps_bench_loop']
     assert j['roofline']['bound'] == 'mfma' and j['cpu_baseline']['kind'] == 'port' and j['cpu_baseline']['value'] > 0
     p = j['parity']
