@@ -241,31 +241,37 @@ struct SparseLsa {
   std::vector<double> adj_cost;
   // segment tree over scan positions (leaf p: the column at remaining[p]); absent leaves hold -inf
   int64_t leaves = 1;
-  std::vector<double> mx, mxu;       // max v over present leaves / over present unassigned leaves
+  std::vector<double> T;             // node k: T[2k] = max v over present leaves, T[2k+1] = over present unassigned leaves (one cache line per node pair)
   std::vector<int64_t> remaining, pos_of;
   std::vector<double> u, v;
   std::vector<int64_t> col4row, row4col;
 
   void set_leaf(int64_t p, double val, bool unassigned) {
     int64_t k = leaves + p;
-    mx[(size_t)k] = val;
-    mxu[(size_t)k] = unassigned ? val : -INFINITY;
+    T[2 * (size_t)k] = val;
+    T[2 * (size_t)k + 1] = unassigned ? val : -INFINITY;
+    // upwards until a node's two maxima come out unchanged: its ancestors are functions of it alone on this path (round 5:
+    // most leaf updates of a search -- a column leaving the aggregate and coming back -- do not touch a subtree maximum;
+    // the walk to the root was 2/3 of a matching step at thousands of objects per slice)
     for (k >>= 1; k >= 1; k >>= 1) {
-      mx[(size_t)k] = std::max(mx[(size_t)(2 * k)], mx[(size_t)(2 * k + 1)]);
-      mxu[(size_t)k] = std::max(mxu[(size_t)(2 * k)], mxu[(size_t)(2 * k + 1)]);
+      const double a = std::max(T[2 * (size_t)(2 * k)], T[2 * (size_t)(2 * k + 1)]);
+      const double b = std::max(T[2 * (size_t)(2 * k) + 1], T[2 * (size_t)(2 * k + 1) + 1]);
+      if (a == T[2 * (size_t)k] && b == T[2 * (size_t)k + 1]) break;
+      T[2 * (size_t)k] = a;
+      T[2 * (size_t)k + 1] = b;
     }
   }
   // first position whose value satisfies fl(C - val) <= t (pred is monotone in val: test the node maxima)
   template <typename P> int64_t first_pos(P pred) const {
-    if (!pred(mx[1])) return -1;
+    if (!pred(T[2])) return -1;
     int64_t k = 1;
-    while (k < leaves) k = pred(mx[(size_t)(2 * k)]) ? 2 * k : 2 * k + 1;
+    while (k < leaves) k = pred(T[2 * (size_t)(2 * k)]) ? 2 * k : 2 * k + 1;
     return k - leaves;
   }
   template <typename P> int64_t last_unassigned_pos(P pred) const {
-    if (!pred(mxu[1])) return -1;
+    if (!pred(T[3])) return -1;
     int64_t k = 1;
-    while (k < leaves) k = pred(mxu[(size_t)(2 * k + 1)]) ? 2 * k + 1 : 2 * k;
+    while (k < leaves) k = pred(T[2 * (size_t)(2 * k + 1) + 1]) ? 2 * k + 1 : 2 * k;
     return k - leaves;
   }
 };
@@ -301,8 +307,7 @@ int lsa_maximize_sparse(int64_t R, int64_t Cn, int64_t nnz, const int64_t* er, c
     }
   }
   while (S.leaves < nc) S.leaves <<= 1;
-  S.mx.assign((size_t)(2 * S.leaves), -INFINITY);
-  S.mxu.assign((size_t)(2 * S.leaves), -INFINITY);
+  S.T.assign((size_t)(4 * S.leaves), -INFINITY);
   S.remaining.resize((size_t)nc);
   S.pos_of.resize((size_t)nc);
   S.u.assign((size_t)nr, 0.0);
@@ -313,12 +318,12 @@ int lsa_maximize_sparse(int64_t R, int64_t Cn, int64_t nnz, const int64_t* er, c
   for (int64_t p = 0; p < nc; ++p) {
     S.remaining[(size_t)p] = nc - 1 - p;
     S.pos_of[(size_t)(nc - 1 - p)] = p;
-    S.mx[(size_t)(S.leaves + p)] = 0.0;
-    S.mxu[(size_t)(S.leaves + p)] = 0.0;
+    S.T[2 * (size_t)(S.leaves + p)] = 0.0;
+    S.T[2 * (size_t)(S.leaves + p) + 1] = 0.0;
   }
   for (int64_t k = S.leaves - 1; k >= 1; --k) {
-    S.mx[(size_t)k] = std::max(S.mx[(size_t)(2 * k)], S.mx[(size_t)(2 * k + 1)]);
-    S.mxu[(size_t)k] = std::max(S.mxu[(size_t)(2 * k)], S.mxu[(size_t)(2 * k + 1)]);
+    S.T[2 * (size_t)k] = std::max(S.T[2 * (size_t)(2 * k)], S.T[2 * (size_t)(2 * k + 1)]);
+    S.T[2 * (size_t)k + 1] = std::max(S.T[2 * (size_t)(2 * k) + 1], S.T[2 * (size_t)(2 * k + 1) + 1]);
   }
   // per-search scratch (sized once)
   std::vector<char> nonplain((size_t)nc, 0), visited_col((size_t)nc, 0), touched((size_t)nc, 0);
@@ -369,26 +374,36 @@ int lsa_maximize_sparse(int64_t R, int64_t Cn, int64_t nnz, const int64_t* er, c
       step_c.push_back(cs);
       step_row.push_back(i);
       if (cs < Cst) Cst = cs;
-      // the scan: minimum over the remaining columns with the dense loop's order rule
-      double lowest = INFINITY;
-      int64_t first_p = -1, last_un_p = -1;
-      if (S.mx[1] != -INFINITY) {                      // plain columns present
-        const double t = Cst - S.mx[1];
-        const double Cc = Cst;
-        auto pred = [Cc, t](double val) { return val != -INFINITY && Cc - val <= t; };
-        lowest = t;
-        first_p = S.first_pos(pred);
-        last_un_p = S.last_unassigned_pos(pred);
-      }
+      // the scan: minimum over the remaining columns with the dense loop's order rule ("a strictly lower value wins; among
+      // equal values the LAST unassigned column in scan order, else the FIRST column").  The non-plain columns first: when
+      // one of them is strictly below what the plain columns offer -- the usual case: an object with a real overlap --
+      // the two tree descents are never looked at (round 5; they were half of a search)
+      double npl = INFINITY;
+      int64_t np_first = -1, np_last_un = -1;
       for (int64_t j : np_list) {
         if (visited_col[(size_t)j]) continue;
         const double val = spcx[(size_t)j];
         const int64_t p = S.pos_of[(size_t)j];
         const bool un = S.row4col[(size_t)j] == -1;
-        if (val < lowest) { lowest = val; first_p = p; last_un_p = un ? p : -1; }
-        else if (val == lowest) {
-          if (first_p < 0 || p < first_p) first_p = p;
-          if (un && p > last_un_p) last_un_p = p;
+        if (np_first < 0 || val < npl) { npl = val; np_first = p; np_last_un = un ? p : -1; }
+        else if (val == npl) {
+          if (p < np_first) np_first = p;
+          if (un && p > np_last_un) np_last_un = p;
+        }
+      }
+      double lowest = npl;
+      int64_t first_p = np_first, last_un_p = np_last_un;
+      if (S.T[2] != -INFINITY) {                      // plain columns present
+        const double t = Cst - S.T[2];
+        if (np_first < 0 || t <= npl) {
+          const double Cc = Cst;
+          auto pred = [Cc, t](double val) { return val != -INFINITY && Cc - val <= t; };
+          const int64_t tf = S.first_pos(pred), tl = S.last_unassigned_pos(pred);
+          if (np_first < 0 || t < npl) { lowest = t; first_p = tf; last_un_p = tl; }
+          else {      // equal: the candidates of both kinds compete by position
+            if (tf >= 0 && tf < first_p) first_p = tf;
+            if (tl > last_un_p) last_un_p = tl;
+          }
         }
       }
       if (lowest == INFINITY) return -1;
@@ -1018,18 +1033,10 @@ int emp_sm_step_begin(emp_stack_matcher* h, int64_t idx, int* nt, int* nm) {
     std::sort(ents.begin(), ents.end(), [](const emp_stack_matcher::Ent& a, const emp_stack_matcher::Ent& b) { return a.t < b.t; });
     for (const auto& e : ents) ++deg_r[(size_t)e.t];
   }
-  // connected components of the overlap graph: single pairs are assigned here, the rest forms the solver's block
-  std::vector<int> parent((size_t)(nt_ + nm_));
-  for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int)i;
-  auto find = [&](int a) { while (parent[(size_t)a] != a) { parent[(size_t)a] = parent[(size_t)parent[(size_t)a]]; a = parent[(size_t)a]; } return a; };
-  for (int j = 0; j < nm_; ++j)
-    for (const auto& e : h->col_ent[(size_t)j]) {
-      const int a = find(e.t), b2 = find(nt_ + j);
-      if (a != b2) parent[(size_t)std::max(a, b2)] = std::min(a, b2);
-    }
-  std::vector<char> root_conflict((size_t)(nt_ + nm_), 0);
-  for (int i = 0; i < nt_; ++i) if (deg_r[(size_t)i] > 1) root_conflict[(size_t)find(i)] = 1;
-  for (int j = 0; j < nm_; ++j) if (h->col_ent[(size_t)j].size() > 1) root_conflict[(size_t)find(nt_ + j)] = 1;
+  // does any object compete for a partner?  (degree > 1 on either side)
+  bool any_conflict = false;
+  for (int i = 0; i < nt_ && !any_conflict; ++i) any_conflict = deg_r[(size_t)i] > 1;
+  for (int j = 0; j < nm_ && !any_conflict; ++j) any_conflict = h->col_ent[(size_t)j].size() > 1;
   // A slice with competing overlaps: the reference hands the WHOLE nt x nm matrix to scipy (matcher.py:216-218).  Round 2
   // restricted the solver to the conflict components (single pairs are in every optimal assignment): the same optimum
   // VALUE always and the same assignment whenever the optimum is unique, but with exactly tied IoU sums which optimum
@@ -1045,8 +1052,6 @@ int emp_sm_step_begin(emp_stack_matcher* h, int64_t idx, int* nt, int* nm) {
     const char* e = getenv("EMP_SM_SCIPY");      // the caller solves with scipy itself: it gets the dense whole matrix, as the reference's call
     if (e && e[0] == '1' && full_mode == 2) full_mode = 1;
   }
-  bool any_conflict = false;
-  for (size_t k = 0; k < root_conflict.size(); ++k) any_conflict |= root_conflict[k] != 0;
   const bool full = full_mode == 1 && any_conflict;
   if (full_mode == 2 && any_conflict) {
     std::vector<int64_t> er, ec, rr, cc;
@@ -1071,6 +1076,22 @@ int emp_sm_step_begin(emp_stack_matcher* h, int64_t idx, int* nt, int* nm) {
     for (int i = 0; i < nt_; ++i) h->blk_rows.push_back(i);
     for (int j = 0; j < nm_; ++j) h->blk_cols.push_back(j);
   } else {
+    // connected components of the overlap graph (only this mode -- round 2's conflict block, EMP_SM_FULL_LSA=0 -- and a
+    // slice without any conflict, where every root is conflict-free, need them: the union-find ran in every step until
+    // round 5): single pairs are assigned here, the rest forms the solver's block
+    std::vector<int> parent((size_t)(nt_ + nm_));
+    for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int)i;
+    auto find = [&](int a) { while (parent[(size_t)a] != a) { parent[(size_t)a] = parent[(size_t)parent[(size_t)a]]; a = parent[(size_t)a]; } return a; };
+    std::vector<char> root_conflict((size_t)(nt_ + nm_), 0);
+    if (any_conflict) {
+      for (int j = 0; j < nm_; ++j)
+        for (const auto& e : h->col_ent[(size_t)j]) {
+          const int a = find(e.t), b2 = find(nt_ + j);
+          if (a != b2) parent[(size_t)std::max(a, b2)] = std::min(a, b2);
+        }
+      for (int i = 0; i < nt_; ++i) if (deg_r[(size_t)i] > 1) root_conflict[(size_t)find(i)] = 1;
+      for (int j = 0; j < nm_; ++j) if (h->col_ent[(size_t)j].size() > 1) root_conflict[(size_t)find(nt_ + j)] = 1;
+    }
     for (int i = 0; i < nt_; ++i) if (deg_r[(size_t)i] > 0 && root_conflict[(size_t)find(i)]) h->blk_rows.push_back(i);
     for (int j = 0; j < nm_; ++j) {
       if (h->col_ent[(size_t)j].empty()) continue;
