@@ -34,7 +34,7 @@ using namespace emp;
 extern "C" {
 
 const char* emp_last_error(void) { return g_err; }
-int emp_abi_version(void) { return 2; }      // 2: emp_pdl_config carries the encoder (RegNet) fields
+int emp_abi_version(void) { return 3; }      // 2: emp_pdl_config carries the encoder (RegNet) fields; 3: precision 2 (fp16x3), emp_conv2d_nhwc_f16x3
 
 int emp_device_count(void) {
   int n = 0;

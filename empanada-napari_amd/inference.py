@@ -79,7 +79,7 @@ def load_model(model_config, device):
     if isinstance(m, HipPanopticDeepLab):
         return m
     sd, cfg = load_model_spec(model_config)
-    # 'precision' ('fp16' / 'fp32'): an optional key of the model config (no reference counterpart); None = the library's
+    # 'precision' ('fp16' / 'fp32' / 'fp16x3'): an optional key of the model config (no reference counterpart); None = the library's
     # default -- the fp16 engine for a ResNet50 model, the fp32 mode for a RegNet one -- or the environment's EMP_PRECISION
     return HipPanopticDeepLab(sd, cfg, device=device, precision=model_config.get('precision'))
 

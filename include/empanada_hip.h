@@ -109,7 +109,12 @@ EMP_API int emp_pdl_finalize(emp_pdl_t* net);
  * autocast); in this mode the float heads meet the north star's 1e-3 in the MAX norm (~1e-5 measured), at roughly a
  * tenth of the fp16 engine's rate -- it is the device-side comparator, not the bench.  Same entry points and output
  * tensors; emp_pdl_tap is not available (emp_pdl_tap_raw hands out every fp32 NHWC map of the last forward by name).
- * The environment variable EMP_PRECISION=fp32 selects it for networks that do not call this. */
+ * The environment variable EMP_PRECISION=fp32 selects it for networks that do not call this.
+ * Round 5 (ABI version 3) -- 2: the fp16x3 MODE: the fp32 mode's graph, maps and weights, every convolution on the FP16
+ * matrix pipe with both operands split into fp16 pairs and three MFMAs per product into an fp32 accumulator
+ * (csrc/conv16x3.hip; weights split once at emp_pdl_finalize).  Heads within 1e-3 of the reference's fp32 forward in the
+ * MAX norm on every tile and weight draw tested (2.4e-5 worst on the centre map), at ~2.2x the fp32 mode's rate: the mode
+ * for results that must meet the tolerance as written.  EMP_PRECISION=fp16x3 selects it. */
 EMP_API int emp_pdl_set_precision(emp_pdl_t* net, int precision);
 EMP_API int emp_pdl_precision(const emp_pdl_t* net);
 /* Number of parameters the network expects, and the name of the i-th one. */

@@ -62,7 +62,7 @@ def test_a_stuck_slab_job_costs_the_block_not_the_headline():
     """the z-slab job runs as a child job with a bound (bench.slab_job_child): one that does not finish is killed and
     leaves an `error` entry; the headline line of the N ranks is printed all the same"""
     j = _bench(['--gpus', '2', '--steps', '1', '--warmup', '1', '--batch', '2', '--size', '256', '--slab-size', '512',
-                '--slab-depth', '6', '--engine2d', '0', '--latency', '0', '--no-cpu-baseline', '--slab-timeout', '4'],
+                '--slab-depth', '6', '--engine2d', '0', '--latency', '0', '--no-cpu-baseline', '--slab-timeout', '1.5'],      # (a warm box finishes the job in under 4 s)
                env={'EMP_BENCH_SHARE_GPU': '1'})
     assert j['n_gpus'] == 2 and j['value'] > 0
     assert 'killed after' in j['stack3d']['error']
