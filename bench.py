@@ -145,11 +145,13 @@ def parity_block(model, eng, ref, sub, mul, dev):
             'final_prob_rms': round(rms(e_prob), 6), 'final_prob_frac_over_1e3': round(float((e_prob > 1e-3).mean()), 6),
             'fg_flip_frac': round(float(((pan > 0) != (want > 0)).mean()), 6),
             'foreground_fraction': round(float((want > 0).mean()), 4),
-            'tolerance': 'north star: 1e-3; met in rms on the centre / semantic heat-maps, NOT in the max norm with fp16 maps '
-                         '(DESIGN.md section 2); label maps are bit-exact given identical head tensors'}
+            'tolerance': 'north star: 1e-3.  The fp16 engine (this line\'s `value`) sits AT 1e-3 in rms -- 0.82e-3 .. 1.38e-3 on the centre map '
+                         'over 8 tiles x 3 weight seeds (profiles/r05_parity_stats.json) -- and at ~5e-3 in the max norm; the mode that '
+                         'meets 1e-3 in the max norm on every sample is precision=\'fp16x3\' (`fp16x3_mode` in this line), the exact one '
+                         '\'fp32\'.  Label maps are bit-exact given identical head tensors'}
 
 
-def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3, precision='fp32'):
+def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3, precision='fp32', ref=None):
     """Rate of the library's fp32 REFERENCE MODE (precision='fp32', csrc/ref32.hip) or of its fp16x3 mode (the same graph with
     split-fp16 convolutions on the fp16 matrix pipe, csrc/conv16x3.hip) on the same workload: the same step (forward +
     probability + voting + merge -> int64 label maps) over `batch` of the bench's tiles, outside the timed region of
@@ -190,6 +192,18 @@ def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3, precisi
                        '(operands split hi + lo, fp32 accumulate); heads within 1e-3 of the fp32 forward in the MAX norm on every '
                        'one of 8 tiles x 3 weight seeds (2.4e-5 worst, tests/test_gpu_fp16x3.py) -- the tolerance-compliant mode '
                        'for throughput; same step as `value`'}
+    if ref:      # the checker side: the oracle's fp32 heads of tile 0 of the cpu_baseline sample (cpu_baseline(keep=))
+        import numpy as np
+        sig = lambda v: 1.0 / (1.0 + np.exp(-v.astype(np.float64)))
+        o = m32(torch.from_numpy(ref['tile'])[None, None].to(dev), 2, interpolate_ins=False, sub=float(sub), mul=float(mul))
+        o = {k: v.float().cpu().numpy() for k, v in o.items()}
+        h4, w4 = o['ctr_hmp'].shape[-2:]
+        coarse = m32.tap_raw('semantic_head.out', (1, o['sem_logits'].shape[1], h4, w4)).float().cpu().numpy()
+        res['parity'] = {'vs': 'fp32 oracle forward, tile 0 of the cpu_baseline sample',
+                         'ctr_max': float(np.abs(o['ctr_hmp'] - ref['ctr_hmp']).max()),
+                         'sem_max': float(np.abs(sig(coarse) - sig(ref['sem_coarse'])).max()),
+                         'off_max_px': float(np.abs(o['offsets'] - ref['offsets']).max()),
+                         'tolerance': 'north star: 1e-3 -- met in the MAX norm'}
     del m32, e32
     torch.cuda.empty_cache()
     return res
@@ -525,8 +539,8 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
             assert outs[0].dtype == np.int32 and outs[0].shape == (S, S)
         except Exception as e:
             res['engine2d_tiles_per_s'] = {'error': f'{type(e).__name__}: {e}'}
+    ref0 = {}
     if world == 1 and not args.no_cpu_baseline:
-        ref0 = {}
         res['cpu_baseline'] = cpu_baseline(cfg, P, S, args.cpu_tiles, 1234, keep=ref0)
         try:
             res['parity'] = parity_block(model, eng, ref0, sub, mul, dev)
@@ -541,9 +555,11 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
     else:
         res['cpu_baseline'] = None
     if world == 1 and args.fp32_mode > 0 and S <= 1024:
+        ref_heads = ref0 if (not args.no_cpu_baseline and 'ctr_hmp' in ref0) else None
         for key, prec, mult in (('fp32_mode', 'fp32', 1), ('fp16x3_mode', 'fp16x3', 2)):
             try:
-                res[key] = fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=min(mult * args.fp32_mode, B), precision=prec)
+                res[key] = fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=min(mult * args.fp32_mode, B), precision=prec,
+                                           ref=ref_heads)
             except Exception as e:      # noqa: BLE001 -- the headline line must not depend on the extra measurement
                 res[key] = {'error': f'{type(e).__name__}: {e}'}
     if world == 1 and args.latency:
