@@ -13,17 +13,19 @@
 // Tile: 128 pixels x BN couts (128 or 64), K walked tap-major in steps of 32 channels (two
 // 16-channel chunks, each inside one tap because Cin16 % 16 == 0), four waves; A = weights, B = pixels, so a lane's four
 // accumulator values are four consecutive couts of one pixel (float4 stores).  Operands are staged global -> registers
-// (prefetched two steps ahead) -> split -> LDS (two buffers of fp16 hi / lo tiles, one barrier per step; rows padded to 40
-// halfs: conflict-free ds_read_b128 fragments).  Activations are split in the kernel (5 vector ops per element); weights arrive either as fp32 (the C ABI's
+// (prefetched two steps ahead) -> split -> LDS (two buffers of fp16 hi / lo tiles, one barrier per step; 64-byte rows with an
+// XOR chunk swizzle: conflict-free ds_read_b128 fragments and 128 contiguous bytes per ds_write_b128 lane group).  Activations are split in the kernel (5 vector ops per element); weights arrive either as fp32 (the C ABI's
 // emp_conv2d_nhwc_f16x3) or already split -- `Conv32::wpair`, one uint32 per weight = hi | lo << 16, made once at
 // emp_pdl_finalize by split_pairs -- and then only change lanes (v_perm).
 // Values must fit fp16's range (|x| <= 65504), as every map of the fp16 engine does.
+#include <type_traits>
+
 #include "common.h"
 
 namespace emp {
 namespace {
 
-constexpr int X_BK = 32, X_LD = 40;
+constexpr int X_BK = 32, X_LD = 32;      // LDS rows are the step's 32 halfs = 64 B, four 16-byte chunks
 
 template <int ACT>
 __device__ __forceinline__ float x_act(float x) {
@@ -32,40 +34,40 @@ __device__ __forceinline__ float x_act(float x) {
   return x;
 }
 
-// 16 fp32 values -> 16 hi halfs + 16 lo halfs, written as two 16-byte LDS stores each
-__device__ __forceinline__ void split_store(const float4 (&r)[4], half_t* hi, half_t* lo) {
-  f16x8 h[2], l[2];
+// 16-byte chunk c of tile row r lives at chunk position c ^ swz(r): with the fragment addressing below (lane -> row
+// lane % 16, chunk lane / 16) every one of gfx950's four non-contiguous ds_read_b128 lane groups touches 64 distinct
+// banks -- the image of conv_igemm256.hip.  (Round 5's first layout -- rows padded to 80 B -- measured 50 % of its LDS
+// cycles as bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/conv16x3_pmc.sh.)
+__device__ __forceinline__ int swz(int r) { return (-((r & 15) >> 2)) & 3; }
+
+// 8 fp32 values -> 8 hi halfs + 8 lo halfs, one 16-byte LDS store each
+__device__ __forceinline__ void split_store(const float4 (&r)[2], half_t* hi, half_t* lo) {
+  f16x8 h, l;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < 2; ++q) {
     const float v[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const half_t a = (half_t)v[e];
-      h[q >> 1][(q & 1) * 4 + e] = a;
-      l[q >> 1][(q & 1) * 4 + e] = (half_t)(v[e] - (float)a);
+      h[q * 4 + e] = a;
+      l[q * 4 + e] = (half_t)(v[e] - (float)a);
     }
   }
-  *reinterpret_cast<f16x8*>(hi) = h[0];
-  *reinterpret_cast<f16x8*>(hi + 8) = h[1];
-  *reinterpret_cast<f16x8*>(lo) = l[0];
-  *reinterpret_cast<f16x8*>(lo + 8) = l[1];
+  *reinterpret_cast<f16x8*>(hi) = h;
+  *reinterpret_cast<f16x8*>(lo) = l;
 }
 
-// 16 pre-split weights (uint32 = hi | lo << 16, carried in float4 registers) -> the same two pairs of LDS stores
-__device__ __forceinline__ void pair_store(const float4 (&r)[4], half_t* hi, half_t* lo) {
-  uint4 h[2], l[2];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t p0 = __float_as_uint(r[q].x), p1 = __float_as_uint(r[q].y), p2 = __float_as_uint(r[q].z), p3 = __float_as_uint(r[q].w);
-    const uint32_t h01 = __builtin_amdgcn_perm(p1, p0, 0x05040100u), h23 = __builtin_amdgcn_perm(p3, p2, 0x05040100u);
-    const uint32_t l01 = __builtin_amdgcn_perm(p1, p0, 0x07060302u), l23 = __builtin_amdgcn_perm(p3, p2, 0x07060302u);
-    if (q & 1) { h[q >> 1].z = h01; h[q >> 1].w = h23; l[q >> 1].z = l01; l[q >> 1].w = l23; }
-    else { h[q >> 1].x = h01; h[q >> 1].y = h23; l[q >> 1].x = l01; l[q >> 1].y = l23; }
-  }
-  *reinterpret_cast<uint4*>(hi) = h[0];
-  *reinterpret_cast<uint4*>(hi + 8) = h[1];
-  *reinterpret_cast<uint4*>(lo) = l[0];
-  *reinterpret_cast<uint4*>(lo + 8) = l[1];
+// 8 pre-split weights (uint32 = hi | lo << 16, carried in float4 registers) -> the same two stores
+__device__ __forceinline__ void pair_store(const float4 (&r)[2], half_t* hi, half_t* lo) {
+  uint4 h, l;
+  const uint32_t p0 = __float_as_uint(r[0].x), p1 = __float_as_uint(r[0].y), p2 = __float_as_uint(r[0].z), p3 = __float_as_uint(r[0].w);
+  const uint32_t p4 = __float_as_uint(r[1].x), p5 = __float_as_uint(r[1].y), p6 = __float_as_uint(r[1].z), p7 = __float_as_uint(r[1].w);
+  h.x = __builtin_amdgcn_perm(p1, p0, 0x05040100u); h.y = __builtin_amdgcn_perm(p3, p2, 0x05040100u);
+  h.z = __builtin_amdgcn_perm(p5, p4, 0x05040100u); h.w = __builtin_amdgcn_perm(p7, p6, 0x05040100u);
+  l.x = __builtin_amdgcn_perm(p1, p0, 0x07060302u); l.y = __builtin_amdgcn_perm(p3, p2, 0x07060302u);
+  l.z = __builtin_amdgcn_perm(p5, p4, 0x07060302u); l.w = __builtin_amdgcn_perm(p7, p6, 0x07060302u);
+  *reinterpret_cast<uint4*>(hi) = h;
+  *reinterpret_cast<uint4*>(lo) = l;
 }
 
 template <int ACT, int BM, int BN, bool WPAIR, bool DB>
@@ -73,10 +75,12 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
   constexpr int WC = BN / 64;          // waves along the couts (64 couts each)
   constexpr int WP = 4 / WC;           // waves along the pixels
   constexpr int NJ = BM / WP / 16;     // 16-pixel fragments per wave
-  constexpr int XC = BM / 128;         // 16-channel chunks of the pixel tile per thread and step (BM rows x 2 chunks / 256)
-  // two LDS buffers: step k computes from buffer k % 2 while the operands of step k + 1 (loaded during step k - 1) are split
-  // into the other one and the loads of step k + 2 are in flight -- one barrier per step, two steps of latency cover
-  // DB = false (short K: the launch is its prologue and epilogue): one buffer, two barriers per step, three workgroups per CU
+  constexpr int NXS = BM / 64;         // (row, 8-channel chunk) pieces of the pixel tile per thread and step
+  constexpr int NWS = BN / 64;         // ... of the weight tile
+  // DB: two LDS buffers: step k computes from buffer k % 2 while the operands of step k + 1 (loaded during step k - 1) are
+  // split into the other one and the loads of step k + 2 are in flight -- one barrier per step, two steps of latency
+  // cover.  DB = false (short K: the launch is its prologue and epilogue): one buffer, two barriers per step, three
+  // workgroups per CU
   constexpr int NB = DB ? 2 : 1;
   __shared__ __attribute__((aligned(16))) half_t Xh[NB][BM * X_LD];
   __shared__ __attribute__((aligned(16))) half_t Xl[NB][BM * X_LD];
@@ -90,96 +94,100 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
   const int HoWo = p.Ho * p.Wo;
   const int M = p.N * HoWo;
   const int K = p.KH * p.KW * p.Cin;
-  // staging roles.  pixels: BM == 256: thread -> row tid, both 16-channel chunks; BM == 128: row tid / 2, chunk tid % 2.
-  // weights (BN rows): row tid / 2, chunk tid % 2
-  const int xrow = XC == 2 ? tid : tid >> 1, xch0 = XC == 2 ? 0 : (tid & 1);
-  const int am = m0 + xrow;
-  int an = 0, aoy = 0, aox = 0;
-  const bool xrow_ok = am < M;
-  if (xrow_ok) {
-    an = am / HoWo;
-    const int r = am - an * HoWo;
-    aoy = r / p.Wo;
-    aox = r - aoy * p.Wo;
+  // staging roles: piece s of thread t = row t / 4 + 64 s, 8-channel chunk t % 4 -- eight consecutive lanes store 128
+  // contiguous bytes of two rows (the ds_write_b128 lane group), four lanes load 128 contiguous bytes of one row
+  const int srow = tid >> 2, sch = tid & 3;
+  int an[NXS], aoy[NXS], aox[NXS];
+  bool xok[NXS];
+#pragma unroll
+  for (int s2 = 0; s2 < NXS; ++s2) {
+    const int am = m0 + srow + 64 * s2;
+    xok[s2] = am < M;
+    an[s2] = aoy[s2] = aox[s2] = 0;
+    if (xok[s2]) {
+      an[s2] = am / HoWo;
+      const int r = am - an[s2] * HoWo;
+      aoy[s2] = r / p.Wo;
+      aox[s2] = r - aoy[s2] * p.Wo;
+    }
   }
-  const int wr = tid >> 1, wch = tid & 1;
-  const bool wrole = wr < BN;
-  const bool wok = wrole && n0 + wr < p.Cout;
-  const float* wrow = WPAIR ? reinterpret_cast<const float*>(p.wpair) : p.w;
-  wrow = wok ? wrow + (size_t)(gco + n0 + wr) * K : nullptr;
+  const float* wrow[NWS];
+#pragma unroll
+  for (int s2 = 0; s2 < NWS; ++s2) {
+    const int co = n0 + srow + 64 * s2;
+    const float* base = WPAIR ? reinterpret_cast<const float*>(p.wpair) : p.w;
+    wrow[s2] = co < p.Cout ? base + (size_t)(gco + co) * K + sch * 8 : nullptr;
+  }
   const int wc = (wave % WC) * 64, wp = (wave / WC) * (NJ * 16);
   f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float4 rx[XC][4], rw[4];
-  auto gload = [&](int k0) {
+  // (a second register set -- loads issued three steps ahead instead of two -- measured 3 % slower: 204 VGPRs)
+  constexpr int NR = 1;
+  float4 rx[NR][NXS][2], rw[NR][NWS][2];
+  // the loader walks K in order (every call is the next step): tap and channel of this thread's chunk advance by
+  // increments -- no division inside the loop (round 5: the two integer divisions and the 64-bit index arithmetic of a
+  // per-step recomputation were a third of the kernel's vector instructions)
+  int g_k = sch * 8, g_c0 = sch * 8, g_ky = 0, g_kx = 0;
+  while (g_c0 >= p.Cin) { g_c0 -= p.Cin; if (++g_kx == p.KW) { g_kx = 0; ++g_ky; } }      // (a chunk of 8 channels lies inside one tap: Cin % 16 == 0)
+  int oy0[NXS], ox0[NXS], pix0[NXS];
 #pragma unroll
-    for (int c = 0; c < XC; ++c) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rx[c][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int kk = k0 + (xch0 + c) * 16;
-      if (xrow_ok && kk < K) {
-        const int tap = kk / p.Cin, c0 = kk - tap * p.Cin;
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const int iy = aoy * p.stride - p.pad + ky * p.dil, ix = aox * p.stride - p.pad + kx * p.dil;
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-          const float4* src = reinterpret_cast<const float4*>(gin + (((size_t)an * p.H + iy) * p.W + ix) * p.in_ld + c0);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) rx[c][q] = src[q];
-        }
-      }
-    }
-    const int kw = k0 + wch * 16;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (wrow && kw < K) {
-      const float4* src = reinterpret_cast<const float4*>(wrow + kw);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rw[q] = src[q];
-    }
-  };
-  auto stage = [&](int b) {
-#pragma unroll
-    for (int c = 0; c < XC; ++c)
-      split_store(rx[c], Xh[b] + xrow * X_LD + (xch0 + c) * 16, Xl[b] + xrow * X_LD + (xch0 + c) * 16);
-    if (wrole) {
-      if (WPAIR) pair_store(rw, Wh[b] + wr * X_LD + wch * 16, Wl[b] + wr * X_LD + wch * 16);
-      else split_store(rw, Wh[b] + wr * X_LD + wch * 16, Wl[b] + wr * X_LD + wch * 16);
-    }
-  };
-  const int fr = lane & 15, fk = (lane >> 4) * 8;
-  gload(0);
-  if (DB) {
-    stage(0);
-    if (X_BK < K) gload(X_BK);
+  for (int s2 = 0; s2 < NXS; ++s2) {
+    oy0[s2] = aoy[s2] * p.stride - p.pad;
+    ox0[s2] = aox[s2] * p.stride - p.pad;
+    pix0[s2] = an[s2] * p.H * p.W;
   }
-  int b = 0;
-  for (int k0 = 0; k0 < K; k0 += X_BK, b ^= (DB ? 1 : 0)) {
-    if (DB) {
-      __syncthreads();      // buffer b is complete; nobody reads buffer b ^ 1 (step k - 1) any more
-      if (k0 + X_BK < K) {
-        stage(b ^ 1);                                   // the registers hold step k + 1
-        if (k0 + 2 * X_BK < K) gload(k0 + 2 * X_BK);    // in flight behind this step's and the next step's MFMAs
-      }
-    } else {
-      __syncthreads();      // the previous step's fragment reads are done
-      stage(0);
-      __syncthreads();
-      if (k0 + X_BK < K) gload(k0 + X_BK);
+  auto gload = [&](int k0, auto RS) {
+    constexpr int rs = decltype(RS)::value;
+    // every piece is loaded unconditionally: an out-of-range one (padding tap, row beyond M / Cout, K tail) reads the zero
+    // page instead -- no zero-filled registers, no divergent branch around the loads
+    const bool kok = g_k < K;
+#pragma unroll
+    for (int s2 = 0; s2 < NXS; ++s2) {
+      const int iy = oy0[s2] + g_ky * p.dil, ix = ox0[s2] + g_kx * p.dil;
+      const bool ok = xok[s2] && kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const float4* src = reinterpret_cast<const float4*>(ok ? gin + (size_t)(pix0[s2] + iy * p.W + ix) * p.in_ld + g_c0 : p.zero);
+      rx[rs][s2][0] = src[0];
+      rx[rs][s2][1] = src[1];
     }
+#pragma unroll
+    for (int s2 = 0; s2 < NWS; ++s2) {
+      const float4* src = reinterpret_cast<const float4*>((wrow[s2] && kok) ? wrow[s2] + k0 : p.zero);
+      rw[rs][s2][0] = src[0];
+      rw[rs][s2][1] = src[1];
+    }
+    g_k += X_BK;
+    g_c0 += X_BK;
+    while (g_c0 >= p.Cin) { g_c0 -= p.Cin; if (++g_kx == p.KW) { g_kx = 0; ++g_ky; } }
+  };
+  const int soff = srow * X_LD + ((sch ^ swz(srow)) << 3);      // (row + 64 s keeps the row's swizzle key)
+  auto stage = [&](int b, auto RS) {
+    constexpr int rs = decltype(RS)::value;
+#pragma unroll
+    for (int s2 = 0; s2 < NXS; ++s2) split_store(rx[rs][s2], Xh[b] + soff + s2 * 64 * X_LD, Xl[b] + soff + s2 * 64 * X_LD);
+#pragma unroll
+    for (int s2 = 0; s2 < NWS; ++s2) {
+      if (WPAIR) pair_store(rw[rs][s2], Wh[b] + soff + s2 * 64 * X_LD, Wl[b] + soff + s2 * 64 * X_LD);
+      else split_store(rw[rs][s2], Wh[b] + soff + s2 * 64 * X_LD, Wl[b] + soff + s2 * 64 * X_LD);
+    }
+  };
+  const int fr = lane & 15, fq = lane >> 4;
+  const int foff = fr * X_LD + ((fq ^ swz(fr)) << 3);           // fragment: row fr of a 16-row block, chunk fq
+  using R0 = std::integral_constant<int, 0>;
+  auto mma = [&](int b) {
     // the wave's weight fragments stay in registers for the step (32 VGPRs); the pixel fragments stream through
     f16x8 wh[4], wl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      wh[i] = *reinterpret_cast<const f16x8*>(Wh[b] + (wc + i * 16 + fr) * X_LD + fk);
-      wl[i] = *reinterpret_cast<const f16x8*>(Wl[b] + (wc + i * 16 + fr) * X_LD + fk);
+      wh[i] = *reinterpret_cast<const f16x8*>(Wh[b] + (wc + i * 16) * X_LD + foff);
+      wl[i] = *reinterpret_cast<const f16x8*>(Wl[b] + (wc + i * 16) * X_LD + foff);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const f16x8 xh = *reinterpret_cast<const f16x8*>(Xh[b] + (wp + j * 16 + fr) * X_LD + fk);
-      const f16x8 xl = *reinterpret_cast<const f16x8*>(Xl[b] + (wp + j * 16 + fr) * X_LD + fk);
+      const f16x8 xh = *reinterpret_cast<const f16x8*>(Xh[b] + (wp + j * 16) * X_LD + foff);
+      const f16x8 xl = *reinterpret_cast<const f16x8*>(Xl[b] + (wp + j * 16) * X_LD + foff);
       // consecutive MFMAs write different accumulators (a dependent one would wait for its predecessor's passes)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh, acc[i][j], 0, 0, 0);
@@ -187,6 +195,31 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl, acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh, acc[i][j], 0, 0, 0);
+    }
+  };
+  if (DB) {
+    // step k computes from LDS buffer k % 2 while the registers (step k + 1, loaded during step k - 1) are split into the
+    // other buffer and the loads of step k + 2 go out: one barrier per step, two steps of MFMAs between a load and its use
+    gload(0, R0());
+    stage(0, R0());
+    if (X_BK < K) gload(X_BK, R0());
+    int b = 0;
+    for (int k0 = 0; k0 < K; k0 += X_BK, b ^= 1) {
+      __syncthreads();      // buffer b is complete; nobody reads buffer b ^ 1 (step k - 1) any more
+      if (k0 + X_BK < K) {
+        stage(b ^ 1, R0());
+        if (k0 + 2 * X_BK < K) gload(k0 + 2 * X_BK, R0());
+      }
+      mma(b);
+    }
+  } else {
+    gload(0, R0());
+    for (int k0 = 0; k0 < K; k0 += X_BK) {
+      __syncthreads();      // the previous step's fragment reads are done
+      stage(0, R0());
+      __syncthreads();
+      if (k0 + X_BK < K) gload(k0 + X_BK, R0());
+      mma(0);
     }
   }
   // epilogue (conv32_kernel's): bias (+ per-image bias) (+ residual), activation, store (NHWC slice or k2s2 pixel shuffle).
@@ -296,11 +329,15 @@ __global__ void __launch_bounds__(256) split_pairs_kernel(const float* __restric
 
 // the checks of launch_conv32 (ref32.hip) have run: same contract
 int launch_conv16x3(const Conv32& p, hipStream_t s) {
-  if (p.wpair) {
-    EMP_REQUIRE(((uintptr_t)p.wpair % 16) == 0, "conv16x3: misaligned weight pairs");
-    return launch_pair<true>(p, s);
+  EMP_REQUIRE((int64_t)p.N * p.H * p.W < (1ll << 31), "conv16x3: input map too large for 32-bit pixel indices");
+  Conv32 q = p;
+  q.zero = reinterpret_cast<const float*>(zero_page());
+  EMP_REQUIRE(q.zero != nullptr, "conv16x3: no zero page");
+  if (q.wpair) {
+    EMP_REQUIRE(((uintptr_t)q.wpair % 16) == 0, "conv16x3: misaligned weight pairs");
+    return launch_pair<true>(q, s);
   }
-  return launch_pair<false>(p, s);
+  return launch_pair<false>(q, s);
 }
 
 // fp32 weights -> one uint32 per weight: fp16(x) | fp16(x - fp16(x)) << 16 (emp_pdl_finalize in the fp16x3 mode)
