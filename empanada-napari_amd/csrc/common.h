@@ -174,6 +174,7 @@ struct Conv32 {
   int groups;       // > 1: grouped convolution -- Cout and Cin are PER GROUP (Cin padded to 16), weights [G * Cout][KH*KW][Cin]
   int cin_g;        // grouped: real input channels per group (the channel step from one group to the next); else 0
   int x3;           // 1: the fp16x3 mode -- the same convolution on the fp16 matrix pipe with split operands (conv16x3.hip)
+  int x3_mt, x3_nt, x3_mtx;   // x3 only: pixel tiles, cout tiles, pixel tiles per XCD (set by launch_conv16x3)
   const float* zero;          // x3 only: 64 B of zeros (the source of out-of-range operand chunks), set by launch_conv16x3
   const uint32_t* wpair;      // x3 only, optional: the weights already split, one uint32 = fp16 hi | fp16 lo << 16, layout of `w`
 };

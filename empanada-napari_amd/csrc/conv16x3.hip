@@ -87,7 +87,16 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
   __shared__ __attribute__((aligned(16))) half_t Wh[NB][BN * X_LD];
   __shared__ __attribute__((aligned(16))) half_t Wl[NB][BN * X_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // XCD-aware raster (consecutive workgroup ids go round-robin over the 8 XCDs): XCD x owns the pixel tiles
+  // [x * mtx, (x + 1) * mtx) and walks them with the cout tile fastest, so the nt workgroups that read the same pixel tile
+  // run side by side on ONE XCD and share it through that XCD's L2 (with blockIdx.y = cout tile they were a whole grid row
+  // apart: every cout tile re-read its pixels from HBM)
+  // x3_mtx == 0 (short K or one cout tile, where the raster measured slower): pixel tile fastest, the cout tiles a grid row apart
+  const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;
+  const int mtile = p.x3_mtx ? xcd * p.x3_mtx + jj / p.x3_nt : bid % p.x3_mt;
+  const int ntile = p.x3_mtx ? jj % p.x3_nt : bid / p.x3_mt;
+  if (mtile >= p.x3_mt) return;
+  const int m0 = mtile * BM, n0 = ntile * BN;
   // grouped convolution (RegNet's 3x3): blockIdx.z = group, as conv32_kernel (ref32.hip)
   const int g = blockIdx.z, gco = g * p.Cout;
   const float* gin = p.in + (size_t)g * p.cin_g;
@@ -302,14 +311,19 @@ int launch_tile(const Conv32& p, dim3 grid, hipStream_t s) {
 }
 
 template <bool WPAIR>
-int launch_pair(const Conv32& p, hipStream_t s) {
+int launch_pair(Conv32 p, hipStream_t s) {
   const int G = p.groups > 1 ? p.groups : 1;
   const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
   const int bn = p.Cout > 64 ? 128 : 64;
   const unsigned nt = (unsigned)((p.Cout + bn - 1) / bn);
   // (a 256-pixel tile -- half the weight tile's trips through LDS per product -- measured 1.4-2.4x SLOWER on every shape of
   // the network at batch 8: one workgroup per CU leaves nothing to run behind a barrier; profiles/r05_conv16x3.txt)
-  const dim3 grid((unsigned)((M + 127) / 128), nt, (unsigned)G);
+  p.x3_mt = (int)((M + 127) / 128);
+  p.x3_nt = (int)nt;
+  const int kk = p.KH * p.KW * p.Cin;
+  const int rk = [] { const char* e = getenv("EMP_X3_RASTER_K"); return e ? atoi(e) : 256; }();
+  p.x3_mtx = (nt >= 2 && kk >= rk) ? (p.x3_mt + 7) / 8 : 0;
+  const dim3 grid((unsigned)(p.x3_mtx ? 8 * p.x3_mtx * p.x3_nt : p.x3_mt * p.x3_nt), 1u, (unsigned)G);
   const int kdb = [] { const char* e = getenv("EMP_X3_KDB"); return e ? atoi(e) : 1024; }();     // K from which the two-buffer pipeline runs (measured: profiles/r05_conv16x3.txt)
   const bool db = p.KH * p.KW * p.Cin >= kdb;
   if (db) return bn == 128 ? launch_tile<128, 128, WPAIR, true>(p, grid, s) : launch_tile<128, 64, WPAIR, true>(p, grid, s);
