@@ -22,7 +22,9 @@ PER_FILE = {
     'postprocess.hip': ['-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt'],
 }
 SOURCES = ['abi.hip', 'conv_igemm.hip', 'layers.hip', 'pointrend.hip', 'postprocess.hip', 'pdl_net.hip', 'sparse.hip',
-           'sepconv.hip', 'sepconv_precise.hip', 'conv_igemm256.hip', 'conv_igemm_s64.hip', 'conv3x3c64.hip', 'stem.hip', 'matcher.hip', 'ref32.hip', 'conv16x3.hip']
+           'sepconv.hip', 'sepconv_precise.hip', 'conv_igemm256.hip', 'conv_igemm_s64.hip', 'conv3x3c64.hip', 'stem.hip', 'matcher.hip', 'ref32.hip', 'conv16x3.hip', 'conv_igemm_grouped.hip']
+# sources that #include another source: rebuilt when that one changes
+INCLUDES = {'conv_igemm_grouped.hip': ['conv_igemm.hip']}
 
 
 def _hipcc():
@@ -49,7 +51,8 @@ def build_all(verbose=False, force=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace('.hip', '.o'))
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr):
+        dep = max([os.path.getmtime(s), hdr] + [os.path.getmtime(os.path.join(CSRC, d)) for d in INCLUDES.get(src, [])])
+        if force or not os.path.exists(o) or os.path.getmtime(o) < dep:
             cmd = [hipcc] + COMMON + PER_FILE.get(src, []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)

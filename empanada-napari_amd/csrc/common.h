@@ -88,6 +88,8 @@ struct ConvParams {
 
 // variant: 0 = auto, 1 = register-staged, 2 = LDS-DMA staged
 int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream);
+// the generic tile as a grouped convolution, blockIdx.y = group (conv_igemm_grouped.hip): p describes one group
+int launch_conv_igemm_grouped(const ConvParams& p, int groups, int gs_in, long long gs_w, int gs_out, hipStream_t stream);
 // 256x256 tile for the MFMA-bound layers (conv_igemm256.hip)
 bool conv_igemm256_supported(const ConvParams& p);
 bool conv_uses_256(const ConvParams& p);      // launch_conv_igemm's auto choice

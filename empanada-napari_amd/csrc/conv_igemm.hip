@@ -34,6 +34,27 @@
 // the cout tiles of one pixel tile run back to back on the same XCD.
 #include "common.h"
 
+// The same kernel as a GROUPED convolution (nn.Conv2d(groups = g): the 3x3 of a RegNet bottleneck) is compiled from this
+// source by conv_igemm_grouped.hip, which defines EMP_IGEMM_GROUPED before including it: blockIdx.y = group, the group's
+// input-channel / weight / output-channel strides arrive as extra KERNEL ARGUMENTS and ConvParams is untouched -- the struct
+// is part of the tuned kernels' code generation (FINDINGS 44).  In this translation unit both macros expand to the tokens
+// that were here before.
+#ifdef EMP_IGEMM_GROUPED
+#define EMP_IGEMM_KARGS const ConvParams p_, const int gs_in, const long long gs_w, const int gs_out
+#define EMP_IGEMM_KPROLOGUE                                                \
+  ConvParams p = p_;                                                       \
+  {                                                                        \
+    const int g_ = blockIdx.y;                                             \
+    p.in += (size_t)g_ * gs_in;                                            \
+    p.wgt += (size_t)g_ * (size_t)gs_w;                                    \
+    p.out += (size_t)g_ * gs_out;                                          \
+    if (p.bias) p.bias += (size_t)g_ * gs_out;                             \
+  }
+#else
+#define EMP_IGEMM_KARGS const ConvParams p
+#define EMP_IGEMM_KPROLOGUE
+#endif
+
 #include <type_traits>
 
 namespace emp {
@@ -88,7 +109,8 @@ __device__ __forceinline__ size_t out_offset(const ConvParams& p, int m, int co,
 }
 
 template <int BM, int BN, int WPM, int WPN, bool GLDS, bool EPI_LDS, int OCC>
-__global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(EMP_IGEMM_KARGS) {
+  EMP_IGEMM_KPROLOGUE
   constexpr int TM = BM / WPM, TN = BN / WPN;
   constexpr int PT = TM / 16, CT = TN / 16;
   constexpr int A_ITERS = BM / 32, B_ITERS = BN / 32;
@@ -419,6 +441,48 @@ __global__ void __launch_bounds__(256, OCC) conv_igemm_kernel(const ConvParams p
   }
 }
 
+#ifdef EMP_IGEMM_GROUPED
+template <int BM, int BN, int WPM, int WPN, bool GLDS, bool EPI_LDS, int OCC = 2>
+int launch_grouped_tpl(ConvParams p, int groups, int gs_in, long long gs_w, int gs_out, hipStream_t stream) {
+  p.mt = cdiv(p.M, BM);
+  p.nt = cdiv(p.Cout, BN);
+  p.mt_per_xcd = cdiv(p.mt, 8);
+  const int grid = 8 * p.mt_per_xcd * p.nt;
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WPM, WPN, GLDS, EPI_LDS, OCC>), dim3(grid, groups), dim3(256), 0, stream, p, gs_in,
+                     gs_w, gs_out);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+}  // namespace
+
+// p describes ONE group (Cin = the group's input channels padded to 64 with zero weights, Cout = its output channels);
+// group g reads p.in + g * gs_in, weights p.wgt + g * gs_w, writes p.out + g * gs_out (bias likewise).  Plain conv only.
+int launch_conv_igemm_grouped(const ConvParams& p, int groups, int gs_in, long long gs_w, int gs_out, hipStream_t stream) {
+  EMP_REQUIRE(groups >= 1 && groups < 65536, "grouped conv: bad group count %d", groups);
+  EMP_REQUIRE(p.Cin % BK == 0 && p.Cin > 0 && p.in_ld % 8 == 0 && (groups - 1) * gs_in + p.Cin <= p.in_ld && gs_in % 8 == 0,
+              "grouped conv: Cin=%d (multiple of 64), channel step %d (multiple of 8), row %d", p.Cin, gs_in, p.in_ld);
+  EMP_REQUIRE(p.Cout % 8 == 0 && p.Cout > 0 && gs_out % 8 == 0 && gs_out >= p.Cout && p.out_ld % 8 == 0 &&
+                  (groups - 1) * gs_out + p.Cout <= p.out_ld, "grouped conv: Cout=%d, cout step %d, row %d", p.Cout, gs_out, p.out_ld);
+  EMP_REQUIRE(gs_w % 8 == 0 && gs_w >= (long long)p.Cout * p.KH * p.KW * p.Cin, "grouped conv: weight stride %lld", gs_w);
+  EMP_REQUIRE(!p.in2 && !p.out2 && !p.out3 && !p.next_w && !p.res && !p.bias_n && p.ps_cout == 0, "grouped conv: plain convolutions only");
+  EMP_REQUIRE(p.act >= 0 && p.act <= 2, "grouped conv: act must be 0, 1 or 2");
+  EMP_REQUIRE(((uintptr_t)p.in % 16) == 0 && ((uintptr_t)p.out % 16) == 0 && ((uintptr_t)p.wgt % 16) == 0 &&
+                  ((uintptr_t)p.zero % 256) == 0 && p.zero != nullptr, "grouped conv: pointers must be 16-byte aligned (zero page 256)");
+  EMP_REQUIRE((int64_t)p.N * p.Ho * p.Wo < (1ll << 31), "grouped conv: too many output pixels");
+  ConvParams q = p;
+  {
+    const int CB = p.Cin / 64, KT = p.KH * p.KW;
+    int kg = (KT > 1 && CB > 4 && CB % 4 == 0) ? 4 : CB;
+    q.kgroup = kg;
+  }
+  // 64-wide cout tiles when they pad less (56 -> 64, 72 -> 128 either way: the 128 x 64 tile then has twice the workgroups)
+  if (p.Cout <= 64 || cdiv(p.Cout, 64) * 64 <= cdiv(p.Cout, 128) * 128)
+    return launch_grouped_tpl<128, 64, 2, 2, true, true, 3>(q, groups, gs_in, gs_w, gs_out, stream);
+  return launch_grouped_tpl<128, 128, 2, 2, true, true>(q, groups, gs_in, gs_w, gs_out, stream);
+}
+
+#else   // !EMP_IGEMM_GROUPED
 template <int BM, int BN, int WPM, int WPN, bool GLDS, bool EPI_LDS, int OCC = 2>
 int launch_tpl(ConvParams p, hipStream_t stream) {
   p.mt = cdiv(p.M, BM);
@@ -564,5 +628,7 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   if (v == 2) return launch_tpl<64, 64, 2, 2, true, false, 5>(q, stream);
   return launch_tpl<64, 64, 2, 2, true, true, 5>(q, stream);
 }
+
+#endif  // EMP_IGEMM_GROUPED
 
 }  // namespace emp

@@ -106,6 +106,10 @@ struct emp_pdl {
     return 0;
   }();
   bool fp32_graph() const { return precision != 0; }
+  // RegNet on the fp16 engine: the grouped 3x3 as ONE launch (blockIdx.y = group, conv_igemm_grouped.hip); EMP_REGNET_GROUPED=0:
+  // one launch per group with its couts padded to 64 / 128 for the register-weight kernels (round 4; A/B)
+  bool regnet_grouped = [] { const char* e = getenv("EMP_REGNET_GROUPED"); return !(e && e[0] == '0'); }();
+  int64_t regnet_group_tiles = [] { const char* e = getenv("EMP_REGNET_GROUP_TILES"); return e ? atoll(e) : 2048ll; }();
   struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; };
   std::map<std::string, W32> w32;
   std::map<std::string, std::pair<float*, size_t>> pool32;      // name -> (device buffer, floats)
@@ -835,9 +839,30 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
         const std::string p = "encoder.stage" + std::to_string(si) + ".block" + std::to_string(b);
         const int sb = b == 1 ? c.rn_strides[si - 1] : 1;
         RC(conv(n, p + ".bottleneck.a.0", A(xname), 0, A(p + ".a"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
-        for (int gi = 0; gi < g; ++gi)
-          RC(conv(n, p + ".bottleneck.b.0#" + std::to_string(gi), A(p + ".a"), gi * gw, A(p + ".b"), gi * gw, sb, 1, 1, 1, nullptr,
-                  nullptr, s));
+        // one grouped launch, unless every group alone already fills the chip with the register-weight 3x3 kernel's tiles
+        // (stride 1, >= 2048 tiles of 8 x 16 pixels: the big maps of a big batch, where that kernel is the faster one)
+        const Act& ain = A(p + ".a");
+        const bool per_group = !n->regnet_grouped || (sb == 1 && (int64_t)N * cdiv(ain.H, 8) * cdiv(ain.W, 16) >= n->regnet_group_tiles);
+        if (!per_group) {
+          // one launch, blockIdx.y = group (conv_igemm_grouped.hip): Cout = the group width exactly, Cin = it padded to 64
+          const DevConv& dc = n->convs.at(p + ".bottleneck.b.0#grouped");
+          const Act& in = A(p + ".a");
+          const Act& out = A(p + ".b");
+          ConvParams q{};
+          q.in = in.p; q.wgt = dc.w; q.bias = dc.b; q.out = out.p; q.zero = rawp<half_t>(n, "zero");
+          q.N = in.N; q.H = in.H; q.W = in.W; q.Cin = dc.cin_pad; q.in_ld = in.ld;
+          q.Cout = gw; q.KH = 3; q.KW = 3; q.stride = sb; q.pad = 1; q.dil = 1;
+          q.Ho = (in.H + 2 - 3) / sb + 1;
+          q.Wo = (in.W + 2 - 3) / sb + 1;
+          EMP_REQUIRE(q.Ho == out.H && q.Wo == out.W && in.N == out.N, "%s: grouped 3x3 output shape mismatch", p.c_str());
+          q.out_ld = out.ld; q.act = 1; q.M = q.N * q.Ho * q.Wo;
+          n->flops += 2.0 * (double)q.M * cw * (double)(gw * 9);
+          RC(launch_conv_igemm_grouped(q, g, gw, (long long)gw * 9 * dc.cin_pad, gw, s));
+        } else {
+          for (int gi = 0; gi < g; ++gi)
+            RC(conv(n, p + ".bottleneck.b.0#" + std::to_string(gi), A(p + ".a"), gi * gw, A(p + ".b"), gi * gw, sb, 1, 1, 1, nullptr,
+                    nullptr, s));
+        }
         if (c.rn_se) {
           RC(conv(n, p + ".bottleneck.se.se.0#pad", A(p + ".b"), 0, A(p + ".se1"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
           RC(conv(n, p + ".bottleneck.se.se.2", A(p + ".se1"), 0, A(p + ".se2"), 0, 1, 0, 1, 0, nullptr, nullptr, s));
@@ -1980,6 +2005,15 @@ int emp_pdl_finalize(emp_pdl_t* n) {
             std::copy(hb.b.begin() + (size_t)gi * gw, hb.b.begin() + (size_t)(gi + 1) * gw, t.b.begin());
             const std::string tn = p + ".bottleneck.b.0#" + std::to_string(gi);
             n->params[tn] = t;
+            const int rc = pack_conv(n, tn);
+            n->params.erase(tn);
+            if (rc) return rc;
+          }
+          // ... and all groups in one blob [g][gw][9][gw padded to 64] for the grouped launch (no cout padding: a group
+          // stores its own couts only, the groups run side by side)
+          {
+            const std::string tn = p + ".bottleneck.b.0#grouped";
+            n->params[tn] = hb;
             const int rc = pack_conv(n, tn);
             n->params.erase(tn);
             if (rc) return rc;
