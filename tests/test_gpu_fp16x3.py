@@ -207,3 +207,66 @@ def test_fp16x3_rate():
     print('rates:', rate)
     _save('rate_batch8_1024', rate)
     assert rate['fp16x3']['tiles_per_s'] > 1.5 * rate['fp32']['tiles_per_s'], rate
+
+
+def test_fp16x3_through_the_engine2d_api():
+    """a maintainer selects the mode with one key of the model config (`model_config['precision'] = 'fp16x3'`, no reference
+    counterpart): Engine2d builds the network from the state dict in that mode, and its label map is the oracle pipeline's
+    on the fp32 forward's heads up to fp32 near-ties -- what the fp16 engine cannot promise (0.13 % foreground flips)"""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.inference import Engine2d
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model, postprocess as opp, sparse as osp
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg = dict(weights.MITONET_PDL_CFG)
+    sd = weights.seeded_state_dict(cfg, seed=0)
+    for name, shift in (('ins_center.head.1.bias', 0.75), ('semantic_head.head.1.bias', 1.0), ('semantic_pr.point_head.predictor.bias', 1.0)):
+        sd[name] = sd[name] + shift
+    mc = {'model': sd, 'precision': 'fp16x3', 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+          'norms': {'mean': 0.57571, 'std': 0.12765}}
+    eng = Engine2d(mc, label_divisor=10000, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5)
+    assert eng.engine.model.precision == 'fp16x3'
+    img = synth.em_tiles(1, 512, seed=31)[0]
+    got = eng.infer(img)
+    assert got.shape == img.shape and got.dtype == np.int32
+    P = weights.fold_state_dict(sd, cfg)
+    x = torch.from_numpy(normalize(img[None], 0.57571, 0.12765))[:, None]
+    ref = {k: v.numpy() for k, v in pdl_model.pdl_forward(P, x, cfg, 2, False).items()}
+    ref['sem'] = opp.logits_to_prob(ref['sem_logits'])
+    oeng = opp.RenderEngine(lambda *_: ref, [1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                            coarse_boundaries=True)
+    want = osp.force_connected_pan(oeng.postprocess(ref['sem'], oeng.cells(ref['ctr_hmp'], ref['offsets'], 1))[0].astype(np.int32), [1], 10000)
+    n_ref, n_got = len(np.unique(want)) - 1, len(np.unique(got)) - 1
+    flips = float(((got > 0) != (want > 0)).mean())
+    print(f'Engine2d fp16x3: {n_got} vs {n_ref} instances, foreground flips {flips:.2e}')
+    assert n_ref > 20 and abs(n_got - n_ref) <= 1 and flips < 2e-4
+
+
+@pytest.mark.parametrize('tag', ['x', 'y'])
+def test_fp16x3_regnet_forward_vs_the_fp32_mode(tag):
+    """RegNet encoders (grouped 3x3 on blockIdx.z, per-pixel squeeze-excite gate) in the fp16x3 mode against the fp32 mode
+    -- the library's default for them -- on two 512^2 tiles: heads within 1e-3 in the max norm"""
+    sys_path = os.path.join(ROOT, 'tests')
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from test_regnet import regnet_model
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize_params
+    cfg, P = regnet_model(tag)
+    tiles = torch.from_numpy(synth.em_tiles(2, 512, seed=5))[:, None].cuda()
+    sub, mul = normalize_params(0.57571, 0.12765, 255)
+    outs = {}
+    for prec in ('fp16x3', 'fp32'):
+        m = HipPanopticDeepLab(P, cfg, folded=True, precision=prec)
+        assert m.precision == prec
+        outs[prec] = {k: v.double() for k, v in m(tiles, 2, False, sub=float(sub), mul=float(mul)).items()}
+        torch.cuda.synchronize()
+        del m
+    for k in ('ctr_hmp', 'offsets'):
+        a, b = outs['fp16x3'][k], outs['fp32'][k]
+        scale = max(1.0, float(b.pow(2).mean().sqrt()))
+        err = float((a - b).abs().max()) / scale
+        print(tag, k, err)
+        assert err < TOL, (k, err)
