@@ -113,7 +113,7 @@ EMP_API int emp_pdl_finalize(emp_pdl_t* net);
  * Round 5 (ABI version 3) -- 2: the fp16x3 MODE: the fp32 mode's graph, maps and weights, every convolution on the FP16
  * matrix pipe with both operands split into fp16 pairs and three MFMAs per product into an fp32 accumulator
  * (csrc/conv16x3.hip; weights split once at emp_pdl_finalize).  Heads within 1e-3 of the reference's fp32 forward in the
- * MAX norm on every tile and weight draw tested (2.4e-5 worst on the centre map), at ~2.2x the fp32 mode's rate: the mode
+ * MAX norm on every tile and weight draw tested (2.4e-5 worst on the centre map), at ~2.5x the fp32 mode's rate: the mode
  * for results that must meet the tolerance as written.  EMP_PRECISION=fp16x3 selects it. */
 EMP_API int emp_pdl_set_precision(emp_pdl_t* net, int precision);
 EMP_API int emp_pdl_precision(const emp_pdl_t* net);
