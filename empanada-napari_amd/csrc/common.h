@@ -176,6 +176,10 @@ struct Conv32 {
   int groups;       // > 1: grouped convolution -- Cout and Cin are PER GROUP (Cin padded to 16), weights [G * Cout][KH*KW][Cin]
   int cin_g;        // grouped: real input channels per group (the channel step from one group to the next); else 0
   int x3;           // 1: the fp16x3 mode -- the same convolution on the fp16 matrix pipe with split operands (conv16x3.hip)
+  // x3 only, optional: a fused 1x1 head (heads.py:14) -- the kernel does not store the activation map; instead every cout
+  // tile writes, per pixel, the partial sums of head_c dot products of relu(out) with head_w[h][Cout] over its couts to
+  // head_part[(cout tile * M + pixel) * head_c + h]; launch_head_finish_f32 adds the tiles in ascending order (+ bias)
+  const float* head_w; float* head_part; int head_c;
   int x3_mt, x3_nt, x3_mtx;   // x3 only: pixel tiles, cout tiles, pixel tiles per XCD (set by launch_conv16x3)
   const float* zero;          // x3 only: 64 B of zeros (the source of out-of-range operand chunks), set by launch_conv16x3
   const uint32_t* wpair;      // x3 only, optional: the weights already split, one uint32 = fp16 hi | fp16 lo << 16, layout of `w`
@@ -183,6 +187,8 @@ struct Conv32 {
 int launch_conv32(const Conv32& p, hipStream_t s);
 int launch_conv16x3(const Conv32& p, hipStream_t s);      // called by launch_conv32 when p.x3 (its checks have run)
 int launch_split_pairs(const float* w, uint32_t* out, int64_t n, hipStream_t s);
+int conv16x3_cout_tiles(int Cout);      // cout tiles of a launch (the size of head_part's first dimension)
+int launch_head_finish_f32(const float* part, int tiles, int N, int P, int C, const float* b, float* out, hipStream_t s);
 int launch_stem3x3s2_f32(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
                          const float* w /*[9][C]*/, const float* b, int C, float* out, int out_ld, hipStream_t s);
 int launch_gate_mul_f32(float* x, int x_ld, const float* g, int g_ld, int64_t rows, int C, hipStream_t s);

@@ -70,7 +70,7 @@ __device__ __forceinline__ void pair_store(const float4 (&r)[2], half_t* hi, hal
   *reinterpret_cast<uint4*>(lo) = l;
 }
 
-template <int ACT, int BM, int BN, bool WPAIR, bool DB>
+template <int ACT, int BM, int BN, bool WPAIR, bool DB, bool HEAD = false>
 __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 p) {
   constexpr int WC = BN / 64;          // waves along the couts (64 couts each)
   constexpr int WP = 4 / WC;           // waves along the pixels
@@ -231,6 +231,58 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
       mma(0);
     }
   }
+  if (HEAD) {
+    // fused 1x1 head: per pixel, head_c dot products of the activated outputs with head_w over this workgroup's couts.
+    // Fixed order: a lane's 16 couts ascending, the four lane groups by two butterfly steps, the cout-halves of the tile
+    // (waves wc = 0, 64) in ascending order through LDS, the cout tiles in launch_head_finish_f32 -- deterministic.
+    __syncthreads();                       // the last step's fragment reads are done: the X tiles become scratch
+    float* red = reinterpret_cast<float*>(&Xh[0][0]);      // [WC][BM][4] floats = 4 KiB per cout half
+    const int hcn = p.head_c;
+    float bi[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = n0 + wc + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bi[i][e] = (p.bias && col + e < p.Cout) ? p.bias[gco + col + e] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = n0 + wc + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = col + e < p.Cout ? x_act<ACT>(acc[i][j][e] + bi[i][e]) : 0.f;
+          const int cw = col + e < p.Cout ? col + e : 0;
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+            if (h < hcn) sum[h] = fmaf(v, p.head_w[(size_t)h * p.Cout + cw], sum[h]);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        sum[h] += __shfl_xor(sum[h], 16);
+        sum[h] += __shfl_xor(sum[h], 32);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) red[((wave % WC) * BM + wp + j * 16 + fr) * 4 + h] = sum[h];
+      }
+    }
+    __syncthreads();
+    if (tid < BM) {
+      const int m = m0 + tid;
+      if (m < M) {
+        for (int h = 0; h < hcn; ++h) {
+          float t = red[tid * 4 + h];
+          if (WC == 2) t += red[(BM + tid) * 4 + h];
+          p.head_part[((size_t)ntile * M + m) * hcn + h] = t;
+        }
+      }
+    }
+    return;
+  }
   // epilogue (conv32_kernel's): bias (+ per-image bias) (+ residual), activation, store (NHWC slice or k2s2 pixel shuffle).
   // acc[i][j][e] <-> cout n0 + wc + 16 i + 4 (lane / 16) + e, pixel m0 + wp + 16 j + lane % 16
   const bool vec = p.ps_cout == 0 && (p.Cout & 3) == 0 && (gco & 3) == 0 && (p.out_ld & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 &&
@@ -325,9 +377,30 @@ int launch_pair(Conv32 p, hipStream_t s) {
   p.x3_mtx = (nt >= 2 && kk >= rk) ? (p.x3_mt + 7) / 8 : 0;
   const dim3 grid((unsigned)(p.x3_mtx ? 8 * p.x3_mtx * p.x3_nt : p.x3_mt * p.x3_nt), 1u, (unsigned)G);
   const int kdb = [] { const char* e = getenv("EMP_X3_KDB"); return e ? atoi(e) : 1024; }();     // K from which the two-buffer pipeline runs (measured: profiles/r05_conv16x3.txt)
+  if (p.head_w) {      // fused head: one-buffer variant, ReLU (the separable head blocks: K = the decoder width)
+    EMP_REQUIRE(p.head_part && p.head_c >= 1 && p.head_c <= 4 && p.act == 1 && G == 1 && !p.res && !p.bias_n && p.ps_cout == 0,
+                "conv16x3: fused head needs ReLU, 1..4 head channels, a plain ungrouped convolution");
+    if (bn == 128) hipLaunchKernelGGL((conv16x3_kernel<1, 128, 128, WPAIR, false, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv16x3_kernel<1, 128, 64, WPAIR, false, true>), grid, dim3(256), 0, s, p);
+    EMP_LAUNCH_CHECK();
+    return EMP_OK;
+  }
   const bool db = p.KH * p.KW * p.Cin >= kdb;
   if (db) return bn == 128 ? launch_tile<128, 128, WPAIR, true>(p, grid, s) : launch_tile<128, 64, WPAIR, true>(p, grid, s);
   return bn == 128 ? launch_tile<128, 128, WPAIR, false>(p, grid, s) : launch_tile<128, 64, WPAIR, false>(p, grid, s);
+}
+
+// out[n][h][pix] = b[h] + sum over the cout tiles t (ascending) of part[(t * N * P + n * P + pix) * C + h]
+__global__ void __launch_bounds__(256) head_finish32_kernel(const float* __restrict__ part, int tiles, int64_t MP, int P, int C,
+                                                            const float* __restrict__ b, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < MP * C; i += (int64_t)gridDim.x * 256) {
+    const int h = (int)(i / MP);
+    const int64_t m = i - (int64_t)h * MP;
+    float t = b ? b[h] : 0.f;
+    for (int k = 0; k < tiles; ++k) t += part[((size_t)k * MP + m) * C + h];
+    const int64_t n = m / P, pix = m - n * P;
+    out[((size_t)n * C + h) * P + pix] = t;
+  }
 }
 
 __global__ void __launch_bounds__(256) split_pairs_kernel(const float* __restrict__ w, uint32_t* __restrict__ out, int64_t n) {
@@ -352,6 +425,17 @@ int launch_conv16x3(const Conv32& p, hipStream_t s) {
     return launch_pair<true>(q, s);
   }
   return launch_pair<false>(q, s);
+}
+
+int conv16x3_cout_tiles(int Cout) { return Cout > 64 ? (Cout + 127) / 128 : 1; }
+
+int launch_head_finish_f32(const float* part, int tiles, int N, int P, int C, const float* b, float* out, hipStream_t s) {
+  EMP_REQUIRE(part && out && tiles >= 1 && C >= 1 && C <= 4, "head_finish: bad arguments");
+  const int64_t MP = (int64_t)N * P, total = MP * C;
+  const int64_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(head_finish32_kernel, dim3((unsigned)(g > 65535 ? 65535 : g)), dim3(256), 0, s, part, tiles, MP, P, C, b, out);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
 }
 
 // fp32 weights -> one uint32 per weight: fp16(x) | fp16(x - fp16(x)) << 16 (emp_pdl_finalize in the fp16x3 mode)

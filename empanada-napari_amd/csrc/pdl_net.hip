@@ -108,6 +108,8 @@ struct emp_pdl {
   bool fp32_graph() const { return precision != 0; }
   // RegNet on the fp16 engine: the grouped 3x3 as ONE launch (blockIdx.y = group, conv_igemm_grouped.hip); EMP_REGNET_GROUPED=0:
   // one launch per group with its couts padded to 64 / 128 for the register-weight kernels (round 4; A/B)
+  // fp16x3 mode: the heads' 1x1 fused into the pointwise conv (EMP_X3_FUSE_HEAD=0: the separate head1x1_32 launch; A/B)
+  bool x3_fuse_head = [] { const char* e = getenv("EMP_X3_FUSE_HEAD"); return !(e && e[0] == '0'); }();
   bool regnet_grouped = [] { const char* e = getenv("EMP_REGNET_GROUPED"); return !(e && e[0] == '0'); }();
   int64_t regnet_group_tiles = [] { const char* e = getenv("EMP_REGNET_GROUP_TILES"); return e ? atoll(e) : 2048ll; }();
   struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; };
@@ -1502,7 +1504,8 @@ int finalize32(emp_pdl* n) {
 
 // out[:, :, :, out_coff : out_coff + Cout) = act(conv(in[:, :, :, in_coff : in_coff + Cin16)) + bias (+ bias_n) (+ res))
 int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const T32& out, int out_coff, int stride, int pad,
-        int dil, int act, const T32* res, const float* bias_n, hipStream_t s, int ps_cout = 0, int groups = 1) {
+        int dil, int act, const T32* res, const float* bias_n, hipStream_t s, int ps_cout = 0, int groups = 1,
+        const float* head_w = nullptr, float* head_part = nullptr, int head_c = 0) {
   const emp_pdl::W32& w = n->w32.at(wname);
   Conv32 p{};
   if (groups > 1) {      // grouped 3x3 of a RegNet block: w.cin is the group width, w.cout all output channels
@@ -1522,6 +1525,8 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
   p.act = act; p.ps_cout = ps_cout;
   p.x3 = n->precision == 2;
   p.wpair = p.x3 ? w.wp : nullptr;
+  p.head_w = head_w; p.head_part = head_part; p.head_c = head_c;      // (fp16x3 only: the map `out` is then not written)
+  EMP_REQUIRE(!head_w || p.x3, "%s: the fused head exists in the fp16x3 mode only", wname.c_str());
   const int up = ps_cout ? 2 : 1;
   EMP_REQUIRE(p.Ho * up == out.H && p.Wo * up == out.W && in.N == out.N, "%s (fp32): output shape mismatch", wname.c_str());
   EMP_REQUIRE(in_coff + (groups - 1) * w.cin + w.cin16 <= in.ld && out_coff + (ps_cout ? ps_cout : w.cout) <= out.ld,
@@ -1789,15 +1794,26 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
     const T32& xin = k == 0 ? semx : insx;
     RC32(mk(p + ".dw", hq, wq, n->dec_ch));
     RC32(dw(xin, p + ".head.0.0.sepconv.0", 5, A(p + ".dw")));
-    RC32(mk(p + ".pw", hq, wq, n->dec_ch));
-    RC32(c32(n, p + ".head.0.0.sepconv.1", A(p + ".dw"), 0, A(p + ".pw"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
     float* dst;
     RC32(buf32(n, p + ".out", (size_t)N * hc[k] * hq * wq, &dst));
     if (k == 1 && !interp) dst = o_ctr;
     if (k == 2 && !interp) dst = o_off;
     head_out[k] = dst;
-    RC32(launch_head1x1_f32(A(p + ".pw").p, N, hq * wq, n->dec_ch, n->dec_ch, n->f32w.at(p + ".head.1.w"), n->f32w.at(p + ".head.1.b"),
-                            hc[k], dst, (int64_t)hq * wq, nullptr, s));
+    if (n->precision == 2 && n->x3_fuse_head && hc[k] <= 4) {
+      // fp16x3 mode: the head's 1x1 inside the pointwise conv's epilogue (conv16x3.hip HEAD): the dec_ch-wide map is
+      // neither written nor read back; every cout tile leaves per-pixel partial sums, added in ascending order
+      const int tiles = conv16x3_cout_tiles(n->dec_ch);
+      float* part;
+      RC32(buf32(n, p + ".part", (size_t)tiles * N * hq * wq * hc[k], &part));
+      RC32(c32(n, p + ".head.0.0.sepconv.1", A(p + ".dw"), 0, A(p + ".dw"), 0, 1, 0, 1, 1, nullptr, nullptr, s, 0, 1,
+               n->f32w.at(p + ".head.1.w"), part, hc[k]));
+      RC32(launch_head_finish_f32(part, tiles, N, hq * wq, hc[k], n->f32w.at(p + ".head.1.b"), dst, s));
+    } else {
+      RC32(mk(p + ".pw", hq, wq, n->dec_ch));
+      RC32(c32(n, p + ".head.0.0.sepconv.1", A(p + ".dw"), 0, A(p + ".pw"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+      RC32(launch_head1x1_f32(A(p + ".pw").p, N, hq * wq, n->dec_ch, n->dec_ch, n->f32w.at(p + ".head.1.w"), n->f32w.at(p + ".head.1.b"),
+                              hc[k], dst, (int64_t)hq * wq, nullptr, s));
+    }
     n->flops += 2.0 * (double)N * hq * wq * n->dec_ch * hc[k];
   }
   if (interp) {
