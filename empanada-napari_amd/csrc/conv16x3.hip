@@ -373,10 +373,10 @@ int launch_pair(Conv32 p, hipStream_t s) {
   p.x3_mt = (int)((M + 127) / 128);
   p.x3_nt = (int)nt;
   const int kk = p.KH * p.KW * p.Cin;
-  const int rk = [] { const char* e = getenv("EMP_X3_RASTER_K"); return e ? atoi(e) : 256; }();
+  static const int rk = [] { const char* e = getenv("EMP_X3_RASTER_K"); return e ? atoi(e) : 256; }();
   p.x3_mtx = (nt >= 2 && kk >= rk) ? (p.x3_mt + 7) / 8 : 0;
   const dim3 grid((unsigned)(p.x3_mtx ? 8 * p.x3_mtx * p.x3_nt : p.x3_mt * p.x3_nt), 1u, (unsigned)G);
-  const int kdb = [] { const char* e = getenv("EMP_X3_KDB"); return e ? atoi(e) : 1024; }();     // K from which the two-buffer pipeline runs (measured: profiles/r05_conv16x3.txt)
+  static const int kdb = [] { const char* e = getenv("EMP_X3_KDB"); return e ? atoi(e) : 1024; }();     // K from which the two-buffer pipeline runs (measured: profiles/r05_conv16x3.txt)
   if (p.head_w) {      // fused head: one-buffer variant, ReLU (the separable head blocks: K = the decoder width)
     EMP_REQUIRE(p.head_part && p.head_c >= 1 && p.head_c <= 4 && p.act == 1 && G == 1 && !p.res && !p.bias_n && p.ps_cout == 0,
                 "conv16x3: fused head needs ReLU, 1..4 head channels, a plain ungrouped convolution");
