@@ -32,7 +32,10 @@ block) and v2 ``blosc`` (``create_dataset`` of zarr-python 2, multigpu.py:202-20
 16-byte header, block offsets, per-block split streams, byte shuffle -- is decoded here with lz4 / zstd / zlib inner
 codecs (blosclz, snappy and bit-shuffle are refused; restated from c-blosc's published frame format: no blosc library here
 to pin it against, tests build frames by hand from the same description).  New stores are written uncompressed or with
-gzip / zlib / zstd.  Sharding and transposes are refused loudly.  When the real ``zarr`` package is importable,
+gzip / zlib / zstd.  Round 5: zarr v3 **sharded** arrays (the ``sharding_indexed`` codec of ``create_array(..., shards=)``:
+inner chunks + an index of (offset, nbytes) pairs with a CRC-32C, restated from the zarr v3 sharding specification -- like the
+Blosc frame, unpinned here: no zarr package to write a sample) are read and written; a partial write of a shard reads,
+patches and rewrites the whole shard.  Transposes are refused loudly.  When the real ``zarr`` package is importable,
 ``open_store`` returns zarr's own objects instead.
 
 Only what the reference's path touches is implemented: groups, n-d arrays, basic indexing with integers and
@@ -136,6 +139,44 @@ def blosc1_decode(raw):
     return b''.join(out)
 
 
+_CRC32C_TABLE = None
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), the checksum of zarr v3's ``crc32c`` codec -- byte-wise table
+    method; only shard indexes (a few KB) go through it.  crc32c(b'123456789') == 0xE3069283."""
+    global _CRC32C_TABLE
+    if _CRC32C_TABLE is None:
+        t = []
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            t.append(c)
+        _CRC32C_TABLE = t
+    c = crc ^ 0xFFFFFFFF
+    for b in bytes(data):
+        c = _CRC32C_TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _v3_pipeline(path, codecs, what):
+    """the ``bytes`` [+ gzip | zstd] pipelines this module speaks -> (endian, codec, level)"""
+    if not codecs or codecs[0].get('name') != 'bytes':
+        raise NotImplementedError(f'{path}: the first {what} codec must be "bytes" (got {[c.get("name") for c in codecs]}): '
+                                  f'transposes need the zarr package')
+    endian = '>' if (codecs[0].get('configuration') or {}).get('endian', 'little') == 'big' else '<'
+    codec, level = None, 5
+    for c in codecs[1:]:
+        if c.get('name') == 'gzip' and codec is None:
+            codec, level = 'gzip', int((c.get('configuration') or {}).get('level', 5))
+        elif c.get('name') == 'zstd' and codec is None:      # (a frame checksum, if present, is verified by the decoder)
+            codec, level = 'zstd', int((c.get('configuration') or {}).get('level', 0))
+        else:
+            raise NotImplementedError(f'{path}: {what} codec {c.get("name")} needs the zarr package')
+    return endian, codec, level
+
+
 def _write_json(path, obj):
     tmp = path + '.tmp'
     with open(tmp, 'w') as f:
@@ -213,28 +254,35 @@ class DirArray:
             self.sep, self.key_prefix = conf.get('separator', '.'), ''
         else:
             raise NotImplementedError(f'{path}: chunk key encoding {enc.get("name")}')
-        endian, self.codec, self.level = '<', None, 5
         codecs = m.get('codecs', [])
-        if not codecs or codecs[0].get('name') != 'bytes':
-            raise NotImplementedError(f'{path}: the first codec must be "bytes" (got {[c.get("name") for c in codecs]}): '
-                                      f'transposes / sharding need the zarr package')
-        if (codecs[0].get('configuration') or {}).get('endian', 'little') == 'big':
-            endian = '>'
-        for c in codecs[1:]:
-            if c.get('name') == 'gzip' and self.codec is None:
-                self.codec, self.level = 'gzip', int((c.get('configuration') or {}).get('level', 5))
-            elif c.get('name') == 'zstd' and self.codec is None:
-                conf_z = c.get('configuration') or {}      # (a frame checksum, if present, is verified by the decoder)
-                self.codec, self.level = 'zstd', int(conf_z.get('level', 0))
-            else:
-                raise NotImplementedError(f'{path}: codec {c.get("name")} needs the zarr package')
+        self.inner = None
+        if len(codecs) == 1 and codecs[0].get('name') == 'sharding_indexed':
+            # round 5: zarr v3 sharding (zarr-python 3's ``create_array(..., shards=)``): the chunk grid's chunks are SHARDS --
+            # one file each -- holding the inner chunks (``chunk_shape``, C order over the shard) back to back plus an
+            # index of (offset, nbytes) uint64 pairs, one per inner chunk in C order, (2^64 - 1, 2^64 - 1) = absent, encoded
+            # by ``index_codecs`` (little-endian ``bytes`` + ``crc32c``: four checksum bytes behind the index) at the end
+            # (default) or the start of the file
+            conf = codecs[0].get('configuration') or {}
+            inner = tuple(int(c) for c in conf['chunk_shape'])
+            if len(inner) != len(self.chunks) or any(sc % ic for sc, ic in zip(self.chunks, inner)):
+                raise ValueError(f'{path}: inner chunks {inner} do not tile the shards {self.chunks}')
+            endian, self.codec, self.level = _v3_pipeline(path, conf.get('codecs', []), 'inner')
+            ic = conf.get('index_codecs', [{'name': 'bytes'}, {'name': 'crc32c'}])
+            names = [c.get('name') for c in ic]
+            if names not in (['bytes'], ['bytes', 'crc32c']) or (ic[0].get('configuration') or {}).get('endian', 'little') != 'little':
+                raise NotImplementedError(f'{path}: shard index codecs {names}')
+            self.inner = inner
+            self.index_crc = names[-1] == 'crc32c'
+            self.index_at_end = conf.get('index_location', 'end') == 'end'
+        else:
+            endian, self.codec, self.level = _v3_pipeline(path, codecs, 'array')
         self.dtype = np.dtype(kind if kind in ('?', 'i1', 'u1') else endian + kind)
         fv = m.get('fill_value', 0)
         self.fill_value = 0 if fv is None else fv
 
     # ---- creation ----
     @classmethod
-    def create(cls, path, shape, dtype, chunks, overwrite=False, fill_value=0, zarr_format=2, compressor=None):
+    def create(cls, path, shape, dtype, chunks, overwrite=False, fill_value=0, zarr_format=2, compressor=None, shards=None):
         if os.path.exists(path):
             if not overwrite:
                 raise FileExistsError(path)
@@ -250,6 +298,8 @@ class DirArray:
         dt = np.dtype(dtype)
         if compressor not in (None, 'gzip', 'zlib', 'zstd'):
             raise NotImplementedError(f'compressor {compressor!r}: None, "gzip", "zlib" or "zstd"')
+        if shards is not None and zarr_format != 3:
+            raise ValueError('shards are a zarr v3 feature (zarr_format=3)')
         if zarr_format == 2:
             _write_json(os.path.join(path, '.zarray'), {
                 'zarr_format': 2, 'shape': list(shape), 'chunks': list(chunks), 'dtype': dt.str,
@@ -267,10 +317,21 @@ class DirArray:
                 codecs.append({'name': 'gzip', 'configuration': {'level': 1}})
             elif compressor == 'zstd':      # zarr-python 3's own default codec
                 codecs.append({'name': 'zstd', 'configuration': {'level': 0, 'checksum': False}})
+            grid_chunks = chunks
+            if shards is not None:
+                # zarr-python 3's ``create_array(chunks=<inner>, shards=<shard>)``: the grid's chunks are the shards
+                shards = tuple(int(c) for c in (shards if np.iterable(shards) else (shards,)))
+                if len(shards) != len(shape) or any(sc % ic for sc, ic in zip(shards, chunks)):
+                    raise ValueError(f'shards {shards} must be whole multiples of the chunks {chunks}')
+                codecs = [{'name': 'sharding_indexed', 'configuration': {
+                    'chunk_shape': list(chunks), 'codecs': codecs,
+                    'index_codecs': [{'name': 'bytes', 'configuration': {'endian': 'little'}}, {'name': 'crc32c'}],
+                    'index_location': 'end'}}]
+                grid_chunks = shards
             fv = bool(fill_value) if dt.kind == 'b' else (float(fill_value) if dt.kind == 'f' else int(fill_value))
             _write_json(os.path.join(path, 'zarr.json'), {
                 'zarr_format': 3, 'node_type': 'array', 'shape': list(shape), 'data_type': names[key],
-                'chunk_grid': {'name': 'regular', 'configuration': {'chunk_shape': list(chunks)}},
+                'chunk_grid': {'name': 'regular', 'configuration': {'chunk_shape': list(grid_chunks)}},
                 'chunk_key_encoding': {'name': 'default', 'configuration': {'separator': '/'}},
                 'fill_value': fv, 'codecs': codecs, 'attributes': {}})
         else:
@@ -299,10 +360,70 @@ class DirArray:
             key = self.key_prefix                  # zero-dimensional v3 array: the single chunk is "c"
         return os.path.join(self.path, *key.split('/'))
 
+    def _read_shard(self, p):
+        """one shard file -> the full shard as an array (absent inner chunks hold the fill value)"""
+        with open(p, 'rb') as f:
+            raw = f.read()
+        grid = tuple(sc // ic for sc, ic in zip(self.chunks, self.inner))
+        n = int(np.prod(grid))
+        isz = 16 * n + (4 if self.index_crc else 0)
+        if len(raw) < isz:
+            raise ValueError(f'{p}: {len(raw)} bytes cannot hold a shard index of {isz}')
+        ib = raw[len(raw) - isz:] if self.index_at_end else raw[:isz]
+        if self.index_crc and crc32c(ib[:-4]) != int.from_bytes(ib[-4:], 'little'):
+            raise ValueError(f'{p}: shard index checksum mismatch')
+        index = np.frombuffer(ib, dtype='<u8', count=2 * n).reshape(n, 2)
+        out = np.full(self.chunks, self.fill_value, dtype=self.dtype)
+        nb = int(np.prod(self.inner)) * self.dtype.itemsize
+        absent = np.uint64(0xFFFFFFFFFFFFFFFF)
+        for k, pos in enumerate(itertools.product(*(range(g) for g in grid))):
+            off, size = index[k]
+            if off == absent and size == absent:
+                continue
+            if int(off) + int(size) > len(raw):
+                raise ValueError(f'{p}: inner chunk {pos} lies outside the shard')
+            data = raw[int(off):int(off) + int(size)]
+            a = np.frombuffer(data if self.codec is None else _decompress(self.codec, data, nb), dtype=self.dtype)
+            if a.size != int(np.prod(self.inner)):
+                raise ValueError(f'{p}: inner chunk {pos} has {a.size} items, expected {self.inner}')
+            out[tuple(slice(i * c, (i + 1) * c) for i, c in zip(pos, self.inner))] = a.reshape(self.inner)
+        return out
+
+    def _write_shard(self, tmp, block):
+        """the whole shard at once (every inner chunk present): chunks, then the index (+ crc32c) where the metadata says"""
+        grid = tuple(sc // ic for sc, ic in zip(self.chunks, self.inner))
+        parts = []
+        for pos in itertools.product(*(range(g) for g in grid)):
+            data = np.ascontiguousarray(block[tuple(slice(i * c, (i + 1) * c) for i, c in zip(pos, self.inner))]).tobytes()
+            if self.codec == 'gzip':
+                data = gzip.compress(data, self.level, mtime=0)
+            elif self.codec == 'zstd':
+                data = _arrow_codec('zstd').compress(data, asbytes=True)
+            parts.append(data)
+        n = len(parts)
+        isz = 16 * n + (4 if self.index_crc else 0)
+        index = np.zeros((n, 2), dtype='<u8')
+        off = 0 if self.index_at_end else isz
+        for k, d in enumerate(parts):
+            index[k] = (off, len(d))
+            off += len(d)
+        ib = index.tobytes()
+        if self.index_crc:
+            ib += crc32c(ib).to_bytes(4, 'little')
+        with open(tmp, 'wb') as f:
+            if not self.index_at_end:
+                f.write(ib)
+            for d in parts:
+                f.write(d)
+            if self.index_at_end:
+                f.write(ib)
+
     def _read_chunk(self, idx):
         p = self._chunk_path(idx)
         if not os.path.isfile(p):
             return None
+        if getattr(self, 'inner', None) is not None:
+            return self._read_shard(p)
         if self.codec is None:
             a = np.fromfile(p, dtype=self.dtype)
         else:
@@ -320,7 +441,9 @@ class DirArray:
             os.makedirs(d, exist_ok=True)
         tmp = p + '.partial'
         block = np.ascontiguousarray(block, dtype=self.dtype)
-        if self.codec is None:
+        if getattr(self, 'inner', None) is not None:
+            self._write_shard(tmp, block)
+        elif self.codec is None:
             block.tofile(tmp)
         else:
             data = block.tobytes()
@@ -470,11 +593,11 @@ class DirGroup:
         else:
             raise ValueError(f'zarr_format {fmt}: 2 or 3')
 
-    def create_array(self, name, shape, dtype, chunks=None, overwrite=False, fill_value=0, compressor=None, **ignored):
+    def create_array(self, name, shape, dtype, chunks=None, overwrite=False, fill_value=0, compressor=None, shards=None, **ignored):
         if self.mode == 'r':
             raise PermissionError(f'{self.path} was opened read-only')
         return DirArray.create(os.path.join(self.path, name), shape, dtype, chunks, overwrite=overwrite,
-                               fill_value=fill_value, zarr_format=self.zarr_format, compressor=compressor)
+                               fill_value=fill_value, zarr_format=self.zarr_format, compressor=compressor, shards=shards)
 
     create_dataset = create_array
 

@@ -340,3 +340,85 @@ def test_blosc_refuses_what_it_cannot_decode():
         zstore.blosc1_decode(bytes(frame))
     with pytest.raises(ValueError):
         zstore.blosc1_decode(bytes(frame[:40]))
+
+
+def test_crc32c_known_answers():
+    """the checksum of zarr v3's ``crc32c`` codec (Castagnoli): the standard check value and RFC 3720's vectors"""
+    assert zstore.crc32c(b'123456789') == 0xE3069283
+    assert zstore.crc32c(b'') == 0
+    assert zstore.crc32c(bytes(32)) == 0x8A9136AA             # iSCSI, RFC 3720 B.4: 32 bytes of zeros
+    assert zstore.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43    # 32 bytes of ones
+    assert zstore.crc32c(bytes(range(32))) == 0x46DD794E      # 32 incrementing bytes
+
+
+@pytest.mark.parametrize('compressor', [None, 'gzip', 'zstd'])
+def test_sharded_v3_arrays_round_trip(tmp_path, compressor):
+    """zarr v3 sharding (``create_array(chunks=<inner>, shards=<shard>)``): metadata, shard files with their index at the end,
+    partial writes (read - patch - rewrite of a shard), reads across shards"""
+    if compressor == 'zstd':
+        pytest.importorskip('pyarrow')
+    g = zstore.open_store(str(tmp_path / 's.zarr'), mode='w', zarr_format=3)
+    a = g.create_array('v', shape=(20, 33, 17), dtype=np.uint16, chunks=(4, 8, 8), shards=(8, 16, 16), compressor=compressor)
+    m = json.load(open(tmp_path / 's.zarr' / 'v' / 'zarr.json'))
+    assert m['chunk_grid']['configuration']['chunk_shape'] == [8, 16, 16]
+    sc = m['codecs'][0]
+    assert sc['name'] == 'sharding_indexed' and sc['configuration']['chunk_shape'] == [4, 8, 8]
+    assert [c['name'] for c in sc['configuration']['index_codecs']] == ['bytes', 'crc32c']
+    rng = np.random.default_rng(5)
+    ref = rng.integers(0, 60000, size=(20, 33, 17), dtype=np.uint16)
+    a[...] = ref
+    b = zstore.open_store(str(tmp_path / 's.zarr'), mode='r')['v']
+    assert b.chunks == (8, 16, 16) and b.inner == (4, 8, 8) and b.shape == ref.shape
+    np.testing.assert_array_equal(b[...], ref)
+    np.testing.assert_array_equal(b[3:11, 5:30, 2:17], ref[3:11, 5:30, 2:17])
+    np.testing.assert_array_equal(b[19], ref[19])
+    # a shard file: the index sits at the end, 2 x 2 x 2 inner chunks x 16 bytes + 4 bytes of CRC-32C over it
+    raw = open(tmp_path / 's.zarr' / 'v' / 'c' / '0' / '0' / '0', 'rb').read()
+    idx = np.frombuffer(raw[-(16 * 8 + 4):-4], dtype='<u8').reshape(8, 2)
+    assert int(idx[0, 0]) == 0 and int(idx[:, 1].sum()) == len(raw) - (16 * 8 + 4)
+    assert zstore.crc32c(raw[-(16 * 8 + 4):-4]) == int.from_bytes(raw[-4:], 'little')
+    if compressor is None:
+        assert int(idx[0, 1]) == 4 * 8 * 8 * 2
+        np.testing.assert_array_equal(np.frombuffer(raw[:512], '<u2').reshape(4, 8, 8), ref[:4, :8, :8])
+    # partial write into two shards
+    a[6:10, 10:20, 0:3] = 7
+    ref[6:10, 10:20, 0:3] = 7
+    np.testing.assert_array_equal(zstore.open_store(str(tmp_path / 's.zarr'), mode='r')['v'][...], ref)
+
+
+def test_sharded_v3_reader_handles_absent_chunks_index_at_start_and_bad_checksums(tmp_path):
+    """a shard written elsewhere: index at the START, one inner chunk absent (offset = nbytes = 2^64 - 1 -> fill value),
+    chunks stored out of order; and a corrupted index is refused"""
+    d = tmp_path / 'w.zarr' / 'v'
+    os.makedirs(d / 'c' / '0')
+    meta = {'zarr_format': 3, 'node_type': 'array', 'shape': [4, 8], 'data_type': 'int32',
+            'chunk_grid': {'name': 'regular', 'configuration': {'chunk_shape': [4, 8]}},
+            'chunk_key_encoding': {'name': 'default', 'configuration': {'separator': '/'}}, 'fill_value': -3,
+            'codecs': [{'name': 'sharding_indexed', 'configuration': {
+                'chunk_shape': [2, 4], 'codecs': [{'name': 'bytes', 'configuration': {'endian': 'little'}}],
+                'index_codecs': [{'name': 'bytes', 'configuration': {'endian': 'little'}}, {'name': 'crc32c'}],
+                'index_location': 'start'}}], 'attributes': {}}
+    json.dump({'zarr_format': 3, 'node_type': 'group'}, open(tmp_path / 'w.zarr' / 'zarr.json', 'w'))
+    json.dump(meta, open(d / 'zarr.json', 'w'))
+    ref = np.arange(32, dtype='<i4').reshape(4, 8)
+    chunks = {(0, 0): ref[:2, :4], (0, 1): ref[:2, 4:], (1, 1): ref[2:, 4:]}       # (1, 0) absent
+    isz = 16 * 4 + 4
+    order = [(1, 1), (0, 0), (0, 1)]                                               # stored out of order
+    index = np.full((4, 2), 0xFFFFFFFFFFFFFFFF, dtype='<u8')
+    body, off = b'', isz
+    for pos in order:
+        data = np.ascontiguousarray(chunks[pos]).tobytes()
+        index[pos[0] * 2 + pos[1]] = (off, len(data))
+        body += data
+        off += len(data)
+    ib = index.tobytes()
+    open(d / 'c' / '0' / '0', 'wb').write(ib + zstore.crc32c(ib).to_bytes(4, 'little') + body)
+    a = zstore.open_store(str(tmp_path / 'w.zarr'), mode='r')['v']
+    want = ref.copy()
+    want[2:, :4] = -3
+    np.testing.assert_array_equal(a[...], want)
+    bad = bytearray(open(d / 'c' / '0' / '0', 'rb').read())
+    bad[3] ^= 0x40
+    open(d / 'c' / '0' / '0', 'wb').write(bytes(bad))
+    with pytest.raises(ValueError, match='checksum'):
+        zstore.open_store(str(tmp_path / 'w.zarr'), mode='r')['v'][...]
