@@ -176,6 +176,10 @@ struct Conv32 {
   int groups;       // > 1: grouped convolution -- Cout and Cin are PER GROUP (Cin padded to 16), weights [G * Cout][KH*KW][Cin]
   int cin_g;        // grouped: real input channels per group (the channel step from one group to the next); else 0
   int x3;           // 1: the fp16x3 mode -- the same convolution on the fp16 matrix pipe with split operands (conv16x3.hip)
+  // x3 only, optional: a second source K-concatenated behind the first (the bottleneck's projection shortcut folded into
+  // conv3, as ConvParams::in2): a 1x1 convolution of in2 (N, H2, W2, in2_ld) at stride2 summed into the same accumulators;
+  // weight rows are then [KH*KW*Cin | Cin2] long (Cin2 % 16 == 0)
+  const float* in2; int in2_ld, Cin2, H2, W2, stride2;
   // x3 only, optional: a fused 1x1 head (heads.py:14) -- the kernel does not store the activation map; instead every cout
   // tile writes, per pixel, the partial sums of head_c dot products of relu(out) with head_w[h][Cout] over its couts to
   // head_part[(cout tile * M + pixel) * head_c + h]; launch_head_finish_f32 adds the tiles in ascending order (+ bias)

@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
   const float* gin = p.in + (size_t)g * p.cin_g;
   const int HoWo = p.Ho * p.Wo;
   const int M = p.N * HoWo;
-  const int K = p.KH * p.KW * p.Cin;
+  const int K1 = p.KH * p.KW * p.Cin;                 // K of the main source
+  const int K = K1 + (p.in2 ? p.Cin2 : 0);            // + the second source's channels (Conv32::in2)
   // staging roles: piece s of thread t = row t / 4 + 64 s, 8-channel chunk t % 4 -- eight consecutive lanes store 128
   // contiguous bytes of two rows (the ds_write_b128 lane group), four lanes load 128 contiguous bytes of one row
   const int srow = tid >> 2, sch = tid & 3;
@@ -141,25 +142,35 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
   // per-step recomputation were a third of the kernel's vector instructions)
   int g_k = sch * 8, g_c0 = sch * 8, g_ky = 0, g_kx = 0;
   while (g_c0 >= p.Cin) { g_c0 -= p.Cin; if (++g_kx == p.KW) { g_kx = 0; ++g_ky; } }      // (a chunk of 8 channels lies inside one tap: Cin % 16 == 0)
-  int oy0[NXS], ox0[NXS], pix0[NXS];
+  int oy0[NXS], ox0[NXS], pix0[NXS], pix2[NXS];
 #pragma unroll
   for (int s2 = 0; s2 < NXS; ++s2) {
     oy0[s2] = aoy[s2] * p.stride - p.pad;
     ox0[s2] = aox[s2] * p.stride - p.pad;
     pix0[s2] = an[s2] * p.H * p.W;
+    pix2[s2] = p.in2 ? (an[s2] * p.H2 + aoy[s2] * p.stride2) * p.W2 + aox[s2] * p.stride2 : 0;
   }
   auto gload = [&](int k0, auto RS) {
     constexpr int rs = decltype(RS)::value;
     // every piece is loaded unconditionally: an out-of-range one (padding tap, row beyond M / Cout, K tail) reads the zero
     // page instead -- no zero-filled registers, no divergent branch around the loads
     const bool kok = g_k < K;
+    if (g_k < K1) {
 #pragma unroll
-    for (int s2 = 0; s2 < NXS; ++s2) {
-      const int iy = oy0[s2] + g_ky * p.dil, ix = ox0[s2] + g_kx * p.dil;
-      const bool ok = xok[s2] && kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const float4* src = reinterpret_cast<const float4*>(ok ? gin + (size_t)(pix0[s2] + iy * p.W + ix) * p.in_ld + g_c0 : p.zero);
-      rx[rs][s2][0] = src[0];
-      rx[rs][s2][1] = src[1];
+      for (int s2 = 0; s2 < NXS; ++s2) {
+        const int iy = oy0[s2] + g_ky * p.dil, ix = ox0[s2] + g_kx * p.dil;
+        const bool ok = xok[s2] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float4* src = reinterpret_cast<const float4*>(ok ? gin + (size_t)(pix0[s2] + iy * p.W + ix) * p.in_ld + g_c0 : p.zero);
+        rx[rs][s2][0] = src[0];
+        rx[rs][s2][1] = src[1];
+      }
+    } else {      // the second source (Conv32::in2): its pixel at stride2, channel g_k - K1; or the K tail: zeros
+#pragma unroll
+      for (int s2 = 0; s2 < NXS; ++s2) {
+        const float4* src = reinterpret_cast<const float4*>((xok[s2] && kok) ? p.in2 + (size_t)pix2[s2] * p.in2_ld + (g_k - K1) : p.zero);
+        rx[rs][s2][0] = src[0];
+        rx[rs][s2][1] = src[1];
+      }
     }
 #pragma unroll
     for (int s2 = 0; s2 < NWS; ++s2) {
@@ -417,6 +428,11 @@ __global__ void __launch_bounds__(256) split_pairs_kernel(const float* __restric
 // the checks of launch_conv32 (ref32.hip) have run: same contract
 int launch_conv16x3(const Conv32& p, hipStream_t s) {
   EMP_REQUIRE((int64_t)p.N * p.H * p.W < (1ll << 31), "conv16x3: input map too large for 32-bit pixel indices");
+  EMP_REQUIRE(!p.in2 || (p.Cin2 > 0 && p.Cin2 % 16 == 0 && p.in2_ld % 4 == 0 && p.in2_ld >= p.Cin2 && ((uintptr_t)p.in2 % 16) == 0 &&
+                         p.stride2 >= 1 && (p.Ho - 1) * p.stride2 < p.H2 && (p.Wo - 1) * p.stride2 < p.W2 && p.groups <= 1 &&
+                         (int64_t)p.N * p.H2 * p.W2 < (1ll << 31)),
+              "conv16x3: second source: Cin2=%d (multiple of 16), row %d, %dx%d at stride %d must cover the %dx%d output", p.Cin2,
+              p.in2_ld, p.H2, p.W2, p.stride2, p.Ho, p.Wo);
   Conv32 q = p;
   q.zero = reinterpret_cast<const float*>(zero_page());
   EMP_REQUIRE(q.zero != nullptr, "conv16x3: no zero page");

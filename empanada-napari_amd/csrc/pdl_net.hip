@@ -109,10 +109,11 @@ struct emp_pdl {
   // RegNet on the fp16 engine: the grouped 3x3 as ONE launch (blockIdx.y = group, conv_igemm_grouped.hip); EMP_REGNET_GROUPED=0:
   // one launch per group with its couts padded to 64 / 128 for the register-weight kernels (round 4; A/B)
   // fp16x3 mode: the heads' 1x1 fused into the pointwise conv (EMP_X3_FUSE_HEAD=0: the separate head1x1_32 launch; A/B)
+  bool x3_fuse_ds = [] { const char* e = getenv("EMP_X3_FUSE_DS"); return !(e && e[0] == '0'); }();      // conv3 + projection shortcut as one K-concatenated conv (A/B)
   bool x3_fuse_head = [] { const char* e = getenv("EMP_X3_FUSE_HEAD"); return !(e && e[0] == '0'); }();
   bool regnet_grouped = [] { const char* e = getenv("EMP_REGNET_GROUPED"); return !(e && e[0] == '0'); }();
   int64_t regnet_group_tiles = [] { const char* e = getenv("EMP_REGNET_GROUP_TILES"); return e ? atoll(e) : 2048ll; }();
-  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; };
+  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; int cin2 = 0, cin2_16 = 0; };
   std::map<std::string, W32> w32;
   std::map<std::string, std::pair<float*, size_t>> pool32;      // name -> (device buffer, floats)
   std::map<std::string, std::array<int, 4>> geom32;             // zero-tailed RegNet maps: the geometry a buffer was last cleared for
@@ -1369,6 +1370,38 @@ int pack32(emp_pdl* n, const std::string& name, int cin_to = 0, const HostParam*
   return EMP_OK;
 }
 
+// fp16x3 mode: conv3 and the projection shortcut of a bottleneck as one fp32 weight matrix [Cout][cin3_16 | cin_ds_16] with
+// the summed (folded BN) bias -- relu(conv3(c2) + downsample(x)) as a single convolution over the concatenated K
+// (Conv32::in2; the fp16 engine's pack_conv3_ds): the shortcut map is neither written nor read back
+int pack32_conv3_ds(emp_pdl* n, const std::string& block) {
+  const HostParam& h3 = n->params.at(block + ".conv3");
+  const HostParam& hd = n->params.at(block + ".downsample.0");
+  EMP_REQUIRE(h3.shape.size() == 4 && hd.shape.size() == 4 && h3.shape[0] == hd.shape[0] && h3.shape[2] == 1 && hd.shape[2] == 1 &&
+                  h3.b.size() == hd.b.size(), "%s: conv3 / downsample shapes do not match", block.c_str());
+  emp_pdl::W32 w;
+  w.cout = (int)h3.shape[0];
+  w.cin = (int)h3.shape[1];
+  w.cin16 = round_up(w.cin, 16);
+  w.cin2 = (int)hd.shape[1];
+  w.cin2_16 = round_up(w.cin2, 16);
+  const size_t K = (size_t)w.cin16 + w.cin2_16;
+  std::vector<float> pk((size_t)w.cout * K, 0.f), b((size_t)w.cout);
+  for (int o = 0; o < w.cout; ++o) {
+    for (int i = 0; i < w.cin; ++i) pk[o * K + i] = h3.w[(size_t)o * w.cin + i];
+    for (int i = 0; i < w.cin2; ++i) pk[o * K + w.cin16 + i] = hd.w[(size_t)o * w.cin2 + i];
+    b[o] = h3.b[o] + hd.b[o];
+  }
+  void* d;
+  int rc = dev_upload(n, pk.data(), pk.size() * sizeof(float), &d);
+  if (rc) return rc;
+  w.w = (float*)d;
+  rc = dev_upload(n, b.data(), b.size() * sizeof(float), &d);
+  if (rc) return rc;
+  w.b = (float*)d;
+  n->w32[block + ".conv3+ds"] = w;
+  return EMP_OK;
+}
+
 // depthwise (C,1,k,k) -> [k*k][C] fp32
 int pack32_dw(emp_pdl* n, const std::string& name, int cpad) {
   const HostParam& hp = n->params.at(name);
@@ -1431,6 +1464,7 @@ int finalize32(emp_pdl* n) {
         RC32(pack32(n, p + ".conv2"));
         RC32(pack32(n, p + ".conv3"));
         if (b == 0) RC32(pack32(n, p + ".downsample.0"));
+        if (b == 0 && n->precision == 2) RC32(pack32_conv3_ds(n, p));
       }
   }
   if (c.arch == 1) {
@@ -1490,7 +1524,7 @@ int finalize32(emp_pdl* n) {
     // kernel's weight staging is a lane permutation instead of five vector operations per element (conv16x3.hip)
     for (auto& kv : n->w32) {
       emp_pdl::W32& w = kv.second;
-      const int64_t cnt = (int64_t)w.cout * w.kh * w.kw * w.cin16;
+      const int64_t cnt = (int64_t)w.cout * (w.kh * w.kw * w.cin16 + w.cin2_16);
       void* d = nullptr;
       EMP_CHECK_HIP(hipMalloc(&d, (size_t)(cnt > 0 ? cnt : 4) * sizeof(uint32_t)));
       n->owned.push_back(d);
@@ -1505,7 +1539,7 @@ int finalize32(emp_pdl* n) {
 // out[:, :, :, out_coff : out_coff + Cout) = act(conv(in[:, :, :, in_coff : in_coff + Cin16)) + bias (+ bias_n) (+ res))
 int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const T32& out, int out_coff, int stride, int pad,
         int dil, int act, const T32* res, const float* bias_n, hipStream_t s, int ps_cout = 0, int groups = 1,
-        const float* head_w = nullptr, float* head_part = nullptr, int head_c = 0) {
+        const float* head_w = nullptr, float* head_part = nullptr, int head_c = 0, const T32* in2 = nullptr, int stride2 = 1) {
   const emp_pdl::W32& w = n->w32.at(wname);
   Conv32 p{};
   if (groups > 1) {      // grouped 3x3 of a RegNet block: w.cin is the group width, w.cout all output channels
@@ -1526,6 +1560,13 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
   p.x3 = n->precision == 2;
   p.wpair = p.x3 ? w.wp : nullptr;
   p.head_w = head_w; p.head_part = head_part; p.head_c = head_c;      // (fp16x3 only: the map `out` is then not written)
+  if (in2) {      // K-concatenated second source (fp16x3 only: weights packed by pack32_conv3_ds)
+    EMP_REQUIRE(p.x3 && w.cin2_16 > 0 && w.cin2_16 <= in2->ld && in2->N == in.N, "%s: second source mismatch", wname.c_str());
+    p.in2 = in2->p; p.in2_ld = in2->ld; p.Cin2 = w.cin2_16; p.H2 = in2->H; p.W2 = in2->W; p.stride2 = stride2;
+    n->flops += 2.0 * (double)p.N * p.Ho * p.Wo * w.cout * (double)w.cin2;
+  } else {
+    EMP_REQUIRE(w.cin2_16 == 0, "%s: packed for two sources", wname.c_str());
+  }
   EMP_REQUIRE(!head_w || p.x3, "%s: the fused head exists in the fp16x3 mode only", wname.c_str());
   const int up = ps_cout ? 2 : 1;
   EMP_REQUIRE(p.Ho * up == out.H && p.Wo * up == out.W && in.N == out.N, "%s (fp32): output shape mismatch", wname.c_str());
@@ -1630,12 +1671,19 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
         RC32(mk(p + ".c2", ho, wo, planes));
         RC32(c32(n, p + ".conv2", A(p + ".c1"), 0, A(p + ".c2"), 0, sb, dil, dil, 1, nullptr, nullptr, s));
         const T32* idn = &A(x);
+        RC32(mk(p, ho, wo, planes * 4));
+        if (b == 0 && n->precision == 2 && n->x3_fuse_ds) {
+          // fp16x3 mode: relu(conv3(c2) + downsample(x)) as one convolution over the concatenated K (the shortcut map is
+          // neither written nor read back)
+          RC32(c32(n, p + ".conv3+ds", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, 1, nullptr, nullptr, s, 0, 1, nullptr, nullptr, 0, &xin, sb));
+          x = p;
+          continue;
+        }
         if (b == 0) {
           RC32(mk(p + ".ds", ho, wo, planes * 4));
           RC32(c32(n, p + ".downsample.0", xin, 0, A(p + ".ds"), 0, sb, 0, 1, 0, nullptr, nullptr, s));
           idn = &A(p + ".ds");
         }
-        RC32(mk(p, ho, wo, planes * 4));
         RC32(c32(n, p + ".conv3", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, 1, idn, nullptr, s));
         x = p;
       }
