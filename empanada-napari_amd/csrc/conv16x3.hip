@@ -70,7 +70,7 @@ __device__ __forceinline__ void pair_store(const float4 (&r)[2], half_t* hi, hal
   *reinterpret_cast<uint4*>(lo) = l;
 }
 
-template <int ACT, int BM, int BN, bool WPAIR, bool DB, bool HEAD = false>
+template <int ACT, int BM, int BN, bool WPAIR, bool DB, bool HEAD = false, bool IN2 = false>
 __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 p) {
   constexpr int WC = BN / 64;          // waves along the couts (64 couts each)
   constexpr int WP = 4 / WC;           // waves along the pixels
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
   const int HoWo = p.Ho * p.Wo;
   const int M = p.N * HoWo;
   const int K1 = p.KH * p.KW * p.Cin;                 // K of the main source
-  const int K = K1 + (p.in2 ? p.Cin2 : 0);            // + the second source's channels (Conv32::in2)
+  const int K = K1 + (IN2 ? p.Cin2 : 0);              // + the second source's channels (Conv32::in2; instantiations of their own)
   // staging roles: piece s of thread t = row t / 4 + 64 s, 8-channel chunk t % 4 -- eight consecutive lanes store 128
   // contiguous bytes of two rows (the ds_write_b128 lane group), four lanes load 128 contiguous bytes of one row
   const int srow = tid >> 2, sch = tid & 3;
@@ -148,18 +148,18 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
     oy0[s2] = aoy[s2] * p.stride - p.pad;
     ox0[s2] = aox[s2] * p.stride - p.pad;
     pix0[s2] = an[s2] * p.H * p.W;
-    pix2[s2] = p.in2 ? (an[s2] * p.H2 + aoy[s2] * p.stride2) * p.W2 + aox[s2] * p.stride2 : 0;
+    pix2[s2] = IN2 ? (an[s2] * p.H2 + aoy[s2] * p.stride2) * p.W2 + aox[s2] * p.stride2 : 0;
   }
   auto gload = [&](int k0, auto RS) {
     constexpr int rs = decltype(RS)::value;
     // every piece is loaded unconditionally: an out-of-range one (padding tap, row beyond M / Cout, K tail) reads the zero
     // page instead -- no zero-filled registers, no divergent branch around the loads
     const bool kok = g_k < K;
-    if (g_k < K1) {
+    if (!IN2 || g_k < K1) {
 #pragma unroll
       for (int s2 = 0; s2 < NXS; ++s2) {
         const int iy = oy0[s2] + g_ky * p.dil, ix = ox0[s2] + g_kx * p.dil;
-        const bool ok = xok[s2] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const bool ok = xok[s2] && (IN2 || kok) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const float4* src = reinterpret_cast<const float4*>(ok ? gin + (size_t)(pix0[s2] + iy * p.W + ix) * p.in_ld + g_c0 : p.zero);
         rx[rs][s2][0] = src[0];
         rx[rs][s2][1] = src[1];
@@ -393,6 +393,13 @@ int launch_pair(Conv32 p, hipStream_t s) {
                 "conv16x3: fused head needs ReLU, 1..4 head channels, a plain ungrouped convolution");
     if (bn == 128) hipLaunchKernelGGL((conv16x3_kernel<1, 128, 128, WPAIR, false, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv16x3_kernel<1, 128, 64, WPAIR, false, true>), grid, dim3(256), 0, s, p);
+    EMP_LAUNCH_CHECK();
+    return EMP_OK;
+  }
+  if (p.in2) {      // K-concatenated second source: instantiations of their own (conv3 + projection shortcut: ReLU, Cout >= 256)
+    EMP_REQUIRE(p.act == 1 && bn == 128 && G == 1 && p.ps_cout == 0, "conv16x3: a second source needs ReLU and Cout > 64");
+    if (p.KH * p.KW * p.Cin + p.Cin2 >= kdb) hipLaunchKernelGGL((conv16x3_kernel<1, 128, 128, WPAIR, true, false, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv16x3_kernel<1, 128, 128, WPAIR, false, false, true>), grid, dim3(256), 0, s, p);
     EMP_LAUNCH_CHECK();
     return EMP_OK;
   }

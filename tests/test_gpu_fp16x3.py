@@ -206,7 +206,8 @@ def test_fp16x3_rate():
         torch.cuda.empty_cache()
     print('rates:', rate)
     _save('rate_batch8_1024', rate)
-    assert rate['fp16x3']['tiles_per_s'] > 1.5 * rate['fp32']['tiles_per_s'], rate
+    assert rate['fp16x3']['tiles_per_s'] > 2.0 * rate['fp32']['tiles_per_s'], rate
+    assert rate['fp16x3']['tiles_per_s'] > 360.0, rate      # measured 400-404 (VERDICT r04 item 4's target: >= 400)
 
 
 def test_fp16x3_through_the_engine2d_api():
