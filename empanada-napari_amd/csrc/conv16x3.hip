@@ -40,6 +40,10 @@ __device__ __forceinline__ float x_act(float x) {
 // cycles as bank conflicts: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/conv16x3_pmc.sh.)
 __device__ __forceinline__ int swz(int r) { return (-((r & 15) >> 2)) & 3; }
 
+// workgroup barrier that orders LDS traffic only: a __syncthreads() would also drain vmcnt, i.e. wait for the global loads
+// that were issued precisely to stay in flight across it (the prefetch of the next steps)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // 8 fp32 values -> 8 hi halfs + 8 lo halfs, one 16-byte LDS store each
 __device__ __forceinline__ void split_store(const float4 (&r)[2], half_t* hi, half_t* lo) {
   f16x8 h, l;
@@ -225,7 +229,7 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
     if (X_BK < K) gload(X_BK, R0());
     int b = 0;
     for (int k0 = 0; k0 < K; k0 += X_BK, b ^= 1) {
-      __syncthreads();      // buffer b is complete; nobody reads buffer b ^ 1 (step k - 1) any more
+      lds_barrier();        // buffer b is complete; nobody reads buffer b ^ 1 (step k - 1) any more (the loads stay in flight)
       if (k0 + X_BK < K) {
         stage(b ^ 1, R0());
         if (k0 + 2 * X_BK < K) gload(k0 + 2 * X_BK, R0());
@@ -235,9 +239,9 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
   } else {
     gload(0, R0());
     for (int k0 = 0; k0 < K; k0 += X_BK) {
-      __syncthreads();      // the previous step's fragment reads are done
+      lds_barrier();        // the previous step's fragment reads are done
       stage(0, R0());
-      __syncthreads();
+      lds_barrier();
       if (k0 + X_BK < K) gload(k0 + X_BK, R0());
       mma(0);
     }
@@ -364,6 +368,199 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
   }
 }
 
+// ---- long-K variant with split roles (round 5) ---------------------------------------------------------------------
+// 128 pixels x 128 couts, EIGHT waves: waves 0-3 stage (global -> registers -> split -> LDS), waves 4-7 only read fragments
+// and issue MFMAs -- one of each per SIMD, so the split's vector work and LDS stores run beside the matrix pipe instead of in
+// front of it.  Three LDS slots of 32 KiB (hi / lo tiles of pixels and weights); in step k the stagers fill slot (k + 2) % 3
+// (read last in step k - 1) while the multipliers consume slot k % 3; ONE barrier per step.  One workgroup per CU.
+constexpr int XS_TILE = 128 * X_LD;                     // halfs per tile
+constexpr int XS_SLOT_HALFS = 4 * XS_TILE;
+
+template <int ACT, bool WPAIR, int XS_SLOTS>
+__global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 2 : 1) conv16x3s_kernel(const Conv32 p) {
+  extern __shared__ __attribute__((aligned(16))) char xs_lds[];
+  half_t* const L = reinterpret_cast<half_t*>(xs_lds);      // slot s: Xh | Xl | Wh | Wl at L + s * XS_SLOT_HALFS
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool stager = wave < 4;
+  const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;
+  const int mtile = p.x3_mtx ? xcd * p.x3_mtx + jj / p.x3_nt : bid % p.x3_mt;
+  const int ntile = p.x3_mtx ? jj % p.x3_nt : bid / p.x3_mt;
+  if (mtile >= p.x3_mt) return;
+  const int m0 = mtile * 128, n0 = ntile * 128;
+  const int g = blockIdx.z, gco = g * p.Cout;
+  const float* gin = p.in + (size_t)g * p.cin_g;
+  const int HoWo = p.Ho * p.Wo;
+  const int M = p.N * HoWo;
+  const int K = p.KH * p.KW * p.Cin;
+  const int nsteps = (K + X_BK - 1) / X_BK;
+  if (stager) {
+    // ---- waves 0-3: the loader of conv16x3_kernel (piece s of thread t = row t / 4 + 64 s, 8-channel chunk t % 4) ----
+    const int srow = tid >> 2, sch = tid & 3;
+    bool xok[2];
+    int oy0[2], ox0[2], pix0[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int am = m0 + srow + 64 * s2;
+      xok[s2] = am < M;
+      int an = 0, aoy = 0, aox = 0;
+      if (xok[s2]) {
+        an = am / HoWo;
+        const int r = am - an * HoWo;
+        aoy = r / p.Wo;
+        aox = r - aoy * p.Wo;
+      }
+      oy0[s2] = aoy * p.stride - p.pad;
+      ox0[s2] = aox * p.stride - p.pad;
+      pix0[s2] = an * p.H * p.W;
+    }
+    const float* wrow[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int co = n0 + srow + 64 * s2;
+      const float* base = WPAIR ? reinterpret_cast<const float*>(p.wpair) : p.w;
+      wrow[s2] = co < p.Cout ? base + (size_t)(gco + co) * K + sch * 8 : nullptr;
+    }
+    float4 rx[2][2], rw[2][2];
+    int g_k = sch * 8, g_c0 = sch * 8, g_ky = 0, g_kx = 0;
+    while (g_c0 >= p.Cin) { g_c0 -= p.Cin; if (++g_kx == p.KW) { g_kx = 0; ++g_ky; } }
+    auto gload = [&](int k0) {
+      const bool kok = g_k < K;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int iy = oy0[s2] + g_ky * p.dil, ix = ox0[s2] + g_kx * p.dil;
+        const bool ok = xok[s2] && kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float4* src = reinterpret_cast<const float4*>(ok ? gin + (size_t)(pix0[s2] + iy * p.W + ix) * p.in_ld + g_c0 : p.zero);
+        rx[s2][0] = src[0];
+        rx[s2][1] = src[1];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const float4* src = reinterpret_cast<const float4*>((wrow[s2] && kok) ? wrow[s2] + k0 : p.zero);
+        rw[s2][0] = src[0];
+        rw[s2][1] = src[1];
+      }
+      g_k += X_BK;
+      g_c0 += X_BK;
+      while (g_c0 >= p.Cin) { g_c0 -= p.Cin; if (++g_kx == p.KW) { g_kx = 0; ++g_ky; } }
+    };
+    const int soff = srow * X_LD + ((sch ^ swz(srow)) << 3);
+    auto stage = [&](int slot) {
+      half_t* const S = L + slot * XS_SLOT_HALFS;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) split_store(rx[s2], S + soff + s2 * 64 * X_LD, S + XS_TILE + soff + s2 * 64 * X_LD);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (WPAIR) pair_store(rw[s2], S + 2 * XS_TILE + soff + s2 * 64 * X_LD, S + 3 * XS_TILE + soff + s2 * 64 * X_LD);
+        else split_store(rw[s2], S + 2 * XS_TILE + soff + s2 * 64 * X_LD, S + 3 * XS_TILE + soff + s2 * 64 * X_LD);
+      }
+    };
+    // the stagers run A = XS_SLOTS - 1 steps ahead of the multipliers
+    constexpr int A = XS_SLOTS - 1;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+      if (a < nsteps) { gload(a * X_BK); stage(a); }
+    if (A < nsteps) gload(A * X_BK);
+    lds_barrier();
+    for (int k = 0; k < nsteps; ++k) {
+      if (k + A < nsteps) {
+        stage((k + A) % XS_SLOTS);                         // the registers hold step k + A; its slot was read last in step k - 1
+        if (k + A + 1 < nsteps) gload((k + A + 1) * X_BK);
+      }
+      lds_barrier();
+    }
+    return;
+  }
+  // ---- waves 4-7: fragments and MFMAs ----
+  const int cw = wave - 4;
+  const int wc = (cw & 1) * 64, wp = (cw >> 1) * 64;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int foff = fr * X_LD + ((fq ^ swz(fr)) << 3);
+  lds_barrier();
+  for (int k = 0; k < nsteps; ++k) {
+    const half_t* const S = L + (k % XS_SLOTS) * XS_SLOT_HALFS;
+    f16x8 wh[4], wl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      wh[i] = *reinterpret_cast<const f16x8*>(S + 2 * XS_TILE + (wc + i * 16) * X_LD + foff);
+      wl[i] = *reinterpret_cast<const f16x8*>(S + 3 * XS_TILE + (wc + i * 16) * X_LD + foff);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f16x8 xh = *reinterpret_cast<const f16x8*>(S + (wp + j * 16) * X_LD + foff);
+      const f16x8 xl = *reinterpret_cast<const f16x8*>(S + XS_TILE + (wp + j * 16) * X_LD + foff);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh, acc[i][j], 0, 0, 0);
+    }
+    lds_barrier();
+  }
+  // epilogue: the 16-byte form of conv16x3_kernel (the launcher sends everything else to that kernel)
+  float4 bi[4];
+  bool cok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int col = n0 + wc + i * 16 + (lane >> 4) * 4;
+    cok[i] = col < p.Cout;
+    bi[i] = (cok[i] && p.bias) ? *reinterpret_cast<const float4*>(p.bias + gco + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + wp + j * 16 + fr;
+    if (m >= M) continue;
+    const int n = m / HoWo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!cok[i]) continue;
+      const int co = gco + n0 + wc + i * 16 + (lane >> 4) * 4;
+      float4 t = make_float4(acc[i][j][0] + bi[i].x, acc[i][j][1] + bi[i].y, acc[i][j][2] + bi[i].z, acc[i][j][3] + bi[i].w);
+      if (p.bias_n) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias_n + (size_t)n * p.Cout + co);
+        t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+      }
+      if (p.res) {
+        const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
+        t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+      }
+      *reinterpret_cast<float4*>(p.out + (size_t)m * p.out_ld + co) =
+          make_float4(x_act<ACT>(t.x), x_act<ACT>(t.y), x_act<ACT>(t.z), x_act<ACT>(t.w));
+    }
+  }
+}
+
+// can the split-role kernel take this launch?  (its epilogue is the vector form only)
+inline bool xs_epilogue_ok(const Conv32& p, int gco_step) {
+  return p.ps_cout == 0 && (p.Cout & 3) == 0 && (gco_step & 3) == 0 && (p.out_ld & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 &&
+         (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && (!p.bias_n || (((uintptr_t)p.bias_n) & 15) == 0) &&
+         (!p.res || ((p.res_ld & 3) == 0 && (((uintptr_t)p.res) & 15) == 0));
+}
+
+template <bool WPAIR, int SLOTS>
+int launch_spec(const Conv32& p, dim3 grid, hipStream_t s) {
+  constexpr int LDS = SLOTS * XS_SLOT_HALFS * 2;
+  auto go = [&](auto kern) -> int {
+    static bool once = false;
+    if (!once) {
+      EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+      once = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), LDS, s, p);
+    EMP_LAUNCH_CHECK();
+    return EMP_OK;
+  };
+  if (p.act == 1) return go(&conv16x3s_kernel<1, WPAIR, SLOTS>);
+  if (p.act == 2) return go(&conv16x3s_kernel<2, WPAIR, SLOTS>);
+  return go(&conv16x3s_kernel<0, WPAIR, SLOTS>);
+}
+
 template <int BM, int BN, bool WPAIR, bool DB>
 int launch_tile(const Conv32& p, dim3 grid, hipStream_t s) {
   if (p.act == 1) hipLaunchKernelGGL((conv16x3_kernel<1, BM, BN, WPAIR, DB>), grid, dim3(256), 0, s, p);
@@ -404,6 +601,9 @@ int launch_pair(Conv32 p, hipStream_t s) {
     return EMP_OK;
   }
   const bool db = p.KH * p.KW * p.Cin >= kdb;
+  static const int spec = [] { const char* e = getenv("EMP_X3_SPEC"); return e ? atoi(e) : 2; }();      // 0: the four-wave kernel everywhere; 2 / 3: LDS slots of the split-role kernel (A/B; 3 slots = one workgroup per CU measured slower)
+  if (db && spec && bn == 128 && xs_epilogue_ok(p, p.Cout))
+    return spec == 3 ? launch_spec<WPAIR, 3>(p, grid, s) : launch_spec<WPAIR, 2>(p, grid, s);
   if (db) return bn == 128 ? launch_tile<128, 128, WPAIR, true>(p, grid, s) : launch_tile<128, 64, WPAIR, true>(p, grid, s);
   return bn == 128 ? launch_tile<128, 128, WPAIR, false>(p, grid, s) : launch_tile<128, 64, WPAIR, false>(p, grid, s);
 }
