@@ -54,6 +54,7 @@ PROTOTYPES = {
     'emp_copy_d2d': (c_int, [vp, vp, sz, vp]),
     'emp_conv2d_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+    'emp_conv256_pack_weights': (c_int, [vp, vp, c_int, c_int, c_int, c_int, vp]),
     'emp_conv2d_grouped_nhwc_f32': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_int, c_int, c_int,
                                             c_int, c_int, c_int, c_int, c_int, vp]),
     'emp_conv2d_nhwc_f32': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int,

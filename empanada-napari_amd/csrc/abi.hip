@@ -34,7 +34,7 @@ using namespace emp;
 extern "C" {
 
 const char* emp_last_error(void) { return g_err; }
-int emp_abi_version(void) { return 3; }      // 2: emp_pdl_config carries the encoder (RegNet) fields; 3: precision 2 (fp16x3), emp_conv2d_nhwc_f16x3
+int emp_abi_version(void) { return 4; }      // 2: emp_pdl_config carries the encoder (RegNet) fields; 3: precision 2 (fp16x3), emp_conv2d_nhwc_f16x3; 4: emp_conv256_pack_weights
 
 int emp_device_count(void) {
   int n = 0;
@@ -58,7 +58,7 @@ int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_l
                         void* stream) {
   EMP_REQUIRE(d_in && d_w && d_out, "conv2d: null pointer");
   EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d: bad geometry");
-  EMP_REQUIRE(variant >= 0 && (variant & 15) <= 3 && ((variant >> 4) & 15) <= 7 && ((variant >> 8) & 255) <= 64 && (variant >> 16) <= 15, "conv2d: bad variant %d", variant);
+  EMP_REQUIRE(variant >= 0 && (variant & 15) <= 3 && ((variant >> 4) & 15) <= 7 && ((variant >> 8) & 255) <= 64 && (variant >> 16) <= 31, "conv2d: bad variant %d", variant);
   ConvParams p{};
   p.in = (const half_t*)d_in;
   p.wgt = (const half_t*)d_w;
@@ -79,6 +79,10 @@ int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_l
   p.ps_cout = 0;
   p.M = N * p.Ho * p.Wo;
   return launch_conv_igemm(p, variant, (hipStream_t)stream);
+}
+
+int emp_conv256_pack_weights(const void* d_w, void* d_packed, int Cout, int KT, int Cin, int Cin2, void* stream) {
+  return conv256_pack_weights((const half_t*)d_w, (half_t*)d_packed, Cout, KT, Cin, Cin2, (hipStream_t)stream);
 }
 
 int emp_conv2d_nhwc_f32(const float* d_in, int N, int H, int W, int Cin, int in_ld, const float* d_w, const float* d_bias,

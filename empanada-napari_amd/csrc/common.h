@@ -93,7 +93,11 @@ int launch_conv_igemm_grouped(const ConvParams& p, int groups, int gs_in, long l
 // 256x256 tile for the MFMA-bound layers (conv_igemm256.hip)
 bool conv_igemm256_supported(const ConvParams& p);
 bool conv_uses_256(const ConvParams& p);      // launch_conv_igemm's auto choice
-int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg = 0, int mode = 0);
+int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg = 0, int mode = 0, bool wpacked = false);
+// packed weight image of the 256 x 256 tile (conv_igemm256.hip): ConvParams::wgt = the image, launch with wpacked (variant bit 20
+// of launch_conv_igemm); made once per layer for the default K walk
+int conv256_pack_kgroup(int KT, int Cin);
+int conv256_pack_weights(const half_t* w, half_t* out, int Cout, int KT, int Cin, int Cin2, hipStream_t stream);
 bool conv_b2b_supported(const ConvParams& p);   // can the 256x256 tile run p with its next_* convolution fused in
 // half tile, two workgroups per CU, for the short-K layers (conv_igemm256.hip)
 bool conv_igemm_h256_supported(const ConvParams& p);

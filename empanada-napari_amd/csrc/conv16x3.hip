@@ -74,6 +74,29 @@ __device__ __forceinline__ void pair_store(const float4 (&r)[2], half_t* hi, hal
   *reinterpret_cast<uint4*>(lo) = l;
 }
 
+// the same for FOUR values: one 8-byte LDS store each (the split-role kernel's whole-line pieces)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_store4(const float4& r, half_t* hi, half_t* lo) {
+  const float v[4] = {r.x, r.y, r.z, r.w};
+  f16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const half_t a = (half_t)v[e];
+    h[e] = a;
+    l[e] = (half_t)(v[e] - (float)a);
+  }
+  *reinterpret_cast<f16x4*>(hi) = h;
+  *reinterpret_cast<f16x4*>(lo) = l;
+}
+__device__ __forceinline__ void pair_store4(const float4& r, half_t* hi, half_t* lo) {
+  const uint32_t p0 = __float_as_uint(r.x), p1 = __float_as_uint(r.y), p2 = __float_as_uint(r.z), p3 = __float_as_uint(r.w);
+  uint2 h, l;
+  h.x = __builtin_amdgcn_perm(p1, p0, 0x05040100u); h.y = __builtin_amdgcn_perm(p3, p2, 0x05040100u);
+  l.x = __builtin_amdgcn_perm(p1, p0, 0x07060302u); l.y = __builtin_amdgcn_perm(p3, p2, 0x07060302u);
+  *reinterpret_cast<uint2*>(hi) = h;
+  *reinterpret_cast<uint2*>(lo) = l;
+}
+
 template <int ACT, int BM, int BN, bool WPAIR, bool DB, bool HEAD = false, bool IN2 = false>
 __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 p) {
   constexpr int WC = BN / 64;          // waves along the couts (64 couts each)
@@ -377,7 +400,7 @@ constexpr int XS_TILE = 128 * X_LD;                     // halfs per tile
 constexpr int XS_SLOT_HALFS = 4 * XS_TILE;
 
 template <int ACT, bool WPAIR, int XS_SLOTS>
-__global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 2 : 1) conv16x3s_kernel(const Conv32 p) {
+__global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(const Conv32 p) {
   extern __shared__ __attribute__((aligned(16))) char xs_lds[];
   half_t* const L = reinterpret_cast<half_t*>(xs_lds);      // slot s: Xh | Xl | Wh | Wl at L + s * XS_SLOT_HALFS
   const int tid = threadIdx.x, lane = tid & 63;
@@ -395,80 +418,135 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 2 : 1) conv16x3s_kernel(c
   const int K = p.KH * p.KW * p.Cin;
   const int nsteps = (K + X_BK - 1) / X_BK;
   if (stager) {
-    // ---- waves 0-3: the loader of conv16x3_kernel (piece s of thread t = row t / 4 + 64 s, 8-channel chunk t % 4) ----
-    const int srow = tid >> 2, sch = tid & 3;
-    bool xok[2];
-    int oy0[2], ox0[2], pix0[2];
+    // ---- waves 0-3: global -> registers -> split -> LDS.  Piece i of thread t = row t / 8 + 32 i, FOUR-channel chunk t % 8:
+    // eight consecutive lanes read one whole 128-byte line (a row's 32 fp32 channels of the step).  (The four-wave kernel's
+    // piece -- 8 channels as two 16-byte loads, four lanes per row -- touches every line in two instructions, half of it
+    // each: the texture path then spends its cycles on the line, not the bytes: 33 TD-busy cycles per load instruction
+    // measured against 16 for whole lines, and that path, not the matrix pipe, is what this kernel waits for.)
+    const int srow = tid >> 3, sc4 = tid & 7;
+    const float* wrow[4];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int am = m0 + srow + 64 * s2;
-      xok[s2] = am < M;
-      int an = 0, aoy = 0, aox = 0;
-      if (xok[s2]) {
-        an = am / HoWo;
-        const int r = am - an * HoWo;
-        aoy = r / p.Wo;
-        aox = r - aoy * p.Wo;
-      }
-      oy0[s2] = aoy * p.stride - p.pad;
-      ox0[s2] = aox * p.stride - p.pad;
-      pix0[s2] = an * p.H * p.W;
-    }
-    const float* wrow[2];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const int co = n0 + srow + 64 * s2;
+    for (int i = 0; i < 4; ++i) {
+      const int co = n0 + srow + 32 * i;
       const float* base = WPAIR ? reinterpret_cast<const float*>(p.wpair) : p.w;
-      wrow[s2] = co < p.Cout ? base + (size_t)(gco + co) * K + sch * 8 : nullptr;
+      wrow[i] = co < p.Cout ? base + (size_t)(gco + co) * K + sc4 * 4 : nullptr;
     }
-    float4 rx[2][2], rw[2][2];
-    int g_k = sch * 8, g_c0 = sch * 8, g_ky = 0, g_kx = 0;
-    while (g_c0 >= p.Cin) { g_c0 -= p.Cin; if (++g_kx == p.KW) { g_kx = 0; ++g_ky; } }
-    auto gload = [&](int k0) {
-      const bool kok = g_k < K;
+    // TWO register sets: the loads of step k + A + 1 and k + A + 2 are in flight while step k + A is split and stored (the
+    // stagers' registers are free -- the allocation is the multipliers' -- and one step of the multipliers is shorter than a
+    // loaded HBM round trip).  Every step issues its eight loads unconditionally (past K: the zero page), so that the wait
+    // in front of a split is a counted vmcnt(8), not a drain.
+    // Addresses advance by increments (Cin % 32 == 0 here: a tap is a whole number of steps and the tap changes at the same
+    // step in every lane, i.e. on scalar counters): one 64-bit add per pointer and step instead of the tap arithmetic --
+    // the stagers share their SIMD's issue port with the multipliers' MFMAs.
+    float4 rx[2][4], rw[2][4];
+    const char* px[4];
+    const char* pw[4];
+    uint32_t dx[4], dw[4];                      // bytes per step: 128, or 0 on the zero page
+    const int csteps = p.Cin / X_BK;            // steps per tap
+    int c_left = csteps, g_t = 0, g_ky = 0, g_kx = 0;
+    // (the pixel's coordinates are recomputed at every tap change -- KH * KW times per workgroup -- instead of living in
+    // registers through the loop)
+    auto set_tap = [&](bool live) {
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int iy = oy0[s2] + g_ky * p.dil, ix = ox0[s2] + g_kx * p.dil;
-        const bool ok = xok[s2] && kok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const float4* src = reinterpret_cast<const float4*>(ok ? gin + (size_t)(pix0[s2] + iy * p.W + ix) * p.in_ld + g_c0 : p.zero);
-        rx[s2][0] = src[0];
-        rx[s2][1] = src[1];
+      for (int i = 0; i < 4; ++i) {
+        int sr = srow;
+        asm volatile("" : "+v"(sr));      // (nothing of this hoisted out of the loop as an invariant: it would be spilled there)
+        const int am = m0 + sr + 32 * i;
+        const int an = am / HoWo, r = am - an * HoWo;
+        const int aoy = r / p.Wo, aox = r - aoy * p.Wo;
+        const int iy = aoy * p.stride - p.pad + g_ky * p.dil, ix = aox * p.stride - p.pad + g_kx * p.dil;
+        const bool ok = live && am < M && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        int sc = sc4 * 4;
+        asm volatile("" : "+v"(sc));
+        px[i] = reinterpret_cast<const char*>(ok ? gin + ((size_t)((an * p.H + iy) * p.W + ix) * p.in_ld + sc) : p.zero);
+        dx[i] = ok ? X_BK * 4u : 0u;
       }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const float4* src = reinterpret_cast<const float4*>((wrow[s2] && kok) ? wrow[s2] + k0 : p.zero);
-        rw[s2][0] = src[0];
-        rw[s2][1] = src[1];
-      }
-      g_k += X_BK;
-      g_c0 += X_BK;
-      while (g_c0 >= p.Cin) { g_c0 -= p.Cin; if (++g_kx == p.KW) { g_kx = 0; ++g_ky; } }
     };
-    const int soff = srow * X_LD + ((sch ^ swz(srow)) << 3);
-    auto stage = [&](int slot) {
+    set_tap(true);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pw[i] = reinterpret_cast<const char*>(wrow[i] ? wrow[i] : p.zero);
+      dw[i] = wrow[i] ? X_BK * 4u : 0u;
+    }
+    auto gload = [&](auto SET) {
+      constexpr int R = decltype(SET)::value;
+#if defined(EMP_X3_ABLATE) && EMP_X3_ABLATE == 1      // diagnostic build: no global loads (stale registers)
+      ++g_t;
+      return;
+#endif
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rx[R][i] = *reinterpret_cast<const float4*>(px[i]);
+        px[i] += dx[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        rw[R][i] = *reinterpret_cast<const float4*>(pw[i]);
+        pw[i] += dw[i];
+      }
+      ++g_t;
+      if (--c_left == 0) {                      // next tap (wave-uniform)
+        c_left = csteps;
+        if (++g_kx == p.KW) { g_kx = 0; ++g_ky; }
+        set_tap(g_t < nsteps);
+      }
+      if (g_t == nsteps) {                      // past K: everything reads the zero page from here on
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { pw[i] = reinterpret_cast<const char*>(p.zero); dw[i] = 0u; }
+      }
+    };
+    // LDS position of the piece: row, 16-byte chunk (sc4 / 2) ^ swz(row), 8-byte half sc4 % 2 (rows 32 i apart share swz)
+    const int soff = srow * X_LD + ((((sc4 >> 1) ^ swz(srow)) << 3) | ((sc4 & 1) << 2));
+    auto stage = [&](auto SET, int slot) {
+      constexpr int R = decltype(SET)::value;
+#if defined(EMP_X3_ABLATE) && EMP_X3_ABLATE == 2      // diagnostic build: no split, no LDS stores
+      asm volatile("" :: "v"(rx[R][0].x), "v"(rx[R][3].w), "v"(rw[R][0].x), "v"(rw[R][3].w));
+      return;
+#endif
       half_t* const S = L + slot * XS_SLOT_HALFS;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) split_store(rx[s2], S + soff + s2 * 64 * X_LD, S + XS_TILE + soff + s2 * 64 * X_LD);
+      for (int i = 0; i < 4; ++i) split_store4(rx[R][i], S + soff + i * 32 * X_LD, S + XS_TILE + soff + i * 32 * X_LD);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        if (WPAIR) pair_store(rw[s2], S + 2 * XS_TILE + soff + s2 * 64 * X_LD, S + 3 * XS_TILE + soff + s2 * 64 * X_LD);
-        else split_store(rw[s2], S + 2 * XS_TILE + soff + s2 * 64 * X_LD, S + 3 * XS_TILE + soff + s2 * 64 * X_LD);
+      for (int i = 0; i < 4; ++i) {
+        if (WPAIR) pair_store4(rw[R][i], S + 2 * XS_TILE + soff + i * 32 * X_LD, S + 3 * XS_TILE + soff + i * 32 * X_LD);
+        else split_store4(rw[R][i], S + 2 * XS_TILE + soff + i * 32 * X_LD, S + 3 * XS_TILE + soff + i * 32 * X_LD);
       }
     };
-    // the stagers run A = XS_SLOTS - 1 steps ahead of the multipliers
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // the stagers run A = XS_SLOTS - 1 steps ahead of the multipliers in LDS and two more steps ahead in registers;
+    // step t lives in register set t & 1
     constexpr int A = XS_SLOTS - 1;
 #pragma unroll
     for (int a = 0; a < A; ++a)
-      if (a < nsteps) { gload(a * X_BK); stage(a); }
-    if (A < nsteps) gload(A * X_BK);
+      if (a < nsteps) { gload(S0{}); stage(S0{}, a); }
+    // sets: step A -> set A & 1, step A + 1 -> the other one
+    if ((A & 1) == 0) { gload(S0{}); gload(S1{}); }
+    else { gload(S1{}); gload(S0{}); }
     lds_barrier();
-    for (int k = 0; k < nsteps; ++k) {
-      if (k + A < nsteps) {
-        stage((k + A) % XS_SLOTS);                         // the registers hold step k + A; its slot was read last in step k - 1
-        if (k + A + 1 < nsteps) gload((k + A + 1) * X_BK);
-      }
+    // main loop without a condition inside (the compiler's counted waits need the same loads pending on every path:
+    // with a guarded body it drains to vmcnt(0) in front of every split); the tail stages what is left and keeps the
+    // multipliers' barrier count
+    using SA = std::integral_constant<int, A & 1>;          // set of step k + A for even k
+    using SB = std::integral_constant<int, (A + 1) & 1>;
+    const int kst = nsteps - A;                             // steps k that still stage one
+    int k = 0;
+    for (; k + 1 < kst; k += 2) {
+      stage(SA{}, (k + A) % XS_SLOTS);                      // its slot was read last in step k - 1
+      gload(SA{});                                          // step k + A + 2 (past K: zeros, never staged)
       lds_barrier();
+      __builtin_amdgcn_sched_barrier(0);                    // (no split arithmetic hoisted over the barrier: 128 registers)
+      stage(SB{}, (k + 1 + A) % XS_SLOTS);
+      gload(SB{});
+      lds_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (k < kst) {
+      stage(SA{}, (k + A) % XS_SLOTS);
+      lds_barrier();
+      ++k;
+    }
+    for (; k < nsteps; ++k) lds_barrier();
     return;
   }
   // ---- waves 4-7: fragments and MFMAs ----
@@ -482,24 +560,42 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 2 : 1) conv16x3s_kernel(c
   const int fr = lane & 15, fq = lane >> 4;
   const int foff = fr * X_LD + ((fq ^ swz(fr)) << 3);
   lds_barrier();
+#if defined(EMP_X3_ABLATE) && EMP_X3_ABLATE == 4      // diagnostic build: no fragment reads (loop-invariant operands)
+  f16x8 abw, abx;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { abw[e] = (half_t)(float)(lane + e); abx[e] = (half_t)(float)(lane - e); }
+  asm volatile("" : "+v"(abw), "+v"(abx));
+#endif
   for (int k = 0; k < nsteps; ++k) {
     const half_t* const S = L + (k % XS_SLOTS) * XS_SLOT_HALFS;
     f16x8 wh[4], wl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+#if defined(EMP_X3_ABLATE) && EMP_X3_ABLATE == 4
+      wh[i] = abw; wl[i] = abx;
+#else
       wh[i] = *reinterpret_cast<const f16x8*>(S + 2 * XS_TILE + (wc + i * 16) * X_LD + foff);
       wl[i] = *reinterpret_cast<const f16x8*>(S + 3 * XS_TILE + (wc + i * 16) * X_LD + foff);
+#endif
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#if defined(EMP_X3_ABLATE) && EMP_X3_ABLATE == 4
+      const f16x8 xh = abx, xl = abw;
+#else
       const f16x8 xh = *reinterpret_cast<const f16x8*>(S + (wp + j * 16) * X_LD + foff);
       const f16x8 xl = *reinterpret_cast<const f16x8*>(S + XS_TILE + (wp + j * 16) * X_LD + foff);
+#endif
+#if defined(EMP_X3_ABLATE) && EMP_X3_ABLATE == 3      // diagnostic build: fragment reads, no MFMAs
+      asm volatile("" :: "v"(xh), "v"(xl), "v"(wh[j]), "v"(wl[j]));
+#else
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh, acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl, acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh, acc[i][j], 0, 0, 0);
+#endif
     }
     lds_barrier();
   }
@@ -602,7 +698,7 @@ int launch_pair(Conv32 p, hipStream_t s) {
   }
   const bool db = p.KH * p.KW * p.Cin >= kdb;
   static const int spec = [] { const char* e = getenv("EMP_X3_SPEC"); return e ? atoi(e) : 2; }();      // 0: the four-wave kernel everywhere; 2 / 3: LDS slots of the split-role kernel (A/B; 3 slots = one workgroup per CU measured slower)
-  if (db && spec && bn == 128 && xs_epilogue_ok(p, p.Cout))
+  if (db && spec && bn == 128 && p.Cin % X_BK == 0 && xs_epilogue_ok(p, p.Cout))      // (its stagers step whole taps: Cin % 32 == 0)
     return spec == 3 ? launch_spec<WPAIR, 3>(p, grid, s) : launch_spec<WPAIR, 2>(p, grid, s);
   if (db) return bn == 128 ? launch_tile<128, 128, WPAIR, true>(p, grid, s) : launch_tile<128, 64, WPAIR, true>(p, grid, s);
   return bn == 128 ? launch_tile<128, 128, WPAIR, false>(p, grid, s) : launch_tile<128, 64, WPAIR, false>(p, grid, s);

@@ -566,6 +566,10 @@ int launch_conv_igemm(const ConvParams& p, int variant, hipStream_t stream) {
   //  128->512: 0.316 vs 0.278) -- with two workgroups per CU the global-load latency is already covered and the
   //  second barrier per 64 channels costs more than the deeper prefetch saves)
   int v = variant & 15, tile = (variant >> 4) & 15, kg = (variant >> 8) & 255, mode256 = (variant >> 16) & 15;
+  if ((variant >> 20) & 1) {      // ConvParams::wgt is the 256 x 256 tile's packed image (conv256_pack_weights): that tile, default K walk
+    EMP_REQUIRE(!p.next_w && conv_igemm256_supported(p), "conv: packed weights belong to the 256x256 tile");
+    return launch_conv_igemm256(p, stream, 0, mode256, true);
+  }
   if (p.next_w) {
     EMP_REQUIRE(conv_b2b_supported(p), "conv: a fused next convolution needs the 256x256 tile (Cout == 256, >= 192 tiles)");
     return launch_conv_igemm256(p, stream, kg, mode256);

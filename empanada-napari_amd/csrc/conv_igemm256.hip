@@ -261,7 +261,12 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
   const int HoWo = p.Ho * p.Wo;
   const int KT = p.KH * p.KW;
   const int CB = p.Cin / KS;              // 32-channel slabs per tap
-  const int KG = p.kgroup;                // slabs per K-walk group (divides CB)
+  // kgroup < 0: ConvParams::wgt is this tile's PACKED weight image (pack256_kernel below, written once per network by
+  // pdl_net.hip): the 1 KiB piece a DMA instruction moves -- 16 cout rows x 64 B of one K-tile -- is contiguous there, in
+  // K-walk order, so the instruction asks L2 for eight whole 128-byte lines instead of sixteen half lines (round 5:
+  // TCP_TCC_READ_REQ 143.7 M of 64 B per ASPP launch, the texture-data path 94 % busy: profiles/r05_conv256_requests.txt)
+  const bool wpacked = p.kgroup < 0;
+  const int KG = wpacked ? -p.kgroup : p.kgroup;      // slabs per K-walk group (divides CB)
   const int KT1 = KT * CB;                // K-tiles of the main source
   const int KTOT = KT1 + (p.in2 ? p.Cin2 / KS : 0);
   const bool pointwise = (KT == 1) && p.stride == 1 && p.pad == 0;
@@ -311,7 +316,9 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
     const int row = (wave + 8 * i) * 16 + srow;
     const int co = n0 + (row & ~31) + perm32b(row & 31);
     b_base[i] = b_cur[i] = p.wgt + (size_t)co * (KT * p.Cin + (p.in2 ? p.Cin2 : 0)) + schunk * 8;
+    if (wpacked) b_cur[i] = p.wgt + (((size_t)ntile * KTOT * 16 + (wave + 8 * i)) * 512 + l * 8);
   }
+  const int b_step = wpacked ? 16 * 512 : KS;      // halfs per K-tile: the packed image holds the 16 pieces of a K-tile side by side
   int st_ky = 0, st_kx = 0, st_cb = 0, st_grp = 0, st_u = 0;
   const half_t* src[4];      // sources of the next K-tile's 4 pieces (2 pixel, 2 cout)
   auto stage_prep = [&]() {   // address work of K-tile st_u (kept out of the MFMA slot)
@@ -334,7 +341,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
           a_inc[i] = ok ? KS : 0;
         }
       }
-      if (KG != CB) {
+      if (KG != CB && !wpacked) {
         const int koff = (st_ky * p.KW + st_kx) * p.Cin + c0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) b_cur[i] = b_base[i] + koff;
@@ -345,7 +352,7 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
       src[i] = a_cur[i];
       a_cur[i] += a_inc[i];
       src[2 + i] = b_cur[i];
-      b_cur[i] += KS;
+      b_cur[i] += b_step;
     }
     if (++st_cb == KG) {
       st_cb = 0;
@@ -687,6 +694,32 @@ bool conv_igemm256_supported(const ConvParams& p) {
   return p.Cout % 256 == 0 && p.ps_cout == 0 && p.Cin % KS == 0 && p.KH * p.KW * (p.Cin / KS) + (p.in2 ? p.Cin2 / KS : 0) >= 1;
 }
 
+// Packed weight image for conv_igemm256_kernel (ConvParams::kgroup < 0): [cout tile of 256][K-tile in walk order][piece of 16
+// rows][lane][8 halfs] -- the bytes lane l of the wave that stages piece pc of K-tile t writes to LDS, in LDS order, i.e. the
+// row permutation (perm32b), the chunk swizzle and the K walk (groups of kg slabs, tap-major inside a group, the second
+// source's channels behind the main source's) are applied here once instead of by every workgroup's address arithmetic.
+__global__ void __launch_bounds__(256) pack256_kernel(const half_t* __restrict__ w, half_t* __restrict__ out, int Cout, int KT,
+                                                      int Cin, int Cin2, int KG) {
+  const int CB = Cin / KS, KT1 = KT * CB, KTOT = KT1 + Cin2 / KS, Krow = KT * Cin + Cin2;
+  const int64_t total = (int64_t)(Cout / 256) * KTOT * 16 * 64;      // 16-byte chunks
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int l = (int)(i & 63), pc = (int)((i >> 6) & 15);
+    const int64_t tt = i >> 10;
+    const int t = (int)(tt % KTOT), ntile = (int)(tt / KTOT);
+    const int row = pc * 16 + (l >> 2);
+    const int co = ntile * 256 + (row & ~31) + perm32b(row & 31);
+    const int chunk = (l & 3) ^ ((-(l >> 4)) & 3);
+    int koff;
+    if (t < KT1) {
+      const int per = KT * KG, g = t / per, idx = t - g * per, tap = idx / KG, cb = idx - tap * KG;
+      koff = tap * Cin + (g * KG + cb) * KS;
+    } else {
+      koff = KT * Cin + (t - KT1) * KS;
+    }
+    *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(w + (size_t)co * Krow + koff + chunk * 8);
+  }
+}
+
 template <int DMA_EARLY, bool B2B = false>
 static int launch256(const ConvParams& p, int grid, hipStream_t stream) {
   static bool attr_set = false;
@@ -702,7 +735,7 @@ static int launch256(const ConvParams& p, int grid, hipStream_t stream) {
 }
 
 // kg: channel slabs (32 ch) per K-walk group, 0 = default; mode: 0 = default, 1 / 2 = 2 / 4 DMA pieces issued early
-int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode) {
+int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode, bool wpacked) {
   EMP_REQUIRE(conv_igemm256_supported(p), "conv256: unsupported shape (Cout=%d)", p.Cout);
   EMP_REQUIRE(p.next_w == nullptr || conv_b2b_supported(p), "conv256: the fused next convolution needs Cout == 256 (got %d)", p.Cout);
   EMP_REQUIRE(p.out2 == nullptr || (p.split % 256 == 0 && p.split > 0 && p.split < p.Cout && p.out3 == nullptr &&
@@ -716,6 +749,10 @@ int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode) {
     if (KT == 1 || kg > CB || CB % kg != 0) kg = CB;
     p.kgroup = kg;
   }
+  if (wpacked) {      // ConvParams::wgt is conv256_pack_weights' image, made for the walk group conv256_pack_kgroup returns
+    EMP_REQUIRE(p.next_w == nullptr && p.kgroup == conv256_pack_kgroup(p.KH * p.KW, p.Cin), "conv256: packed weights need the default K walk");
+    p.kgroup = -p.kgroup;
+  }
   static const int env_mode = [] { const char* e = getenv("EMP_CONV256_MODE"); return e ? atoi(e) : 0; }();
   if (mode == 0) mode = env_mode;
   p.mt = cdiv(p.M, 256);
@@ -726,6 +763,25 @@ int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode) {
   if (mode == 1) return launch256<2>(p, grid, stream);
   if (mode == 2) return launch256<4>(p, grid, stream);
   return launch256<0>(p, grid, stream);
+}
+
+// the K-walk group (32-channel slabs) launch_conv_igemm256 takes by default: the packed image is laid out along it
+int conv256_pack_kgroup(int KT, int Cin) {
+  const int CB = Cin / KS;
+  static const int env_kg = [] { const char* e = getenv("EMP_CONV256_KGROUP"); return e ? atoi(e) : 0; }();
+  int kg = env_kg ? env_kg : 8;
+  if (KT == 1 || kg > CB || CB % kg != 0) kg = CB;
+  return kg;
+}
+// w: [Cout][KT * Cin + Cin2] halfs -> out: the same number of halfs as a packed image (Cout % 256 == 0, Cin, Cin2 % 32 == 0)
+int conv256_pack_weights(const half_t* w, half_t* out, int Cout, int KT, int Cin, int Cin2, hipStream_t stream) {
+  EMP_REQUIRE(w && out && Cout > 0 && Cout % 256 == 0 && Cin > 0 && Cin % KS == 0 && Cin2 >= 0 && Cin2 % KS == 0 && KT >= 1,
+              "conv256_pack_weights: bad shape (Cout=%d Cin=%d Cin2=%d)", Cout, Cin, Cin2);
+  const int64_t chunks = (int64_t)Cout * (KT * Cin + Cin2) / 8;
+  hipLaunchKernelGGL(pack256_kernel, dim3((unsigned)std::min<int64_t>((chunks + 255) / 256, 4096)), dim3(256), 0, stream, w, out, Cout,
+                     KT, Cin, Cin2, conv256_pack_kgroup(KT, Cin));
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
 }
 
 // half tile (conv_igemm_h256_kernel): 128 pixels x 256 couts when Cout % 256 == 0, else 256 pixels x 128 couts

@@ -42,6 +42,7 @@ struct Act {  // NHWC fp16 activation
 
 struct DevConv {  // packed conv weights
   half_t* w = nullptr;
+  half_t* w256 = nullptr;         // the 256 x 256 tile's image of w (conv256_pack_weights), made at the first launch that takes that tile
   float* b = nullptr;
   int cout = 0, cin = 0, cin_pad = 0, kh = 1, kw = 1;
   int cin2 = 0, cin2_pad = 0;     // K-concatenated second source (conv3 + projection shortcut)
@@ -66,6 +67,7 @@ struct emp_pdl {
   bool fuse_stem = [] { const char* e = getenv("EMP_FUSE_STEM"); return !(e && e[0] == '0'); }();   // stem.hip
   bool fuse_ds = [] { const char* e = getenv("EMP_FUSE_DS"); return !(e && e[0] == '0'); }();       // conv3 + downsample in one GEMM
   bool fuse_b2b = [] { const char* e = getenv("EMP_FUSE_B2B"); return !(e && e[0] == '0'); }();     // conv3 + the next block's conv1
+  bool pack256 = [] { const char* e = getenv("EMP_CONV256_PACK"); return !(e && e[0] == '0'); }();   // packed weight images for the 256 x 256 tile (A/B runs: 0)
   bool fuse_proj = [] { const char* e = getenv("EMP_FUSE_PROJ"); return !(e && e[0] == '0'); }();   // low-level projections + the next stage's conv1
   bool fuse_aspp = [] { const char* e = getenv("EMP_FUSE_ASPP"); return !(e && e[0] == '0'); }();   // the two decoders' ASPP branches as one conv each
   bool fuse_sepconv = [] { const char* e = getenv("EMP_FUSE_SEPCONV"); return !(e && e[0] == '0'); }();
@@ -722,7 +724,7 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
          const Act* in2 = nullptr, int stride2 = 1, const Act* out2 = nullptr, int out2_coff = 0, int split = 0,
          const std::string* next_name = nullptr, const Act* next_out = nullptr, bool* fused_next = nullptr,
          const Act* out3 = nullptr, int out3_coff = 0, int split3 = 0) {
-  const DevConv& dc = n->convs.at(wname);
+  DevConv& dc = n->convs.at(wname);
   ConvParams p{};
   if (out3) {     // couts [split3, Cout) go to a third tensor (ConvParams::out3)
     EMP_REQUIRE(out2 && out3->N == out.N && out3->H == out.H && out3->W == out.W && out3_coff + dc.cout - split3 <= out3->ld,
@@ -782,6 +784,20 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
   if (n->layer_log)   // EMP_LAYER_LOG=<file>: one line per MFMA launch, in launch order (tools/layer_roofline.py)
     fprintf(n->layer_log, "conv,%s,%d,%d,%d,%d,%d,%d,%d,%d\n", wname.c_str(), p.M, dc.cin_pad + dc.cin2_pad, dc.cout, dc.kh,
             stride, dil, res ? 1 : 0, in.N * in.H * in.W);
+  int variant = 0;
+  if (n->pack256 && !p.next_w && conv_uses_256(p)) {
+    // the 256 x 256 tile reads its weights from a packed image (whole 128-byte lines per LDS-DMA instruction): made once,
+    // at the first launch of this layer that takes the tile (batch-dependent), on the launch's stream
+    if (!dc.w256) {
+      const size_t halfs = (size_t)dc.cout * (dc.kh * dc.kw * dc.cin_pad + dc.cin2_pad);
+      EMP_CHECK_HIP(hipMalloc((void**)&dc.w256, halfs * sizeof(half_t)));
+      n->owned.push_back(dc.w256);
+      const int prc = conv256_pack_weights(dc.w, dc.w256, dc.cout, dc.kh * dc.kw, dc.cin_pad, dc.cin2_pad, s);
+      if (prc) return prc;
+    }
+    p.wgt = dc.w256;
+    variant = 1 << 20;
+  }
   if (n->profile && !p.next_w && conv_uses_256(p)) {     // the fused back-to-back launches are another kernel symbol
     if (n->prof_used == n->prof_events.size()) {
       hipEvent_t a, b;
@@ -791,12 +807,12 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
     }
     auto& ev = n->prof_events[n->prof_used++];
     EMP_CHECK_HIP(hipEventRecord(ev.first, s));
-    const int rc = launch_conv_igemm(p, 0, s);
+    const int rc = launch_conv_igemm(p, variant, s);
     EMP_CHECK_HIP(hipEventRecord(ev.second, s));
     n->prof_flops += 2.0 * (double)p.M * dc.cout * kflop;
     return rc;
   }
-  return launch_conv_igemm(p, 0, s);
+  return launch_conv_igemm(p, variant, s);
 }
 
 #define RC(x)            \

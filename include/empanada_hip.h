@@ -191,13 +191,24 @@ EMP_API const char* emp_pdl_tap_name(const emp_pdl_t* net, int i);
  *   variant: 0 = automatic.  Otherwise staging (bits 0-3: 1 registers | 2 LDS-DMA | 3 LDS-DMA + LDS-transposed epilogue)
  *     + 16 * tile (1 128x128 | 2 128x64 | 3 64x64 | 4 256x256 | 5 half tile 128x256 / 256x128 | 6 64->64 3x3 with
  *     register weights | 7 64x64 with a deep LDS-DMA ring, the batch-1 path) + 256 * K-walk group; every tile gives
- *     bit-identical results (same K order), the parity tests force each one. */
+ *     bit-identical results (same K order), the parity tests force each one.
+ *     + (1 << 20): d_w is the 256x256 tile's PACKED weight image (emp_conv256_pack_weights, round 5) -- that tile, its
+ *     default K walk, the same bits out. */
 EMP_API int emp_conv2d_nhwc_f16(const void* d_in, int N, int H, int W, int Cin, int in_ld,
                         const void* d_w, const float* d_bias, const float* d_bias_n,
                         const void* d_res, int res_ld,
                         void* d_out, int out_ld, int Cout,
                         int KH, int KW, int stride, int pad, int dil, int relu,
                         int variant, void* stream);
+
+/* Packed weight image for the 256x256 convolution tile (round 5; csrc/conv_igemm256.hip pack256_kernel): the network
+ * (emp_pdl_*) makes one per layer at the first launch that takes the tile.  Every 1 KiB piece an LDS-DMA instruction moves
+ * (16 cout rows x 32 channels of one K step) is contiguous in the image, in the kernel's K-walk order, so the instruction
+ * fetches whole 128-byte lines.  replaces: nothing in the reference (nn.Conv2d weights, resnet.py:109-129, re-laid out).
+ *   d_w      : (Cout, KT * Cin + Cin2) fp16 -- the weights of emp_conv2d_nhwc_f16 (KT = KH*KW; Cin2 = the K-concatenated
+ *              second source's channels, 0 if none); Cout % 256 == 0, Cin % 32 == 0, Cin2 % 32 == 0
+ *   d_packed : the same number of halfs */
+EMP_API int emp_conv256_pack_weights(const void* d_w, void* d_packed, int Cout, int KT, int Cin, int Cin2, void* stream);
 
 /* The convolution of the fp32 REFERENCE MODE (round 4, csrc/ref32.hip; emp_pdl_set_precision): NHWC fp32 maps, fp32
  * weights (Cout, KH*KW, Cin) with Cin % 16 == 0 (pad with zero weights), every product on the exact fp32 matrix pipe
