@@ -503,6 +503,287 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same tile with WHOLE-LINE pixel fetches (round 5).  PMC on the kernel above (profiles/r05_conv256_requests.txt): its
+// LDS-DMA pieces are 16 rows x 64 B -- half a 128-byte line per row, the other half belongs to the next K-tile -- so L2 sees
+// 144 M requests of 64 B per ASPP launch and the texture-data return path is 94 % busy; the same bytes asked for as whole lines
+// (a timing-only experiment) took 3-10 % less.  The weights get there by a packed image (pack256_kernel); the pixels by
+// K-tile PAIRS: a pixel piece is 8 rows x 128 B (64 channels), a pixel slot holds 256 rows of 128 B = the two K-tiles of a
+// pair side by side, and the K-tile's half is picked by the fragment address.
+//   LDS (160 KiB, all of it): cout ring  4 x 16 KiB, K-tile t in slot t & 3, rows of 64 B as above, filled 3 K-tiles ahead;
+//                             pixel ring 3 x 32 KiB, pair u in slot u % 3, rows of 128 B, filled two pairs ahead.
+//   128-byte rows: logical 16-byte chunk c (0..7: K-tile half = c / 4) of row r lives at chunk c ^ ((r >> 1) & 7) -- with
+//   lane (fr, fq) reading row fr, chunk 4 h + fq, each of gfx950's ds_read_b128 lane groups ({0-3, 12-15, 20-27}, ...)
+//   touches 8 chunk positions in even rows and the same 8 in odd rows = 64 distinct banks.
+//   Schedule per wave: K-tile t issues its 2 cout pieces of K-tile t + 3 first and, for even t = 2u, the 4 pixel pieces of
+//   pair u + 2 behind them, all in the shadow of the MFMAs.  In LOAD(T) the wave needs its cout pieces of K-tile T + 1 (issued
+//   first in K-tile T - 2) and, for odd T, its pixel pieces of pair (T + 1) / 2 (issued in K-tile T - 3): everything younger
+//   is the 4 pixel pieces of whichever of T - 2, T - 1 is even plus the 2 cout pieces of T - 1 = vmcnt(6), always.
+//   Same K order, same fragments, same epilogue: bit-identical to the kernel above (tests/test_gpu_conv_packed.py).
+constexpr int WW_SLOT = 256 * 64;                 // cout slot
+constexpr int WP_SLOT = 256 * 128;                // pixel slot (a K-tile pair)
+constexpr int WP_BASE = 4 * WW_SLOT;
+constexpr int WIDE_LDS_BYTES = WP_BASE + 3 * WP_SLOT;      // 163840
+
+__global__ void __launch_bounds__(512, 1) conv_igemm256w_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(1024))) char lds[];
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, j = bid >> 3;
+  const int mtile = xcd * p.mt_per_xcd + j / p.nt;
+  const int ntile = j % p.nt;
+  if (mtile >= p.mt) return;
+  const int m0 = mtile * 256, n0 = ntile * 256;
+
+  const int tid = threadIdx.x, l = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wc = wave & 3;
+  const int HoWo = p.Ho * p.Wo;
+  const int KT = p.KH * p.KW;
+  const int CB = p.Cin / KS;
+  const bool wpacked = p.kgroup < 0;
+  const int KG = wpacked ? -p.kgroup : p.kgroup;      // even (launcher)
+  const int KT1 = KT * CB;
+  const int KTOT = KT1 + (p.in2 ? p.Cin2 / KS : 0);   // even, >= 8 (launcher)
+  const int KP1 = KT1 >> 1;                           // pairs of the main source
+  const bool pointwise = (KT == 1) && p.stride == 1 && p.pad == 0;
+
+  // ---- cout staging: as the kernel above (pieces {w, w + 8} of 16 rows x 64 B per K-tile) ----
+  const half_t* b_base[2];
+  const half_t* b_cur[2];
+  {
+    const int srow = l >> 2, schunk = (l & 3) ^ ((-(l >> 4)) & 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (wave + 8 * i) * 16 + srow;
+      const int co = n0 + (row & ~31) + perm32b(row & 31);
+      b_base[i] = b_cur[i] = p.wgt + (size_t)co * (KT * p.Cin + (p.in2 ? p.Cin2 : 0)) + schunk * 8;
+      if (wpacked) b_cur[i] = p.wgt + (((size_t)ntile * KTOT * 16 + (wave + 8 * i)) * 512 + l * 8);
+    }
+  }
+  const int b_step = wpacked ? 16 * 512 : KS;
+  int w_t = 0, w_ky = 0, w_kx = 0, w_cb = 0, w_grp = 0;      // K-tile the next cout pieces belong to, and its place in the walk
+  auto w_prep = [&]() {
+    if (!wpacked && KG != CB && w_cb == 0 && w_t < KT1) {
+      const int koff = (w_ky * p.KW + w_kx) * p.Cin + w_grp * KG * KS;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) b_cur[i] = b_base[i] + koff;
+    }
+    if (++w_cb == KG) {
+      w_cb = 0;
+      if (++w_kx == p.KW) {
+        w_kx = 0;
+        if (++w_ky == p.KH) { w_ky = 0; ++w_grp; }
+      }
+    }
+  };
+  auto dma_w = [&](int i) {      // cout piece i of K-tile w_t
+    char* dst = lds + (w_t & 3) * WW_SLOT + (wave + 8 * i) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)b_cur[i],
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    b_cur[i] += b_step;
+  };
+
+  // ---- pixel staging: pieces {w, w + 8, w + 16, w + 24} of 8 rows x 128 B per K-tile PAIR ----
+  const int prow = l >> 3;                                             // row within the piece
+  const int pchunk = (l & 7) ^ (((wave & 1) << 2) | (prow >> 1));      // logical chunk this lane fetches: position ^ ((row >> 1) & 7)
+  int a_iy0[4], a_ix0[4], a_pix[4];
+  const half_t* a_cur[4];
+  int a_inc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + (wave + 8 * i) * 8 + prow;
+    a_iy0[i] = a_ix0[i] = -(1 << 28);
+    a_pix[i] = 0;
+    a_cur[i] = p.zero;
+    a_inc[i] = 0;
+    if (m < p.M) {
+      if (pointwise) {
+        a_cur[i] = p.in + (size_t)m * p.in_ld + pchunk * 8;
+        a_inc[i] = 2 * KS;
+      } else {
+        const int n = m / HoWo;
+        const int r = m - n * HoWo;
+        const int oy = r / p.Wo;
+        const int ox = r - oy * p.Wo;
+        a_iy0[i] = oy * p.stride - p.pad;
+        a_ix0[i] = ox * p.stride - p.pad;
+        a_pix[i] = n * p.H * p.W;
+      }
+    }
+  }
+  int p_u = 0, p_ky = 0, p_kx = 0, p_cb = 0, p_grp = 0, p_slot = 0;      // pair the next pixel pieces belong to
+  const int KG2 = KG >> 1;
+  auto p_prep = [&]() {
+    if (p_u == KP1 && p.in2) {      // the main source is exhausted: the walk continues in the second one (its pixel at stride2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (wave + 8 * i) * 8 + prow;
+        a_cur[i] = p.zero;
+        a_inc[i] = 0;
+        if (m < p.M) {
+          const int n = m / HoWo;
+          const int r = m - n * HoWo;
+          const int oy = r / p.Wo;
+          const int ox = r - oy * p.Wo;
+          a_cur[i] = p.in2 + (((size_t)n * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.in2_ld + pchunk * 8;
+          a_inc[i] = 2 * KS;
+        }
+      }
+    }
+    if (p_cb == 0 && p_u < KP1 && !pointwise) {
+      const int c0 = p_grp * KG * KS + pchunk * 8;
+      const int dy = p_ky * p.dil, dx = p_kx * p.dil;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        a_cur[i] = ok ? p.in + ((size_t)(a_pix[i] + iy * p.W + ix) * p.in_ld + c0) : p.zero;
+        a_inc[i] = ok ? 2 * KS : 0;
+      }
+    }
+    if (++p_cb == KG2) {
+      p_cb = 0;
+      if (++p_kx == p.KW) {
+        p_kx = 0;
+        if (++p_ky == p.KH) { p_ky = 0; ++p_grp; }
+      }
+    }
+  };
+  auto dma_p = [&](int i) {      // pixel piece i of pair p_u into pixel slot p_slot
+    char* dst = lds + WP_BASE + p_slot * WP_SLOT + (wave + 8 * i) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_cur[i],
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    a_cur[i] += a_inc[i];
+  };
+  auto p_next = [&]() { ++p_u; p_slot = (p_slot == 2) ? 0 : p_slot + 1; };
+
+  // ---- fragment addressing (lane-constant) ----
+  const int fr = l & 15, fq = l >> 4;
+  const int w_off = wc * 64 * 64 + fr * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);                    // + ct * 1024
+  const int p_off = WP_BASE + grp * 128 * 128 + fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);       // + q * 2048; ^ 64 for the pair's second K-tile
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f16x8 pf[8], wf[4];
+
+  // ---- prologue: pairs 0, 1 and K-tiles 0, 1, 2 in flight (in the order the steady state's counted wait assumes) ----
+  p_prep();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_p(i);
+  p_next();
+  w_prep();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) dma_w(i);
+  ++w_t;
+  w_prep();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) dma_w(i);
+  ++w_t;
+  p_prep();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_p(i);
+  p_next();
+  w_prep();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) dma_w(i);
+  ++w_t;
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // pair 0 and K-tile 0 landed
+  lds_barrier();
+  if (grp == 1) lds_barrier();      // group 1 runs one slot behind group 0
+
+  int r_slot = 0;      // pixel slot of the pair being read
+  auto load_frags = [&](int t, int h) {
+    const char* wb = lds + (t & 3) * WW_SLOT + w_off;
+    const char* pb = lds + r_slot * WP_SLOT + (p_off ^ (h << 6));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wf[c] = *reinterpret_cast<const f16x8*>(wb + c * 1024);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pf[q] = *reinterpret_cast<const f16x8*>(pb + q * 2048);
+  };
+  auto mfmas = [&](int q) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[c], pf[q], acc[c][q], 0, 0, 0);
+  };
+  // main loop: pairs (t, t + 1) whose look-ahead exists (cout K-tile t + 4, pixel pair t / 2 + 2)
+  int t = 0;
+  for (; t + 5 < KTOT; t += 2) {
+    // ---- even K-tile: LOAD, then 32 MFMAs with 2 cout + 4 pixel pieces issued in their shadow ----
+    load_frags(t, 0);
+    w_prep();
+    p_prep();
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mfmas(q);
+      if (q & 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (q == 1) { dma_w(0); dma_w(1); }
+        if (q == 3) { dma_p(0); dma_p(1); }
+        if (q == 5) dma_p(2);
+        if (q == 7) dma_p(3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    ++w_t;
+    p_next();
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    // ---- odd K-tile: the pair's second half, 2 cout pieces ----
+    load_frags(t + 1, 1);
+    w_prep();
+    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mfmas(q);
+      if (q == 1 || q == 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        dma_w(q >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    ++w_t;
+    r_slot = (r_slot == 2) ? 0 : r_slot + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+  }
+  // tail: the last four K-tiles (t = KTOT - 4 here); only the cout pieces of K-tile KTOT - 1 are still to be staged
+#pragma unroll 1
+  for (int tt = 0; tt < 4; ++tt, ++t) {
+    load_frags(t, t & 1);
+    if (tt == 0) {
+      w_prep();
+      dma_w(0);
+      dma_w(1);
+      ++w_t;
+      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mfmas(q);
+    __builtin_amdgcn_s_setprio(0);
+    if (t & 1) r_slot = (r_slot == 2) ? 0 : r_slot + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+  }
+  if (grp == 0) lds_barrier();      // equal barrier count for both groups
+  wave_epilogue_any(p, acc, m0 + grp * 128, n0 + wc * 64, fr, fq, HoWo);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Half tile: one "group" of the kernel above as its own workgroup -- 4 waves, PXR pixels x COR couts with
 // PXR + COR = 384 (128 x 256 or 256 x 128), the same 128 x 64 wave tile (12 fragment reads per 32 MFMAs), K-tiles of
 // 32 channels through a ring of THREE 24 KiB slots filled two K-tiles ahead, ONE LDS-only barrier per K-tile, and TWO
@@ -760,6 +1041,23 @@ int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode, boo
   p.mt_per_xcd = cdiv(p.mt, 8);
   const int grid = 8 * p.mt_per_xcd * p.nt;
   if (p.next_w) return launch256<0, true>(p, grid, stream);
+  {
+    // whole-line pixel fetches (conv_igemm256w_kernel): K-tile pairs need 64-channel granularity along the whole walk
+    static const bool wide_on = [] { const char* e = getenv("EMP_CONV256_WIDE"); return !(e && e[0] == '0'); }();      // A/B runs
+    const int kga = p.kgroup < 0 ? -p.kgroup : p.kgroup;
+    const int ktot = p.KH * p.KW * (p.Cin / KS) + (p.in2 ? p.Cin2 / KS : 0);
+    if (wide_on && mode == 0 && p.Cin % (2 * KS) == 0 && (!p.in2 || p.Cin2 % (2 * KS) == 0) && kga % 2 == 0 && ktot >= 8) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm256w_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_BYTES));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(conv_igemm256w_kernel, dim3(grid), dim3(512), WIDE_LDS_BYTES, stream, p);
+      EMP_LAUNCH_CHECK();
+      return EMP_OK;
+    }
+  }
   if (mode == 1) return launch256<2>(p, grid, stream);
   if (mode == 2) return launch256<4>(p, grid, stream);
   return launch256<0>(p, grid, stream);
