@@ -469,7 +469,7 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
     if B == 32 and S == 1024 and mb == 32:
         traffic, step_traffic, traffic_src = traffic_from_profiles()
     fwd_tflops = flops_fwd / (fwd_ms_per_step * 1e-3) / 1e12
-    # dominant kernel: conv_igemm256_kernel, every launch of the timed region bracketed by HIP events on its stream
+    # dominant kernel: the 256x256 tile (conv_igemm256w_kernel since round 5), every launch of the timed region bracketed by HIP events on its stream
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     res = {
         'metric': 'EM tiles/sec (1024^2 fp16)', 'value': round(value, 2), 'unit': 'tiles/s', 'n_gpus': world,
@@ -488,7 +488,7 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
                      'traffic_note': 'average HBM bytes per launch of this kernel (2*FETCH_SIZE + WRITE_SIZE, separate '
                                      'rocprofv3 PMC passes); NOT measured in this run: ' + str(traffic_src),
                      'step_traffic_all_kernels': step_traffic,
-                     'kernel': 'conv_igemm256_kernel<0, false> (256x256 implicit-GEMM tile: ASPP 3x3, layer3/4 convs, projection shortcuts; the <0, true> instantiation with the fused next conv is not counted)',
+                     'kernel': 'conv_igemm256w_kernel (256x256 implicit-GEMM tile, whole-line LDS-DMA: ASPP 3x3, layer3/4 convs, projection shortcuts; conv_igemm256_kernel<0, true> with the fused next conv is not counted)',
                      'launches_per_step': dom_launches / max(args.steps, 1),
                      'kernel_ms_per_step': round(dom_ms / max(args.steps, 1), 3),
                      'kernel_share_of_step': round(dom_ms / max(args.steps, 1) / ms_per_step, 3),

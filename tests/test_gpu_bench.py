@@ -90,7 +90,7 @@ def test_profile_tools_read_the_step_count_off_the_trace(tmp_path):
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     steps, rows, total_us = sb.breakdown(d)
     assert steps == j['forward_steps_bench_loop'] == j['forward_calls_total'] == 5
-    dom = [(c, us) for k, c, us, _ in rows if k.startswith('conv_igemm256_kernel<0, false>')][0]
+    dom = [(c, us) for k, c, us, _ in rows if k.startswith('conv_igemm256w_kernel')][0]
     assert dom[0] == 29 == j['roofline']['launches_per_step']
     assert total_us / 1e3 < 1.05 * j['ms_per_step'], (total_us, j['ms_per_step'])
     # the HIP-event figure of the line and the trace agree on the dominant kernel's time per step

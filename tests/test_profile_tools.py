@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 STEM = '_ZN3emp12_GLOBAL__N_116stem_pool_kernelIhEEvPKT_ffiiiiiPKfS6_PDF16_i'
-CONV = 'void emp::(anonymous namespace)::conv_igemm256_kernel<0, false>(emp::ConvParams)'
+CONV = 'void emp::(anonymous namespace)::conv_igemm256w_kernel(emp::ConvParams)'      # round 5: the whole-line form takes the plain launches
 B2B = 'void emp::(anonymous namespace)::conv_igemm256_kernel<0, true>(emp::ConvParams)'
 FILL = '__amd_rocclr_fillBufferAligned'
 
@@ -51,7 +51,7 @@ def test_step_breakdown_counts_steps_in_the_trace(tmp_path, steps):
     n, rows, total = sb.breakdown(d)
     assert n == steps
     per = {k: (c, us) for k, c, us, _ in rows}
-    conv = [v for k, v in per.items() if k.startswith('conv_igemm256_kernel<0, false>')][0]
+    conv = [v for k, v in per.items() if k.startswith('conv_igemm256w_kernel')][0]
     assert conv[0] == 29 and abs(conv[1] - 29 * 400.0) < 1e-6
     b2b = [v for k, v in per.items() if k.startswith('conv_igemm256_kernel<0, true>')][0]
     assert b2b[0] == 2
@@ -106,7 +106,7 @@ def test_committed_step_breakdown_fits_in_the_step():
     if not lines[0].startswith('#'):
         pytest.skip(f'{os.path.basename(p)} predates the trace-derived step count')
     rows = list(csv.reader(l for l in lines if not l.startswith('#')))
-    dom = [r for r in rows if r[0].startswith('conv_igemm256_kernel<0, false>')][0]
+    dom = [r for r in rows if r[0].startswith('conv_igemm256w_kernel')][0]
     assert float(dom[1]) == 29.0
     total = [r for r in rows if r[0] == 'TOTAL kernel time'][0]
     b = _latest('r*_bench.json')
