@@ -174,7 +174,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3_c64_kernel(const C64Params p) 
 // couts 16w..16w+15 x 1152 K = 36 fragments = 144 VGPRs and multiplies them with ALL eight pixel rows of the tile.
 // A halo row's fragment (120 ds_read_b128 per tile and wave) feeds the up to three output rows it belongs to, in an
 // order that keeps every output's K walk tap-major / channel-ascending (bit-identical to conv_igemm_kernel).
-// Halo rows are 256 B (4 pixels per LDS-DMA instruction, 45 pieces + 3 dump pieces = 6 per wave); a wave's 16 couts
+// Halo rows are 256 B = 16 chunks of 16 B, chunk c of halo pixel hp at chunk c ^ (hp & 15) (round 5: the XOR was 3 bits wide, so the
+// fq = 0 and fq = 1 lanes of a ds_read_b128 group shared eight chunk positions -- 49 % of the kernel's LDS cycles were bank conflicts);
+// 4 pixels per LDS-DMA instruction, 45 pieces + 3 dump pieces = 6 per wave; a wave's 16 couts
 // are 32 B per pixel, so the finished tile is transposed through the just-consumed halo slot into whole 256-byte rows.
 // ---------------------------------------------------------------------------
 constexpr int C128_NDMA = 6;                                // per wave and tile: 48 >= 45
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_c128_kernel(const C64Params p)
       const int hy = hp / C64_IW, hx = hp - hy * C64_IW;
       const int iy = y0 + hy - 1, ix = x0 + hx - 1;
       const bool ok = valid && hp < C64_NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const half_t* src = ok ? p.in + (((size_t)n * p.H + iy) * p.W + ix) * p.in_ld + (((lane & 15) ^ (hp & 7)) << 3)
+      const half_t* src = ok ? p.in + (((size_t)n * p.H + iy) * p.W + ix) * p.in_ld + (((lane & 15) ^ (hp & 15)) << 3)
                              : p.zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(hb + piece * 1024), 16, 0, 0);
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_c128_kernel(const C64Params p)
       f16x8 pf[4];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
-        pf[kk] = *reinterpret_cast<const f16x8*>(hb + hp * 256 + (((kk * 4 + fq) ^ (hp & 7)) << 4));
+        pf[kk] = *reinterpret_cast<const f16x8*>(hb + hp * 256 + (((kk * 4 + fq) ^ (hp & 15)) << 4));
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_c128_kernel(const C64Params p)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) o[r4] = (half_t)c64_act<ACT>(acc[y][r4] + bv[r4]);
       const int chunk = 2 * wave + (fq >> 1);                   // 16-byte chunk of couts 16w + 4fq .. +3
-      *reinterpret_cast<f16x4*>(hb + px * 256 + ((chunk ^ (px & 7)) << 4) + (fq & 1) * 8) = o;
+      *reinterpret_cast<f16x4*>(hb + px * 256 + ((chunk ^ (px & 15)) << 4) + (fq & 1) * 8) = o;
     }
     c64_barrier();
     {
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3_c128_kernel(const C64Params p)
         const int q = k * 512 + tid;                            // 2048 chunks: pixel q >> 4, chunk q & 15
         const int px = q >> 4, c = q & 15;
         const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
-        const f16x8 v = *reinterpret_cast<const f16x8*>(hb + px * 256 + ((c ^ (px & 7)) << 4));
+        const f16x8 v = *reinterpret_cast<const f16x8*>(hb + px * 256 + ((c ^ (px & 15)) << 4));
         if (oy < p.H && ox < p.W)
           *reinterpret_cast<f16x8*>(p.out + (((size_t)n * p.H + oy) * p.W + ox) * p.out_ld + c * 8) = v;
       }

@@ -130,7 +130,10 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const T* __restrict__ im
         o.h[r] = __builtin_elementwise_max(h2, f16x2{(half_t)0.f, (half_t)0.f});
         o.u[r] = (o.u[r] & keep) | (0xFC00FC00u & ~keep);      // outside the conv map: (-inf, -inf); a bit select, no branch
       }
-      *reinterpret_cast<f16x4*>(&st[q][ct * 16 + fq * 4]) = o.v;
+      // 16-byte chunk c of conv pixel q lives at chunk c ^ (q & 7): the rows are 128 B = all 32 banks apart, so the 16 lanes of a
+      // ds_write_b64 group (16 consecutive pixels, same couts) hit ONE pair of banks without it (round 5 census: 81 % of this
+      // kernel's LDS cycles were bank conflicts)
+      *reinterpret_cast<f16x4*>(&st[q][(((ct * 2 + (fq >> 1)) ^ (q & 7)) << 3) + (fq & 1) * 4]) = o.v;
     }
   }
   __syncthreads();
@@ -148,7 +151,8 @@ __global__ void __launch_bounds__(256) stem_pool_kernel(const T* __restrict__ im
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(&st[(2 * py + dy) * ST + 2 * px + dx][cg * 8]);
+        const int sq = (2 * py + dy) * ST + 2 * px + dx;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(&st[sq][(cg ^ (sq & 7)) * 8]);
 #pragma unroll
         for (int c = 0; c < 8; ++c) m[c] = fmaxf(m[c], (float)v[c]);
       }
