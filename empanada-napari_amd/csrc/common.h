@@ -191,10 +191,13 @@ struct Conv32 {
   int x3_mt, x3_nt, x3_mtx;   // x3 only: pixel tiles, cout tiles, pixel tiles per XCD (set by launch_conv16x3)
   const float* zero;          // x3 only: 64 B of zeros (the source of out-of-range operand chunks), set by launch_conv16x3
   const uint32_t* wpair;      // x3 only, optional: the weights already split, one uint32 = fp16 hi | fp16 lo << 16, layout of `w`
+  const half_t* wimg;         // x3 only, optional: the weights as the split-role kernel's LDS image (launch_x3_weight_image), fetched by LDS-DMA
 };
 int launch_conv32(const Conv32& p, hipStream_t s);
 int launch_conv16x3(const Conv32& p, hipStream_t s);      // called by launch_conv32 when p.x3 (its checks have run)
 int launch_split_pairs(const float* w, uint32_t* out, int64_t n, hipStream_t s);
+int64_t x3_weight_image_halfs(int Cout, int K, int Cin);      // 0: the shape never reaches the kernel that reads images
+int launch_x3_weight_image(const float* w, half_t* out, int Cout, int K, hipStream_t s);
 int conv16x3_cout_tiles(int Cout);      // cout tiles of a launch (the size of head_part's first dimension)
 int launch_head_finish_f32(const float* part, int tiles, int N, int P, int C, const float* b, float* out, hipStream_t s);
 int launch_stem3x3s2_f32(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,

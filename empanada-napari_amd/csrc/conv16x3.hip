@@ -399,10 +399,20 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
 constexpr int XS_TILE = 128 * X_LD;                     // halfs per tile
 constexpr int XS_SLOT_HALFS = 4 * XS_TILE;
 
-template <int ACT, bool WPAIR, int XS_SLOTS>
+// WIMG (round 5, late): the weights come from a packed IMAGE (Conv32::wimg, x3_weight_image_kernel: per cout tile and step the
+// hi tile and the lo tile exactly as they lie in LDS, 16 KiB contiguous) by LDS-DMA, three steps deep in a ring of their own --
+// no registers, no split, no LDS stores for half of the operand bytes, and twice the bytes in flight (finding 51: register
+// staging bounded them).  LDS then: pixel slots 2 x [Xh | Xl] + cout slots 3 x [Wh | Wl] = 80 KiB, two workgroups per CU.
+template <int ACT, bool WPAIR, int XS_SLOTS, bool WIMG = false>
 __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(const Conv32 p) {
-  extern __shared__ __attribute__((aligned(16))) char xs_lds[];
+  static_assert(!WIMG || XS_SLOTS == 2, "the image variant has two pixel slots");
+  extern __shared__ __attribute__((aligned(1024))) char xs_lds[];
   half_t* const L = reinterpret_cast<half_t*>(xs_lds);      // slot s: Xh | Xl | Wh | Wl at L + s * XS_SLOT_HALFS
+  // (WIMG: the cout ring is an LDS object of its own, so that the compiler can tell the stagers' ds_writes -- pixel slots -- from
+  // the LDS-DMA's destination: with one array it drained vmcnt in front of every staging pass)
+  __shared__ __attribute__((aligned(1024))) half_t xs_wring[WIMG ? 3 * 2 * XS_TILE : 8];
+  auto xslot = [&](int s) { return WIMG ? L + s * 2 * XS_TILE : L + s * XS_SLOT_HALFS; };                                   // Xh | Xl
+  auto wslot = [&](int s) { return WIMG ? xs_wring + s * 2 * XS_TILE : L + s * XS_SLOT_HALFS + 2 * XS_TILE; };            // Wh | Wl
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool stager = wave < 4;
@@ -479,10 +489,12 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
         rx[R][i] = *reinterpret_cast<const float4*>(px[i]);
         px[i] += dx[i];
       }
+      if constexpr (!WIMG) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        rw[R][i] = *reinterpret_cast<const float4*>(pw[i]);
-        pw[i] += dw[i];
+        for (int i = 0; i < 4; ++i) {
+          rw[R][i] = *reinterpret_cast<const float4*>(pw[i]);
+          pw[i] += dw[i];
+        }
       }
       ++g_t;
       if (--c_left == 0) {                      // next tap (wave-uniform)
@@ -503,23 +515,43 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
       asm volatile("" :: "v"(rx[R][0].x), "v"(rx[R][3].w), "v"(rw[R][0].x), "v"(rw[R][3].w));
       return;
 #endif
-      half_t* const S = L + slot * XS_SLOT_HALFS;
+      half_t* const SX = xslot(slot);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) split_store4(rx[R][i], S + soff + i * 32 * X_LD, S + XS_TILE + soff + i * 32 * X_LD);
+      for (int i = 0; i < 4; ++i) split_store4(rx[R][i], SX + soff + i * 32 * X_LD, SX + XS_TILE + soff + i * 32 * X_LD);
+      if constexpr (!WIMG) {
+        half_t* const SW = wslot(slot);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (WPAIR) pair_store4(rw[R][i], S + 2 * XS_TILE + soff + i * 32 * X_LD, S + 3 * XS_TILE + soff + i * 32 * X_LD);
-        else split_store4(rw[R][i], S + 2 * XS_TILE + soff + i * 32 * X_LD, S + 3 * XS_TILE + soff + i * 32 * X_LD);
+        for (int i = 0; i < 4; ++i) {
+          if (WPAIR) pair_store4(rw[R][i], SW + soff + i * 32 * X_LD, SW + XS_TILE + soff + i * 32 * X_LD);
+          else split_store4(rw[R][i], SW + soff + i * 32 * X_LD, SW + XS_TILE + soff + i * 32 * X_LD);
+        }
       }
+    };
+    // WIMG: this wave's four 1 KiB pieces of step t's [Wh | Wl] image into cout slot t % 3 (t clamped: the last steps' extra
+    // issues rewrite a slot nobody reads any more -- every step issues, so the counted waits below are constants).  Buffer
+    // form: descriptor + scalar piece offset + ONE lane-offset register (64-bit per-lane addresses made the register
+    // allocator move pending pixel loads out of the way, i.e. wait for them, at the top of every iteration)
+    const int dma_voff = lane * 16;
+    __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(WIMG ? p.wimg : nullptr), 0, 0x7fffffff, 0x00020000);
+    auto dma_w = [&](int t) {
+      const int tc = t < nsteps ? t : nsteps - 1;
+      const int soff0 = (((ntile * nsteps + tc) * 16 + wave * 4) * 512) * 2;      // bytes (launcher: the image is below 2 GiB)
+      half_t* dst = wslot(t % 3) + wave * 4 * 512;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (__attribute__((address_space(3))) void*)(dst + i * 512), 16, dma_voff,
+                                                 soff0 + i * 1024, 0, 0);
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     // the stagers run A = XS_SLOTS - 1 steps ahead of the multipliers in LDS and two more steps ahead in registers;
     // step t lives in register set t & 1
     constexpr int A = XS_SLOTS - 1;
+    if constexpr (WIMG) dma_w(0);                           // (older than step 0's pixel loads: their wait covers it)
 #pragma unroll
     for (int a = 0; a < A; ++a)
       if (a < nsteps) { gload(S0{}); stage(S0{}, a); }
+    if constexpr (WIMG) dma_w(1);
     // sets: step A -> set A & 1, step A + 1 -> the other one
     if ((A & 1) == 0) { gload(S0{}); gload(S1{}); }
     else { gload(S1{}); gload(S0{}); }
@@ -531,16 +563,24 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
     using SB = std::integral_constant<int, (A + 1) & 1>;
     const int kst = nsteps - A;                             // steps k that still stage one
     int k = 0;
+    // WIMG: iteration k issues the cout image of step k + 2 FIRST (its slot was read last in step k - 1), then stages and
+    // loads pixels; before the barrier that opens step k + 1 the image of step k + 1 (first thing issued in iteration
+    // k - 1) must have landed: younger than it are iteration k - 1's 4 pixel loads and iteration k's 4 + 4 = vmcnt(12)
     for (; k + 1 < kst; k += 2) {
+      if constexpr (WIMG) dma_w(k + 2);
       stage(SA{}, (k + A) % XS_SLOTS);                      // its slot was read last in step k - 1
       gload(SA{});                                          // step k + A + 2 (past K: zeros, never staged)
+      if constexpr (WIMG) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       lds_barrier();
       __builtin_amdgcn_sched_barrier(0);                    // (no split arithmetic hoisted over the barrier: 128 registers)
+      if constexpr (WIMG) dma_w(k + 3);
       stage(SB{}, (k + 1 + A) % XS_SLOTS);
       gload(SB{});
+      if constexpr (WIMG) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       lds_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (WIMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail: everything issued has landed
     if (k < kst) {
       stage(SA{}, (k + A) % XS_SLOTS);
       lds_barrier();
@@ -567,15 +607,16 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
   asm volatile("" : "+v"(abw), "+v"(abx));
 #endif
   for (int k = 0; k < nsteps; ++k) {
-    const half_t* const S = L + (k % XS_SLOTS) * XS_SLOT_HALFS;
+    const half_t* const SX = xslot(k % XS_SLOTS);
+    const half_t* const SW = wslot(WIMG ? k % 3 : k % XS_SLOTS);
     f16x8 wh[4], wl[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #if defined(EMP_X3_ABLATE) && EMP_X3_ABLATE == 4
       wh[i] = abw; wl[i] = abx;
 #else
-      wh[i] = *reinterpret_cast<const f16x8*>(S + 2 * XS_TILE + (wc + i * 16) * X_LD + foff);
-      wl[i] = *reinterpret_cast<const f16x8*>(S + 3 * XS_TILE + (wc + i * 16) * X_LD + foff);
+      wh[i] = *reinterpret_cast<const f16x8*>(SW + (wc + i * 16) * X_LD + foff);
+      wl[i] = *reinterpret_cast<const f16x8*>(SW + XS_TILE + (wc + i * 16) * X_LD + foff);
 #endif
     }
 #pragma unroll
@@ -583,8 +624,8 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
 #if defined(EMP_X3_ABLATE) && EMP_X3_ABLATE == 4
       const f16x8 xh = abx, xl = abw;
 #else
-      const f16x8 xh = *reinterpret_cast<const f16x8*>(S + (wp + j * 16) * X_LD + foff);
-      const f16x8 xl = *reinterpret_cast<const f16x8*>(S + XS_TILE + (wp + j * 16) * X_LD + foff);
+      const f16x8 xh = *reinterpret_cast<const f16x8*>(SX + (wp + j * 16) * X_LD + foff);
+      const f16x8 xl = *reinterpret_cast<const f16x8*>(SX + XS_TILE + (wp + j * 16) * X_LD + foff);
 #endif
 #if defined(EMP_X3_ABLATE) && EMP_X3_ABLATE == 3      // diagnostic build: fragment reads, no MFMAs
       asm volatile("" :: "v"(xh), "v"(xl), "v"(wh[j]), "v"(wl[j]));
@@ -639,9 +680,9 @@ inline bool xs_epilogue_ok(const Conv32& p, int gco_step) {
          (!p.res || ((p.res_ld & 3) == 0 && (((uintptr_t)p.res) & 15) == 0));
 }
 
-template <bool WPAIR, int SLOTS>
+template <bool WPAIR, int SLOTS, bool WIMG = false>
 int launch_spec(const Conv32& p, dim3 grid, hipStream_t s) {
-  constexpr int LDS = SLOTS * XS_SLOT_HALFS * 2;
+  constexpr int LDS = WIMG ? 4 * XS_TILE * 2 : SLOTS * XS_SLOT_HALFS * 2;      // dynamic part (WIMG: + 48 KiB static cout ring)
   auto go = [&](auto kern) -> int {
     static bool once = false;
     if (!once) {
@@ -652,9 +693,9 @@ int launch_spec(const Conv32& p, dim3 grid, hipStream_t s) {
     EMP_LAUNCH_CHECK();
     return EMP_OK;
   };
-  if (p.act == 1) return go(&conv16x3s_kernel<1, WPAIR, SLOTS>);
-  if (p.act == 2) return go(&conv16x3s_kernel<2, WPAIR, SLOTS>);
-  return go(&conv16x3s_kernel<0, WPAIR, SLOTS>);
+  if (p.act == 1) return go(&conv16x3s_kernel<1, WPAIR, SLOTS, WIMG>);
+  if (p.act == 2) return go(&conv16x3s_kernel<2, WPAIR, SLOTS, WIMG>);
+  return go(&conv16x3s_kernel<0, WPAIR, SLOTS, WIMG>);
 }
 
 template <int BM, int BN, bool WPAIR, bool DB>
@@ -698,8 +739,11 @@ int launch_pair(Conv32 p, hipStream_t s) {
   }
   const bool db = p.KH * p.KW * p.Cin >= kdb;
   static const int spec = [] { const char* e = getenv("EMP_X3_SPEC"); return e ? atoi(e) : 2; }();      // 0: the four-wave kernel everywhere; 2 / 3: LDS slots of the split-role kernel (A/B; 3 slots = one workgroup per CU measured slower)
-  if (db && spec && bn == 128 && p.Cin % X_BK == 0 && xs_epilogue_ok(p, p.Cout))      // (its stagers step whole taps: Cin % 32 == 0)
+  if (db && spec && bn == 128 && p.Cin % X_BK == 0 && xs_epilogue_ok(p, p.Cout)) {      // (its stagers step whole taps: Cin % 32 == 0)
+    static const bool wimg_on = [] { const char* e = getenv("EMP_X3_WIMG"); return !(e && e[0] == '0'); }();      // A/B runs
+    if (p.wimg && wimg_on && G == 1 && spec == 2 && (int64_t)nt * (kk / X_BK) * 16384 < (1ll << 31)) return launch_spec<WPAIR, 2, true>(p, grid, s);
     return spec == 3 ? launch_spec<WPAIR, 3>(p, grid, s) : launch_spec<WPAIR, 2>(p, grid, s);
+  }
   if (db) return bn == 128 ? launch_tile<128, 128, WPAIR, true>(p, grid, s) : launch_tile<128, 64, WPAIR, true>(p, grid, s);
   return bn == 128 ? launch_tile<128, 128, WPAIR, false>(p, grid, s) : launch_tile<128, 64, WPAIR, false>(p, grid, s);
 }
@@ -757,11 +801,49 @@ int launch_head_finish_f32(const float* part, int tiles, int N, int P, int C, co
   return EMP_OK;
 }
 
+// Weight IMAGE of the split-role kernel's WIMG variant: [cout tile of 128][step of 32 k][hi tile | lo tile], a tile = 128 rows
+// of 64 B with 16-byte chunk c of row r at chunk c ^ swz(r) -- the bytes of the kernel's [Wh | Wl] LDS slot; rows past Cout
+// are zeros.  w: [Cout][K] fp32, K % 32 == 0.
+__global__ void __launch_bounds__(256) x3_weight_image_kernel(const float* __restrict__ w, half_t* __restrict__ out, int Cout, int K) {
+  const int nsteps = K / X_BK, ntiles = (Cout + 127) / 128;
+  const int64_t total = (int64_t)ntiles * nsteps * 128 * 4;      // (row, logical chunk) pairs
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i & 3), r = (int)((i >> 2) & 127);
+    const int64_t ts = i >> 9;
+    const int st = (int)(ts % nsteps), nt = (int)(ts / nsteps);
+    const int co = nt * 128 + r;
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = co < Cout ? w[(size_t)co * K + st * X_BK + c * 8 + e] : 0.f;
+      const half_t a = (half_t)x;
+      h[e] = a;
+      l[e] = (half_t)(x - (float)a);
+    }
+    half_t* base = out + (size_t)ts * 2 * XS_TILE + r * X_LD + ((c ^ swz(r)) << 3);
+    *reinterpret_cast<f16x8*>(base) = h;
+    *reinterpret_cast<f16x8*>(base + XS_TILE) = l;
+  }
+}
+
 // fp32 weights -> one uint32 per weight: fp16(x) | fp16(x - fp16(x)) << 16 (emp_pdl_finalize in the fp16x3 mode)
 int launch_split_pairs(const float* w, uint32_t* out, int64_t n, hipStream_t s) {
   if (n <= 0) return EMP_OK;
   int64_t g = (n + 255) / 256;
   hipLaunchKernelGGL(split_pairs_kernel, dim3((unsigned)(g > 65535 ? 65535 : g)), dim3(256), 0, s, w, out, n);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+// halfs of conv16x3's weight image for a [Cout][K] convolution, or 0 where the split-role kernel cannot take it
+int64_t x3_weight_image_halfs(int Cout, int K, int Cin) {
+  if (Cout <= 64 || K % X_BK != 0 || Cin % X_BK != 0) return 0;
+  return (int64_t)((Cout + 127) / 128) * (K / X_BK) * 2 * XS_TILE;
+}
+int launch_x3_weight_image(const float* w, half_t* out, int Cout, int K, hipStream_t s) {
+  EMP_REQUIRE(w && out && Cout > 0 && K > 0 && K % X_BK == 0, "x3_weight_image: bad shape");
+  const int64_t total = (int64_t)((Cout + 127) / 128) * (K / X_BK) * 512;
+  hipLaunchKernelGGL(x3_weight_image_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, s, w, out, Cout, K);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }

@@ -115,7 +115,7 @@ struct emp_pdl {
   bool x3_fuse_head = [] { const char* e = getenv("EMP_X3_FUSE_HEAD"); return !(e && e[0] == '0'); }();
   bool regnet_grouped = [] { const char* e = getenv("EMP_REGNET_GROUPED"); return !(e && e[0] == '0'); }();
   int64_t regnet_group_tiles = [] { const char* e = getenv("EMP_REGNET_GROUP_TILES"); return e ? atoll(e) : 2048ll; }();
-  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; int cin2 = 0, cin2_16 = 0; };
+  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; int cin2 = 0, cin2_16 = 0; half_t* wimg = nullptr; };
   std::map<std::string, W32> w32;
   std::map<std::string, std::pair<float*, size_t>> pool32;      // name -> (device buffer, floats)
   std::map<std::string, std::array<int, 4>> geom32;             // zero-tailed RegNet maps: the geometry a buffer was last cleared for
@@ -1546,6 +1546,15 @@ int finalize32(emp_pdl* n) {
       n->owned.push_back(d);
       w.wp = (uint32_t*)d;
       RC32(launch_split_pairs(w.w, w.wp, cnt, nullptr));
+      // long-K layers (the split-role kernel's): the weights once more as that kernel's LDS image, fetched by LDS-DMA
+      const int K = w.kh * w.kw * w.cin16;
+      const int64_t ih = (w.cin2_16 == 0 && K >= 1024) ? x3_weight_image_halfs(w.cout, K, w.cin16) : 0;
+      if (ih > 0) {
+        EMP_CHECK_HIP(hipMalloc(&d, (size_t)ih * sizeof(half_t)));
+        n->owned.push_back(d);
+        w.wimg = (half_t*)d;
+        RC32(launch_x3_weight_image(w.w, w.wimg, w.cout, K, nullptr));
+      }
     }
     EMP_CHECK_HIP(hipStreamSynchronize(nullptr));
   }
@@ -1575,6 +1584,7 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
   p.act = act; p.ps_cout = ps_cout;
   p.x3 = n->precision == 2;
   p.wpair = p.x3 ? w.wp : nullptr;
+  p.wimg = (p.x3 && groups <= 1) ? w.wimg : nullptr;
   p.head_w = head_w; p.head_part = head_part; p.head_c = head_c;      // (fp16x3 only: the map `out` is then not written)
   if (in2) {      // K-concatenated second source (fp16x3 only: weights packed by pack32_conv3_ds)
     EMP_REQUIRE(p.x3 && w.cin2_16 > 0 && w.cin2_16 <= in2->ld && in2->N == in.N, "%s: second source mismatch", wname.c_str());
