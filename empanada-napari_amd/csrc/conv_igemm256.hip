@@ -1046,7 +1046,8 @@ int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode, boo
     static const bool wide_on = [] { const char* e = getenv("EMP_CONV256_WIDE"); return !(e && e[0] == '0'); }();      // A/B runs
     const int kga = p.kgroup < 0 ? -p.kgroup : p.kgroup;
     const int ktot = p.KH * p.KW * (p.Cin / KS) + (p.in2 ? p.Cin2 / KS : 0);
-    if (wide_on && mode == 0 && p.Cin % (2 * KS) == 0 && (!p.in2 || p.Cin2 % (2 * KS) == 0) && kga % 2 == 0 && ktot >= 8) {
+    if (wide_on && mode == 0 && p.Cin % (2 * KS) == 0 && (!p.in2 || p.Cin2 % (2 * KS) == 0) && kga % 2 == 0 && ktot >= 8 &&
+        (int64_t)p.N * p.H * p.W < (1ll << 31)) {      // (its pixel indices are 32-bit)
       static bool attr_set = false;
       if (!attr_set) {
         EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm256w_kernel),
