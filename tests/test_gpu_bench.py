@@ -95,3 +95,41 @@ def test_profile_tools_read_the_step_count_off_the_trace(tmp_path):
     assert total_us / 1e3 < 1.05 * j['ms_per_step'], (total_us, j['ms_per_step'])
     # the HIP-event figure of the line and the trace agree on the dominant kernel's time per step
     assert abs(dom[1] / 1e3 - j['roofline']['kernel_ms_per_step']) < 0.08 * j['roofline']['kernel_ms_per_step']
+
+
+def test_dominant_kernel_asks_l2_for_whole_lines(tmp_path):
+    """Finding 52 as a test (profiles/r05_conv256_requests.txt): on the ASPP 3x3 shape the 256x256 tile's LDS-DMA used to ask
+    L2 for half lines -- 64-byte row pieces: ~67 B per TCP->TCC read request -- and, with packed weight images and K-tile
+    pairs for the pixels, asks for whole ones: >= 120 B per request for the same bytes.  rocprofv3 --pmc TCP_TCC_READ_REQ_sum
+    around tools/one_conv.py; bytes through L1 per launch = workgroups x K-tiles x 32 KiB (every operand byte is staged once
+    per workgroup)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    if shutil.which('rocprofv3') is None:
+        pytest.skip('rocprofv3 not on PATH')
+    B, H, Cin, Cout, k = 8, 64, 2048, 256, 3
+    l1_bytes = (B * H * H // 256) * (Cout // 256) * (k * k * Cin // 32) * 32768
+
+    def requests(name, packed, env):
+        d = str(tmp_path / name)
+        e = dict(os.environ, TMPDIR=str(tmp_path), **env)
+        r = subprocess.run(['rocprofv3', '--pmc', 'TCP_TCC_READ_REQ_sum', '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p',
+                            '--', sys.executable, os.path.join(ROOT, 'tools', 'one_conv.py'), str(H), str(H), str(Cin), str(Cout),
+                            str(k), '4', '64', str(B), str(packed)], capture_output=True, text=True, env=e, cwd=str(tmp_path), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+        assert f, 'no counter file'
+        per = {}
+        for row in csv.DictReader(open(f[0])):
+            if 'conv_igemm256' in row['Kernel_Name'] and row['Counter_Name'] == 'TCP_TCC_READ_REQ_sum':
+                per[row['Dispatch_Id']] = per.get(row['Dispatch_Id'], 0.0) + float(row['Counter_Value'])
+        assert per, 'the 256x256 tile did not run'
+        return l1_bytes / (sum(per.values()) / len(per))
+
+    whole = requests('whole', 1, {})
+    half = requests('half', 0, {'EMP_CONV256_WIDE': '0'})
+    print(f'bytes per L2 read request: whole-line kernel + packed weights {whole:.1f}, rounds 2-4 kernel {half:.1f}')
+    assert whole >= 120.0, whole
+    assert half <= 72.0, half

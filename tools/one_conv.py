@@ -1,4 +1,5 @@
-"""Run one conv shape a few times (for rocprofv3 --pmc): python tools/one_conv.py H W Cin Cout k dil variant batch"""
+"""Run one conv shape a few times (for rocprofv3 --pmc): python tools/one_conv.py H W Cin Cout k dil variant batch [packed]
+(packed = 1: the 256x256 tile with its packed weight image, emp_conv256_pack_weights + variant bit 20)"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +15,10 @@ x = torch.randn((B, H, W, Cin), device=dev).to(torch.float16)
 w = (torch.randn((Cout, k * k, Cin), device=dev) / np.sqrt(Cin * k * k)).to(torch.float16)
 b = torch.randn((Cout,), device=dev)
 out = torch.empty((B, H, W, Cout), device=dev, dtype=torch.float16)
+if len(sys.argv) > 9 and int(sys.argv[9]):
+    wp = torch.empty_like(w)
+    _abi.check(lib.emp_conv256_pack_weights(_abi.ptr(w), _abi.ptr(wp), Cout, k * k, Cin, 0, _abi.stream_ptr(dev)), 'pack')
+    w, v = wp, v | (1 << 20)
 for _ in range(3):
     _abi.check(lib.emp_conv2d_nhwc_f16(_abi.ptr(x), B, H, W, Cin, Cin, _abi.ptr(w), _abi.ptr(b), None, None, 0,
                                        _abi.ptr(out), Cout, Cout, k, k, 1, p, d, 1, v, _abi.stream_ptr(dev)), 'conv')
