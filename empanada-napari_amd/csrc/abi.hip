@@ -2,7 +2,10 @@
 // operator-level entry points that are not tied to a network object.
 #include <stdarg.h>
 
+#include <map>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 #include "common.h"
 
@@ -27,6 +30,19 @@ const void* zero_page() {
   return page;
 }
 
+int ensure_dyn_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> done;      // (device, kernel) -> bytes granted
+  int dev = 0;
+  EMP_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = done.find({dev, kernel});
+  if (it != done.end() && it->second >= bytes) return EMP_OK;
+  EMP_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done[{dev, kernel}] = bytes;
+  return EMP_OK;
+}
+
 }  // namespace emp
 
 using namespace emp;
@@ -34,7 +50,7 @@ using namespace emp;
 extern "C" {
 
 const char* emp_last_error(void) { return g_err; }
-int emp_abi_version(void) { return 4; }      // 2: emp_pdl_config carries the encoder (RegNet) fields; 3: precision 2 (fp16x3), emp_conv2d_nhwc_f16x3; 4: emp_conv256_pack_weights
+int emp_abi_version(void) { return 5; }      // 2: emp_pdl_config carries the encoder (RegNet) fields; 3: precision 2 (fp16x3), emp_conv2d_nhwc_f16x3; 4: emp_conv256_pack_weights; 5: the hl32 plane format (emp_hl32_*, emp_x3p_pack_weights, emp_conv2d_hl32_f16x3), emp_conv2d_nhwc_f16x3_ex, default precision 2
 
 int emp_device_count(void) {
   int n = 0;
@@ -117,6 +133,94 @@ int emp_conv2d_nhwc_f16x3(const float* d_in, int N, int H, int W, int Cin, int i
   p.x3 = 1;
   if (groups > 1) { p.groups = groups; p.cin_g = cin_g; }
   return launch_conv32(p, (hipStream_t)stream);
+}
+
+// Test and tuning entry of every variant of the fp16x3 convolution that the network reaches and emp_conv2d_nhwc_f16x3 cannot
+// express: pre-split weight pairs, the split-role kernel's LDS-DMA weight image, a K-concatenated second source,
+// the fused 1x1 head, an hl32 output.  Allocates its temporaries (synchronising: not a hot-path call).
+int emp_conv2d_nhwc_f16x3_ex(const float* d_in, int N, int H, int W, int Cin, int in_ld, const float* d_w, const float* d_bias,
+                             const float* d_bias_n, const float* d_res, int res_ld, void* d_out, int out_ld, int out_fmt, int Cout, int KH,
+                             int KW, int stride, int pad, int dil, int act, int wmode, const float* d_in2, int H2, int W2, int Cin2,
+                             int in2_ld, int stride2, const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
+                             void* stream) {
+  EMP_REQUIRE(d_in && d_w && (d_out || d_head_w), "conv2d_f16x3_ex: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0 && wmode >= 0 && wmode <= 2,
+              "conv2d_f16x3_ex: bad geometry (wmode 0 fp32 weights, 1 split pairs, 2 pairs + LDS-DMA image)");
+  hipStream_t s = (hipStream_t)stream;
+  Conv32 p{};
+  p.in = d_in; p.in_ld = in_ld; p.w = d_w; p.bias = d_bias; p.bias_n = d_bias_n; p.res = d_res; p.res_ld = res_ld;
+  p.out = (float*)d_out; p.out_ld = out_ld; p.out_fmt = out_fmt;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  EMP_REQUIRE(p.Ho > 0 && p.Wo > 0 && (d_head_w || out_ld >= Cout) && (d_res == nullptr || res_ld >= Cout), "conv2d_f16x3_ex: bad output geometry");
+  p.act = act;
+  p.x3 = 1;
+  if (d_in2) { p.in2 = d_in2; p.in2_ld = in2_ld; p.Cin2 = Cin2; p.H2 = H2; p.W2 = W2; p.stride2 = stride2; }
+  const int64_t Krow = (int64_t)KH * KW * Cin + (d_in2 ? Cin2 : 0);
+  std::vector<void*> tmp;
+  auto cleanup = [&]() { for (void* q : tmp) (void)hipFree(q); };
+  int rc = EMP_OK;
+  if (wmode >= 1) {
+    void* d = nullptr;
+    if (hipMalloc(&d, (size_t)Cout * Krow * sizeof(uint32_t)) != hipSuccess) { cleanup(); set_error("conv2d_f16x3_ex: out of memory"); return EMP_ERR_NOMEM; }
+    tmp.push_back(d);
+    p.wpair = (const uint32_t*)d;
+    rc = launch_split_pairs(d_w, (uint32_t*)d, (int64_t)Cout * Krow, s);
+  }
+  if (!rc && wmode == 2 && !d_in2) {
+    const int64_t ih = x3_weight_image_halfs(Cout, (int)Krow, Cin);
+    if (ih > 0) {
+      void* d = nullptr;
+      if (hipMalloc(&d, (size_t)ih * sizeof(half_t)) != hipSuccess) { cleanup(); set_error("conv2d_f16x3_ex: out of memory"); return EMP_ERR_NOMEM; }
+      tmp.push_back(d);
+      p.wimg = (const half_t*)d;
+      rc = launch_x3_weight_image(d_w, (half_t*)d, Cout, (int)Krow, s);
+    }
+  }
+  const int64_t MP = (int64_t)N * p.Ho * p.Wo;
+  const int tiles = conv16x3_cout_tiles(Cout);
+  if (!rc && d_head_w) {
+    EMP_REQUIRE(d_head_out && head_c >= 1 && head_c <= 4, "conv2d_f16x3_ex: the fused head writes (N, head_c, Ho * Wo) floats, head_c <= 4");
+    void* d = nullptr;
+    if (hipMalloc(&d, (size_t)tiles * MP * head_c * sizeof(float)) != hipSuccess) { cleanup(); set_error("conv2d_f16x3_ex: out of memory"); return EMP_ERR_NOMEM; }
+    tmp.push_back(d);
+    p.head_w = d_head_w; p.head_part = (float*)d; p.head_c = head_c;
+    if (!p.out) { p.out = d_head_out; p.out_ld = Cout; }      // never written: the fused head stores no activation map
+  }
+  if (!rc) rc = launch_conv32(p, s);
+  if (!rc && d_head_w) rc = launch_head_finish_f32(p.head_part, tiles, N, p.Ho * p.Wo, head_c, d_head_b, d_head_out, s);
+  hipError_t e = hipStreamSynchronize(s);
+  cleanup();
+  if (!rc && e != hipSuccess) { set_error("conv2d_f16x3_ex: %s", hipGetErrorString(e)); return EMP_ERR_HIP; }
+  return rc;
+}
+
+int emp_hl32_from_f32(const float* d_in, void* d_out, int64_t rows, int C, int in_ld, int out_ld, void* stream) {
+  return launch_hl32_from_f32(d_in, (half_t*)d_out, rows, C, in_ld, out_ld, (hipStream_t)stream);
+}
+int emp_hl32_to_f32(const void* d_in, float* d_out, int64_t rows, int C, int in_ld, int out_ld, void* stream) {
+  return launch_hl32_to_f32((const half_t*)d_in, d_out, rows, C, in_ld, out_ld, (hipStream_t)stream);
+}
+int emp_x3p_pack_weights(const float* d_w, void* d_img, int Cout, int K, void* stream) {
+  return launch_x3p_pack(d_w, (half_t*)d_img, Cout, K, (hipStream_t)stream);
+}
+int emp_conv2d_hl32_f16x3(const void* d_in, int N, int H, int W, int Cin, int in_ld, const void* d_wimg, const float* d_bias,
+                          const float* d_bias_n, const void* d_res, int res_ld, int res_fmt, void* d_out, int out_ld, int out_fmt,
+                          int Cout, int KH, int KW, int stride, int pad, int dil, int act, void* stream) {
+  EMP_REQUIRE(d_in && d_wimg && d_out, "conv2d_hl32_f16x3: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d_hl32_f16x3: bad geometry");
+  Conv32 p{};
+  p.in = (const float*)d_in; p.in_ld = in_ld; p.in_fmt = 1; p.wimgp = (const half_t*)d_wimg;
+  p.bias = d_bias; p.bias_n = d_bias_n; p.res = (const float*)d_res; p.res_ld = res_ld; p.res_fmt = res_fmt;
+  p.out = (float*)d_out; p.out_ld = out_ld; p.out_fmt = out_fmt;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  EMP_REQUIRE(p.Ho > 0 && p.Wo > 0 && out_ld >= Cout && (d_res == nullptr || res_ld >= Cout), "conv2d_hl32_f16x3: bad output geometry");
+  p.act = act;
+  p.x3 = 1;
+  return launch_conv16x3p(p, (hipStream_t)stream);
 }
 
 int emp_conv2d_grouped_nhwc_f32(const float* d_in, int N, int H, int W, int groups, int cin_g, int Cin16, int in_ld, const float* d_w,

@@ -39,6 +39,11 @@ void set_error(const char* fmt, ...);
 // A 256-byte device buffer of zeros (source for out-of-bounds LDS-DMA lanes).
 const void* zero_page();
 
+// Opt a kernel into more than 64 KiB of dynamic LDS, once per (device, kernel symbol): hipFuncSetAttribute's effect is per
+// device, and a `static bool` at the call site is shared by every kernel pointer of the same TYPE that passes through a generic
+// lambda (the three ACT instantiations of conv16x3s_kernel shared one flag; a second GPU in the process got none)
+int ensure_dyn_lds(const void* kernel, int bytes);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -192,12 +197,24 @@ struct Conv32 {
   const float* zero;          // x3 only: 64 B of zeros (the source of out-of-range operand chunks), set by launch_conv16x3
   const uint32_t* wpair;      // x3 only, optional: the weights already split, one uint32 = fp16 hi | fp16 lo << 16, layout of `w`
   const half_t* wimg;         // x3 only, optional: the weights as the split-role kernel's LDS image (launch_x3_weight_image), fetched by LDS-DMA
+  // x3 only (round 6): "hl32" maps -- rows of 2 * ld halfs, per block of 32 channels 32 hi halfs then 32 lo halfs (x = hi + lo,
+  // hi = fp16(x), lo = fp16(x - hi): the operand split done once by the producer) -- the plane region's format (conv16x3p.hip)
+  int in_fmt, out_fmt, res_fmt;      // 0: fp32 rows, 1: hl32 rows (in / out / res then point at halfs; ld stays the channel count)
+  const half_t* wimgp;               // the weights as conv16x3p_kernel's packed image (launch_x3p_pack); needs in_fmt == 1
 };
 int launch_conv32(const Conv32& p, hipStream_t s);
 int launch_conv16x3(const Conv32& p, hipStream_t s);      // called by launch_conv32 when p.x3 (its checks have run)
 int launch_split_pairs(const float* w, uint32_t* out, int64_t n, hipStream_t s);
 int64_t x3_weight_image_halfs(int Cout, int K, int Cin);      // 0: the shape never reaches the kernel that reads images
 int launch_x3_weight_image(const float* w, half_t* out, int Cout, int K, hipStream_t s);
+// 256 x 256 tile over hl32 maps, both operands by LDS-DMA (conv16x3p.hip)
+bool conv16x3p_supported(const Conv32& p);                    // shape only (Cout % 256, Cin % 32, >= 4 K steps, plain convolution)
+int launch_conv16x3p(const Conv32& p, hipStream_t s);
+int64_t x3p_image_halfs(int Cout, int K);                     // 2 * Cout * K, or 0 where the kernel cannot take the shape
+int launch_x3p_pack(const float* w, half_t* out, int Cout, int K, hipStream_t s);
+int launch_hl32_from_f32(const float* in, half_t* out, int64_t rows, int C, int in_ld, int out_ld, hipStream_t s);
+int launch_hl32_to_f32(const half_t* in, float* out, int64_t rows, int C, int in_ld, int out_ld, hipStream_t s);
+int launch_avgpool_hl32(const half_t* in, int N, int HW, int C, int in_ld, float* out, hipStream_t s);
 int conv16x3_cout_tiles(int Cout);      // cout tiles of a launch (the size of head_part's first dimension)
 int launch_head_finish_f32(const float* part, int tiles, int N, int P, int C, const float* b, float* out, hipStream_t s);
 int launch_stem3x3s2_f32(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,

@@ -75,7 +75,6 @@ __device__ __forceinline__ void pair_store(const float4 (&r)[2], half_t* hi, hal
 }
 
 // the same for FOUR values: one 8-byte LDS store each (the split-role kernel's whole-line pieces)
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split_store4(const float4& r, half_t* hi, half_t* lo) {
   const float v[4] = {r.x, r.y, r.z, r.w};
   f16x4 h, l;
@@ -95,6 +94,26 @@ __device__ __forceinline__ void pair_store4(const float4& r, half_t* hi, half_t*
   l.x = __builtin_amdgcn_perm(p1, p0, 0x07060302u); l.y = __builtin_amdgcn_perm(p3, p2, 0x07060302u);
   *reinterpret_cast<uint2*>(hi) = h;
   *reinterpret_cast<uint2*>(lo) = l;
+}
+
+// four consecutive couts of pixel m: one 16-byte store into an fp32 row, or -- Conv32::out_fmt, round 6 -- 8 B of hi and 8 B of lo
+// into an hl32 row (the plane region's format, conv16x3p.hip: the consumer's operand split done here, once)
+template <int ACT>
+__device__ __forceinline__ void store4(const Conv32& p, int m, int co, const float4& t) {
+  const float v[4] = {x_act<ACT>(t.x), x_act<ACT>(t.y), x_act<ACT>(t.z), x_act<ACT>(t.w)};
+  if (p.out_fmt) {
+    half_t* op = reinterpret_cast<half_t*>(p.out) + (size_t)m * (2 * p.out_ld) + (co >> 5) * 64 + (co & 31);
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (half_t)v[e];
+      l[e] = (half_t)(v[e] - (float)h[e]);
+    }
+    *reinterpret_cast<f16x4*>(op) = h;
+    *reinterpret_cast<f16x4*>(op + 32) = l;
+  } else {
+    *reinterpret_cast<float4*>(p.out + (size_t)m * p.out_ld + co) = make_float4(v[0], v[1], v[2], v[3]);
+  }
 }
 
 template <int ACT, int BM, int BN, bool WPAIR, bool DB, bool HEAD = false, bool IN2 = false>
@@ -239,9 +258,9 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh, acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl, acc[i][j], 0, 0, 0);
-#pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl, acc[i][j], 0, 0, 0);
     }
   };
   if (DB) {
@@ -354,8 +373,7 @@ __global__ void __launch_bounds__(256, DB ? 2 : 3) conv16x3_kernel(const Conv32 
           const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
           t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
         }
-        *reinterpret_cast<float4*>(p.out + (size_t)m * p.out_ld + co) =
-            make_float4(x_act<ACT>(t.x), x_act<ACT>(t.y), x_act<ACT>(t.z), x_act<ACT>(t.w));
+        store4<ACT>(p, m, co, t);
       }
     }
     return;
@@ -633,9 +651,9 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[i], xh, acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl, acc[i][j], 0, 0, 0);
-#pragma unroll
       for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xh, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[i], xl, acc[i][j], 0, 0, 0);
 #endif
     }
     lds_barrier();
@@ -667,8 +685,7 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
         const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
         t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
       }
-      *reinterpret_cast<float4*>(p.out + (size_t)m * p.out_ld + co) =
-          make_float4(x_act<ACT>(t.x), x_act<ACT>(t.y), x_act<ACT>(t.z), x_act<ACT>(t.w));
+      store4<ACT>(p, m, co, t);
     }
   }
 }
@@ -684,11 +701,7 @@ template <bool WPAIR, int SLOTS, bool WIMG = false>
 int launch_spec(const Conv32& p, dim3 grid, hipStream_t s) {
   constexpr int LDS = WIMG ? 4 * XS_TILE * 2 : SLOTS * XS_SLOT_HALFS * 2;      // dynamic part (WIMG: + 48 KiB static cout ring)
   auto go = [&](auto kern) -> int {
-    static bool once = false;
-    if (!once) {
-      EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-      once = true;
-    }
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), LDS)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(512), LDS, s, p);
     EMP_LAUNCH_CHECK();
     return EMP_OK;
@@ -780,6 +793,11 @@ int launch_conv16x3(const Conv32& p, hipStream_t s) {
                          (int64_t)p.N * p.H2 * p.W2 < (1ll << 31)),
               "conv16x3: second source: Cin2=%d (multiple of 16), row %d, %dx%d at stride %d must cover the %dx%d output", p.Cin2,
               p.in2_ld, p.H2, p.W2, p.stride2, p.Ho, p.Wo);
+  EMP_REQUIRE(p.in_fmt == 0 && p.res_fmt == 0, "conv16x3: hl32 inputs / residuals belong to conv16x3p");
+  EMP_REQUIRE(!p.out_fmt || (!p.head_w && p.ps_cout == 0 && (p.Cout & 3) == 0 && p.groups <= 1 && p.out_ld % 32 == 0 && (((uintptr_t)p.out) & 127) == 0 &&
+                             (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && (!p.bias_n || (((uintptr_t)p.bias_n) & 15) == 0) &&
+                             (!p.res || ((p.res_ld & 3) == 0 && (((uintptr_t)p.res) & 15) == 0))),
+              "conv16x3: an hl32 output needs the vector epilogue (Cout %% 4, whole 128-byte row blocks, aligned operands)");
   Conv32 q = p;
   q.zero = reinterpret_cast<const float*>(zero_page());
   EMP_REQUIRE(q.zero != nullptr, "conv16x3: no zero page");

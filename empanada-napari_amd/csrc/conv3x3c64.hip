@@ -317,14 +317,12 @@ int launch_conv3x3_c64(const ConvParams& q, hipStream_t stream) {
   int grid = 256;
   while (grid > 8 && grid > p.tiles) grid -= 8;
   auto go = [&](auto kern) -> int {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      3 * C64_SLOT));
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), 3 * C64_SLOT)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 3 * C64_SLOT, stream, p);
     return EMP_OK;
   };
   auto go128 = [&](auto kern) -> int {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      3 * C128_SLOT));
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), 3 * C128_SLOT)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 3 * C128_SLOT, stream, p);
     return EMP_OK;
   };

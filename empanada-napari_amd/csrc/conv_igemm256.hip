@@ -1003,13 +1003,8 @@ __global__ void __launch_bounds__(256) pack256_kernel(const half_t* __restrict__
 
 template <int DMA_EARLY, bool B2B = false>
 static int launch256(const ConvParams& p, int grid, hipStream_t stream) {
-  static bool attr_set = false;
   constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + (B2B ? 64 * 256 * 2 : 0);
-  if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm256_kernel<DMA_EARLY, B2B>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
-  }
+  if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv_igemm256_kernel<DMA_EARLY, B2B>), LDS_BYTES)) return rc;
   hipLaunchKernelGGL((conv_igemm256_kernel<DMA_EARLY, B2B>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
@@ -1048,12 +1043,7 @@ int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode, boo
     const int ktot = p.KH * p.KW * (p.Cin / KS) + (p.in2 ? p.Cin2 / KS : 0);
     if (wide_on && mode == 0 && p.Cin % (2 * KS) == 0 && (!p.in2 || p.Cin2 % (2 * KS) == 0) && kga % 2 == 0 && ktot >= 8 &&
         (int64_t)p.N * p.H * p.W < (1ll << 31)) {      // (its pixel indices are 32-bit)
-      static bool attr_set = false;
-      if (!attr_set) {
-        EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm256w_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, WIDE_LDS_BYTES));
-        attr_set = true;
-      }
+      if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv_igemm256w_kernel), WIDE_LDS_BYTES)) return rc;
       hipLaunchKernelGGL(conv_igemm256w_kernel, dim3(grid), dim3(512), WIDE_LDS_BYTES, stream, p);
       EMP_LAUNCH_CHECK();
       return EMP_OK;
@@ -1090,13 +1080,8 @@ bool conv_igemm_h256_supported(const ConvParams& p) {
 
 template <int PXR, int COR>
 static int launch_h256(ConvParams p, hipStream_t stream) {
-  static bool attr_set = false;
   constexpr int LDS_BYTES = 3 * (PXR + COR) * 64;
-  if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_h256_kernel<PXR, COR>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    attr_set = true;
-  }
+  if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv_igemm_h256_kernel<PXR, COR>), LDS_BYTES)) return rc;
   p.mt = cdiv(p.M, PXR);
   p.nt = p.Cout / COR;
   p.mt_per_xcd = cdiv(p.mt, 8);

@@ -248,12 +248,7 @@ int launch_conv_igemm_s64(ConvParams p, hipStream_t stream, int kg) {
   if (kg == 0) kg = 8;
   if (KT == 1 || kg > CB || CB % kg != 0) kg = CB;
   p.kgroup = kg;
-  static bool attr_set = false;
-  if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_s64_kernel<NS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, NS * 2 * S_SLOT));
-    attr_set = true;
-  }
+  if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&conv_igemm_s64_kernel<NS>), NS * 2 * S_SLOT)) return rc;
   p.mt = cdiv(p.M, 64);
   p.nt = cdiv(p.Cout, 64);
   p.mt_per_xcd = cdiv(p.mt, 8);

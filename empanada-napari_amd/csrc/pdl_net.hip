@@ -101,11 +101,14 @@ struct emp_pdl {
   // fp32 reference mode (emp_pdl_set_precision / EMP_PRECISION=fp32; run32 below): fp32 weights, fp32 activation pool
   // precision 2 = the fp16x3 mode (round 5): the fp32 mode's graph, maps and weights, its convolutions on the fp16 matrix
   // pipe with split operands (conv16x3.hip: three MFMAs per product into an fp32 accumulator)
+  // Round 6: the DEFAULT is 2 -- the mode that meets the north star's tolerance (1e-3 of the reference's fp32 forward in the
+  // max norm) on every network; the fp16 engine (0) is the explicit throughput opt-in (emp_pdl_set_precision(net, 0) /
+  // EMP_PRECISION=fp16: ~5e-3 in the max norm)
   int precision = [] {
     const char* e = getenv("EMP_PRECISION");
+    if (e && (!strcmp(e, "fp16") || !strcmp(e, "16"))) return 0;
     if (e && (!strcmp(e, "fp32") || !strcmp(e, "32"))) return 1;
-    if (e && (!strcmp(e, "fp16x3") || !strcmp(e, "x3"))) return 2;
-    return 0;
+    return 2;
   }();
   bool fp32_graph() const { return precision != 0; }
   // RegNet on the fp16 engine: the grouped 3x3 as ONE launch (blockIdx.y = group, conv_igemm_grouped.hip); EMP_REGNET_GROUPED=0:
@@ -113,9 +116,17 @@ struct emp_pdl {
   // fp16x3 mode: the heads' 1x1 fused into the pointwise conv (EMP_X3_FUSE_HEAD=0: the separate head1x1_32 launch; A/B)
   bool x3_fuse_ds = [] { const char* e = getenv("EMP_X3_FUSE_DS"); return !(e && e[0] == '0'); }();      // conv3 + projection shortcut as one K-concatenated conv (A/B)
   bool x3_fuse_head = [] { const char* e = getenv("EMP_X3_FUSE_HEAD"); return !(e && e[0] == '0'); }();
+  // fp16x3 mode, round 6: the stride-16 region of a ResNet50 network (layer3, layer4, ASPP) as hl32 maps on conv16x3p_kernel's
+  // 256 x 256 tile once a layer3 map has this many pixel tiles (one tile of 256 couts per pixel tile is a whole launch of the
+  // 256-channel layers: at 128 of them -- 8 tiles of 1024^2 -- half the chip idles in those launches and round 5's 128 x 128
+  // kernels are as fast: whole step 411.6 vs 423.4 tiles/s at batch 8, 469.0 vs 426.8 at batch 16; profiles/r06_x3p.txt).
+  // EMP_X3_PLANES=0: never (A/B); EMP_X3_PLANES_MIN_TILES=n
+  bool x3_planes = [] { const char* e = getenv("EMP_X3_PLANES"); return !(e && e[0] == '0'); }();
+  int x3_planes_min_tiles = [] { const char* e = getenv("EMP_X3_PLANES_MIN_TILES"); return e ? atoi(e) : 192; }();
+  bool x3_planes_ready = false;      // set by finalize32: every layer of the region has its packed image
   bool regnet_grouped = [] { const char* e = getenv("EMP_REGNET_GROUPED"); return !(e && e[0] == '0'); }();
   int64_t regnet_group_tiles = [] { const char* e = getenv("EMP_REGNET_GROUP_TILES"); return e ? atoll(e) : 2048ll; }();
-  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; int cin2 = 0, cin2_16 = 0; half_t* wimg = nullptr; };
+  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; int cin2 = 0, cin2_16 = 0; half_t* wimg = nullptr; half_t* wimgp = nullptr; };
   std::map<std::string, W32> w32;
   std::map<std::string, std::pair<float*, size_t>> pool32;      // name -> (device buffer, floats)
   std::map<std::string, std::array<int, 4>> geom32;             // zero-tailed RegNet maps: the geometry a buffer was last cleared for
@@ -1333,7 +1344,7 @@ int run(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, int
 // depthwise / pooling / resampling layers on the fp32 vector pipe.  The ASPP pooling branch still enters the projection
 // as a per-image bias (exact algebra, aspp.py:45-48,99-102).  Slow by design: the device-side fp32 comparator.
 // ======================================================================================================================
-struct T32 { float* p = nullptr; int N = 0, H = 0, W = 0, C = 0, ld = 0; };
+struct T32 { float* p = nullptr; int N = 0, H = 0, W = 0, C = 0, ld = 0; int fmt = 0; };      // fmt 1: an hl32 map (conv16x3p.hip), same bytes
 
 int buf32(emp_pdl* n, const std::string& key, size_t floats, float** out) {
   auto it = n->pool32.find(key);
@@ -1555,8 +1566,28 @@ int finalize32(emp_pdl* n) {
         w.wimg = (half_t*)d;
         RC32(launch_x3_weight_image(w.w, w.wimg, w.cout, K, nullptr));
       }
+      // round 6: the plane region's layers (ResNet layer3 / layer4 and the ASPP convolutions: Cout % 256 == 0, Cin % 32 == 0)
+      // once more as conv16x3p_kernel's packed hi / lo image
+      const bool region = kv.first.find("encoder.layer3.") == 0 || kv.first.find("encoder.layer4.") == 0 || kv.first.find(".aspp.") != std::string::npos;
+      const int64_t ip = (n->x3_planes && n->cfg.encoder == 0 && region && w.cin2_16 == 0 && w.cin16 % 32 == 0 && K >= 128) ? x3p_image_halfs(w.cout, K) : 0;
+      if (ip > 0) {
+        EMP_CHECK_HIP(hipMalloc(&d, (size_t)ip * sizeof(half_t)));
+        n->owned.push_back(d);
+        w.wimgp = (half_t*)d;
+        RC32(launch_x3p_pack(w.w, w.wimgp, w.cout, K, nullptr));
+      }
     }
     EMP_CHECK_HIP(hipStreamSynchronize(nullptr));
+    if (n->x3_planes && c.encoder == 0) {
+      bool ok = true;
+      for (auto& kv : n->w32) {
+        const bool region = kv.first.find("encoder.layer3.") == 0 || kv.first.find("encoder.layer4.") == 0 || kv.first.find(".aspp.") != std::string::npos;
+        const bool boundary = kv.first == "encoder.layer3.0.conv1" || kv.first == "encoder.layer3.0.downsample.0" || kv.first.find("conv3+ds") != std::string::npos;
+        if (region && !boundary && !kv.second.wimgp) ok = false;      // (the boundary layers read the fp32 layer2 map: round 5's kernels)
+      }
+      for (int i = 0; i < (c.arch == 0 ? c.n_stages : 0); ++i) ok = ok && c.low_level_stages[i] <= 2;      // a low-level skip out of the region would need a conversion
+      n->x3_planes_ready = ok;
+    }
   }
   return EMP_OK;
 }
@@ -1573,10 +1604,15 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
     p.groups = groups;
     p.cin_g = w.cin;
   }
-  p.in = in.p + in_coff; p.in_ld = in.ld;
+  // an hl32 map (T32::fmt, the fp16x3 mode's plane region): halfs, channel c of a row at (c / 32) * 64 + c % 32 -- a channel
+  // slice starts at a multiple of 32 channels = coff * 2 halfs = coff floats into the row
+  EMP_REQUIRE((!in.fmt || in_coff % 32 == 0) && (!out.fmt || out_coff % 32 == 0), "%s: hl32 channel slices start at multiples of 32", wname.c_str());
+  EMP_REQUIRE(!in.fmt || (w.wimgp && groups <= 1 && !in2 && !head_w && !ps_cout), "%s: an hl32 input needs the packed image of a plain convolution", wname.c_str());
+  p.in = in.p + in_coff; p.in_ld = in.ld; p.in_fmt = in.fmt;
+  p.wimgp = in.fmt ? w.wimgp : nullptr;
   p.w = w.w; p.bias = w.b; p.bias_n = bias_n;
-  p.res = res ? res->p : nullptr; p.res_ld = res ? res->ld : 0;
-  p.out = out.p + out_coff; p.out_ld = out.ld;
+  p.res = res ? res->p : nullptr; p.res_ld = res ? res->ld : 0; p.res_fmt = res ? res->fmt : 0;
+  p.out = out.p + out_coff; p.out_ld = out.ld; p.out_fmt = out.fmt;
   p.N = in.N; p.H = in.H; p.W = in.W; p.Cin = w.cin16; p.Cout = w.cout / groups; p.KH = w.kh; p.KW = w.kw;
   p.stride = stride; p.pad = pad; p.dil = dil;
   p.Ho = (in.H + 2 * pad - dil * (w.kh - 1) - 1) / stride + 1;
@@ -1610,7 +1646,10 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
   EMP_REQUIRE(c.arch == 0 || (H % 128 == 0 && W % 128 == 0), "BiFPN forward: H=%d W=%d must be multiples of 128", H, W);
   n->flops = 0.0;
   std::map<std::string, T32> T;
-  auto mk = [&](const std::string& k, int H_, int W_, int C_) -> int { T32 t; int rc = t32(n, k, N, H_, W_, C_, &t); T[k] = t; return rc; };
+  auto mk = [&](const std::string& k, int H_, int W_, int C_, int fmt = 0) -> int { T32 t; int rc = t32(n, k, N, H_, W_, C_, &t); t.fmt = fmt; T[k] = t; return rc; };
+  // fp16x3 mode, round 6: layer3 / layer4 / ASPP maps as hl32 planes on conv16x3p_kernel (emp_pdl members x3_planes*)
+  const bool hlr = n->precision == 2 && n->x3_planes_ready && c.encoder == 0 &&
+                      ((int64_t)N * (H / 16) * (W / 16)) / 256 >= n->x3_planes_min_tiles;
   auto A = [&](const std::string& k) -> T32& { return T.at(k); };
   auto dw = [&](const T32& in, const std::string& wname, int K, const T32& out) -> int {
     n->flops += 2.0 * K * K * (double)N * in.H * in.W * in.C;
@@ -1692,13 +1731,17 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
         const std::string p = "encoder.layer" + std::to_string(li) + "." + std::to_string(b);
         const T32 xin = A(x);
         const int ho = (xin.H - 1) / sb + 1, wo = (xin.W - 1) / sb + 1;
-        RC32(mk(p + ".c1", xin.H, xin.W, planes));
+        // plane region (li >= 3): every map hl32 except where round 5's kernels still read it -- layer3.0's conv1 and
+        // conv3 + shortcut take the fp32 layer2 map (and the fp32 c2) and WRITE hl32 (Conv32::out_fmt)
+        const int pl = (hlr && li >= 3) ? 1 : 0;
+        const bool fuse_ds = b == 0 && n->precision == 2 && n->x3_fuse_ds && !(pl && xin.fmt);
+        RC32(mk(p + ".c1", xin.H, xin.W, planes, pl));
         RC32(c32(n, p + ".conv1", xin, 0, A(p + ".c1"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
-        RC32(mk(p + ".c2", ho, wo, planes));
+        RC32(mk(p + ".c2", ho, wo, planes, (pl && !fuse_ds) ? 1 : 0));
         RC32(c32(n, p + ".conv2", A(p + ".c1"), 0, A(p + ".c2"), 0, sb, dil, dil, 1, nullptr, nullptr, s));
         const T32* idn = &A(x);
-        RC32(mk(p, ho, wo, planes * 4));
-        if (b == 0 && n->precision == 2 && n->x3_fuse_ds) {
+        RC32(mk(p, ho, wo, planes * 4, pl));
+        if (fuse_ds) {
           // fp16x3 mode: relu(conv3(c2) + downsample(x)) as one convolution over the concatenated K (the shortcut map is
           // neither written nor read back)
           RC32(c32(n, p + ".conv3+ds", A(p + ".c2"), 0, A(p), 0, 1, 0, 1, 1, nullptr, nullptr, s, 0, 1, nullptr, nullptr, 0, &xin, sb));
@@ -1706,7 +1749,7 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
           continue;
         }
         if (b == 0) {
-          RC32(mk(p + ".ds", ho, wo, planes * 4));
+          RC32(mk(p + ".ds", ho, wo, planes * 4, pl));
           RC32(c32(n, p + ".downsample.0", xin, 0, A(p + ".ds"), 0, sb, 0, 1, 0, nullptr, nullptr, s));
           idn = &A(p + ".ds");
         }
@@ -1714,6 +1757,16 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
         x = p;
       }
       pyr[li] = x;
+    }
+    if (hlr && c.arch == 1) {
+      // the BiFPN reads P4 / P5 with round 5's kernels (128-channel nodes): fp32 copies of the two pyramid levels
+      for (int li = 3; li <= 4; ++li) {
+        const T32 src = A(pyr[li]);
+        const std::string k = pyr[li] + ".f32";
+        RC32(mk(k, src.H, src.W, src.C));
+        RC32(launch_hl32_to_f32(reinterpret_cast<const half_t*>(src.p), A(k).p, (int64_t)N * src.H * src.W, src.C, src.ld, src.C, s));
+        pyr[li] = k;
+      }
     }
   }
   std::string dec_out[2];
@@ -1817,7 +1870,8 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
     const T32 p5 = A(pyr[4]);
     float* pooled;
     RC32(buf32(n, "pooled", (size_t)N * p5.C, &pooled));
-    RC32(launch_avgpool_f32(p5.p, N, p5.H * p5.W, p5.C, p5.ld, pooled, s));
+    if (p5.fmt) RC32(launch_avgpool_hl32(reinterpret_cast<const half_t*>(p5.p), N, p5.H * p5.W, p5.C, p5.ld, pooled, s));
+    else RC32(launch_avgpool_f32(p5.p, N, p5.H * p5.W, p5.C, p5.ld, pooled, s));
     const char* decs[2] = {"semantic_decoder", "instance_decoder"};
     for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
       const std::string p = decs[d];
@@ -1826,7 +1880,7 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
       RC32(buf32(n, p + ".bias_n", (size_t)N * n->aspp_ch, &bias_n));
       RC32(launch_gemv(pooled, N, p5.C, n->f32w.at(p + ".pool.w"), nullptr, n->aspp_ch, 1, poolfeat, s));
       RC32(launch_gemv(poolfeat, N, n->aspp_ch, n->f32w.at(p + ".projpool.w"), nullptr, n->aspp_ch, 0, bias_n, s));
-      RC32(mk(p + ".aspp.cat", p5.H, p5.W, 4 * n->aspp_ch));
+      RC32(mk(p + ".aspp.cat", p5.H, p5.W, 4 * n->aspp_ch, p5.fmt));      // (the projection reads it as it was written; its output is fp32: the up-sampler's input)
       RC32(c32(n, p + ".aspp.convs.0.0", p5, 0, A(p + ".aspp.cat"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
       for (int i = 1; i <= 3; ++i) {
         const int r = c.atrous_rates[i - 1];
@@ -1980,10 +2034,6 @@ int emp_pdl_create(const emp_pdl_config* cfg, emp_pdl_t** out) {
   emp_pdl* n = new (std::nothrow) emp_pdl();
   if (!n) return EMP_ERR_NOMEM;
   n->cfg = *cfg;
-  if (cfg->encoder == 1) {      // RegNet: the fp32 mode unless emp_pdl_set_precision(net, 0) / EMP_PRECISION=fp16 ask for the fp16 engine
-    const char* e = getenv("EMP_PRECISION");
-    n->precision = (e && (!strcmp(e, "fp16") || !strcmp(e, "16"))) ? 0 : (e && (!strcmp(e, "fp16x3") || !strcmp(e, "x3"))) ? 2 : 1;
-  }
   n->dec_ch = cfg->arch == 1 ? cfg->fpn_dim : cfg->decoder_channels;
   n->aspp_ch = cfg->aspp_channels > 0 ? cfg->aspp_channels : cfg->decoder_channels;
   n->ncls = cfg->num_classes;

@@ -600,20 +600,10 @@ int launch_pr_mlp(const half_t* feat, int N, int fh, int fw, int C, int feat_ld,
   const int grid = p.tiles < 256 ? p.tiles : 256;       // one workgroup per CU
   const size_t lds = (size_t)256 * ld * 2;
   if (C == 256) {
-    static bool attr = false;
-    if (!attr) {
-      EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pr_mlp_kernel<256, 320>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr = true;
-    }
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&pr_mlp_kernel<256, 320>), (int)lds)) return rc;
     hipLaunchKernelGGL((pr_mlp_kernel<256, 320>), dim3(grid), dim3(512), lds, s, p);
   } else {
-    static bool attr = false;
-    if (!attr) {
-      EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pr_mlp_kernel<128, 192>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr = true;
-    }
+    if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&pr_mlp_kernel<128, 192>), (int)lds)) return rc;
     hipLaunchKernelGGL((pr_mlp_kernel<128, 192>), dim3(grid), dim3(512), lds, s, p);
   }
   EMP_LAUNCH_CHECK();

@@ -472,6 +472,7 @@ int launch_conv32(const Conv32& p, hipStream_t s) {
   EMP_REQUIRE(G > 1 || p.cin_g == 0, "conv32: cin_g is the grouped form's channel step");
   const int64_t M = (int64_t)p.N * p.Ho * p.Wo;
   EMP_REQUIRE(M > 0 && M < (1ll << 31), "conv32: bad problem size");
+  if (p.x3 && p.in_fmt) return launch_conv16x3p(p, s);      // an hl32 input map: the plane region's 256 x 256 tile (conv16x3p.hip)
   if (p.x3) return launch_conv16x3(p, s);
   const dim3 grid((unsigned)((M + R_BM - 1) / R_BM), (unsigned)((p.Cout + R_BN - 1) / R_BN), (unsigned)G);
   if (p.act == 1) hipLaunchKernelGGL(conv32_kernel<1>, grid, dim3(256), 0, s, p);

@@ -401,12 +401,7 @@ __global__ void __launch_bounds__(256) sepconv5_pack_pw_kernel(const half_t* __r
 
 template <int KS, int NDW, int NMW, int MT, bool HEAD, int ACT>
 int launch_act(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconv5_kernel<KS, NDW, NMW, MT, HEAD, ACT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&sepconv5_kernel<KS, NDW, NMW, MT, HEAD, ACT>), 160 * 1024)) return rc;
   hipLaunchKernelGGL((sepconv5_kernel<KS, NDW, NMW, MT, HEAD, ACT>), dim3(grid), dim3(64 * (NDW + NMW)), lds_bytes, s, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;

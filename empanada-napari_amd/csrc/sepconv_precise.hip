@@ -480,12 +480,7 @@ __global__ void __launch_bounds__(256) sepconvp_pack_pw_kernel(const float* __re
 
 template <int KS, int MT, bool HEAD, int ACT, bool WS>
 int launch_act(const SepParams& p, size_t lds_bytes, int grid, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    EMP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sepconvp_kernel<KS, MT, HEAD, ACT, WS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(&sepconvp_kernel<KS, MT, HEAD, ACT, WS>), 160 * 1024)) return rc;
   hipLaunchKernelGGL((sepconvp_kernel<KS, MT, HEAD, ACT, WS>), dim3(grid), dim3(64 * (SC_NDW + SC_NMW)), lds_bytes, s, p);
   EMP_LAUNCH_CHECK();
   return EMP_OK;

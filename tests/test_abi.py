@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in the header but not exported'
     assert sorted(_abi.PROTOTYPES) == names, 'ctypes prototypes out of sync with the header'
-    assert lib.emp_abi_version() == 4
+    assert lib.emp_abi_version() == 5
 
 
 def test_no_cpu_fallback():

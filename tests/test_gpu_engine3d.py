@@ -24,7 +24,7 @@ def model_config():
     P['semantic_head.head.1'] = (w, b + np.float32(2.5))
     w, b = P['semantic_pr.point_head.predictor']
     P['semantic_pr.point_head.predictor'] = (w, b + np.float32(2.5))
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     return {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
             'norms': {'mean': 0.57571, 'std': 0.12765}}
 
@@ -249,7 +249,7 @@ def test_multiclass_bifpn_orthoplane_consensus():
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
     w, b = P['ins_center.head.1']
     P['ins_center.head.1'] = (w, b + np.float32(0.75))         # centres on small slices (see model_config above)
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     labels, things = [1, 2, 3], [1, 2]
     mc = {'model': model, 'thing_list': things, 'labels': labels, 'class_names': {1: 'mito', 2: 'nucleus', 3: 'droplet'},
           'padding_factor': 128, 'norms': {'mean': 0.57571, 'std': 0.12765}}
@@ -309,7 +309,7 @@ def test_config0_bifpn_single_512_tile_through_engine2d():
     P['ins_center.head.1'] = (w, b + np.float32(0.5))
     w, b = P['semantic_head.head.1']
     P['semantic_head.head.1'] = (w, b + np.float32(1.0))
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 128,
           'norms': {'mean': 0.57571, 'std': 0.12765}}
     img = synth.em_tiles(1, 512, seed=40)[0]

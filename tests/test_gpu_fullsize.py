@@ -18,7 +18,7 @@ def engine():
     from empanada_napari_amd.engines import HipPanopticDeepLab, PanopticDeepLabRenderEngine
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     return PanopticDeepLabRenderEngine(model, thing_list=[1], label_divisor=DIV, nms_threshold=0.1, nms_kernel=3,
                                        confidence_thr=0.5, padding_factor=16, coarse_boundaries=True)
 
@@ -109,7 +109,7 @@ def test_bifpn_batch_of_1024_tiles_is_repeatable_and_image_independent():
     from empanada_napari_amd.engines import HipPanopticDeepLab
     from empanada_napari_amd.preprocess import normalize_params
     cfg = dict(weights.MITONET_MINI_CFG, num_classes=4)
-    model = HipPanopticDeepLab(weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg), cfg, folded=True)
+    model = HipPanopticDeepLab(weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg), cfg, folded=True, precision='fp16')
     tiles = torch.from_numpy(synth.em_tiles(4, 1024, seed=5))[:, None].cuda()
     sub, mul = normalize_params(0.57571, 0.12765, 255)
     a = {k: v.clone() for k, v in model(tiles, 2, interpolate_ins=False, sub=float(sub), mul=float(mul)).items()}
@@ -224,7 +224,7 @@ def test_config4_slices_of_4096_squared(engine, monkeypatch):
         w, b = P[name]
         P[name] = (w, b + np.float32(shift))
     del engine
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
           'norms': {'mean': 0.57571, 'std': 0.12765}}
     kw = dict(label_divisor=DIV, median_kernel_size=3, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5, min_size=200,

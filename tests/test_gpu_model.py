@@ -22,7 +22,7 @@ def setup():
     cfg = dict(weights.MITONET_PDL_CFG)
     sd = weights.seeded_state_dict(cfg, seed=0)
     P = weights.fold_state_dict(sd, cfg)
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     return cfg, P, model
 
 
@@ -158,7 +158,7 @@ def test_bifpn_heads_match_reference_golden(golden_dir, tag, ncls, case):
     from empanada_napari_amd.engines import HipPanopticDeepLab
     g = np.load(os.path.join(golden_dir, 'bifpn_forward.npz'))
     cfg = dict(weights.MITONET_MINI_CFG, num_classes=ncls)
-    model = HipPanopticDeepLab(weights.seeded_state_dict(cfg, seed=3), cfg)
+    model = HipPanopticDeepLab(weights.seeded_state_dict(cfg, seed=3), cfg, precision='fp16')
     x = _norm(g[f'{tag}{case}_image']).cuda()
     out = model(x, int(g[f'{tag}{case}_render_steps']), bool(g[f'{tag}{case}_interpolate_ins']))
     torch.cuda.synchronize()
@@ -192,7 +192,7 @@ def test_fused_launches_equal_unfused_bit_exact(setup):
         os.environ['EMP_FUSE_SEPCONV'] = '0'
         os.environ['EMP_FUSE_STEM'] = '0'
         os.environ['EMP_FUSE_DS'] = '0'      # conv3 + projection shortcut as two launches (shortcut rounded to fp16)
-        plain_model = HipPanopticDeepLab(P, cfg, folded=True)
+        plain_model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     finally:
         for k, v in old.items():
             if v is None:
@@ -233,11 +233,11 @@ def test_fused_point_head_equals_unfused_launches_bit_exact(arch):
         cfg = dict(weights.MITONET_MINI_CFG, num_classes=4)
         P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
     x = _norm(synth.em_tiles(3, 256, seed=41)).cuda()
-    fused_model = HipPanopticDeepLab(P, cfg, folded=True)
+    fused_model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     old = os.environ.get('EMP_FUSE_PR')
     try:
         os.environ['EMP_FUSE_PR'] = '0'
-        plain_model = HipPanopticDeepLab(P, cfg, folded=True)
+        plain_model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     finally:
         if old is None:
             os.environ.pop('EMP_FUSE_PR', None)
@@ -268,7 +268,7 @@ def test_back_to_back_conv_fusion_is_bit_identical_and_active(family, tmp_path, 
         monkeypatch.setenv('EMP_FUSE_B2B', fuse)
         log = tmp_path / f'layers_{fuse}.log'
         monkeypatch.setenv('EMP_LAYER_LOG', str(log))
-        model = HipPanopticDeepLab(P, cfg, folded=True)
+        model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
         monkeypatch.delenv('EMP_LAYER_LOG')
         for B, S in ((1, 1024), (2, 256)):
             x = torch.from_numpy(normalize(synth.em_tiles(B, S, seed=5), 0.57571, 0.12765))[:, None].cuda()
@@ -305,9 +305,9 @@ def test_two_stream_decoders_equal_the_single_stream_forward(family, monkeypatch
     cfg = dict(weights.MITONET_PDL_CFG if family == 'pdl' else weights.MITONET_MINI_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=13), cfg)
     monkeypatch.setenv('EMP_PAR_DECODERS', '0')
-    serial = HipPanopticDeepLab(P, cfg, folded=True)
+    serial = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     monkeypatch.delenv('EMP_PAR_DECODERS')
-    par = HipPanopticDeepLab(P, cfg, folded=True)
+    par = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     side = torch.cuda.Stream()
     for B, S in ((1, 1024), (3, 512)):
         x = torch.from_numpy(normalize(synth.em_tiles(B, S, seed=6), 0.57571, 0.12765))[:, None].cuda()
@@ -341,7 +341,7 @@ def test_merged_aspp_branches_are_bit_identical(monkeypatch):
         monkeypatch.setenv('EMP_FUSE_ASPP', fuse)
         log = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'aspp_layers_{fuse}.log')
         monkeypatch.setenv('EMP_LAYER_LOG', log)
-        model = HipPanopticDeepLab(P, cfg, folded=True)
+        model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
         monkeypatch.delenv('EMP_LAYER_LOG')
         out = model(x, 2, False)
         res[fuse] = [out[k].clone() for k in ('sem_logits', 'ctr_hmp', 'offsets')] + [model.tap(t).clone() for t in taps]

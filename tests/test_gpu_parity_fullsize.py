@@ -66,7 +66,7 @@ def case():
     for name, shift in (('ins_center.head.1', 0.75), ('semantic_head.head.1', 1.0), ('semantic_pr.point_head.predictor', 1.0)):
         w, b = P[name]
         P[name] = (w, b + np.float32(shift))
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     img = synth.em_tiles(1, 1024, seed=2024)
     x = torch.from_numpy(normalize(img, 0.57571, 0.12765))[:, None]
     out = {k: v.cpu().numpy() for k, v in model(x.cuda(), 2, False).items()}
@@ -262,10 +262,12 @@ def test_end_to_end_label_flips_vs_fp32_pipeline(case):
     want = oeng.postprocess(r['sem'], oeng.cells(r['ctr_hmp'], r['offsets'], 1))[0]
     # and the post-processing alone on the engine's own heads (bit-exact, as in test_gpu_postprocess.py)
     o = dict(case['out'])
-    o['sem'] = opp.logits_to_prob(o['sem_logits'])
+    # (the engine's own probabilities: the host's sigmoid may round the other way at the 0.5 threshold)
+    from empanada_napari_amd.engines import logits_to_prob
+    o['sem'] = logits_to_prob(torch.from_numpy(np.ascontiguousarray(o['sem_logits'])).cuda()).cpu().numpy()
+    assert float(np.abs(o['sem'] - opp.logits_to_prob(o['sem_logits'])).max()) < 1e-6
     own = oeng.postprocess(o['sem'], oeng.cells(o['ctr_hmp'], o['offsets'], 1))[0]
-    near_thr = np.abs(o['sem'][0, 0] - 0.5) < 1e-6
-    assert np.all((pan == own) | near_thr), f'{int((pan != own).sum())} flips with identical head tensors'
+    assert np.array_equal(pan, own), f'{int((pan != own).sum())} flips with identical head tensors'
     n_hip, n_ref = len(np.unique(pan)) - 1, len(np.unique(want)) - 1
     fg_flip = int(((pan > 0) != (want > 0)).sum())
     verbatim = int((pan != want).sum())
@@ -295,7 +297,7 @@ def test_bifpn_512_tile_vs_fp32_forward(ncls):
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     cfg = dict(weights.MITONET_MINI_CFG, num_classes=ncls)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     x = torch.from_numpy(normalize(synth.em_tiles(1, 512, seed=77), 0.57571, 0.12765))[:, None]
     out = {k: v.cpu() for k, v in model(x.cuda(), 2, False).items()}
     taps = {}
@@ -358,7 +360,7 @@ def test_bifpn_every_layer_is_the_correctly_rounded_fp32_result(ncls):
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     cfg = dict(weights.MITONET_MINI_CFG, num_classes=ncls)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     x = torch.from_numpy(normalize(synth.em_tiles(1, 512, seed=77), 0.57571, 0.12765))[:, None]
     out = {k: v.cpu() for k, v in model(x.cuda(), 2, False).items()}
     heads = {'semantic_head.out': model.tap_raw('semantic_head.out', (1, ncls, 128, 128)).cpu(),

@@ -56,11 +56,11 @@ def test_grouped_conv32_equals_torch(case):
                                            _abi.ptr(out), G * co + 4, co, 3, 3, stride, 1, 1, act, _abi.stream_ptr(dev())) != 0 or ci16 == ci
 
 
-def _model(tag):
+def _model(tag, precision='fp32'):
     from test_regnet import regnet_model
     from empanada_napari_amd.engines import HipPanopticDeepLab
     cfg, P = regnet_model(tag)
-    return cfg, P, HipPanopticDeepLab(P, cfg, folded=True)
+    return cfg, P, HipPanopticDeepLab(P, cfg, folded=True, precision=precision)
 
 
 @pytest.mark.parametrize('tag', ['y', 'x'])
@@ -68,7 +68,7 @@ def test_regnet_forward_matches_the_reference_goldens(golden_dir, tag):
     from empanada_napari_amd.preprocess import normalize
     g = np.load(os.path.join(golden_dir, 'regnet_forward.npz'))
     cfg, P, model = _model(tag)
-    assert model.precision == 'fp32'          # the library's default for a RegNet (precision='fp16' is opt-in)
+    assert model.precision == 'fp32'          # the exact comparator mode (the default is 'fp16x3', precision='fp16' the throughput opt-in)
     for case in 'ab':
         img = g[f'{tag}{case}_image']
         rs, interp = int(g[f'{tag}{case}_render_steps']), bool(g[f'{tag}{case}_interpolate_ins'])
@@ -208,7 +208,7 @@ def test_regnet_state_dict_through_the_public_engines():
     mc = {'model': sd, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
           'norms': {'mean': 0.57571, 'std': 0.12765}}
     eng = Engine2d(mc, label_divisor=1000, nms_kernel=3, nms_threshold=0.1, confidence_thr=0.5)
-    assert eng.engine.model.precision == 'fp32' and eng.engine.model.cfg['encoder'] == 'regnetx_6p4gf'
+    assert eng.engine.model.precision == 'fp16x3' and eng.engine.model.cfg['encoder'] == 'regnetx_6p4gf'
     img = synth.em_tiles(1, 256, seed=21)[0][:200, :232]
     got = eng.infer(img)
     assert got.shape == img.shape and got.dtype == np.int32

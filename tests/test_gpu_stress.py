@@ -106,7 +106,7 @@ def test_stem_pool_repeatable():
     from empanada_napari_amd.engines import HipPanopticDeepLab
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     x = torch.from_numpy(synth.em_tiles(4, 512, seed=9))[:, None].to(dev())
     model(x, 2, False, sub=146.8, mul=0.0307)
     first = model.tap('p1').clone()
@@ -201,7 +201,7 @@ def test_back_to_back_fusion_repeatable_at_batch_32():
     from empanada_napari_amd.preprocess import normalize
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=2), cfg)
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16')
     base = synth.em_tiles(4, 1024, seed=9)
     x = torch.from_numpy(normalize(np.concatenate([base] * 8), 0.57571, 0.12765))[:, None].cuda()
     first = None
