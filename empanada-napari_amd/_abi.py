@@ -64,6 +64,9 @@ PROTOTYPES = {
     'emp_conv2d_nhwc_f16x3_ex': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, vp, c_int, c_int, c_int,
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, c_int, c_int,
                                          vp, vp, c_int, vp, vp]),
+    'emp_sepconv_x3_pack': (c_int, [vp, vp, c_int, c_int, c_int, vp, vp, vp]),
+    'emp_sepconv_x3_nhwc_f32': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, c_int, c_int, vp, c_int, vp, vp, c_int, vp,
+                                        c_int, vp]),
     'emp_hl32_from_f32': (c_int, [vp, vp, c_i64, c_int, c_int, c_int, vp]),
     'emp_hl32_to_f32': (c_int, [vp, vp, c_i64, c_int, c_int, c_int, vp]),
     'emp_x3p_pack_weights': (c_int, [vp, vp, c_int, c_int, vp]),

@@ -22,7 +22,7 @@ PER_FILE = {
     'postprocess.hip': ['-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt'],
 }
 SOURCES = ['abi.hip', 'conv_igemm.hip', 'layers.hip', 'pointrend.hip', 'postprocess.hip', 'pdl_net.hip', 'sparse.hip',
-           'sepconv.hip', 'sepconv_precise.hip', 'conv_igemm256.hip', 'conv_igemm_s64.hip', 'conv3x3c64.hip', 'stem.hip', 'matcher.hip', 'ref32.hip', 'conv16x3.hip', 'conv_igemm_grouped.hip', 'conv16x3p.hip']
+           'sepconv.hip', 'sepconv_precise.hip', 'conv_igemm256.hip', 'conv_igemm_s64.hip', 'conv3x3c64.hip', 'stem.hip', 'matcher.hip', 'ref32.hip', 'conv16x3.hip', 'conv_igemm_grouped.hip', 'conv16x3p.hip', 'sepconv_x3.hip']
 # sources that #include another source: rebuilt when that one changes
 INCLUDES = {'conv_igemm_grouped.hip': ['conv_igemm.hip']}
 

@@ -196,6 +196,19 @@ int emp_conv2d_nhwc_f16x3_ex(const float* d_in, int N, int H, int W, int Cin, in
   return rc;
 }
 
+int emp_sepconv_x3_pack(const float* d_dw, const float* d_pw, int ks, int C, int Cout, float* d_dw_packed, void* d_pw_packed, void* stream) {
+  int rc = launch_sepx3_pack_dw(d_dw, ks, C, C, d_dw_packed, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_sepx3_pack_pw(d_pw, C, C, Cout, (half_t*)d_pw_packed, (hipStream_t)stream);
+}
+int emp_sepconv_x3_nhwc_f32(const float* d_in, int N, int H, int W, int C, int in_ld, const float* d_dw_packed, const void* d_pw_packed,
+                            const float* d_bias, int Cout, int act, float* d_out, int out_ld, const float* d_head_w, const float* d_head_b,
+                            int head_c, float* d_head_out, int ks, void* stream) {
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0, "sepconv_x3: bad geometry");
+  return launch_sepconv_x3(d_in, N, H, W, C, in_ld, d_dw_packed, (const half_t*)d_pw_packed, d_bias, Cout, act, d_out, out_ld, d_head_w,
+                           d_head_b, head_c, d_head_out, (int64_t)H * W, (hipStream_t)stream, ks);
+}
+
 int emp_hl32_from_f32(const float* d_in, void* d_out, int64_t rows, int C, int in_ld, int out_ld, void* stream) {
   return launch_hl32_from_f32(d_in, (half_t*)d_out, rows, C, in_ld, out_ld, (hipStream_t)stream);
 }

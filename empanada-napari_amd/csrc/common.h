@@ -215,6 +215,14 @@ int launch_x3p_pack(const float* w, half_t* out, int Cout, int K, hipStream_t s)
 int launch_hl32_from_f32(const float* in, half_t* out, int64_t rows, int C, int in_ld, int out_ld, hipStream_t s);
 int launch_hl32_to_f32(const half_t* in, float* out, int64_t rows, int C, int in_ld, int out_ld, hipStream_t s);
 int launch_avgpool_hl32(const half_t* in, int N, int HW, int C, int in_ld, float* out, hipStream_t s);
+// fused depthwise + pointwise block of the fp16x3 graph (sepconv_x3.hip): fp32 NHWC in / out, 3 fp16 MFMAs per product
+bool sepconv_x3_supported(int C, int Cout, int head_c, int ks);
+int64_t sepx3_pw_halfs(int C, int Cout);
+int launch_sepx3_pack_pw(const float* w, int pw_ld, int C, int Cout, half_t* packed, hipStream_t s);
+int launch_sepx3_pack_dw(const float* w /*(ks*ks, ld)*/, int ks, int C, int ld, float* packed, hipStream_t s);
+int launch_sepconv_x3(const float* in, int N, int H, int W, int C, int in_ld, const float* dww, const half_t* pww, const float* bias,
+                      int Cout, int act, float* out, int out_ld, const float* head_w, const float* head_b, int head_c, float* hout,
+                      int64_t plane, hipStream_t s, int ks = 5);
 int conv16x3_cout_tiles(int Cout);      // cout tiles of a launch (the size of head_part's first dimension)
 int launch_head_finish_f32(const float* part, int tiles, int N, int P, int C, const float* b, float* out, hipStream_t s);
 int launch_stem3x3s2_f32(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,

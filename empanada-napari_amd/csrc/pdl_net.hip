@@ -124,6 +124,12 @@ struct emp_pdl {
   bool x3_planes = [] { const char* e = getenv("EMP_X3_PLANES"); return !(e && e[0] == '0'); }();
   int x3_planes_min_tiles = [] { const char* e = getenv("EMP_X3_PLANES_MIN_TILES"); return e ? atoi(e) : 192; }();
   bool x3_planes_ready = false;      // set by finalize32: every layer of the region has its packed image
+  // fp16x3 mode, round 6: a separable block (depthwise KxK -> pointwise -> act [-> head 1x1]) as ONE launch (sepconv_x3.hip) once
+  // the map has this many 8 x 16 tiles (a persistent workgroup per CU); EMP_X3_FUSE_SEP=0: the depthwise launch + conv16x3 (A/B)
+  bool x3_fuse_sep = [] { const char* e = getenv("EMP_X3_FUSE_SEP"); return !(e && e[0] == '0'); }();
+  int x3_sep_min_tiles = [] { const char* e = getenv("EMP_X3_SEP_MIN_TILES"); return e ? atoi(e) : 256; }();
+  struct SepX3 { float* dw = nullptr; half_t* pw = nullptr; int C = 0, Cout = 0, ks = 0; };
+  std::map<std::string, SepX3> sepx3;      // by the block's name ("... .sepconv" without the .0 / .1)
   bool regnet_grouped = [] { const char* e = getenv("EMP_REGNET_GROUPED"); return !(e && e[0] == '0'); }();
   int64_t regnet_group_tiles = [] { const char* e = getenv("EMP_REGNET_GROUP_TILES"); return e ? atoll(e) : 2048ll; }();
   struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; int cin2 = 0, cin2_16 = 0; half_t* wimg = nullptr; half_t* wimgp = nullptr; };
@@ -1524,8 +1530,9 @@ int finalize32(emp_pdl* n) {
       for (int i = 0; i < c.n_stages; ++i) {
         const int lp = d == 0 ? c.low_level_proj_sem[i] : c.low_level_proj_ins[i];
         RC32(pack32(n, p + ".project." + std::to_string(i) + ".0"));
-        RC32(pack32_dw(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.0", round_up(xch + lp, 16)));
-        RC32(pack32(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1", round_up(xch + lp, 16)));
+        const int cpad = round_up(xch + lp, n->precision == 2 ? 32 : 16);      // (the fused block walks the channels in chunks of 32)
+        RC32(pack32_dw(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.0", cpad));
+        RC32(pack32(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1", cpad));
         xch = n->dec_ch;
       }
     }
@@ -1545,6 +1552,33 @@ int finalize32(emp_pdl* n) {
     for (int o = 0; o < n->ncls; ++o)
       for (int i = 0; i < K; ++i) w[(size_t)o * ldp + i] = hp.w[(size_t)o * K + i];
     RC32(upload_f32(n, "pr.predictor.w32", w));
+  }
+  if (n->precision == 2 && n->x3_fuse_sep) {
+    // fp16x3 mode, round 6: the separable blocks' weights in the fused kernel's orders (sepconv_x3.hip)
+    for (auto& kv : n->w32) {
+      const std::string& nm = kv.first;
+      if (nm.size() < 10 || nm.compare(nm.size() - 10, 10, ".sepconv.1") != 0) continue;
+      const std::string base = nm.substr(0, nm.size() - 2);      // "... .sepconv"
+      auto dwi = n->f32w.find(base + ".0.dw32");
+      auto hpi = n->params.find(base + ".0");
+      if (dwi == n->f32w.end() || hpi == n->params.end() || hpi->second.shape.size() != 4) continue;
+      const emp_pdl::W32& w = kv.second;
+      const int ks = (int)hpi->second.shape[2], C = w.cin16;
+      if (w.kh != 1 || w.kw != 1 || !sepconv_x3_supported(C, w.cout, 0, ks)) continue;
+      emp_pdl::SepX3 sx;
+      sx.C = C; sx.Cout = w.cout; sx.ks = ks;
+      void* d = nullptr;
+      EMP_CHECK_HIP(hipMalloc(&d, (size_t)ks * ks * C * sizeof(float)));
+      n->owned.push_back(d);
+      sx.dw = (float*)d;
+      RC32(launch_sepx3_pack_dw(dwi->second, ks, C, C, sx.dw, nullptr));
+      EMP_CHECK_HIP(hipMalloc(&d, (size_t)sepx3_pw_halfs(C, w.cout) * sizeof(half_t)));
+      n->owned.push_back(d);
+      sx.pw = (half_t*)d;
+      RC32(launch_sepx3_pack_pw(w.w, C, C, w.cout, sx.pw, nullptr));
+      n->sepx3[base] = sx;
+    }
+    EMP_CHECK_HIP(hipStreamSynchronize(nullptr));
   }
   if (n->precision == 2) {
     // fp16x3 mode: every convolution weight once more as fp16 pairs (hi | lo << 16, the fp32 blob's layout), so that the
@@ -1635,6 +1669,20 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
   EMP_REQUIRE(in_coff + (groups - 1) * w.cin + w.cin16 <= in.ld && out_coff + (ps_cout ? ps_cout : w.cout) <= out.ld,
               "%s (fp32): channel slice out of range (needs %d of a row of %d)", wname.c_str(), in_coff + (groups - 1) * w.cin + w.cin16, in.ld);
   n->flops += 2.0 * (double)p.N * p.Ho * p.Wo * w.cout * (double)(w.cin * w.kh * w.kw);
+  if (n->profile && p.x3 && p.in_fmt) {     // emp_pdl_profile: HIP events around the plane region's launches (the fp16x3 mode's dominant kernel)
+    if (n->prof_used == n->prof_events.size()) {
+      hipEvent_t a, b;
+      EMP_CHECK_HIP(hipEventCreate(&a));
+      EMP_CHECK_HIP(hipEventCreate(&b));
+      n->prof_events.emplace_back(a, b);
+    }
+    auto& ev = n->prof_events[n->prof_used++];
+    EMP_CHECK_HIP(hipEventRecord(ev.first, s));
+    const int rc = launch_conv32(p, s);
+    EMP_CHECK_HIP(hipEventRecord(ev.second, s));
+    n->prof_flops += 3.0 * 2.0 * (double)p.N * p.Ho * p.Wo * w.cout * (double)(w.cin16 * w.kh * w.kw);      // fp16 MFMA flops: three products per MAC
+    return rc;
+  }
   return launch_conv32(p, s);
 }
 
@@ -1654,6 +1702,20 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
   auto dw = [&](const T32& in, const std::string& wname, int K, const T32& out) -> int {
     n->flops += 2.0 * K * K * (double)N * in.H * in.W * in.C;
     return launch_dwconv_f32(in.p, N, in.H, in.W, in.C, in.ld, n->f32w.at(wname + ".dw32"), K, out.p, out.ld, s);
+  };
+  // fp16x3 mode: the separable block `base` (".sepconv") of `in` as one launch, if the fused kernel takes it; *done says so
+  auto sep_x3 = [&](const std::string& base, const T32& in, int act, float* out, int out_ld, const float* hw, const float* hb, int hcn,
+                    float* hout, bool* done) -> int {
+    *done = false;
+    auto it = n->sepx3.find(base);
+    if (n->precision != 2 || it == n->sepx3.end()) return EMP_OK;
+    const emp_pdl::SepX3& sx = it->second;
+    const int64_t tiles = (int64_t)N * ((in.H + 7) / 8) * ((in.W + 15) / 16);
+    if (in.fmt || in.ld < sx.C || tiles < n->x3_sep_min_tiles || !sepconv_x3_supported(sx.C, sx.Cout, hcn, sx.ks)) return EMP_OK;
+    *done = true;
+    n->flops += 2.0 * sx.ks * sx.ks * (double)N * in.H * in.W * in.C + 2.0 * (double)N * in.H * in.W * sx.Cout * (double)n->w32.at(base + ".1").cin;
+    return launch_sepconv_x3(in.p, N, in.H, in.W, sx.C, in.ld, sx.dw, sx.pw, n->w32.at(base + ".1").b, sx.Cout, act, out, out_ld, hw, hb, hcn,
+                             hout, (int64_t)in.H * in.W, s, sx.ks);
   };
   // ---- encoder ----
   std::string x, pyr[5];
@@ -1793,6 +1855,12 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
                         float ca, float cb, float cc, int mode, int h_, int w_, const std::string& outname) -> int {
           RC32(mk(q + ".fz", h_, w_, F));
           RC32(launch_fuse_combine_f32(a, b2, c3, ca, cb, cc, mode, N, h_, w_, F, A(q + ".fz").p, s));
+          {
+            bool fused = false;
+            RC32(mk(outname, h_, w_, F));
+            RC32(sep_x3(dirpre + ".after_combines.0.0.sepconv", A(q + ".fz"), 2, A(outname).p, A(outname).ld, nullptr, nullptr, 0, nullptr, &fused));
+            if (fused) return EMP_OK;
+          }
           RC32(mk(q + ".dw", h_, w_, F));
           RC32(dw(A(q + ".fz"), dirpre + ".after_combines.0.0.sepconv.0", 3, A(q + ".dw")));
           RC32(mk(outname, h_, w_, F));
@@ -1859,10 +1927,14 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
         xx = cn;
       }
       const T32 cat = A(xx);
-      RC32(mk(dp + ".dw", cat.H, cat.W, 2 * F));
-      RC32(dw(cat, dp + ".fusion.0.sepconv.0", 5, A(dp + ".dw")));
       RC32(mk(dp + ".out", cat.H, cat.W, F));
-      RC32(c32(n, dp + ".fusion.0.sepconv.1", A(dp + ".dw"), 0, A(dp + ".out"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+      bool fused = false;
+      RC32(sep_x3(dp + ".fusion.0.sepconv", cat, 1, A(dp + ".out").p, A(dp + ".out").ld, nullptr, nullptr, 0, nullptr, &fused));
+      if (!fused) {
+        RC32(mk(dp + ".dw", cat.H, cat.W, 2 * F));
+        RC32(dw(cat, dp + ".fusion.0.sepconv.0", 5, A(dp + ".dw")));
+        RC32(c32(n, dp + ".fusion.0.sepconv.1", A(dp + ".dw"), 0, A(dp + ".out"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+      }
       dec_out[d] = dp + ".out";
     }
   } else {
@@ -1893,16 +1965,20 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
       for (int i = 0; i < c.n_stages; ++i) {
         const T32 low = A(pyr[c.low_level_stages[i]]);
         const int lp = d == 0 ? c.low_level_proj_sem[i] : c.low_level_proj_ins[i];
-        const int cpad = round_up(xch + lp, 16);
+        const int cpad = round_up(xch + lp, n->precision == 2 ? 32 : 16);      // (finalize32 packed the block's weights for this width)
         const std::string q = p + ".stage" + std::to_string(i);
         RC32(mk(q + ".cat", low.H, low.W, cpad));
         const T32 xa = A(xx);
         RC32(launch_bilinear_ac_f32_nhwc(xa.p, N, xa.H, xa.W, xch, xa.ld, A(q + ".cat").p, low.H, low.W, cpad, s));
         RC32(c32(n, p + ".project." + std::to_string(i) + ".0", low, 0, A(q + ".cat"), xch, 1, 0, 1, 1, nullptr, nullptr, s));
-        RC32(mk(q + ".dw", low.H, low.W, cpad));
-        RC32(dw(A(q + ".cat"), p + ".fuse." + std::to_string(i) + ".0.sepconv.0", 5, A(q + ".dw")));
         RC32(mk(q + ".out", low.H, low.W, n->dec_ch));
-        RC32(c32(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1", A(q + ".dw"), 0, A(q + ".out"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+        bool fused = false;
+        RC32(sep_x3(p + ".fuse." + std::to_string(i) + ".0.sepconv", A(q + ".cat"), 1, A(q + ".out").p, A(q + ".out").ld, nullptr, nullptr, 0, nullptr, &fused));
+        if (!fused) {
+          RC32(mk(q + ".dw", low.H, low.W, cpad));
+          RC32(dw(A(q + ".cat"), p + ".fuse." + std::to_string(i) + ".0.sepconv.0", 5, A(q + ".dw")));
+          RC32(c32(n, p + ".fuse." + std::to_string(i) + ".0.sepconv.1", A(q + ".dw"), 0, A(q + ".out"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+        }
         xx = q + ".out";
         xch = n->dec_ch;
       }
@@ -1920,13 +1996,21 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
   for (int k = 0; k < 3; ++k) {
     const std::string p = heads[k];
     const T32& xin = k == 0 ? semx : insx;
-    RC32(mk(p + ".dw", hq, wq, n->dec_ch));
-    RC32(dw(xin, p + ".head.0.0.sepconv.0", 5, A(p + ".dw")));
     float* dst;
     RC32(buf32(n, p + ".out", (size_t)N * hc[k] * hq * wq, &dst));
     if (k == 1 && !interp) dst = o_ctr;
     if (k == 2 && !interp) dst = o_off;
     head_out[k] = dst;
+    {   // fp16x3 mode, round 6: depthwise + pointwise + ReLU + the head's 1x1 in one launch (sepconv_x3.hip, head_c <= 2)
+      bool fused = false;
+      RC32(sep_x3(p + ".head.0.0.sepconv", xin, 1, nullptr, 0, n->f32w.at(p + ".head.1.w"), n->f32w.at(p + ".head.1.b"), hc[k], dst, &fused));
+      if (fused) {
+        n->flops += 2.0 * (double)N * hq * wq * n->dec_ch * hc[k];
+        continue;
+      }
+    }
+    RC32(mk(p + ".dw", hq, wq, n->dec_ch));
+    RC32(dw(xin, p + ".head.0.0.sepconv.0", 5, A(p + ".dw")));
     if (n->precision == 2 && n->x3_fuse_head && hc[k] <= 4) {
       // fp16x3 mode: the head's 1x1 inside the pointwise conv's epilogue (conv16x3.hip HEAD): the dec_ch-wide map is
       // neither written nor read back; every cout tile leaves per-pixel partial sums, added in ascending order

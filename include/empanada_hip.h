@@ -281,6 +281,22 @@ EMP_API int emp_conv2d_hl32_f16x3(const void* d_in, int N, int H, int W, int Cin
                         void* d_out, int out_ld, int out_fmt, int Cout,
                         int KH, int KW, int stride, int pad, int dil, int act, void* stream);
 
+/* Round 6 -- the depthwise-separable block of the fp16x3 mode as ONE launch (csrc/sepconv_x3.hip): replaces
+ * nn.Conv2d(C,C,k,groups=C,padding=k/2,bias=False) -> nn.Conv2d(C,Cout,1) -> folded BatchNorm -> ReLU / SiLU (models/blocks.py:15-33;
+ * decoders/panoptic_deeplab.py:68-80, heads.py:12-15) and, with d_head_w, the head's final 1x1 (heads.py:14) on fp32 NHWC maps.
+ * The depthwise half runs in fp32 (taps ky-major / kx-minor, an fmaf chain from 0); its result goes to LDS as the fp16 pair
+ * hi + lo and meets the pointwise weights (hi + lo) in three fp16 MFMAs per product, fp32 accumulate from the bias.
+ *   emp_sepconv_x3_pack : d_dw (k*k, C) fp32 taps, d_pw (Cout, C) fp32 -> d_dw_packed (k*k*C floats), d_pw_packed (2*C*Cout halfs)
+ *   emp_sepconv_x3_nhwc_f32 : C % 32 == 0, 64 <= C <= 448, Cout 128 or 256, k 5 (or 3 without a head), act 0 / 1 / 2;
+ *                          exactly one of d_out (N,H,W,out_ld) and the head output d_head_out (N, head_c, H*W), head_c <= 2 */
+EMP_API int emp_sepconv_x3_pack(const float* d_dw, const float* d_pw, int ks, int C, int Cout,
+                        float* d_dw_packed, void* d_pw_packed, void* stream);
+EMP_API int emp_sepconv_x3_nhwc_f32(const float* d_in, int N, int H, int W, int C, int in_ld,
+                        const float* d_dw_packed, const void* d_pw_packed, const float* d_bias, int Cout, int act,
+                        float* d_out, int out_ld,
+                        const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
+                        int ks, void* stream);
+
 /* The same convolution with `groups` groups (nn.Conv2d(groups=g), the 3x3 of a RegNet bottleneck:
  * empanada/models/encoders/regnet.py:51-77 via blocks.py:134-153): group g reads input channels [g * cin_g, g * cin_g +
  * Cin16) -- Cin16 = cin_g padded to a multiple of 16, the padding meeting zero weights, so a row of the input must hold
