@@ -132,6 +132,8 @@ PROTOTYPES = {
     'emp_fill_holes_slices': (c_int, [vp, c_i64, c_i64, c_i64]),
     'emp_rle_extract_work_bytes': (sz, [c_int, c_int, c_int]),
     'emp_rle_extract': (c_int, [vp, c_int, c_int, c_int, vp, vp, c_int, vp, vp]),
+    'emp_ccl_range': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, vp, vp]),
+    'emp_rle_extract_range': (c_int, [vp, c_int, c_int, c_int, c_int, c_i64, c_i64, vp, vp, c_int, vp, vp]),
     'emp_rle_fill': (c_int, [vp, vp, vp, c_i64, vp, c_i64, c_int, vp]),
     'emp_rle_fill_ordered': (c_int, [vp, vp, vp, vp, c_i64, vp, c_i64, c_int, vp, vp]),
     'emp_rle_pair_intersections': (c_int, [vp, vp, vp, vp, c_i64, vp]),

@@ -67,6 +67,7 @@ struct ConvParams {
   int mt, nt;      // tiles along pixels / couts
   int mt_per_xcd;  // ceil(mt/8)
   int kgroup;      // channel slabs (64 ch) per K-walk group, set by launch_conv_igemm
+  int ngroup;      // 256 x 256 tiles only (round 6): cout tiles an XCD keeps resident while it walks its pixel tiles; 0 = all of them (cout tile fastest)
   // optional second source, K-concatenated behind the first one (1x1 main conv only): a strided 1x1 conv of `in2`
   // summed into the same accumulators -- the bottleneck's downsample branch folded into conv3.
   // Weight rows are then [KH*KW*Cin | Cin2] long.

@@ -250,8 +250,16 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256_kernel(const ConvParams 
 
   const int bid = blockIdx.x;
   const int xcd = bid & 7, j = bid >> 3;
-  const int mtile = xcd * p.mt_per_xcd + j / p.nt;
-  const int ntile = j % p.nt;
+  int mtile = xcd * p.mt_per_xcd + j / p.nt;
+  int ntile = j % p.nt;
+  if (p.ngroup > 0) {
+    // intermediate raster (round 6): the XCD keeps `ngroup` cout tiles resident and walks ALL its pixel
+    // tiles under them, then the next group -- the weights (ngroup x K x 512 B) survive the rounds' output in L2, the
+    // activations are re-read nt / ngroup times instead of the weights mt_per_xcd times
+    const int per = p.mt_per_xcd * p.ngroup, g = j / per, rem = j - g * per;
+    mtile = xcd * p.mt_per_xcd + rem / p.ngroup;
+    ntile = g * p.ngroup + rem % p.ngroup;
+  }
   if (mtile >= p.mt) return;
   const int m0 = mtile * 256, n0 = ntile * 256;
 
@@ -528,8 +536,16 @@ __global__ void __launch_bounds__(512, 1) conv_igemm256w_kernel(const ConvParams
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int bid = blockIdx.x;
   const int xcd = bid & 7, j = bid >> 3;
-  const int mtile = xcd * p.mt_per_xcd + j / p.nt;
-  const int ntile = j % p.nt;
+  int mtile = xcd * p.mt_per_xcd + j / p.nt;
+  int ntile = j % p.nt;
+  if (p.ngroup > 0) {
+    // intermediate raster (round 6): the XCD keeps `ngroup` cout tiles resident and walks ALL its pixel
+    // tiles under them, then the next group -- the weights (ngroup x K x 512 B) survive the rounds' output in L2, the
+    // activations are re-read nt / ngroup times instead of the weights mt_per_xcd times
+    const int per = p.mt_per_xcd * p.ngroup, g = j / per, rem = j - g * per;
+    mtile = xcd * p.mt_per_xcd + rem / p.ngroup;
+    ntile = g * p.ngroup + rem % p.ngroup;
+  }
   if (mtile >= p.mt) return;
   const int m0 = mtile * 256, n0 = ntile * 256;
 
@@ -1034,6 +1050,12 @@ int launch_conv_igemm256(ConvParams p, hipStream_t stream, int kg, int mode, boo
   p.mt = cdiv(p.M, 256);
   p.nt = p.Cout / 256;
   p.mt_per_xcd = cdiv(p.mt, 8);
+  {
+    // EMP_CONV256_NGROUP=g: the intermediate raster for the 1x1 convolutions with at least 2g cout tiles (A/B; the measured
+    // outcome is in profiles/r06_conv_raster.txt)
+    static const int env_ng = [] { const char* e = getenv("EMP_CONV256_NGROUP"); return e ? atoi(e) : 0; }();
+    p.ngroup = (env_ng > 0 && p.KH * p.KW == 1 && p.nt >= 2 * env_ng && p.nt % env_ng == 0 && !p.next_w) ? env_ng : 0;
+  }
   const int grid = 8 * p.mt_per_xcd * p.nt;
   if (p.next_w) return launch256<0, true>(p, grid, stream);
   {

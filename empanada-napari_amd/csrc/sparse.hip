@@ -52,6 +52,22 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* sh, ui
   return base + inc - v;
 }
 
+// A label map as the kernels read it.  RANGE (round 6): the class isolation of rle.py:46-48 /
+// inference.py:270-272 -- "keep the labels of [lo, hi), everything else is background" -- applied at the read, on the int64 (or
+// int32) panoptic map itself, instead of a torch.where pass (and an int64 -> int32 pass) per class in front of the kernels.
+template <typename T, bool RANGE>
+struct Img {
+  const T* p;
+  int64_t lo, hi;
+  __device__ __forceinline__ int32_t operator[](size_t i) const {
+    const T v = p[i];
+    if (RANGE) return (v >= (T)lo && v < (T)hi) ? (int32_t)v : 0;
+    return (int32_t)v;
+  }
+  __device__ __host__ __forceinline__ Img at(size_t off) const { return Img{p + off, lo, hi}; }
+};
+typedef Img<int32_t, false> ImgPlain;
+
 // ---------------------------------------------------------------------------
 // connected components: lock-free union-find on linear pixel indices; a root is the smallest
 // index of its component, so ranking the roots in index order IS raster order of first pixels.
@@ -81,7 +97,8 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   }
 }
 
-__global__ void __launch_bounds__(256) ccl_init_kernel(const int32_t* __restrict__ in, int* __restrict__ parent,
+template <class IM>
+__global__ void __launch_bounds__(256) ccl_init_kernel(const IM in, int* __restrict__ parent,
                                                        int64_t total, int hw) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
     parent[i] = in[i] != 0 ? (int)(i % hw) : -1;
@@ -91,12 +108,13 @@ __global__ void __launch_bounds__(256) ccl_init_kernel(const int32_t* __restrict
 // as far as the run lies inside the pixel's wave -- one ballot instead of one union per pixel.  A run that continues
 // from the previous wave is linked by ccl_merge_kernel (lane 0).  Same indexing as the merge kernel: 64 consecutive
 // image-local pixels per wave.
-__global__ void __launch_bounds__(256) ccl_init_rows_kernel(const int32_t* __restrict__ in, int* __restrict__ parent_all,
+template <class IM>
+__global__ void __launch_bounds__(256) ccl_init_rows_kernel(const IM in, int* __restrict__ parent_all,
                                                             int hw, int w) {
   const int n = blockIdx.y;
   const int p = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
-  const int32_t* im = in + (size_t)n * hw;
+  const IM im = in.at((size_t)n * hw);
   const bool live = p < hw;
   const int32_t v = live ? im[p] : 0;
   const int x = live ? p % w : 0;
@@ -112,13 +130,14 @@ __global__ void __launch_bounds__(256) ccl_init_rows_kernel(const int32_t* __res
 //   up-left       only if `up` differs and `left` differs (else the left pixel's `up` union is this one)
 //   up-right      only if `up` differs and `right` differs (else the right pixel's `up` union is this one)
 // In the interior of a blob no pixel issues a union: the atomics are left to run ends and corners.
-__global__ void __launch_bounds__(256) ccl_merge_kernel(const int32_t* __restrict__ in, int* __restrict__ parent_all,
+template <class IM>
+__global__ void __launch_bounds__(256) ccl_merge_kernel(const IM in, int* __restrict__ parent_all,
                                                         int h, int w) {
   const int n = blockIdx.y;
   const int hw = h * w;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= hw) return;
-  const int32_t* im = in + (size_t)n * hw;
+  const IM im = in.at((size_t)n * hw);
   int* parent = parent_all + (size_t)n * hw;
   const int32_t v = im[p];
   if (v == 0) return;
@@ -140,7 +159,8 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(const int32_t* __restric
 
 // 26-connected components of a volume (skimage.measure.label on a 3-D array, full connectivity): the 13 neighbours
 // that precede a voxel in raster order
-__global__ void __launch_bounds__(256) ccl_merge3d_kernel(const int32_t* __restrict__ im, int* __restrict__ parent,
+template <class IM>
+__global__ void __launch_bounds__(256) ccl_merge3d_kernel(const IM im, int* __restrict__ parent,
                                                           int d, int h, int w) {
   const int64_t total = (int64_t)d * h * w;
   const int64_t p64 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -292,7 +312,8 @@ __global__ void __launch_bounds__(256) fc_apply_kernel(const int32_t* __restrict
 // flags: bit0 = run start (label != 0 and differs from the previous element),
 //        bit1 = run end   (label != 0 and differs from the next element)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t run_flags(const int32_t* im, int hw, int e0, uint32_t* fs, uint32_t* fe) {
+template <class IM>
+__device__ __forceinline__ uint32_t run_flags(const IM& im, int hw, int e0, uint32_t* fs, uint32_t* fe) {
   uint32_t s = 0, e = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -311,12 +332,13 @@ __device__ __forceinline__ uint32_t run_flags(const int32_t* im, int hw, int e0,
   *fe = e;
   return (uint32_t)__popc(s) | ((uint32_t)__popc(e) << 16);
 }
-__global__ void __launch_bounds__(256) rle_count_kernel(const int32_t* __restrict__ in, int hw,
+template <class IM>
+__global__ void __launch_bounds__(256) rle_count_kernel(const IM in, int hw,
                                                         uint32_t* __restrict__ blockcnt, int nb) {
   __shared__ uint32_t sh[8];
   const int n = blockIdx.y;
   uint32_t fs, fe;
-  uint32_t c = run_flags(in + (size_t)n * hw, hw, blockIdx.x * CHUNK + threadIdx.x * 8, &fs, &fe);
+  uint32_t c = run_flags(in.at((size_t)n * hw), hw, blockIdx.x * CHUNK + threadIdx.x * 8, &fs, &fe);
   uint32_t total;
   block_excl_scan(c & 0xffffu, sh, &total);  // starts and ends are equinumerous per image, not per block
   if (threadIdx.x == 0) blockcnt[((size_t)n * nb + blockIdx.x) * 2] = total;
@@ -348,12 +370,13 @@ __global__ void __launch_bounds__(256) rle_scan_kernel(const uint32_t* __restric
   if (threadIdx.x == 0) totals[n] = (int32_t)cs;
 }
 // runs (max_runs, 3) per image: {start, length, label}; ends are written as start + length later
-__global__ void __launch_bounds__(256) rle_write_kernel(const int32_t* __restrict__ in, int hw,
+template <class IM>
+__global__ void __launch_bounds__(256) rle_write_kernel(const IM in, int hw,
                                                         const uint32_t* __restrict__ blockoff, int nb,
                                                         int32_t* __restrict__ runs_all, int max_runs) {
   __shared__ uint32_t sh[8];
   const int n = blockIdx.y;
-  const int32_t* im = in + (size_t)n * hw;
+  const IM im = in.at((size_t)n * hw);
   int32_t* runs = runs_all + (size_t)n * max_runs * 3;
   const int e0 = blockIdx.x * CHUNK + threadIdx.x * 8;
   uint32_t fs, fe;
@@ -437,16 +460,9 @@ __global__ void __launch_bounds__(256) rle_fill_ordered_kernel(const int64_t* __
 
 using namespace emp;
 
-extern "C" {
-
-size_t emp_ccl8_work_bytes(int N, int H, int W) {
-  const size_t hw = (size_t)H * W;
-  const size_t nb = (hw + CHUNK - 1) / CHUNK;
-  return (size_t)N * (hw * 8 + nb * 8) + 512;
-}
-
 // depth == 0: N images of H x W, 8-connected; depth > 0: ONE volume depth x H x W, 26-connected
-static int ccl_run(const int32_t* d_in, int N, int depth, int H, int W, int32_t* d_out, int32_t* d_num, void* d_work,
+template <class IM>
+static int ccl_run(const IM d_in, int N, int depth, int H, int W, int32_t* d_out, int32_t* d_num, void* d_work,
                    hipStream_t s) {
   const int64_t hw64 = (int64_t)(depth > 0 ? depth : 1) * H * W;
   EMP_REQUIRE(hw64 < (1ll << 30), "ccl: image / volume too large (< 2^30 elements)");
@@ -458,14 +474,14 @@ static int ccl_run(const int32_t* d_in, int N, int depth, int H, int W, int32_t*
   uint32_t* blockoff = blockcnt + (size_t)N * nb;
   const int64_t total = (int64_t)N * hw;
   if (depth > 0)
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(grid_for(total)), dim3(256), 0, s, d_in, parent, total, hw);
+    hipLaunchKernelGGL(ccl_init_kernel<IM>, dim3(grid_for(total)), dim3(256), 0, s, d_in, parent, total, hw);
   else
-    hipLaunchKernelGGL(ccl_init_rows_kernel, dim3(cdiv(hw, 256), N), dim3(256), 0, s, d_in, parent, hw, W);
+    hipLaunchKernelGGL(ccl_init_rows_kernel<IM>, dim3(cdiv(hw, 256), N), dim3(256), 0, s, d_in, parent, hw, W);
   EMP_LAUNCH_CHECK();
   if (depth > 0)
-    hipLaunchKernelGGL(ccl_merge3d_kernel, dim3(cdiv(hw, 256)), dim3(256), 0, s, d_in, parent, depth, H, W);
+    hipLaunchKernelGGL(ccl_merge3d_kernel<IM>, dim3(cdiv(hw, 256)), dim3(256), 0, s, d_in, parent, depth, H, W);
   else
-    hipLaunchKernelGGL(ccl_merge_kernel, dim3(cdiv(hw, 256), N), dim3(256), 0, s, d_in, parent, H, W);
+    hipLaunchKernelGGL(ccl_merge_kernel<IM>, dim3(cdiv(hw, 256), N), dim3(256), 0, s, d_in, parent, H, W);
   EMP_LAUNCH_CHECK();
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3(cdiv(hw, 256), N), dim3(256), 0, s, parent, hw);
   EMP_LAUNCH_CHECK();
@@ -480,9 +496,49 @@ static int ccl_run(const int32_t* d_in, int N, int depth, int H, int W, int32_t*
   return EMP_OK;
 }
 
+template <class IM>
+static int rle_extract_run(const IM d_labels, int N, int H, int W, int32_t* d_runs, int32_t* d_num_runs, int max_runs,
+                           void* d_work, hipStream_t s) {
+  EMP_REQUIRE(d_labels.p && d_runs && d_num_runs && d_work && N > 0 && H > 0 && W > 0 && max_runs > 0,
+              "rle_extract: bad arguments");
+  EMP_REQUIRE((int64_t)H * W < (1ll << 30), "rle_extract: image too large");
+  const int hw = H * W;
+  const int nb = cdiv(hw, CHUNK);
+  uint32_t* blockcnt = (uint32_t*)d_work;
+  uint32_t* blockoff = blockcnt + (size_t)N * nb * 2;
+  hipLaunchKernelGGL(rle_count_kernel<IM>, dim3(nb, N), dim3(256), 0, s, d_labels, hw, blockcnt, nb);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rle_scan_kernel, dim3(N), dim3(256), 0, s, blockcnt, blockoff, nb, d_num_runs);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rle_write_kernel<IM>, dim3(nb, N), dim3(256), 0, s, d_labels, hw, blockoff, nb, d_runs, max_runs);
+  EMP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rle_fixup_kernel, dim3(cdiv(max_runs, 256), N), dim3(256), 0, s, d_runs, d_num_runs, max_runs);
+  EMP_LAUNCH_CHECK();
+  return EMP_OK;
+}
+
+extern "C" {
+
+size_t emp_ccl8_work_bytes(int N, int H, int W) {
+  const size_t hw = (size_t)H * W;
+  const size_t nb = (hw + CHUNK - 1) / CHUNK;
+  return (size_t)N * (hw * 8 + nb * 8) + 512;
+}
+
+
 int emp_ccl8(const int32_t* d_in, int N, int H, int W, int32_t* d_out, int32_t* d_num, void* d_work, void* stream) {
   EMP_REQUIRE(d_in && d_out && d_work && N > 0 && H > 0 && W > 0, "ccl8: bad arguments");
-  return ccl_run(d_in, N, 0, H, W, d_out, d_num, d_work, (hipStream_t)stream);
+  return ccl_run(ImgPlain{d_in, 0, 0}, N, 0, H, W, d_out, d_num, d_work, (hipStream_t)stream);
+}
+
+// emp_ccl8 / emp_ccl26 of the labels of [lo, hi) of an int32 (in_bytes 4) or int64 (8) map, the rest read as background: the
+// class isolation of rle.py:46-48 folded into the kernels' reads (depth 0: N images, 8-connected; depth > 0: one volume)
+int emp_ccl_range(const void* d_in, int in_bytes, int N, int depth, int H, int W, int64_t lo, int64_t hi, int32_t* d_out, int32_t* d_num,
+                  void* d_work, void* stream) {
+  EMP_REQUIRE(d_in && d_out && d_work && N > 0 && H > 0 && W > 0 && depth >= 0 && (depth == 0 || N == 1), "ccl_range: bad arguments");
+  EMP_REQUIRE((in_bytes == 4 || in_bytes == 8) && lo >= 0 && hi > lo && hi <= (1ll << 31) - 1, "ccl_range: 4- or 8-byte labels, 0 <= lo < hi < 2^31");
+  if (in_bytes == 8) return ccl_run(Img<int64_t, true>{(const int64_t*)d_in, lo, hi}, N, depth, H, W, d_out, d_num, d_work, (hipStream_t)stream);
+  return ccl_run(Img<int32_t, true>{(const int32_t*)d_in, lo, hi}, N, depth, H, W, d_out, d_num, d_work, (hipStream_t)stream);
 }
 
 size_t emp_force_connected_work_bytes(int N, int H, int W) {
@@ -513,7 +569,7 @@ int emp_force_connected(const int64_t* d_pan, int N, int H, int W, const int32_t
       hipLaunchKernelGGL(fc_select_kernel<int32_t>, dim3(grid_for(total)), dim3(256), 0, s, (const int32_t*)d_out, d_out, sel,
                          total, lo, hi, 0);
     EMP_LAUNCH_CHECK();
-    const int rc = ccl_run(sel, N, 0, H, W, sel, nullptr, ccl_work, s);   // relabel does not read its input: in place
+    const int rc = ccl_run(ImgPlain{sel, 0, 0}, N, 0, H, W, sel, nullptr, ccl_work, s);   // relabel does not read its input: in place
     if (rc) return rc;
     hipLaunchKernelGGL(fc_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, sel, d_out, total, (int32_t)lo);
     EMP_LAUNCH_CHECK();
@@ -524,7 +580,7 @@ int emp_force_connected(const int64_t* d_pan, int N, int H, int W, const int32_t
 // work buffer: emp_ccl8_work_bytes(1, D * H, W)
 int emp_ccl26(const int32_t* d_in, int D, int H, int W, int32_t* d_out, int32_t* d_num, void* d_work, void* stream) {
   EMP_REQUIRE(d_in && d_out && d_work && D > 0 && H > 0 && W > 0, "ccl26: bad arguments");
-  return ccl_run(d_in, 1, D, H, W, d_out, d_num, d_work, (hipStream_t)stream);
+  return ccl_run(ImgPlain{d_in, 0, 0}, 1, D, H, W, d_out, d_num, d_work, (hipStream_t)stream);
 }
 
 int emp_morph_cross3d(const uint32_t* d_in, uint32_t* d_out, int D, int H, int W, int op, void* stream) {
@@ -540,25 +596,19 @@ size_t emp_rle_extract_work_bytes(int N, int H, int W) {
   return (size_t)N * nb * 16 + 512;
 }
 
+
 int emp_rle_extract(const int32_t* d_labels, int N, int H, int W, int32_t* d_runs, int32_t* d_num_runs, int max_runs,
                     void* d_work, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
-  EMP_REQUIRE(d_labels && d_runs && d_num_runs && d_work && N > 0 && H > 0 && W > 0 && max_runs > 0,
-              "rle_extract: bad arguments");
-  EMP_REQUIRE((int64_t)H * W < (1ll << 30), "rle_extract: image too large");
-  const int hw = H * W;
-  const int nb = cdiv(hw, CHUNK);
-  uint32_t* blockcnt = (uint32_t*)d_work;
-  uint32_t* blockoff = blockcnt + (size_t)N * nb * 2;
-  hipLaunchKernelGGL(rle_count_kernel, dim3(nb, N), dim3(256), 0, s, d_labels, hw, blockcnt, nb);
-  EMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rle_scan_kernel, dim3(N), dim3(256), 0, s, blockcnt, blockoff, nb, d_num_runs);
-  EMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rle_write_kernel, dim3(nb, N), dim3(256), 0, s, d_labels, hw, blockoff, nb, d_runs, max_runs);
-  EMP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rle_fixup_kernel, dim3(cdiv(max_runs, 256), N), dim3(256), 0, s, d_runs, d_num_runs, max_runs);
-  EMP_LAUNCH_CHECK();
-  return EMP_OK;
+  return rle_extract_run(ImgPlain{d_labels, 0, 0}, N, H, W, d_runs, d_num_runs, max_runs, d_work, (hipStream_t)stream);
+}
+
+// emp_rle_extract of the labels of [lo, hi) of an int32 / int64 map (the rest is background): rle.py:46-48's isolation at the read
+int emp_rle_extract_range(const void* d_labels, int in_bytes, int N, int H, int W, int64_t lo, int64_t hi, int32_t* d_runs,
+                          int32_t* d_num_runs, int max_runs, void* d_work, void* stream) {
+  EMP_REQUIRE((in_bytes == 4 || in_bytes == 8) && lo >= 0 && hi > lo && hi <= (1ll << 31) - 1, "rle_extract_range: 4- or 8-byte labels, 0 <= lo < hi < 2^31");
+  if (in_bytes == 8)
+    return rle_extract_run(Img<int64_t, true>{(const int64_t*)d_labels, lo, hi}, N, H, W, d_runs, d_num_runs, max_runs, d_work, (hipStream_t)stream);
+  return rle_extract_run(Img<int32_t, true>{(const int32_t*)d_labels, lo, hi}, N, H, W, d_runs, d_num_runs, max_runs, d_work, (hipStream_t)stream);
 }
 
 int emp_rle_fill(const int64_t* d_starts, const int64_t* d_lens, const int64_t* d_vals, int64_t nruns, void* d_volume,

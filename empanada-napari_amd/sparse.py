@@ -60,9 +60,32 @@ def ccl8(labels):
     return out, num
 
 
+def _label_bytes(t):
+    if t.dtype == torch.int32:
+        return 4
+    if t.dtype == torch.int64:
+        return 8
+    raise TypeError(f'label maps are int32 or int64 device tensors, got {t.dtype}')
+
+
 @torch.no_grad()
-def extract_runs(labels, max_runs=1 << 16):
-    """labels (N,H,W) int32 cuda -> list of (n_i,3) int64 numpy arrays {start, length, label} in raster order."""
+def ccl8_range(labels, lo, hi):
+    """ccl8 of the labels of [lo, hi) of an int32 / int64 (N,H,W) map, everything else background: the class isolation of
+    rle.py:46-48 inside the kernels' reads (no select pass, no int64 -> int32 pass) -> components (N,H,W) int32."""
+    lib = _lib()
+    labels = labels.contiguous()
+    N, H, W = labels.shape
+    out = torch.empty((N, H, W), dtype=torch.int32, device=labels.device)
+    work = torch.empty((int(lib.emp_ccl8_work_bytes(N, H, W)),), dtype=torch.uint8, device=labels.device)
+    _abi.check(lib.emp_ccl_range(_abi.ptr(labels), _label_bytes(labels), N, 0, H, W, int(lo), int(hi), _abi.ptr(out), None, _abi.ptr(work),
+                                 _abi.stream_ptr(labels.device)), 'emp_ccl_range')
+    return out
+
+
+@torch.no_grad()
+def extract_runs(labels, max_runs=1 << 16, lo=None, hi=None):
+    """labels (N,H,W) int32 cuda -> list of (n_i,3) int64 numpy arrays {start, length, label} in raster order.
+    ``lo, hi``: only the labels of [lo, hi) of an int32 / int64 map (the isolation of rle.py:46-48 at the kernels' reads)."""
     lib = _lib()
     labels = labels.contiguous()
     N, H, W = labels.shape
@@ -70,8 +93,13 @@ def extract_runs(labels, max_runs=1 << 16):
     while True:
         runs = torch.empty((N, max_runs, 3), dtype=torch.int32, device=labels.device)
         num = torch.empty((N,), dtype=torch.int32, device=labels.device)
-        _abi.check(lib.emp_rle_extract(_abi.ptr(labels), N, H, W, _abi.ptr(runs), _abi.ptr(num), max_runs,
-                                       _abi.ptr(work), _abi.stream_ptr(labels.device)), 'emp_rle_extract')
+        if lo is None:
+            _abi.check(lib.emp_rle_extract(_abi.ptr(labels), N, H, W, _abi.ptr(runs), _abi.ptr(num), max_runs,
+                                           _abi.ptr(work), _abi.stream_ptr(labels.device)), 'emp_rle_extract')
+        else:
+            _abi.check(lib.emp_rle_extract_range(_abi.ptr(labels), _label_bytes(labels), N, H, W, int(lo), int(hi), _abi.ptr(runs),
+                                                 _abi.ptr(num), max_runs, _abi.ptr(work), _abi.stream_ptr(labels.device)),
+                       'emp_rle_extract_range')
         counts = num.cpu().numpy()
         if counts.max(initial=0) <= max_runs:
             break
@@ -114,22 +142,32 @@ def _as_device_i32(pan, device=None):
     return pan.to(_dev(device), non_blocking=True).to(torch.int32)
 
 
+def _as_device_labels(pan, device=None):
+    """a label map on the device as the range kernels read it: int32 and int64 stay what they are (no conversion pass)"""
+    if isinstance(pan, np.ndarray):
+        pan = torch.from_numpy(np.ascontiguousarray(pan))
+    pan = pan.to(_dev(device), non_blocking=True)
+    return pan if pan.dtype in (torch.int32, torch.int64) else pan.to(torch.int64)
+
+
 @torch.no_grad()
 def pan_stack_to_rle_segs(pan, labels, label_divisor, thing_list, force_connected=True):
     """Batched rle.pan_seg_to_rle_seg (rle.py:26-86): pan (N,H,W) integer labels (numpy or cuda tensor)
     -> list of N rle_seg dicts {class: {instance_id: attrs}}."""
-    pan = _as_device_i32(pan)
+    pan = _as_device_labels(pan)
     N, H, W = pan.shape
     segs = [dict() for _ in range(N)]
     for label in labels:
         lo = label * label_divisor
         hi = lo + label_divisor
-        inst = torch.where((pan >= lo) & (pan < hi), pan, torch.zeros_like(pan))
-        off = 0
+        # (round 6: the class isolation -- rle.py:46-48 -- happens at the kernels' reads: no select pass per class)
         if force_connected and label in thing_list:
-            inst, _ = ccl8(inst)
+            per_image = extract_runs(ccl8_range(pan, lo, hi))
             off = lo   # rle.py:68-69: component index + min_id
-        for n, runs in enumerate(extract_runs(inst)):
+        else:
+            per_image = extract_runs(pan, lo=lo, hi=hi)
+            off = 0
+        for n, runs in enumerate(per_image):
             segs[n][label] = _runs_to_attrs(runs, W, off)
     return segs
 
@@ -155,17 +193,15 @@ def force_connected(pan, thing_list, label_divisor, out=None):
 def pan_stack_to_runs(pan, labels, label_divisor, thing_list, force_connected=True):
     """The GPU half of pan_stack_to_rle_segs without building Python objects: pan (N,H,W) ->
     {class: (list of N (n_i,3) int64 {start, length, label} arrays in raster order, id offset)} for StackMatcher.push_runs."""
-    pan = _as_device_i32(pan)
+    pan = _as_device_labels(pan)
     out = {}
     for label in labels:
         lo = label * label_divisor
         hi = lo + label_divisor
-        inst = torch.where((pan >= lo) & (pan < hi), pan, torch.zeros_like(pan))
-        off = 0
         if force_connected and label in thing_list:
-            inst, _ = ccl8(inst)
-            off = lo
-        out[label] = (extract_runs(inst), off)
+            out[label] = (extract_runs(ccl8_range(pan, lo, hi)), lo)
+        else:
+            out[label] = (extract_runs(pan, lo=lo, hi=hi), 0)
     return out
 
 
@@ -726,16 +762,21 @@ def remove_pancakes(object_tracker, min_span=4):
 # runs through 26-connected components + run extraction on the GPU.
 # ----------------------------------------------------------------------------
 @torch.no_grad()
-def ccl26(volume):
-    """volume (D,H,W) int32 cuda -> 26-connected components of equal non-zero label, numbered in raster order."""
+def ccl26(volume, lo=None, hi=None):
+    """volume (D,H,W) int32 cuda -> 26-connected components of equal non-zero label, numbered in raster order.
+    ``lo, hi``: of the labels of [lo, hi) of an int32 / int64 volume only (filters.py:78-80's isolation at the kernels' reads)."""
     lib = _lib()
     volume = volume.contiguous()
     D, H, W = volume.shape
-    out = torch.empty_like(volume)
+    out = torch.empty((D, H, W), dtype=torch.int32, device=volume.device)
     num = torch.empty((1,), dtype=torch.int32, device=volume.device)
     work = torch.empty((int(lib.emp_ccl8_work_bytes(1, D * H, W)),), dtype=torch.uint8, device=volume.device)
-    _abi.check(lib.emp_ccl26(_abi.ptr(volume), D, H, W, _abi.ptr(out), _abi.ptr(num), _abi.ptr(work),
-                             _abi.stream_ptr(volume.device)), 'emp_ccl26')
+    if lo is None:
+        _abi.check(lib.emp_ccl26(_abi.ptr(volume), D, H, W, _abi.ptr(out), _abi.ptr(num), _abi.ptr(work),
+                                 _abi.stream_ptr(volume.device)), 'emp_ccl26')
+    else:
+        _abi.check(lib.emp_ccl_range(_abi.ptr(volume), _label_bytes(volume), 1, D, H, W, int(lo), int(hi), _abi.ptr(out), _abi.ptr(num),
+                                     _abi.ptr(work), _abi.stream_ptr(volume.device)), 'emp_ccl_range')
     return out
 
 
@@ -770,18 +811,18 @@ def _runs_to_attrs3d(runs, shape, id_offset=0):
 def volume_to_instances(volume, labels, label_divisor, thing_list, force_connected=True):
     """filters.pan_seg_to_rle_seg (filters.py:58-116) for a (D,H,W) label volume (numpy or cuda tensor): one flat
     {instance_id: attrs} dict; instance classes are split into 26-connected components first."""
-    vol = _as_device_i32(volume)
+    vol = _as_device_labels(volume)
     D, H, W = vol.shape
     out = {}
     for label in labels:
         lo = label * label_divisor
         hi = lo + label_divisor
-        inst = torch.where((vol >= lo) & (vol < hi), vol, torch.zeros_like(vol))
-        off = 0
         if force_connected and label in thing_list:
-            inst = ccl26(inst)
+            runs = extract_runs(ccl26(vol, lo, hi).view(1, D * H, W), max_runs=1 << 20)[0]
             off = lo
-        runs = extract_runs(inst.view(1, D * H, W), max_runs=1 << 20)[0]
+        else:
+            runs = extract_runs(vol.view(1, D * H, W), max_runs=1 << 20, lo=lo, hi=hi)[0]
+            off = 0
         out.update(_runs_to_attrs3d(runs, (D, H, W), off))
     return out
 

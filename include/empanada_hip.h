@@ -475,6 +475,18 @@ EMP_API size_t emp_rle_extract_work_bytes(int N, int H, int W);
 EMP_API int emp_rle_extract(const int32_t* d_labels, int N, int H, int W, int32_t* d_runs,
                     int32_t* d_num_runs, int max_runs, void* d_work, void* stream);
 
+/* Round 6 -- emp_ccl8 / emp_ccl26 and emp_rle_extract with the class isolation folded into the kernels' reads: the labels of
+ * [lo, hi) of an int32 (in_bytes 4) or int64 (in_bytes 8) panoptic map are kept, everything else reads as background --
+ * pan_seg_to_rle_seg's `instance_seg[outside the class range] = 0` (empanada/inference/rle.py:46-48) and force_connected's
+ * (empanada_napari/inference.py:270-272) without a select pass (and an int64 -> int32 pass) per class in front of the kernels.
+ *   emp_ccl_range : depth 0: N images of H x W, 8-connected (work: emp_ccl8_work_bytes(N, H, W)); depth > 0 (N == 1): one
+ *                   volume depth x H x W, 26-connected (work: emp_ccl8_work_bytes(1, depth * H, W)); d_num may be NULL
+ *   emp_rle_extract_range : as emp_rle_extract; the run labels are the map's own values (hi < 2^31) */
+EMP_API int emp_ccl_range(const void* d_in, int in_bytes, int N, int depth, int H, int W, int64_t lo, int64_t hi,
+                        int32_t* d_out, int32_t* d_num, void* d_work, void* stream);
+EMP_API int emp_rle_extract_range(const void* d_labels, int in_bytes, int N, int H, int W, int64_t lo, int64_t hi,
+                        int32_t* d_runs, int32_t* d_num_runs, int max_runs, void* d_work, void* stream);
+
 /* Run list -> dense volume of elem_bytes-wide integers.  replaces numpy_fill_instances,
  * array_utils.py:754-766 (runs must not overlap: later-overwrites-earlier is not defined here). */
 EMP_API int emp_rle_fill(const int64_t* d_starts, const int64_t* d_lens, const int64_t* d_vals,
