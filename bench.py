@@ -46,6 +46,10 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', choices=['tiles', 'stack3d', 'slabjob'], default='tiles')
     ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--precision', choices=['fp16', 'fp16x3', 'fp32'], default='fp16',
+                    help="tiles workload: precision of the HEADLINE network.  The default is the fp16 engine (BASELINE's metric is quoted "
+                         "in fp16); 'fp16x3' -- the product's default precision -- times the same step on that mode (profiles: "
+                         "`python bench.py --precision fp16x3 --batch 16`), with the roofline block of ITS dominant kernel")
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--micro-batch', type=int, default=0, help='forward in chunks of this many tiles (0 = whole batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -428,7 +432,7 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
 
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-    model = HipPanopticDeepLab(P, cfg, device=dev, folded=True, precision='fp16')      # BASELINE's metric is quoted in fp16: the throughput opt-in (the product's default is 'fp16x3': `fp16x3_mode`)
+    model = HipPanopticDeepLab(P, cfg, device=dev, folded=True, precision=args.precision)      # default 'fp16': BASELINE's metric is quoted in fp16 -- the throughput opt-in (the product's default is 'fp16x3': `fp16x3_mode`)
     eng = PanopticDeepLabRenderEngine(model, thing_list=[1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3,
                                       confidence_thr=0.5, padding_factor=16, coarse_boundaries=True)
     B, S = args.batch, args.size
@@ -497,8 +501,10 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
 
     fwd_ms_per_step = fwd_total_ms / args.steps
     traffic, step_traffic, traffic_src = (None, None, None)
-    if B == 32 and S == 1024 and mb == 32:
+    if B == 32 and S == 1024 and mb == 32 and args.precision == 'fp16':
         traffic, step_traffic, traffic_src = traffic_from_profiles()
+    elif args.precision == 'fp16x3':
+        traffic, traffic_src = x3p_traffic_from_profiles(), 'profiles/r06_x3p_traffic.json'
     fwd_tflops = flops_fwd / (fwd_ms_per_step * 1e-3) / 1e12
     # dominant kernel: the 256x256 tile (conv_igemm256w_kernel since round 5), every launch of the timed region bracketed by HIP events on its stream
     achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
@@ -513,7 +519,7 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
                                f"the explicit throughput opt-in: BASELINE's metric is quoted in fp16); the product's default "
                                f"precision 'fp16x3' -- the one within 1e-3 (max norm) of the reference's fp32 forward -- is timed on "
                                f"the same tiles under `fp16x3_mode`",
-                   'precision': 'fp16', 'default_precision_of_the_product': 'fp16x3',
+                   'precision': args.precision, 'default_precision_of_the_product': 'fp16x3',
                    'tile': S, 'batch_per_gpu': B, 'micro_batch': mb, 'weights': 'seeded random init (seed 0)',
                    'parallelism': f'tile-sharded x{world}, no data-path collective; RCCL ranks: '
                                   f'{world if dist_on and dist.get_backend() == "nccl" else 0}',
@@ -523,7 +529,9 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
                      'traffic_note': 'average HBM bytes per launch of this kernel (2*FETCH_SIZE + WRITE_SIZE, separate '
                                      'rocprofv3 PMC passes); NOT measured in this run: ' + str(traffic_src),
                      'step_traffic_all_kernels': step_traffic,
-                     'kernel': 'conv_igemm256w_kernel (256x256 implicit-GEMM tile, whole-line LDS-DMA: ASPP 3x3, layer3/4 convs, projection shortcuts; conv_igemm256_kernel<0, true> with the fused next conv is not counted)',
+                     'kernel': ('conv_igemm256w_kernel (256x256 implicit-GEMM tile, whole-line LDS-DMA: ASPP 3x3, layer3/4 convs, projection shortcuts; conv_igemm256_kernel<0, true> with the fused next conv is not counted)'
+                                if args.precision == 'fp16' else
+                                'conv16x3p_kernel (256x256 tile over hl32 planes, both operands by LDS-DMA, 3 fp16 MFMAs per product: ResNet layer3 / layer4, ASPP; flops = fp16 MFMA flops)'),
                      'launches_per_step': dom_launches / max(args.steps, 1),
                      'kernel_ms_per_step': round(dom_ms / max(args.steps, 1), 3),
                      'kernel_share_of_step': round(dom_ms / max(args.steps, 1) / ms_per_step, 3),
@@ -589,7 +597,7 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
             res['vs_cpu_baseline'] = None
     else:
         res['cpu_baseline'] = None
-    if world == 1 and args.fp32_mode > 0 and S <= 1024:
+    if world == 1 and args.fp32_mode > 0 and S <= 1024 and args.precision == 'fp16':
         ref_heads = ref0 if (not args.no_cpu_baseline and 'ctr_hmp' in ref0) else None
         for key, prec, mult in (('fp32_mode', 'fp32', 1), ('fp16x3_mode', 'fp16x3', 4)):      # (16 tiles: a launch of the 256-cout layers fills the chip)
             try:

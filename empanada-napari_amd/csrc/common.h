@@ -202,6 +202,7 @@ struct Conv32 {
   // hi = fp16(x), lo = fp16(x - hi): the operand split done once by the producer) -- the plane region's format (conv16x3p.hip)
   int in_fmt, out_fmt, res_fmt;      // 0: fp32 rows, 1: hl32 rows (in / out / res then point at halfs; ld stays the channel count)
   const half_t* wimgp;               // the weights as conv16x3p_kernel's packed image (launch_x3p_pack); needs in_fmt == 1
+  float* out2; int out2_ld, split2;  // conv16x3p only, optional: couts [split2, Cout) go to out2 (format out_fmt), split2 % 256 == 0
 };
 int launch_conv32(const Conv32& p, hipStream_t s);
 int launch_conv16x3(const Conv32& p, hipStream_t s);      // called by launch_conv32 when p.x3 (its checks have run)

@@ -46,6 +46,8 @@ struct X3P {
   const float* bias; const float* bias_n;
   const void* res; int res_ld, res_fmt; // residual: fp32 rows (0) or hl32 rows (1)
   void* out; int out_ld;                // fp32 rows of out_ld floats or hl32 rows of 2 * out_ld halfs (template)
+  void* out2; int out2_ld, split;       // optional: couts [split, Cout) go to out2 (its channel 0 = cout `split`), split % 256 == 0 --
+                                        // two convolutions of one map (the two decoders' ASPP branches) as one launch
   const half_t* zero;
   int N, H, W, Cin, Cout, KH, KW, stride, pad, dil, Ho, Wo;
   int M, mt, nt, mt_per_xcd;
@@ -116,8 +118,12 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& p, f32x4 (&acc)[4][8], i
       }
 #pragma unroll
       for (int r = 0; r < 8; ++r) v[r] = act_p<ACT>(v[r]);
+      const bool second = p.out2 && co0 >= p.split;      // (whole 256-cout tiles: wave-uniform)
+      const int oc = second ? co - p.split : co;
+      const int old_ = second ? p.out2_ld : p.out_ld;
+      void* const obase = second ? p.out2 : p.out;
       if (OUTF) {
-        half_t* op = reinterpret_cast<half_t*>(p.out) + (size_t)m * (2 * p.out_ld) + (co >> 5) * 64 + (co & 31);
+        half_t* op = reinterpret_cast<half_t*>(obase) + (size_t)m * (2 * old_) + (oc >> 5) * 64 + (oc & 31);
         f16x8 h, lo;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -127,7 +133,7 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& p, f32x4 (&acc)[4][8], i
         *reinterpret_cast<f16x8*>(op) = h;
         *reinterpret_cast<f16x8*>(op + 32) = lo;
       } else {
-        float* op = reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + co;
+        float* op = reinterpret_cast<float*>(obase) + (size_t)m * old_ + oc;
         *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
@@ -523,6 +529,12 @@ int launch_conv16x3p(const Conv32& c, hipStream_t s) {
   p.bias = c.bias; p.bias_n = c.bias_n;
   p.res = c.res; p.res_ld = c.res_ld; p.res_fmt = c.res_fmt;
   p.out = c.out; p.out_ld = c.out_ld;
+  if (c.out2) {
+    EMP_REQUIRE(c.split2 > 0 && c.split2 % 256 == 0 && c.split2 < c.Cout && !c.bias_n && !c.res &&
+                    (c.out_fmt ? (c.out2_ld % 32 == 0 && ((uintptr_t)c.out2 % 128) == 0) : (c.out2_ld % 4 == 0 && ((uintptr_t)c.out2 % 16) == 0)),
+                "conv16x3p: a second destination takes whole 256-cout tiles (split=%d)", c.split2);
+    p.out2 = c.out2; p.out2_ld = c.out2_ld; p.split = c.split2;
+  }
   p.zero = reinterpret_cast<const half_t*>(zero_page());
   EMP_REQUIRE(p.zero != nullptr, "conv16x3p: no zero page");
   p.N = c.N; p.H = c.H; p.W = c.W; p.Cin = c.Cin; p.Cout = c.Cout; p.KH = c.KH; p.KW = c.KW; p.stride = c.stride; p.pad = c.pad; p.dil = c.dil;

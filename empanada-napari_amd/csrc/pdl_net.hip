@@ -118,12 +118,14 @@ struct emp_pdl {
   bool x3_fuse_head = [] { const char* e = getenv("EMP_X3_FUSE_HEAD"); return !(e && e[0] == '0'); }();
   // fp16x3 mode, round 6: the stride-16 region of a ResNet50 network (layer3, layer4, ASPP) as hl32 maps on conv16x3p_kernel's
   // 256 x 256 tile once a layer3 map has this many pixel tiles (one tile of 256 couts per pixel tile is a whole launch of the
-  // 256-channel layers: at 128 of them -- 8 tiles of 1024^2 -- half the chip idles in those launches and round 5's 128 x 128
-  // kernels are as fast: whole step 411.6 vs 423.4 tiles/s at batch 8, 469.0 vs 426.8 at batch 16; profiles/r06_x3p.txt).
+  // 256-channel layers of layer3; the ASPP branches of the two decoders run merged, 512 couts per launch.  Whole step, planes vs
+  // round 5's kernels: batch 4 (64 tiles) 413.8 vs 439.2 tiles/s, batch 8 (128) 520.1 vs 469.7, batch 16 545.3 vs 472.0;
+  // profiles/r06_x3p.txt).
   // EMP_X3_PLANES=0: never (A/B); EMP_X3_PLANES_MIN_TILES=n
   bool x3_planes = [] { const char* e = getenv("EMP_X3_PLANES"); return !(e && e[0] == '0'); }();
-  int x3_planes_min_tiles = [] { const char* e = getenv("EMP_X3_PLANES_MIN_TILES"); return e ? atoi(e) : 192; }();
+  int x3_planes_min_tiles = [] { const char* e = getenv("EMP_X3_PLANES_MIN_TILES"); return e ? atoi(e) : 128; }();
   bool x3_planes_ready = false;      // set by finalize32: every layer of the region has its packed image
+  bool x3_merge_aspp = [] { const char* e = getenv("EMP_X3_MERGE_ASPP"); return !(e && e[0] == '0'); }();      // both decoders' ASPP branches as one launch (A/B)
   // fp16x3 mode, round 6: a separable block (depthwise KxK -> pointwise -> act [-> head 1x1]) as ONE launch (sepconv_x3.hip) once
   // the map has this many 8 x 16 tiles (a persistent workgroup per CU); EMP_X3_FUSE_SEP=0: the depthwise launch + conv16x3 (A/B)
   bool x3_fuse_sep = [] { const char* e = getenv("EMP_X3_FUSE_SEP"); return !(e && e[0] == '0'); }();
@@ -1611,6 +1613,38 @@ int finalize32(emp_pdl* n) {
         RC32(launch_x3p_pack(w.w, w.wimgp, w.cout, K, nullptr));
       }
     }
+    if (n->x3_planes && c.encoder == 0 && c.arch == 0 && c.ins_decoder && n->x3_merge_aspp) {
+      // the two decoders' ASPP branch i reads the same p5: [semantic ; instance] weights stacked along Cout, ONE launch with two
+      // destinations (twice the workgroups per launch: a batch of 8 tiles of 1024^2 fills the chip with the 256-channel branches)
+      for (int i = 0; i <= 3; ++i) {
+        const std::string a = "semantic_decoder.aspp.convs." + std::to_string(i) + ".0", b = "instance_decoder.aspp.convs." + std::to_string(i) + ".0";
+        auto ia = n->w32.find(a), ib = n->w32.find(b);
+        if (ia == n->w32.end() || ib == n->w32.end()) continue;
+        const emp_pdl::W32 &wa = ia->second, &wb = ib->second;
+        if (!wa.wimgp || !wb.wimgp || wa.cout != wb.cout || wa.cin16 != wb.cin16 || wa.kh != wb.kh || wa.kw != wb.kw) continue;
+        emp_pdl::W32 m = wa;
+        m.cout = wa.cout + wb.cout; m.wp = nullptr; m.wimg = nullptr; m.wimgp = nullptr;
+        const size_t K = (size_t)wa.kh * wa.kw * wa.cin16, na = (size_t)wa.cout * K, nb = (size_t)wb.cout * K;
+        void* d = nullptr;
+        EMP_CHECK_HIP(hipMalloc(&d, (na + nb) * sizeof(float)));
+        n->owned.push_back(d);
+        m.w = (float*)d;
+        EMP_CHECK_HIP(hipMemcpy(m.w, wa.w, na * sizeof(float), hipMemcpyDeviceToDevice));
+        EMP_CHECK_HIP(hipMemcpy(m.w + na, wb.w, nb * sizeof(float), hipMemcpyDeviceToDevice));
+        EMP_CHECK_HIP(hipMalloc(&d, (size_t)m.cout * sizeof(float)));
+        n->owned.push_back(d);
+        m.b = (float*)d;
+        EMP_CHECK_HIP(hipMemcpy(m.b, wa.b, (size_t)wa.cout * sizeof(float), hipMemcpyDeviceToDevice));
+        EMP_CHECK_HIP(hipMemcpy(m.b + wa.cout, wb.b, (size_t)wb.cout * sizeof(float), hipMemcpyDeviceToDevice));
+        const int64_t ip = x3p_image_halfs(m.cout, (int)K);
+        if (ip <= 0) continue;
+        EMP_CHECK_HIP(hipMalloc(&d, (size_t)ip * sizeof(half_t)));
+        n->owned.push_back(d);
+        m.wimgp = (half_t*)d;
+        RC32(launch_x3p_pack(m.w, m.wimgp, m.cout, (int)K, nullptr));
+        n->w32["decoders.aspp.convs." + std::to_string(i) + ".0"] = m;
+      }
+    }
     EMP_CHECK_HIP(hipStreamSynchronize(nullptr));
     if (n->x3_planes && c.encoder == 0) {
       bool ok = true;
@@ -1629,9 +1663,14 @@ int finalize32(emp_pdl* n) {
 // out[:, :, :, out_coff : out_coff + Cout) = act(conv(in[:, :, :, in_coff : in_coff + Cin16)) + bias (+ bias_n) (+ res))
 int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const T32& out, int out_coff, int stride, int pad,
         int dil, int act, const T32* res, const float* bias_n, hipStream_t s, int ps_cout = 0, int groups = 1,
-        const float* head_w = nullptr, float* head_part = nullptr, int head_c = 0, const T32* in2 = nullptr, int stride2 = 1) {
+        const float* head_w = nullptr, float* head_part = nullptr, int head_c = 0, const T32* in2 = nullptr, int stride2 = 1,
+        const T32* out2 = nullptr, int out2_coff = 0, int split2 = 0) {
   const emp_pdl::W32& w = n->w32.at(wname);
   Conv32 p{};
+  if (out2) {      // couts [split2, Cout) -> out2 (conv16x3p only: the merged ASPP branches)
+    EMP_REQUIRE(in.fmt && out2->fmt == out.fmt && (!out2->fmt || out2_coff % 32 == 0), "%s: a second destination exists on the plane path only", wname.c_str());
+    p.out2 = out2->p + out2_coff; p.out2_ld = out2->ld; p.split2 = split2;
+  }
   if (groups > 1) {      // grouped 3x3 of a RegNet block: w.cin is the group width, w.cout all output channels
     EMP_REQUIRE(w.cout % groups == 0 && in_coff == 0 && out_coff == 0 && !res && !bias_n && !ps_cout, "%s (fp32): bad grouped call",
                 wname.c_str());
@@ -1666,7 +1705,7 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
   EMP_REQUIRE(!head_w || p.x3, "%s: the fused head exists in the fp16x3 mode only", wname.c_str());
   const int up = ps_cout ? 2 : 1;
   EMP_REQUIRE(p.Ho * up == out.H && p.Wo * up == out.W && in.N == out.N, "%s (fp32): output shape mismatch", wname.c_str());
-  EMP_REQUIRE(in_coff + (groups - 1) * w.cin + w.cin16 <= in.ld && out_coff + (ps_cout ? ps_cout : w.cout) <= out.ld,
+  EMP_REQUIRE(in_coff + (groups - 1) * w.cin + w.cin16 <= in.ld && out_coff + (ps_cout ? ps_cout : (out2 ? split2 : w.cout)) <= out.ld,
               "%s (fp32): channel slice out of range (needs %d of a row of %d)", wname.c_str(), in_coff + (groups - 1) * w.cin + w.cin16, in.ld);
   n->flops += 2.0 * (double)p.N * p.Ho * p.Wo * w.cout * (double)(w.cin * w.kh * w.kw);
   if (n->profile && p.x3 && p.in_fmt) {     // emp_pdl_profile: HIP events around the plane region's launches (the fp16x3 mode's dominant kernel)
@@ -1945,6 +1984,17 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
     if (p5.fmt) RC32(launch_avgpool_hl32(reinterpret_cast<const half_t*>(p5.p), N, p5.H * p5.W, p5.C, p5.ld, pooled, s));
     else RC32(launch_avgpool_f32(p5.p, N, p5.H * p5.W, p5.C, p5.ld, pooled, s));
     const char* decs[2] = {"semantic_decoder", "instance_decoder"};
+    // plane region: branch i of BOTH decoders as one launch (weights stacked along Cout at finalize, two destinations)
+    const bool merged_aspp = p5.fmt && c.ins_decoder && n->w32.count("decoders.aspp.convs.0.0") && n->w32.count("decoders.aspp.convs.3.0");
+    if (merged_aspp) {
+      for (int d = 0; d < 2; ++d) RC32(mk(std::string(decs[d]) + ".aspp.cat", p5.H, p5.W, 4 * n->aspp_ch, 1));
+      const T32 &c0 = A("semantic_decoder.aspp.cat"), &c1 = A("instance_decoder.aspp.cat");
+      for (int i = 0; i <= 3; ++i) {
+        const int r = i ? c.atrous_rates[i - 1] : 1;
+        RC32(c32(n, "decoders.aspp.convs." + std::to_string(i) + ".0", p5, 0, c0, i * n->aspp_ch, 1, i ? r : 0, r, 1, nullptr, nullptr, s, 0, 1,
+                 nullptr, nullptr, 0, nullptr, 1, &c1, i * n->aspp_ch, n->aspp_ch));
+      }
+    }
     for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
       const std::string p = decs[d];
       float *poolfeat, *bias_n;
@@ -1952,11 +2002,13 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
       RC32(buf32(n, p + ".bias_n", (size_t)N * n->aspp_ch, &bias_n));
       RC32(launch_gemv(pooled, N, p5.C, n->f32w.at(p + ".pool.w"), nullptr, n->aspp_ch, 1, poolfeat, s));
       RC32(launch_gemv(poolfeat, N, n->aspp_ch, n->f32w.at(p + ".projpool.w"), nullptr, n->aspp_ch, 0, bias_n, s));
-      RC32(mk(p + ".aspp.cat", p5.H, p5.W, 4 * n->aspp_ch, p5.fmt));      // (the projection reads it as it was written; its output is fp32: the up-sampler's input)
-      RC32(c32(n, p + ".aspp.convs.0.0", p5, 0, A(p + ".aspp.cat"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
-      for (int i = 1; i <= 3; ++i) {
-        const int r = c.atrous_rates[i - 1];
-        RC32(c32(n, p + ".aspp.convs." + std::to_string(i) + ".0", p5, 0, A(p + ".aspp.cat"), i * n->aspp_ch, 1, r, r, 1, nullptr, nullptr, s));
+      if (!merged_aspp) {
+        RC32(mk(p + ".aspp.cat", p5.H, p5.W, 4 * n->aspp_ch, p5.fmt));      // (the projection reads it as it was written; its output is fp32: the up-sampler's input)
+        RC32(c32(n, p + ".aspp.convs.0.0", p5, 0, A(p + ".aspp.cat"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
+        for (int i = 1; i <= 3; ++i) {
+          const int r = c.atrous_rates[i - 1];
+          RC32(c32(n, p + ".aspp.convs." + std::to_string(i) + ".0", p5, 0, A(p + ".aspp.cat"), i * n->aspp_ch, 1, r, r, 1, nullptr, nullptr, s));
+        }
       }
       RC32(mk(p + ".aspp", p5.H, p5.W, n->aspp_ch));
       RC32(c32(n, p + ".aspp.project.0", A(p + ".aspp.cat"), 0, A(p + ".aspp"), 0, 1, 0, 1, 1, nullptr, bias_n, s));

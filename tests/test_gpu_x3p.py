@@ -317,3 +317,24 @@ def test_plane_region_forward_vs_oracle_and_vs_round5_path(arch, ncls, size, mon
     scale = float(raw_off.abs().max())
     assert float((as_f32 - raw_off).abs().max()) < 1e-4 * scale
     assert float((raw_on - raw_off).abs().max()) > 1e-2 * scale          # ... and NOT an fp32 map
+
+
+def test_merged_aspp_equals_the_two_launches(monkeypatch):
+    """both decoders' ASPP branch i as ONE conv16x3p launch with two destinations (weights stacked along Cout at finalize):
+    the same K order per cout tile -> the heads are bit-identical to the per-decoder launches (EMP_X3_MERGE_ASPP=0)"""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    x = torch.from_numpy(normalize(synth.em_tiles(2, 256, seed=4), 0.57571, 0.12765))[:, None].cuda()
+    monkeypatch.setenv('EMP_X3_PLANES_MIN_TILES', '1')
+    a = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16x3')
+    monkeypatch.setenv('EMP_X3_MERGE_ASPP', '0')
+    b = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16x3')
+    oa, ob = a(x, 2, False), b(x, 2, False)
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
+    ca = a.tap_raw('instance_decoder.aspp.cat', (2 * 16 * 16, 1024))
+    cb = b.tap_raw('instance_decoder.aspp.cat', (2 * 16 * 16, 1024))
+    assert torch.equal(ca, cb) and float(ca.abs().max()) > 0
