@@ -27,7 +27,7 @@ else:
     for name, cfg0 in (('pdl', weights.MITONET_PDL_CFG), ('bifpn', weights.MITONET_MINI_CFG)):
         cfg = dict(cfg0)
         P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=3), cfg)
-        model = HipPanopticDeepLab(P, cfg, folded=True)
+        model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
         for B, S in ((4, 1024), (1, 1024), (2, 512)):
             x = torch.from_numpy(normalize(synth.em_tiles(B, S, seed=5), 0.57571, 0.12765))[:, None].cuda()
             out = model(x, 2, False)

@@ -13,7 +13,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 cfg = dict(weights.MITONET_MINI_CFG)
 P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-model = HipPanopticDeepLab(P, cfg, folded=True)
+model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
 base = synth.em_tiles(4, S, seed=1)
 x = torch.from_numpy(np.concatenate([base] * (B // 4))[:B])[:, None].cuda()
 sub, mul = normalize_params(0.57571, 0.12765, 255)

@@ -57,7 +57,7 @@ def main():
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 0          # 0: the engine picks (about 16 Mpixel per batch)
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
     mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
           'norms': {'mean': 0.57571, 'std': 0.12765}}
     vol = synth.blob_volume(size, size, size, seed=0, n_blobs=max(8, (size // 32) ** 2), fast=True)

@@ -52,7 +52,7 @@ def main():
         row = {}
         for ncls in (1, 4):
             cfg, P, x, ref = refs[ncls]
-            model = HipPanopticDeepLab(P, cfg, folded=True)
+            model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
             out = {k: v.cpu() for k, v in model(x.cuda(), 2, False).items()}
             for k in ('ctr_hmp', 'offsets'):
                 row[f'512_ncls{ncls}_{k}_rms_rel'], row[f'512_ncls{ncls}_{k}_max_rel'] = rel(out[k], ref[k])

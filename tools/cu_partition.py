@@ -233,7 +233,7 @@ def whole_forward(a, dev, full, s1, s2, sa, sb):
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
     sub, mul = normalize_params(0.57571, 0.12765, 255)
     tiles = torch.from_numpy(synth.em_tiles(32, 1024, seed=1234))[:, None].to(dev)
-    m32 = HipPanopticDeepLab(P, cfg, device=dev, folded=True)
+    m32 = HipPanopticDeepLab(P, cfg, device=dev, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
     m32.reserve(32, 1024, 1024)
 
     def run(pairs, steps):
@@ -259,8 +259,8 @@ def whole_forward(a, dev, full, s1, s2, sa, sb):
     ref = [t.clone() for t in o32[0]]
     del m32, o32
     torch.cuda.empty_cache()
-    ma = HipPanopticDeepLab(P, cfg, device=dev, folded=True)
-    mb = HipPanopticDeepLab(P, cfg, device=dev, folded=True)
+    ma = HipPanopticDeepLab(P, cfg, device=dev, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
+    mb = HipPanopticDeepLab(P, cfg, device=dev, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
     ma.reserve(16, 1024, 1024)
     mb.reserve(16, 1024, 1024)
     ta_, tb_ = tiles[:16], tiles[16:]
@@ -308,7 +308,7 @@ def whole_forward(a, dev, full, s1, s2, sa, sb):
     # (f) four engines of 8 tiles on four unmasked streams: more launches in flight, smaller tails
     del ma, mb
     torch.cuda.empty_cache()
-    ms4 = [HipPanopticDeepLab(P, cfg, device=dev, folded=True) for _ in range(4)]
+    ms4 = [HipPanopticDeepLab(P, cfg, device=dev, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16')) for _ in range(4)]
     for m in ms4:
         m.reserve(8, 1024, 1024)
     st4 = [torch.cuda.Stream(dev) for _ in range(4)]

@@ -9,7 +9,7 @@ from empanada_napari_amd.engines import HipPanopticDeepLab, factor_pad, logits_t
 from empanada_napari_amd.inference import Engine3d, take
 cfg = dict(weights.MITONET_PDL_CFG)
 P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-model = HipPanopticDeepLab(P, cfg, folded=True)
+model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
 mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16, 'norms': {'mean': 0.57571, 'std': 0.12765}}
 S, B = 512, int(sys.argv[1]) if len(sys.argv) > 1 else 16
 vol = synth.blob_volume(64, S, S, seed=0)

@@ -19,7 +19,7 @@ from empanada_napari_amd.inference import Engine2d  # noqa: E402
 chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 cfg = dict(weights.MITONET_PDL_CFG)
 P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-model = HipPanopticDeepLab(P, cfg, folded=True)
+model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
 mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
       'norms': {'mean': 0.57571, 'std': 0.12765}}
 e2 = Engine2d(mc, label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5)

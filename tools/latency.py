@@ -16,7 +16,7 @@ from empanada_napari_amd.preprocess import normalize_params  # noqa: E402
 
 cfg = dict(weights.MITONET_PDL_CFG)
 P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-model = HipPanopticDeepLab(P, cfg, folded=True)
+model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
 eng = PanopticDeepLabRenderEngine(model, [1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
                                   padding_factor=16, coarse_boundaries=True)
 sub, mul = normalize_params(0.57571, 0.12765, 255)

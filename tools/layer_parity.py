@@ -25,7 +25,7 @@ def main():
     torch.set_num_threads(min(os.cpu_count() or 1, 32))      # oneDNN convs stop scaling (and oversubscribe) beyond ~32 threads
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-    model = HipPanopticDeepLab(P, cfg, folded=True)
+    model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
     img = synth.em_tiles(1, size, seed=2024)
     x = torch.from_numpy(normalize(img, 0.57571, 0.12765))[:, None]
     out = model(x.cuda(), 2, False)

@@ -24,7 +24,7 @@ def run(B, S):
     dev = torch.device('cuda:0')
     cfg = dict(weights.MITONET_MINI_CFG if os.environ.get('EMP_MODEL') == 'bifpn' else weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-    model = HipPanopticDeepLab(P, cfg, device=dev, folded=True)
+    model = HipPanopticDeepLab(P, cfg, device=dev, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
     base = synth.em_tiles(min(B, 4), S, seed=1234)
     tiles = torch.from_numpy(np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B])[:, None].to(dev)
     sub, mul = normalize_params(0.57571, 0.12765, 255)

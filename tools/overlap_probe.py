@@ -26,7 +26,7 @@ def main():
     dev = torch.device('cuda', 0)
     cfg = dict(weights.MITONET_PDL_CFG)
     P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-    model = HipPanopticDeepLab(P, cfg, device=dev, folded=True)
+    model = HipPanopticDeepLab(P, cfg, device=dev, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
     eng = PanopticDeepLabRenderEngine(model, thing_list=[1], label_divisor=10000, nms_threshold=0.1, nms_kernel=3,
                                       confidence_thr=0.5, padding_factor=16, coarse_boundaries=True)
     B = a.batch

@@ -21,7 +21,7 @@ from empanada_napari_amd.inference import Engine3d, tracker_consensus  # noqa: E
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 cfg = dict(weights.MITONET_PDL_CFG)
 P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-model = HipPanopticDeepLab(P, cfg, folded=True)
+model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
 mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
       'norms': {'mean': 0.57571, 'std': 0.12765}}
 vol = synth.blob_volume(size, size, size, seed=0, n_blobs=max(8, (size // 32) ** 2), fast=True)

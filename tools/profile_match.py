@@ -19,7 +19,7 @@ D = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 cfg = dict(weights.MITONET_PDL_CFG)
 P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-model = HipPanopticDeepLab(P, cfg, folded=True)
+model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
 mc = {'model': model, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
       'norms': {'mean': 0.57571, 'std': 0.12765}}
 vol = synth.ProceduralVolume((D, S, S), seed=7, cell=48).block(0, 0, D, 'cuda').cpu().numpy()

@@ -10,7 +10,7 @@ from empanada_napari_amd.engines import HipPanopticDeepLab
 from empanada_napari_amd.preprocess import normalize_params
 cfg = dict(weights.MITONET_PDL_CFG)
 P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
-model = HipPanopticDeepLab(P, cfg, folded=True)
+model = HipPanopticDeepLab(P, cfg, folded=True, precision=os.environ.get('EMP_TOOL_PRECISION', 'fp16'))
 sub, mul = normalize_params(0.57571, 0.12765, 255)
 for B, S in ((1, 1024), (2, 1024), (4, 1024), (8, 1024), (16, 1024), (32, 1024), (16, 512), (64, 512)):
     x = torch.from_numpy(synth.em_tiles(B, S, seed=1))[:, None].cuda()
