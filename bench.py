@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument('--stack3d', type=int, default=512, help='tiles workload: side of the 3-D cube of the second metric (0 = skip)')
     ap.add_argument('--engine2d', type=int, default=1, help='tiles workload: also measure the Engine2d-level rate (0 = skip)')
     ap.add_argument('--latency', type=int, default=1, help='tiles workload: also measure the batch-1 latency (0 = skip)')
+    ap.add_argument('--fine-boundaries', type=int, default=1, help='tiles workload: also time the fine-boundary post-processing '
+                                                                   '(coarse_boundaries=False) on 4 of the tiles (0 = skip)')
     ap.add_argument('--fp32-mode', type=int, default=4, help="tiles workload: batch of the fp32 reference mode's rate (precision='fp32'; 0 = skip); "
                     "the fp16x3 mode is measured at twice this batch")
     ap.add_argument('--depth', type=int, default=128, help='stack3d workload: slices per GPU')
@@ -605,7 +607,7 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
                                            ref=ref_heads)
             except Exception as e:      # noqa: BLE001 -- the headline line must not depend on the extra measurement
                 res[key] = {'error': f'{type(e).__name__}: {e}'}
-    if world == 1 and args.latency:
+    if world == 1 and args.fine_boundaries:
         try:
             res['fine_boundaries'] = fine_boundaries_block(model, tiles, sub, mul, batch=min(4, B))
             res['fine_boundaries_ms_per_tile'] = res['fine_boundaries']['ms_per_tile']

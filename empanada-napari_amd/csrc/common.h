@@ -203,6 +203,7 @@ struct Conv32 {
   int in_fmt, out_fmt, res_fmt;      // 0: fp32 rows, 1: hl32 rows (in / out / res then point at halfs; ld stays the channel count)
   const half_t* wimgp;               // the weights as conv16x3p_kernel's packed image (launch_x3p_pack); needs in_fmt == 1
   float* out2; int out2_ld, split2;  // conv16x3p only, optional: couts [split2, Cout) go to out2 (format out_fmt), split2 % 256 == 0
+  int x3p_kg;                        // conv16x3p only: the K-walk group wimgp was packed along (0: tap-major)
 };
 int launch_conv32(const Conv32& p, hipStream_t s);
 int launch_conv16x3(const Conv32& p, hipStream_t s);      // called by launch_conv32 when p.x3 (its checks have run)
@@ -213,7 +214,8 @@ int launch_x3_weight_image(const float* w, half_t* out, int Cout, int K, hipStre
 bool conv16x3p_supported(const Conv32& p);                    // shape only (Cout % 256, Cin % 32, >= 4 K steps, plain convolution)
 int launch_conv16x3p(const Conv32& p, hipStream_t s);
 int64_t x3p_image_halfs(int Cout, int K);                     // 2 * Cout * K, or 0 where the kernel cannot take the shape
-int launch_x3p_pack(const float* w, half_t* out, int Cout, int K, hipStream_t s);
+int x3p_kgroup(int KT, int Cin);                              // the K-walk group the network packs and launches a layer with
+int launch_x3p_pack(const float* w, half_t* out, int Cout, int K, hipStream_t s, int KT = 0, int Cin = 0, int kg = 0);      // KT == 0: linear (tap-major)
 int launch_hl32_from_f32(const float* in, half_t* out, int64_t rows, int C, int in_ld, int out_ld, hipStream_t s);
 int launch_hl32_to_f32(const half_t* in, float* out, int64_t rows, int C, int in_ld, int out_ld, hipStream_t s);
 int launch_avgpool_hl32(const half_t* in, int N, int HW, int C, int in_ld, float* out, hipStream_t s);

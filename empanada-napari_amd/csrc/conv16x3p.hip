@@ -27,8 +27,9 @@
 //     odd slot 2t + 1 : Wh(t + 1), then X(t + 2)        (read last in slot 2t)
 // Before the barrier that closes ANY slot a wave waits for all but its 6 youngest DMA operations -- one constant counted
 // vmcnt(6): Wl(t + 1) has landed a full slot before it is read (slot 2t + 2), Wh(t + 1) likewise (2t + 3), X(t + 2) two slots
-// (2t + 4).  Same K order (tap-major, channels ascending in steps of 32) and the same three products in the same order as
-// conv16x3.hip's kernels: bit-identical accumulators given the same operands (tests/test_gpu_x3p.py).
+// (2t + 4).  With the tap-major K walk (the C ABI's emp_conv2d_hl32_f16x3; X3P::kg = Cin / 32) the K order and the three products per
+// step are conv16x3.hip's: bit-identical accumulators given the same operands (tests/test_gpu_x3p.py).  The network walks K in
+// groups of 128 channels (x3p_kgroup below): another summation order of the same terms.
 #include "common.h"
 
 namespace emp {
@@ -51,6 +52,7 @@ struct X3P {
   const half_t* zero;
   int N, H, W, Cin, Cout, KH, KW, stride, pad, dil, Ho, Wo;
   int M, mt, nt, mt_per_xcd;
+  int kg;      // K steps (32 channels) per K-walk group and tap: the walk is [group of kg * 32 channels][tap][step]; kg == Cin / 32: tap-major
 };
 
 __device__ __forceinline__ int perm32b(int x) {
@@ -200,21 +202,26 @@ __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
       }
     }
   }
-  int x_ky = 0, x_kx = 0, x_cb = 0, x_slot = 0;
+  int x_ky = 0, x_kx = 0, x_cb = 0, x_grp = 0, x_slot = 0;
+  const int KG = p.kg;
   auto x_prep = [&]() {      // address work of the next K step's pixel pieces (in a LOAD phase, out of the MFMAs' way)
     if (x_cb == 0 && !pointwise) {
       const int dy = x_ky * p.dil, dx = x_kx * p.dil;
+      const int c0 = x_grp * KG * (2 * KS) + pchunk * 8;      // halfs into the hl32 row: the group's first 32-channel block
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
         const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        a_cur[i] = ok ? p.in + ((size_t)(a_pix[i] + iy * p.W + ix) * row_halfs + pchunk * 8) : p.zero;
+        a_cur[i] = ok ? p.in + ((size_t)(a_pix[i] + iy * p.W + ix) * row_halfs + c0) : p.zero;
         a_inc[i] = ok ? 2 * KS : 0;
       }
     }
-    if (++x_cb == CB) {
+    if (++x_cb == KG) {
       x_cb = 0;
-      if (++x_kx == p.KW) { x_kx = 0; ++x_ky; }
+      if (++x_kx == p.KW) {
+        x_kx = 0;
+        if (++x_ky == p.KH) { x_ky = 0; ++x_grp; }
+      }
     }
   };
   auto dma_x = [&](int i) {
@@ -391,7 +398,8 @@ __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
 // [cout tile of 256][K step][part: 0 = lo, 1 = hi][piece of 16 rows][lane][8 halfs]: the bytes lane l of the wave that stages piece
 // pc writes to LDS, in LDS order -- conv_igemm256.hip's pack256_kernel with the split applied (rows permuted by perm32b, chunks
 // swizzled).  w: [Cout][K] fp32, K = KH * KW * Cin walked tap-major.
-__global__ void __launch_bounds__(256) x3p_pack_kernel(const float* __restrict__ w, half_t* __restrict__ out, int Cout, int K) {
+__global__ void __launch_bounds__(256) x3p_pack_kernel(const float* __restrict__ w, half_t* __restrict__ out, int Cout, int K, int KT, int Cin,
+                                                       int KG) {
   const int KTOT = K / KS;
   const int64_t total = (int64_t)(Cout / 256) * KTOT * 2 * 16 * 64;      // 16-byte chunks
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -401,7 +409,9 @@ __global__ void __launch_bounds__(256) x3p_pack_kernel(const float* __restrict__
     const int row = pc * 16 + (l >> 2);
     const int co = ntile * 256 + (row & ~31) + perm32b(row & 31);
     const int chunk = (l & 3) ^ ((-(l >> 4)) & 3);
-    const float* src = w + (size_t)co * K + t * KS + chunk * 8;
+    // K step t of the walk [group][tap][step] -> its place in the row (tap-major there): tap * Cin + (g * KG + cb) * 32
+    const int per = KT * KG, g = t / per, idx = t - g * per, tap = idx / KG, cb = idx - tap * KG;
+    const float* src = w + (size_t)co * K + tap * Cin + (g * KG + cb) * KS + chunk * 8;
     f16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -482,10 +492,27 @@ bool conv16x3p_supported(const Conv32& p) {
 
 int64_t x3p_image_halfs(int Cout, int K) { return (Cout % 256 == 0 && K % KS == 0) ? (int64_t)2 * Cout * K : 0; }
 
-int launch_x3p_pack(const float* w, half_t* out, int Cout, int K, hipStream_t s) {
+// the K-walk group (K steps of 32 channels per tap) of a layer in the network: groups of 128 channels -- the nine taps of a 3x3
+// re-read a group's slice of the map (1/16 of layer4's p5) while it is still in L2 / the Infinity Cache instead of coming back to the
+// whole 537 MB map nine times.  Whole fp16x3 step at batch 16, same box: tap-major 554 | 256-channel groups 552 | 128 563-566 |
+// 64 564-566 | 32 560 tiles/s.  EMP_X3P_KGROUP=n (A/B; n >= Cin / 32: tap-major)
+int x3p_kgroup(int KT, int Cin) {
+  const int CB = Cin / KS;
+  static const int env_kg = [] { const char* e = getenv("EMP_X3P_KGROUP"); return e ? atoi(e) : 0; }();
+  int kg = env_kg > 0 ? env_kg : 4;
+  if (KT == 1 || kg > CB || CB % kg != 0) kg = CB;
+  return kg;
+}
+
+// KT, Cin: the taps and channels of the main source (K == KT * Cin); kg: the walk group the kernel will be launched with (0: x3p_kgroup)
+int launch_x3p_pack(const float* w, half_t* out, int Cout, int K, hipStream_t s, int KT, int Cin, int kg) {
   EMP_REQUIRE(w && out && Cout > 0 && Cout % 256 == 0 && K > 0 && K % KS == 0, "x3p_pack: Cout %% 256 and K %% 32 must be 0 (got %d, %d)", Cout, K);
+  if (KT <= 0) { KT = 1; Cin = K; }
+  EMP_REQUIRE(KT * Cin == K && Cin % KS == 0, "x3p_pack: K = %d is not %d taps of %d channels", K, KT, Cin);
+  if (kg <= 0) kg = x3p_kgroup(KT, Cin);
+  EMP_REQUIRE((Cin / KS) % kg == 0, "x3p_pack: the walk group must divide the channel blocks");
   const int64_t chunks = (int64_t)Cout * K / 4;
-  hipLaunchKernelGGL(x3p_pack_kernel, dim3((unsigned)std::min<int64_t>((chunks + 255) / 256, 8192)), dim3(256), 0, s, w, out, Cout, K);
+  hipLaunchKernelGGL(x3p_pack_kernel, dim3((unsigned)std::min<int64_t>((chunks + 255) / 256, 8192)), dim3(256), 0, s, w, out, Cout, K, KT, Cin, kg);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }
@@ -545,6 +572,8 @@ int launch_conv16x3p(const Conv32& c, hipStream_t s) {
   p.mt = cdiv(p.M, 256);
   p.nt = c.Cout / 256;
   p.mt_per_xcd = cdiv(p.mt, 8);
+  p.kg = c.x3p_kg > 0 ? c.x3p_kg : c.Cin / KS;      // (the image was packed along this walk)
+  EMP_REQUIRE((c.Cin / KS) % p.kg == 0, "conv16x3p: the walk group must divide the channel blocks");
   const int grid = 8 * p.mt_per_xcd * p.nt;
   const int act = c.act;
   auto go = [&](auto kern) -> int {

@@ -134,7 +134,7 @@ struct emp_pdl {
   std::map<std::string, SepX3> sepx3;      // by the block's name ("... .sepconv" without the .0 / .1)
   bool regnet_grouped = [] { const char* e = getenv("EMP_REGNET_GROUPED"); return !(e && e[0] == '0'); }();
   int64_t regnet_group_tiles = [] { const char* e = getenv("EMP_REGNET_GROUP_TILES"); return e ? atoll(e) : 2048ll; }();
-  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; int cin2 = 0, cin2_16 = 0; half_t* wimg = nullptr; half_t* wimgp = nullptr; };
+  struct W32 { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, cin16 = 0, kh = 1, kw = 1; uint32_t* wp = nullptr; int cin2 = 0, cin2_16 = 0; half_t* wimg = nullptr; half_t* wimgp = nullptr; int x3p_kg = 0; };
   std::map<std::string, W32> w32;
   std::map<std::string, std::pair<float*, size_t>> pool32;      // name -> (device buffer, floats)
   std::map<std::string, std::array<int, 4>> geom32;             // zero-tailed RegNet maps: the geometry a buffer was last cleared for
@@ -157,6 +157,7 @@ struct emp_pdl {
   double flops = 0.0;
   // live timing of the dominant kernel class (256x256 conv tile): HIP event pairs on the launch stream, summed by
   // emp_pdl_profile_read (bench.py's roofline block)
+  size_t image_bytes = 0;      // packed 256 x 256 weight images made at finalize (fp16 engine)
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
   size_t prof_used = 0;
@@ -807,15 +808,12 @@ int conv(emp_pdl* n, const std::string& wname, const Act& in, int in_coff, const
   if (n->pack256 && !p.next_w && conv_uses_256(p)) {
     // the 256 x 256 tile reads its weights from a packed image (whole 128-byte lines per LDS-DMA instruction): made once,
     // at the first launch of this layer that takes the tile (batch-dependent), on the launch's stream
-    if (!dc.w256) {
-      const size_t halfs = (size_t)dc.cout * (dc.kh * dc.kw * dc.cin_pad + dc.cin2_pad);
-      EMP_CHECK_HIP(hipMalloc((void**)&dc.w256, halfs * sizeof(half_t)));
-      n->owned.push_back(dc.w256);
-      const int prc = conv256_pack_weights(dc.w, dc.w256, dc.cout, dc.kh * dc.kw, dc.cin_pad, dc.cin2_pad, s);
-      if (prc) return prc;
+    // (round 6, ADVICE r05: the images are made by emp_pdl_finalize for every layer whose SHAPE the tile takes -- no allocation,
+    // no device synchronisation and no failure mode inside a forward; a layer without one runs the tile on its plain weights)
+    if (dc.w256) {
+      p.wgt = dc.w256;
+      variant = 1 << 20;
     }
-    p.wgt = dc.w256;
-    variant = 1 << 20;
   }
   if (n->profile && !p.next_w && conv_uses_256(p)) {     // the fused back-to-back launches are another kernel symbol
     if (n->prof_used == n->prof_events.size()) {
@@ -1610,7 +1608,8 @@ int finalize32(emp_pdl* n) {
         EMP_CHECK_HIP(hipMalloc(&d, (size_t)ip * sizeof(half_t)));
         n->owned.push_back(d);
         w.wimgp = (half_t*)d;
-        RC32(launch_x3p_pack(w.w, w.wimgp, w.cout, K, nullptr));
+        w.x3p_kg = x3p_kgroup(w.kh * w.kw, w.cin16);
+        RC32(launch_x3p_pack(w.w, w.wimgp, w.cout, K, nullptr, w.kh * w.kw, w.cin16, w.x3p_kg));
       }
     }
     if (n->x3_planes && c.encoder == 0 && c.arch == 0 && c.ins_decoder && n->x3_merge_aspp) {
@@ -1641,7 +1640,8 @@ int finalize32(emp_pdl* n) {
         EMP_CHECK_HIP(hipMalloc(&d, (size_t)ip * sizeof(half_t)));
         n->owned.push_back(d);
         m.wimgp = (half_t*)d;
-        RC32(launch_x3p_pack(m.w, m.wimgp, m.cout, (int)K, nullptr));
+        m.x3p_kg = x3p_kgroup(m.kh * m.kw, m.cin16);
+        RC32(launch_x3p_pack(m.w, m.wimgp, m.cout, (int)K, nullptr, m.kh * m.kw, m.cin16, m.x3p_kg));
         n->w32["decoders.aspp.convs." + std::to_string(i) + ".0"] = m;
       }
     }
@@ -1683,6 +1683,7 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
   EMP_REQUIRE(!in.fmt || (w.wimgp && groups <= 1 && !in2 && !head_w && !ps_cout), "%s: an hl32 input needs the packed image of a plain convolution", wname.c_str());
   p.in = in.p + in_coff; p.in_ld = in.ld; p.in_fmt = in.fmt;
   p.wimgp = in.fmt ? w.wimgp : nullptr;
+  p.x3p_kg = w.x3p_kg;
   p.w = w.w; p.bias = w.b; p.bias_n = bias_n;
   p.res = res ? res->p : nullptr; p.res_ld = res ? res->ld : 0; p.res_fmt = res ? res->fmt : 0;
   p.out = out.p + out_coff; p.out_ld = out.ld; p.out_fmt = out.fmt;
@@ -2497,6 +2498,24 @@ int emp_pdl_finalize(emp_pdl_t* n) {
     RC(upload_f32(n, "pr.predictor.b", hp.b));
   }
   if (n->fp32_graph()) RC(finalize32(n));      // fp32 reference mode: fp32 copies of every weight
+  if (n->pack256 && !n->fp32_graph()) {
+    // packed weight images of the 256 x 256 tile (whole 128-byte lines per LDS-DMA instruction; conv_igemm256.hip pack256_kernel) for
+    // every layer whose shape the tile takes at SOME batch: Cout % 256 == 0, 64-channel granularity along K, K >= 512 (conv_uses_256's
+    // floor; K >= 128 with a second source).  A second copy of the layer3 / layer4 / ASPP weights (~90 MB; emp_pdl_arena_bytes
+    // counts activations only, as before).
+    for (auto& kv : n->convs) {
+      DevConv& dc = kv.second;
+      const int K = dc.kh * dc.kw * dc.cin_pad + dc.cin2_pad;
+      if (dc.w256 || !dc.w || dc.cout % 256 != 0 || dc.cin_pad % 64 != 0 || dc.cin2_pad % 64 != 0 || K < (dc.cin2_pad ? 128 : 512)) continue;
+      const size_t halfs = (size_t)dc.cout * K;
+      EMP_CHECK_HIP(hipMalloc((void**)&dc.w256, halfs * sizeof(half_t)));
+      n->owned.push_back(dc.w256);
+      n->image_bytes += halfs * sizeof(half_t);
+      const int prc = conv256_pack_weights(dc.w, dc.w256, dc.cout, dc.kh * dc.kw, dc.cin_pad, dc.cin2_pad, nullptr);
+      if (prc) return prc;
+    }
+    EMP_CHECK_HIP(hipStreamSynchronize(nullptr));
+  }
   n->finalized = true;
   return EMP_OK;
 }

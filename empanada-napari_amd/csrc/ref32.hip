@@ -493,7 +493,8 @@ int launch_maxpool3x3s2_f32(const float* in, int N, int H, int W, int C, float* 
 int launch_dwconv_f32(const float* in, int N, int H, int W, int C, int in_ld, const float* w, int K, float* out, int out_ld,
                       hipStream_t s) {
   EMP_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && (K == 3 || K == 5), "dwconv32: bad shape");
-  if (W % 8 == 0) {
+  const char* strip_env = getenv("EMP_DW32_STRIP");      // =0: the one-output-per-thread kernel everywhere (read per call: tests A/B both in one process)
+  if (W % 8 == 0 && !(strip_env && strip_env[0] == '0')) {
     const int64_t strips = (int64_t)N * H * (W / 8) * (C / 4);
     if (K == 5) hipLaunchKernelGGL(dwconv32_strip_kernel<5>, dim3(grid_for(strips)), dim3(256), 0, s, in, N, H, W, C, in_ld, w, out, out_ld, strips);
     else hipLaunchKernelGGL(dwconv32_strip_kernel<3>, dim3(grid_for(strips)), dim3(256), 0, s, in, N, H, W, C, in_ld, w, out, out_ld, strips);

@@ -594,7 +594,7 @@ class Engine3d:
             if on_dev:
                 try:
                     moved = torch.from_numpy(volume).to(eng.model.device)
-                except torch.OutOfMemoryError:
+                except getattr(torch, 'OutOfMemoryError', torch.cuda.OutOfMemoryError):      # (older torch builds have it under torch.cuda only)
                     torch.cuda.empty_cache()
                     on_dev = False
             if not on_dev:

@@ -84,7 +84,7 @@ def test_profile_tools_read_the_step_count_off_the_trace(tmp_path):
     d = str(tmp_path / 'ks')
     r = subprocess.run(['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'ks', '--', sys.executable,
                         os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--stack3d', '0',
-                        '--engine2d', '0', '--latency', '0', '--fp32-mode', '0'],
+                        '--engine2d', '0', '--latency', '0', '--fine-boundaries', '0', '--fp32-mode', '0'],
                        capture_output=True, text=True, env=e, cwd=str(tmp_path), timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])

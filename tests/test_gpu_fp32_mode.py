@@ -170,3 +170,19 @@ def test_fp32_mode_at_baseline_tile_size_and_label_maps():
     print(f'fp32 mode label maps: {n_hip} vs {n_ref} instances, foreground flips {fg:.2e}')
     assert n_ref > 100 and abs(n_hip - n_ref) <= 2
     assert fg < 2e-4          # the fp16 engine: 1.3e-3 of the pixels (tests/test_gpu_parity_fullsize.py)
+
+
+def test_strip_depthwise_kernel_is_the_plain_kernels_fmaf_chain(monkeypatch):
+    """the fp32 mode's depthwise strip kernel (8 outputs per thread, W % 8 == 0) against the one-output kernel it
+    replaced (EMP_DW32_STRIP=0), through the whole fp32-mode forward: the same fmaf chain (ky-major, kx-minor, from 0) -> the same
+    bits in every head on finite inputs (they differ only for -0.0 / inf / NaN taps, which no network produces)"""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.preprocess import normalize
+    cfg, P, model = _models('pdl')
+    x = torch.from_numpy(normalize(synth.em_tiles(2, 256, seed=23), 0.57571, 0.12765))[:, None].cuda()
+    monkeypatch.setenv('EMP_DW32_STRIP', '1')
+    a = {k: v.clone() for k, v in model(x, 2, False).items()}
+    monkeypatch.setenv('EMP_DW32_STRIP', '0')
+    b = model(x, 2, False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
