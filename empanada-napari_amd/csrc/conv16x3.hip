@@ -101,6 +101,10 @@ __device__ __forceinline__ void pair_store4(const float4& r, half_t* hi, half_t*
 template <int ACT>
 __device__ __forceinline__ void store4(const Conv32& p, int m, int co, const float4& t) {
   const float v[4] = {x_act<ACT>(t.x), x_act<ACT>(t.y), x_act<ACT>(t.z), x_act<ACT>(t.w)};
+  if (p.out2 && co >= p.split2) {      // second destination (two convolutions of one map as one launch: the decoders' low-level projections)
+    *reinterpret_cast<float4*>(p.out2 + (size_t)m * p.out2_ld + (co - p.split2)) = make_float4(v[0], v[1], v[2], v[3]);
+    return;
+  }
   if (p.out_fmt) {
     half_t* op = reinterpret_cast<half_t*>(p.out) + (size_t)m * (2 * p.out_ld) + (co >> 5) * 64 + (co & 31);
     f16x4 h, l;
@@ -794,6 +798,10 @@ int launch_conv16x3(const Conv32& p, hipStream_t s) {
               "conv16x3: second source: Cin2=%d (multiple of 16), row %d, %dx%d at stride %d must cover the %dx%d output", p.Cin2,
               p.in2_ld, p.H2, p.W2, p.stride2, p.Ho, p.Wo);
   EMP_REQUIRE(p.in_fmt == 0 && p.res_fmt == 0, "conv16x3: hl32 inputs / residuals belong to conv16x3p");
+  EMP_REQUIRE(!p.out2 || (p.split2 > 0 && p.split2 % 4 == 0 && p.split2 < p.Cout && !p.out_fmt && !p.head_w && p.ps_cout == 0 && (p.Cout & 3) == 0 &&
+                          p.groups <= 1 && (p.out_ld & 3) == 0 && (p.out2_ld & 3) == 0 && (((uintptr_t)p.out) & 15) == 0 && (((uintptr_t)p.out2) & 15) == 0 &&
+                          (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && !p.bias_n && !p.res && p.KH * p.KW * p.Cin < 1024),
+              "conv16x3: a second destination needs the four-wave kernel's vector epilogue (split %% 4, aligned fp32 rows, K < 1024)");
   EMP_REQUIRE(!p.out_fmt || (!p.head_w && p.ps_cout == 0 && (p.Cout & 3) == 0 && p.groups <= 1 && p.out_ld % 32 == 0 && (((uintptr_t)p.out) & 127) == 0 &&
                              (!p.bias || (((uintptr_t)p.bias) & 15) == 0) && (!p.bias_n || (((uintptr_t)p.bias_n) & 15) == 0) &&
                              (!p.res || ((p.res_ld & 3) == 0 && (((uintptr_t)p.res) & 15) == 0))),

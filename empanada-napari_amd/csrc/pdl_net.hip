@@ -125,6 +125,7 @@ struct emp_pdl {
   bool x3_planes = [] { const char* e = getenv("EMP_X3_PLANES"); return !(e && e[0] == '0'); }();
   int x3_planes_min_tiles = [] { const char* e = getenv("EMP_X3_PLANES_MIN_TILES"); return e ? atoi(e) : 128; }();
   bool x3_planes_ready = false;      // set by finalize32: every layer of the region has its packed image
+  bool x3_merge_proj = [] { const char* e = getenv("EMP_X3_MERGE_PROJ"); return !(e && e[0] == '0'); }();      // both decoders' low-level projections as one launch (A/B)
   bool x3_merge_aspp = [] { const char* e = getenv("EMP_X3_MERGE_ASPP"); return !(e && e[0] == '0'); }();      // both decoders' ASPP branches as one launch (A/B)
   // fp16x3 mode, round 6: a separable block (depthwise KxK -> pointwise -> act [-> head 1x1]) as ONE launch (sepconv_x3.hip) once
   // the map has this many 8 x 16 tiles (a persistent workgroup per CU); EMP_X3_FUSE_SEP=0: the depthwise launch + conv16x3 (A/B)
@@ -1580,6 +1581,32 @@ int finalize32(emp_pdl* n) {
     }
     EMP_CHECK_HIP(hipStreamSynchronize(nullptr));
   }
+  if (n->precision == 2 && c.arch == 0 && c.ins_decoder && n->x3_merge_proj) {
+    // fp16x3 mode, round 6: the two decoders' low-level projections of stage i read the same encoder map: weights stacked along
+    // Cout, one launch with two destinations (conv16x3.hip store4) -- the widest map of the network is read once instead of twice
+    for (int i = 0; i < c.n_stages; ++i) {
+      const std::string a = "semantic_decoder.project." + std::to_string(i) + ".0", b = "instance_decoder.project." + std::to_string(i) + ".0";
+      auto ia = n->w32.find(a), ib = n->w32.find(b);
+      if (ia == n->w32.end() || ib == n->w32.end()) continue;
+      const emp_pdl::W32 &wa = ia->second, &wb = ib->second;
+      if (wa.cin16 != wb.cin16 || wa.kh != 1 || wb.kh != 1 || wa.kw != 1 || wb.kw != 1 || wa.cout % 4 || wb.cout % 4 || wa.cin16 >= 1024) continue;
+      emp_pdl::W32 m = wa;
+      m.cout = wa.cout + wb.cout; m.wp = nullptr; m.wimg = nullptr; m.wimgp = nullptr;
+      const size_t na = (size_t)wa.cout * wa.cin16, nb = (size_t)wb.cout * wb.cin16;
+      void* d = nullptr;
+      EMP_CHECK_HIP(hipMalloc(&d, (na + nb) * sizeof(float)));
+      n->owned.push_back(d);
+      m.w = (float*)d;
+      EMP_CHECK_HIP(hipMemcpy(m.w, wa.w, na * sizeof(float), hipMemcpyDeviceToDevice));
+      EMP_CHECK_HIP(hipMemcpy(m.w + na, wb.w, nb * sizeof(float), hipMemcpyDeviceToDevice));
+      EMP_CHECK_HIP(hipMalloc(&d, (size_t)m.cout * sizeof(float)));
+      n->owned.push_back(d);
+      m.b = (float*)d;
+      EMP_CHECK_HIP(hipMemcpy(m.b, wa.b, (size_t)wa.cout * sizeof(float), hipMemcpyDeviceToDevice));
+      EMP_CHECK_HIP(hipMemcpy(m.b + wa.cout, wb.b, (size_t)wb.cout * sizeof(float), hipMemcpyDeviceToDevice));
+      n->w32["decoders.project." + std::to_string(i) + ".0"] = m;
+    }
+  }
   if (n->precision == 2) {
     // fp16x3 mode: every convolution weight once more as fp16 pairs (hi | lo << 16, the fp32 blob's layout), so that the
     // kernel's weight staging is a lane permutation instead of five vector operations per element (conv16x3.hip)
@@ -1667,8 +1694,8 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
         const T32* out2 = nullptr, int out2_coff = 0, int split2 = 0) {
   const emp_pdl::W32& w = n->w32.at(wname);
   Conv32 p{};
-  if (out2) {      // couts [split2, Cout) -> out2 (conv16x3p only: the merged ASPP branches)
-    EMP_REQUIRE(in.fmt && out2->fmt == out.fmt && (!out2->fmt || out2_coff % 32 == 0), "%s: a second destination exists on the plane path only", wname.c_str());
+  if (out2) {      // couts [split2, Cout) -> out2 (the merged ASPP branches on conv16x3p; the merged low-level projections on conv16x3's vector epilogue)
+    EMP_REQUIRE(n->precision == 2 && out2->fmt == out.fmt && (!out2->fmt || out2_coff % 32 == 0) && (in.fmt || !out.fmt), "%s: bad second destination", wname.c_str());
     p.out2 = out2->p + out2_coff; p.out2_ld = out2->ld; p.split2 = split2;
   }
   if (groups > 1) {      // grouped 3x3 of a RegNet block: w.cin is the group width, w.cout all output channels
@@ -1996,6 +2023,28 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
                  nullptr, nullptr, 0, nullptr, 1, &c1, i * n->aspp_ch, n->aspp_ch));
       }
     }
+    // the decoders' low-level projections, both decoders in one launch where finalize32 stacked their weights: the .cat buffers of
+    // both decoders exist before the loop below fills their up-sampled halves
+    bool proj_done[3] = {false, false, false};
+    if (n->precision == 2 && c.ins_decoder) {
+      int xch0 = n->aspp_ch;
+      for (int i = 0; i < c.n_stages; ++i) {
+        const std::string wn = "decoders.project." + std::to_string(i) + ".0";
+        if (n->w32.count(wn)) {
+          const T32 low = A(pyr[c.low_level_stages[i]]);
+          const int cps = round_up(xch0 + c.low_level_proj_sem[i], 32), cpi = round_up(xch0 + c.low_level_proj_ins[i], 32);
+          const std::string qs = std::string(decs[0]) + ".stage" + std::to_string(i), qi = std::string(decs[1]) + ".stage" + std::to_string(i);
+          RC32(mk(qs + ".cat", low.H, low.W, cps));
+          RC32(mk(qi + ".cat", low.H, low.W, cpi));
+          if (!low.fmt && xch0 % 4 == 0) {
+            RC32(c32(n, wn, low, 0, A(qs + ".cat"), xch0, 1, 0, 1, 1, nullptr, nullptr, s, 0, 1, nullptr, nullptr, 0, nullptr, 1, &A(qi + ".cat"), xch0,
+                     c.low_level_proj_sem[i]));
+            proj_done[i] = true;
+          }
+        }
+        xch0 = n->dec_ch;
+      }
+    }
     for (int d = 0; d < (c.ins_decoder ? 2 : 1); ++d) {
       const std::string p = decs[d];
       float *poolfeat, *bias_n;
@@ -2023,7 +2072,7 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
         RC32(mk(q + ".cat", low.H, low.W, cpad));
         const T32 xa = A(xx);
         RC32(launch_bilinear_ac_f32_nhwc(xa.p, N, xa.H, xa.W, xch, xa.ld, A(q + ".cat").p, low.H, low.W, cpad, s));
-        RC32(c32(n, p + ".project." + std::to_string(i) + ".0", low, 0, A(q + ".cat"), xch, 1, 0, 1, 1, nullptr, nullptr, s));
+        if (!proj_done[i]) RC32(c32(n, p + ".project." + std::to_string(i) + ".0", low, 0, A(q + ".cat"), xch, 1, 0, 1, 1, nullptr, nullptr, s));
         RC32(mk(q + ".out", low.H, low.W, n->dec_ch));
         bool fused = false;
         RC32(sep_x3(p + ".fuse." + std::to_string(i) + ".0.sepconv", A(q + ".cat"), 1, A(q + ".out").p, A(q + ".out").ld, nullptr, nullptr, 0, nullptr, &fused));

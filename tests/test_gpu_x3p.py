@@ -338,3 +338,20 @@ def test_merged_aspp_equals_the_two_launches(monkeypatch):
     ca = a.tap_raw('instance_decoder.aspp.cat', (2 * 16 * 16, 1024))
     cb = b.tap_raw('instance_decoder.aspp.cat', (2 * 16 * 16, 1024))
     assert torch.equal(ca, cb) and float(ca.abs().max()) > 0
+
+
+def test_merged_low_level_projections_equal_the_two_launches(monkeypatch):
+    """the two decoders' low-level projections (decoders/panoptic_deeplab.py:68-80: a 1x1 conv of the same encoder map each) as ONE
+    launch with two destinations (conv16x3.hip store4): bit-identical heads"""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=2), cfg)
+    x = torch.from_numpy(normalize(synth.em_tiles(2, 192, seed=9), 0.57571, 0.12765))[:, None].cuda()
+    a = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16x3')
+    monkeypatch.setenv('EMP_X3_MERGE_PROJ', '0')
+    b = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16x3')
+    oa, ob = a(x, 2, False), b(x, 2, False)
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
