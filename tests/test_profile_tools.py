@@ -113,3 +113,28 @@ def test_committed_step_breakdown_fits_in_the_step():
     if b and os.path.basename(b)[:3] == os.path.basename(p)[:3]:
         ms = json.load(open(b))['ms_per_step']
         assert float(total[2]) / 1e3 < 1.03 * ms, 'kernel time per step cannot exceed the step (one stream)'
+
+
+def test_committed_fp16x3_profiles_recompute_the_roofline_fraction():
+    """round 6: the default precision's records -- `rocprofv3 --kernel-trace --stats` of `bench.py --precision fp16x3 --batch 16`
+    (12 forward steps) and the PMC traffic file -- must let a reader recompute the fraction the bench line states: 32 launches of
+    conv16x3p_kernel per step, 20.05 TFLOP of fp16 MFMA per step at batch 16 (3 products x 417.7 GFLOP of the plane region per tile)"""
+    p = _latest('r*_fp16x3_kernel_stats.csv')
+    assert p, 'no committed fp16x3 kernel stats'
+    rows = list(csv.DictReader(open(p)))
+    x3p = [r for r in rows if 'conv16x3p_kernel' in r['Name']]
+    stem = [r for r in rows if 'stem7x7_kernel' in r['Name']]
+    assert x3p and stem
+    steps = sum(int(r['Calls']) for r in stem)
+    calls = sum(int(r['Calls']) for r in x3p)
+    assert calls == 32 * steps, (calls, steps)
+    ms_per_step = sum(int(r['TotalDurationNs']) for r in x3p) / steps / 1e6
+    line = json.load(open(_latest('r*_bench_fp16x3_profiled.json')))
+    flops = line['roofline']['kernel_flops_per_step']
+    assert abs(flops - 20.05e12) < 0.02e12, flops
+    frac = flops / (ms_per_step * 1e-3) / 2.5e15
+    assert 0.45 < frac < 0.75, frac
+    assert abs(frac - line['roofline']['frac']) < 0.03, (frac, line['roofline']['frac'])      # the trace and the HIP events agree
+    t = json.load(open(_latest('r*_x3p_traffic.json')))
+    assert t['dispatches'] % 32 == 0 and t['launches_per_step'] == 32
+    assert 1.0 <= t['ratio'] < 3.0 and abs(t['algorithmic_bytes_per_launch'] - 507592704.0) < 1.0
