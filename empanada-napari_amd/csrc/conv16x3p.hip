@@ -30,6 +30,8 @@
 // (2t + 4).  With the tap-major K walk (the C ABI's emp_conv2d_hl32_f16x3; X3P::kg = Cin / 32) the K order and the three products per
 // step are conv16x3.hip's: bit-identical accumulators given the same operands (tests/test_gpu_x3p.py).  The network walks K in
 // groups of 128 channels (x3p_kgroup below): another summation order of the same terms.
+#include <type_traits>
+
 #include "common.h"
 
 namespace emp {
@@ -70,80 +72,97 @@ __device__ __forceinline__ float act_p(float x) {
 
 // lane (fq, fr) owns couts co0 + P * 32 + fq * 8 + [0, 8) of pixel mrow0 + q * 16 + fr (the weight rows are permuted in the
 // image, perm32b): 32 contiguous bytes of an fp32 row, or 16 B of hi and 16 B of lo inside one 32-channel block of an hl32 row
-template <int ACT, int OUTF>
+template <int ACT, int OUTF, int RESF>      // RESF: 0 no residual, 1 fp32 rows, 2 hl32 rows
 __device__ __forceinline__ void x3p_epilogue(const X3P& p, f32x4 (&acc)[4][8], int mrow0, int co0, int fr, int fq, int HoWo) {
-  float bv[2][8];
+  // Two passes (couts P * 32 + fq * 8 + [0, 8) each).  The residual of FOUR pixel fragments at a time is requested up front --
+  // 8 loads in flight per lane, in the K loop's free fragment registers -- instead of one load -> wait -> store round trip per
+  // fragment: with one workgroup per CU nothing else hides that latency, and the short-K launches (conv3 of a bottleneck: 8-16 K
+  // steps) spent more time in 16 serial round trips than in their main loop (finding 66).  Rows past M load row M - 1 and are not stored.
+  const int mlast = p.M - 1;
 #pragma unroll
   for (int P = 0; P < 2; ++P) {
     const int co = co0 + P * 32 + fq * 8;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) bv[P][r] = 0.f;
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
       const float4 b0 = *reinterpret_cast<const float4*>(p.bias + co);
       const float4 b1 = *reinterpret_cast<const float4*>(p.bias + co + 4);
-      bv[P][0] = b0.x; bv[P][1] = b0.y; bv[P][2] = b0.z; bv[P][3] = b0.w;
-      bv[P][4] = b1.x; bv[P][5] = b1.y; bv[P][6] = b1.z; bv[P][7] = b1.w;
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+      bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
     }
-  }
+    const bool second = p.out2 && co0 >= p.split;      // (whole 256-cout tiles: wave-uniform)
+    const int oc = second ? co - p.split : co;
+    const int old_ = second ? p.out2_ld : p.out_ld;
+    void* const obase = second ? p.out2 : p.out;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int m = mrow0 + q * 16 + fr;
-    if (m >= p.M) continue;
-    const float* bn = p.bias_n ? p.bias_n + (size_t)(m / HoWo) * p.Cout : nullptr;
+    for (int qh = 0; qh < 2; ++qh) {      // (four fragments at a time: 32 registers of residual beside the 128 accumulators)
+      constexpr int NRH = RESF == 2 ? 4 : 1, NRF = RESF == 1 ? 4 : 1;
+      f16x8 rh[NRH], rl[NRH];
+      float4 r0[NRF], r1[NRF];
+      if constexpr (RESF == 2) {
 #pragma unroll
-    for (int P = 0; P < 2; ++P) {
-      const int co = co0 + P * 32 + fq * 8;
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[2 * P][q][r] + bv[P][r];
-        v[4 + r] = acc[2 * P + 1][q][r] + bv[P][4 + r];
-      }
-      if (bn) {
-        const float4 b0 = *reinterpret_cast<const float4*>(bn + co);
-        const float4 b1 = *reinterpret_cast<const float4*>(bn + co + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      }
-      if (p.res) {
-        if (p.res_fmt) {      // hi + lo is exact in fp32 (22 bits)
+        for (int u = 0; u < 4; ++u) {
+          const int m = min(mrow0 + (qh * 4 + u) * 16 + fr, mlast);
           const half_t* rp = reinterpret_cast<const half_t*>(p.res) + (size_t)m * (2 * p.res_ld) + (co >> 5) * 64 + (co & 31);
-          const f16x8 rh = *reinterpret_cast<const f16x8*>(rp), rl = *reinterpret_cast<const f16x8*>(rp + 32);
+          rh[u] = *reinterpret_cast<const f16x8*>(rp);
+          rl[u] = *reinterpret_cast<const f16x8*>(rp + 32);
+        }
+      } else if constexpr (RESF == 1) {
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] += (float)rh[r] + (float)rl[r];
-        } else {
+        for (int u = 0; u < 4; ++u) {
+          const int m = min(mrow0 + (qh * 4 + u) * 16 + fr, mlast);
           const float* rp = reinterpret_cast<const float*>(p.res) + (size_t)m * p.res_ld + co;
-          const float4 r0 = *reinterpret_cast<const float4*>(rp), r1 = *reinterpret_cast<const float4*>(rp + 4);
-          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-          v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+          r0[u] = *reinterpret_cast<const float4*>(rp);
+          r1[u] = *reinterpret_cast<const float4*>(rp + 4);
         }
       }
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = act_p<ACT>(v[r]);
-      const bool second = p.out2 && co0 >= p.split;      // (whole 256-cout tiles: wave-uniform)
-      const int oc = second ? co - p.split : co;
-      const int old_ = second ? p.out2_ld : p.out_ld;
-      void* const obase = second ? p.out2 : p.out;
-      if (OUTF) {
-        half_t* op = reinterpret_cast<half_t*>(obase) + (size_t)m * (2 * old_) + (oc >> 5) * 64 + (oc & 31);
-        f16x8 h, lo;
+      for (int u = 0; u < 4; ++u) {
+        const int q = qh * 4 + u;
+        const int m = mrow0 + q * 16 + fr;
+        float v[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          h[r] = (half_t)v[r];
-          lo[r] = (half_t)(v[r] - (float)h[r]);
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[2 * P][q][r] + bv[r];
+          v[4 + r] = acc[2 * P + 1][q][r] + bv[4 + r];
         }
-        *reinterpret_cast<f16x8*>(op) = h;
-        *reinterpret_cast<f16x8*>(op + 32) = lo;
-      } else {
-        float* op = reinterpret_cast<float*>(obase) + (size_t)m * old_ + oc;
-        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (p.bias_n) {
+          const float* bn = p.bias_n + (size_t)(min(m, mlast) / HoWo) * p.Cout + co;
+          const float4 b0 = *reinterpret_cast<const float4*>(bn);
+          const float4 b1 = *reinterpret_cast<const float4*>(bn + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if constexpr (RESF == 2) {      // hi + lo is exact in fp32 (22 bits)
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] += (float)rh[u][r] + (float)rl[u][r];
+        } else if constexpr (RESF == 1) {
+          v[0] += r0[u].x; v[1] += r0[u].y; v[2] += r0[u].z; v[3] += r0[u].w;
+          v[4] += r1[u].x; v[5] += r1[u].y; v[6] += r1[u].z; v[7] += r1[u].w;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = act_p<ACT>(v[r]);
+        if (m >= p.M) continue;
+        if (OUTF) {
+          half_t* op = reinterpret_cast<half_t*>(obase) + (size_t)m * (2 * old_) + (oc >> 5) * 64 + (oc & 31);
+          f16x8 h, lo;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            h[r] = (half_t)v[r];
+            lo[r] = (half_t)(v[r] - (float)h[r]);
+          }
+          *reinterpret_cast<f16x8*>(op) = h;
+          *reinterpret_cast<f16x8*>(op + 32) = lo;
+        } else {
+          float* op = reinterpret_cast<float*>(obase) + (size_t)m * old_ + oc;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
       }
     }
   }
 }
 
-template <int ACT, int OUTF>
+template <int ACT, int OUTF, int RESF>
 __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int bid = blockIdx.x;
@@ -392,7 +411,7 @@ __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
   }
-  x3p_epilogue<ACT, OUTF>(p, acc, m0 + grp * 128, n0 + wc * 64, fr, fq, HoWo);
+  x3p_epilogue<ACT, OUTF, RESF>(p, acc, m0 + grp * 128, n0 + wc * 64, fr, fq, HoWo);
 }
 
 // [cout tile of 256][K step][part: 0 = lo, 1 = hi][piece of 16 rows][lane][8 halfs]: the bytes lane l of the wave that stages piece
@@ -582,14 +601,24 @@ int launch_conv16x3p(const Conv32& c, hipStream_t s) {
     EMP_LAUNCH_CHECK();
     return EMP_OK;
   };
+  const int resf = !c.res ? 0 : (c.res_fmt ? 2 : 1);
+  auto pick = [&](auto A, auto O) -> int {
+    constexpr int a = decltype(A)::value, o = decltype(O)::value;
+    if (resf == 2) return go(&conv16x3p_kernel<a, o, 2>);
+    if (resf == 1) return go(&conv16x3p_kernel<a, o, 1>);
+    return go(&conv16x3p_kernel<a, o, 0>);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
   if (c.out_fmt) {
-    if (act == 1) return go(&conv16x3p_kernel<1, 1>);
-    if (act == 2) return go(&conv16x3p_kernel<2, 1>);
-    return go(&conv16x3p_kernel<0, 1>);
+    if (act == 1) return pick(I1{}, I1{});
+    if (act == 2) return pick(I2{}, I1{});
+    return pick(I0{}, I1{});
   }
-  if (act == 1) return go(&conv16x3p_kernel<1, 0>);
-  if (act == 2) return go(&conv16x3p_kernel<2, 0>);
-  return go(&conv16x3p_kernel<0, 0>);
+  if (act == 1) return pick(I1{}, I0{});
+  if (act == 2) return pick(I2{}, I0{});
+  return pick(I0{}, I0{});
 }
 
 }  // namespace emp
