@@ -172,7 +172,7 @@ def x3p_traffic_from_profiles():
         return None
 
 
-def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3, precision='fp32', ref=None):
+def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3, precision='fp32', ref=None, stack3d=0):
     """Rate of the library's fp32 REFERENCE MODE (precision='fp32', csrc/ref32.hip) or of its fp16x3 mode (the same graph with
     split-fp16 convolutions on the fp16 matrix pipe, csrc/conv16x3.hip) on the same workload: the same step (forward +
     probability + voting + merge -> int64 label maps) over `batch` of the bench's tiles, outside the timed region of
@@ -229,6 +229,12 @@ def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3, precisi
                        'on the 256x256 LDS-DMA tile (csrc/conv16x3p.hip), the separable blocks fused (csrc/sepconv_x3.hip); heads '
                        'within 1e-3 of the fp32 forward in the MAX norm on every one of 8 tiles x 3 weight seeds '
                        '(tests/test_gpu_fp16x3.py); same step as `value`'}
+    if stack3d:      # the 3-D half of the metric in this precision (the same job as the line's `stack3d` block, no CPU leg)
+        try:
+            j3 = stack3d_line(m32, stack3d, with_cpu=False)
+            res['stack3d'] = {k: j3[k] for k in ('value', 'unit', 'volume', 'seconds', 'consensus_objects')}
+        except Exception as e:      # noqa: BLE001
+            res['stack3d'] = {'error': f'{type(e).__name__}: {e}'}
     if ref:      # the checker side: the oracle's fp32 heads of tile 0 of the cpu_baseline sample (cpu_baseline(keep=))
         import numpy as np
         sig = lambda v: 1.0 / (1.0 + np.exp(-v.astype(np.float64)))
@@ -604,7 +610,7 @@ def run_tiles(args, rank, local_rank, world, dist_on, dev):
         for key, prec, mult in (('fp32_mode', 'fp32', 1), ('fp16x3_mode', 'fp16x3', 4)):      # (16 tiles: a launch of the 256-cout layers fills the chip)
             try:
                 res[key] = fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=min(mult * args.fp32_mode, B), precision=prec,
-                                           ref=ref_heads)
+                                           ref=ref_heads, stack3d=args.stack3d if (prec == 'fp16x3' and not dist_on) else 0)
             except Exception as e:      # noqa: BLE001 -- the headline line must not depend on the extra measurement
                 res[key] = {'error': f'{type(e).__name__}: {e}'}
     if world == 1 and args.fine_boundaries:

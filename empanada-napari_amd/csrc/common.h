@@ -129,6 +129,9 @@ int launch_gate_mul_f16(const half_t* x, int x_ld, half_t* g /* in: gate logits,
 // conv1 + bn1 + relu + maxpool on MFMA in one launch (stem.hip): img -> (N,H/4,W/4,64)
 int launch_stem_pool(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
                      const float* w, const float* b, half_t* out, hipStream_t s);
+// the same launch with an fp32 conv tile and an fp32 output (the fp16x3 mode's stem): img -> (N,H/4,W/4,64) fp32
+int launch_stem_pool_f32(const void* img, int dtype, float sub, float mul, int N, int H, int W, int vh, int vw,
+                         const float* w, const float* b, float* out, hipStream_t s);
 // depthwise KxK (K = 3 or 5), stride 1, pad K/2; weights fp16 [K*K][C]
 int launch_dwconv(const half_t* in, int N, int H, int W, int C, int in_ld, const half_t* w, int K,
                   half_t* out, int out_ld, const half_t* zero, hipStream_t s);

@@ -125,6 +125,7 @@ struct emp_pdl {
   bool x3_planes = [] { const char* e = getenv("EMP_X3_PLANES"); return !(e && e[0] == '0'); }();
   int x3_planes_min_tiles = [] { const char* e = getenv("EMP_X3_PLANES_MIN_TILES"); return e ? atoi(e) : 128; }();
   bool x3_planes_ready = false;      // set by finalize32: every layer of the region has its packed image
+  bool x3_fuse_stem = [] { const char* e = getenv("EMP_X3_FUSE_STEM"); return !(e && e[0] == '0'); }();      // stem + max-pool as one MFMA launch (A/B)
   bool x3_merge_proj = [] { const char* e = getenv("EMP_X3_MERGE_PROJ"); return !(e && e[0] == '0'); }();      // both decoders' low-level projections as one launch (A/B)
   bool x3_merge_aspp = [] { const char* e = getenv("EMP_X3_MERGE_ASPP"); return !(e && e[0] == '0'); }();      // both decoders' ASPP branches as one launch (A/B)
   // fp16x3 mode, round 6: a separable block (depthwise KxK -> pointwise -> act [-> head 1x1]) as ONE launch (sepconv_x3.hip) once
@@ -1845,11 +1846,17 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
       pyr[si] = x;
     }
   } else {
-    RC32(mk("stem", H / 2, W / 2, 64));
-    RC32(launch_stem7x7_f32(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("stem").p, s));
     n->flops += 2.0 * N * (H / 2) * (W / 2) * 64.0 * 49.0;
     RC32(mk("p1", H / 4, W / 4, 64));
-    RC32(launch_maxpool3x3s2_f32(A("stem").p, N, H / 2, W / 2, 64, A("p1").p, s));
+    if (n->precision == 2 && n->x3_fuse_stem) {
+      // fp16x3 mode, round 6: conv1 + bn1 + relu + maxpool as one launch on the matrix pipe (stem.hip stem_pool32_kernel: the three-MFMA
+      // split product of every other convolution of the mode, fp32 tile and output); the half-resolution map is never written
+      RC32(launch_stem_pool_f32(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("p1").p, s));
+    } else {
+      RC32(mk("stem", H / 2, W / 2, 64));
+      RC32(launch_stem7x7_f32(img, dtype, sub, mul, N, H, W, vh, vw, n->f32w.at("stem.w"), n->f32w.at("stem.b"), A("stem").p, s));
+      RC32(launch_maxpool3x3s2_f32(A("stem").p, N, H / 2, W / 2, 64, A("p1").p, s));
+    }
     x = "p1";
     pyr[0] = "p1";
     for (int li = 1; li <= 4; ++li) {

@@ -355,3 +355,31 @@ def test_merged_low_level_projections_equal_the_two_launches(monkeypatch):
     oa, ob = a(x, 2, False), b(x, 2, False)
     for k in oa:
         assert torch.equal(oa[k], ob[k]), k
+
+
+def test_fused_fp32_stem_equals_the_two_launches(monkeypatch):
+    """fp16x3 mode: conv1 + bn1 + relu + maxpool (encoders/resnet.py:164-168,219-222) as ONE launch on the matrix pipe with an fp32 tile
+    and output (stem.hip stem_pool32_kernel) against the VALU stem + max-pool launches (EMP_X3_FUSE_STEM=0): the pooled map within
+    the split product's 2^-21, on a raw uint8 tile with ragged borders (factor_pad fused) and on a float tile"""
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize, normalize_params
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=5), cfg)
+    img = synth.em_tiles(2, 256, seed=6)[:, :200, :232]
+    a = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16x3')
+    monkeypatch.setenv('EMP_X3_FUSE_STEM', '0')
+    b = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16x3')
+    sub, mul = normalize_params(0.57571, 0.12765, 255)
+    raw = torch.from_numpy(np.ascontiguousarray(img))[:, None].cuda()
+    flt = torch.from_numpy(normalize(np.ascontiguousarray(img), 0.57571, 0.12765))[:, None].cuda()
+    for x, kw in ((raw, dict(sub=float(sub), mul=float(mul))), (flt, {})):
+        oa = a(x, 2, False, pad_to=(208, 240), **kw)
+        pa = a.tap_raw('p1', (2, 52, 60, 64)).clone()
+        ob = b(x, 2, False, pad_to=(208, 240), **kw)
+        pb = b.tap_raw('p1', (2, 52, 60, 64))
+        scale = float(pb.abs().max())
+        assert scale > 0.1 and float((pa - pb).abs().max()) < 4e-6 * scale
+        for k in ('ctr_hmp', 'offsets'):
+            s = max(1.0, float(ob[k].abs().max()))
+            assert float((oa[k] - ob[k]).abs().max()) < 5e-5 * s, k
