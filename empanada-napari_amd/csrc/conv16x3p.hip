@@ -93,31 +93,32 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& p, f32x4 (&acc)[4][8], i
     const int oc = second ? co - p.split : co;
     const int old_ = second ? p.out2_ld : p.out_ld;
     void* const obase = second ? p.out2 : p.out;
+    constexpr int QG = 4;      // fragments per group
 #pragma unroll
-    for (int qh = 0; qh < 2; ++qh) {      // (four fragments at a time: 32 registers of residual beside the 128 accumulators)
-      constexpr int NRH = RESF == 2 ? 4 : 1, NRF = RESF == 1 ? 4 : 1;
+    for (int qh = 0; qh < 8 / QG; ++qh) {      // (four fragments at a time: 32 registers of residual beside the 128 accumulators)
+      constexpr int NRH = RESF == 2 ? QG : 1, NRF = RESF == 1 ? QG : 1;
       f16x8 rh[NRH], rl[NRH];
       float4 r0[NRF], r1[NRF];
       if constexpr (RESF == 2) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int m = min(mrow0 + (qh * 4 + u) * 16 + fr, mlast);
+        for (int u = 0; u < QG; ++u) {
+          const int m = min(mrow0 + (qh * QG + u) * 16 + fr, mlast);
           const half_t* rp = reinterpret_cast<const half_t*>(p.res) + (size_t)m * (2 * p.res_ld) + (co >> 5) * 64 + (co & 31);
           rh[u] = *reinterpret_cast<const f16x8*>(rp);
           rl[u] = *reinterpret_cast<const f16x8*>(rp + 32);
         }
       } else if constexpr (RESF == 1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int m = min(mrow0 + (qh * 4 + u) * 16 + fr, mlast);
+        for (int u = 0; u < QG; ++u) {
+          const int m = min(mrow0 + (qh * QG + u) * 16 + fr, mlast);
           const float* rp = reinterpret_cast<const float*>(p.res) + (size_t)m * p.res_ld + co;
           r0[u] = *reinterpret_cast<const float4*>(rp);
           r1[u] = *reinterpret_cast<const float4*>(rp + 4);
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int q = qh * 4 + u;
+      for (int u = 0; u < QG; ++u) {
+        const int q = qh * QG + u;
         const int m = mrow0 + q * 16 + fr;
         float v[8];
 #pragma unroll
@@ -411,6 +412,7 @@ __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
   }
+  __builtin_amdgcn_sched_barrier(0);      // (no epilogue address arithmetic hoisted into the last K steps: it spilled there)
   x3p_epilogue<ACT, OUTF, RESF>(p, acc, m0 + grp * 128, n0 + wc * 64, fr, fq, HoWo);
 }
 
