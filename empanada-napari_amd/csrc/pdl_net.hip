@@ -1765,7 +1765,9 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
   auto mk = [&](const std::string& k, int H_, int W_, int C_, int fmt = 0) -> int { T32 t; int rc = t32(n, k, N, H_, W_, C_, &t); t.fmt = fmt; T[k] = t; return rc; };
   // fp16x3 mode, round 6: layer3 / layer4 / ASPP maps as hl32 planes on conv16x3p_kernel (emp_pdl members x3_planes*)
   const bool hlr = n->precision == 2 && n->x3_planes_ready && c.encoder == 0 &&
-                      ((int64_t)N * (H / 16) * (W / 16)) / 256 >= n->x3_planes_min_tiles;
+                      ((int64_t)N * (H / 16) * (W / 16)) / 256 >= n->x3_planes_min_tiles * (c.stage4_stride == 32 ? 2 : 1);
+  // (an encoder at output stride 32 -- the BiFPN networks -- has a quarter of those tiles in layer4: BiFPN-PR with the region on / off
+  //  492 / 513 tiles/s at batch 8, 594 / 581 at 16, 651 / 631 at 32: its threshold is twice the stride-16 one)
   auto A = [&](const std::string& k) -> T32& { return T.at(k); };
   auto dw = [&](const T32& in, const std::string& wname, int K, const T32& out) -> int {
     n->flops += 2.0 * K * K * (double)N * in.H * in.W * in.C;
