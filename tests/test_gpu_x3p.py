@@ -383,3 +383,36 @@ def test_fused_fp32_stem_equals_the_two_launches(monkeypatch):
         for k in ('ctr_hmp', 'offsets'):
             s = max(1.0, float(ob[k].abs().max()))
             assert float((oa[k] - ob[k]).abs().max()) < 5e-5 * s, k
+
+
+@pytest.mark.parametrize('env', [{'EMP_X3_FUSE_DS': '0'}, {'EMP_X3_FUSE_HEAD': '0', 'EMP_X3_FUSE_SEP': '0'}, {'EMP_X3_FUSE_SEP': '0'},
+                                 {'EMP_X3_MERGE_ASPP': '0', 'EMP_X3_MERGE_PROJ': '0'}, {'EMP_X3_FUSE_STEM': '0', 'EMP_X3P_KGROUP': '64'},
+                                 {'EMP_X3_SPEC': '0', 'EMP_X3_PLANES': '0'}, {'EMP_X3_WIMG': '0', 'EMP_X3_PLANES': '0'}])
+def test_every_ab_switch_of_the_mode_stays_within_the_gate(env, monkeypatch):
+    """the A/B switches of the fp16x3 mode select other kernels / launch groupings for the same arithmetic:
+    with the plane region forced on at test size, every combination keeps the heads within 1e-3 (max norm) of the oracle's fp32
+    forward and within fp32 rounding of the default configuration"""
+    import os
+    from empanada_napari_amd import synth, weights
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    from empanada_napari_amd.preprocess import normalize
+    from oracle import pdl_model
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg = dict(weights.MITONET_PDL_CFG)
+    P = weights.fold_state_dict(weights.seeded_state_dict(cfg, seed=0), cfg)
+    for name, shift in (('ins_center.head.1', 0.75), ('semantic_head.head.1', 1.0), ('semantic_pr.point_head.predictor', 1.0)):
+        w, b = P[name]
+        P[name] = (w, b + np.float32(shift))
+    x = torch.from_numpy(normalize(synth.em_tiles(2, 256, seed=13), 0.57571, 0.12765))[:, None]
+    monkeypatch.setenv('EMP_X3_PLANES_MIN_TILES', '1')
+    base = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16x3')
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = HipPanopticDeepLab(P, cfg, folded=True, precision='fp16x3')
+    ob = {k: v.cpu() for k, v in base(x.cuda(), 2, False).items()}
+    oa = {k: v.cpu() for k, v in alt(x.cuda(), 2, False).items()}
+    ref = pdl_model.pdl_forward(P, x, cfg, 2, False)
+    for k in ('ctr_hmp', 'offsets'):
+        scale = max(1.0, float(ref[k].pow(2).mean().sqrt()))
+        assert float((oa[k] - ref[k]).abs().max()) / scale < 1e-3, (env, k)
+        assert float((oa[k] - ob[k]).abs().max()) / scale < 5e-5, (env, k)
