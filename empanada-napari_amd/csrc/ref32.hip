@@ -239,6 +239,55 @@ __global__ void __launch_bounds__(256) bilinear32_kernel(const float* __restrict
   }
 }
 
+// The same up-sampling for FOUR consecutive output columns per thread (round 6): the four outputs of a row share at most three input
+// columns when W >= 4 w (align_corners: the input step per output column is (w - 1) / (W - 1) < 1/4, three steps < 0.75), so a thread
+// loads each of them once -- 6
+// 16-byte loads per 4 outputs instead of 16 (the one-output kernel sat at 0.95 texture-data busy in the fp16x3 step's PMC census).
+// Same loads, same arithmetic per output: bit-identical to bilinear32_kernel.
+__global__ void __launch_bounds__(256) bilinear32x4_kernel(const float* __restrict__ in, int N, int h, int w, int C, int in_ld,
+                                                           float* __restrict__ out, int H, int W, int out_ld, float sy,
+                                                           float sx, int64_t total) {
+#pragma clang fp contract(off)
+  const int CG = C >> 2, W4 = W >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % CG);
+    int64_t q = i / CG;
+    const int ox0 = (int)(q % W4) * 4; q /= W4;
+    const int oy = (int)(q % H);
+    const int n = (int)(q / H);
+    const float fy = sy * (float)oy;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, hy = 1.f - ly;
+    const float* b = in + (size_t)n * h * w * in_ld + cg * 4;
+    const int xa = (int)(sx * (float)ox0);      // the first output's left column; the others' lie in [xa, xa + 1], their right ones in [xa, xa + 2]
+    float4 r0[3], r1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int xc = min(xa + c, w - 1);
+      r0[c] = *reinterpret_cast<const float4*>(b + ((size_t)y0 * w + xc) * in_ld);
+      r1[c] = *reinterpret_cast<const float4*>(b + ((size_t)y1 * w + xc) * in_ld);
+    }
+    float* op = out + (((size_t)n * H + oy) * W + ox0) * out_ld + cg * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float fx = sx * (float)(ox0 + j);
+      const int x0 = (int)fx;
+      const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+      const float lx = fx - (float)x0, hx = 1.f - lx;
+      const int a = x0 - xa, bb = x1 - xa;      // 0 .. 2
+      const float4 v00 = a == 0 ? r0[0] : (a == 1 ? r0[1] : r0[2]), v01 = bb == 0 ? r0[0] : (bb == 1 ? r0[1] : r0[2]);
+      const float4 v10 = a == 0 ? r1[0] : (a == 1 ? r1[1] : r1[2]), v11 = bb == 0 ? r1[0] : (bb == 1 ? r1[1] : r1[2]);
+      float4 o;
+      o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+      o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+      o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+      o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+      *reinterpret_cast<float4*>(op + (size_t)j * out_ld) = o;
+    }
+  }
+}
+
 // global average pool: one workgroup of 1024 threads per (image, 64 channels) -- lane = channel (a wave reads 256
 // contiguous bytes per pixel), the 16 waves take the pixels round-robin with four independent partial sums each, the 64
 // partials of a channel are added in a fixed order (deterministic).  Round 5: the one-thread-per-channel form of round 4
@@ -513,6 +562,13 @@ int launch_bilinear_ac_f32_nhwc(const float* in, int N, int h, int w, int C, int
   const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
   const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   const int64_t total = (int64_t)N * H * W * (C / 4);
+  const char* x4_env = getenv("EMP_BILINEAR32_X4");      // =0: the one-output kernel (A/B; bit-identical)
+  if (W % 4 == 0 && W >= 4 * w && !(x4_env && x4_env[0] == '0')) {      // up-sampling by >= 4 (3 * sx < 0.75): four output columns per thread
+    hipLaunchKernelGGL(bilinear32x4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, s, in, N, h, w, C, in_ld, out, H, W, out_ld, sy, sx,
+                       total / 4);
+    EMP_LAUNCH_CHECK();
+    return EMP_OK;
+  }
   hipLaunchKernelGGL(bilinear32_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, N, h, w, C, in_ld, out, H, W, out_ld, sy, sx,
                      total);
   EMP_LAUNCH_CHECK();

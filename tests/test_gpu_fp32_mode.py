@@ -186,3 +186,23 @@ def test_strip_depthwise_kernel_is_the_plain_kernels_fmaf_chain(monkeypatch):
     b = model(x, 2, False)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize('arch', ['pdl', 'bifpn'])
+def test_four_column_bilinear_kernel_is_the_plain_kernels_arithmetic(monkeypatch, arch):
+    """Round 6: the fp32 / fp16x3 graph's up-sampler computes four output columns per thread from at most three input columns
+    (bilinear32x4_kernel, csrc/ref32.hip) -- the same loads and the same expression per output as the one-output kernel
+    (EMP_BILINEAR32_X4=0), so every head is bit-identical, in both precisions that use it and on an odd-ratio size"""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.preprocess import normalize
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    cfg, P, _ = _models(arch)
+    for prec, size in (('fp32', 256), ('fp16x3', 384)):
+        model = HipPanopticDeepLab(P, cfg, folded=True, precision=prec)
+        x = torch.from_numpy(normalize(synth.em_tiles(2, size, seed=29), 0.57571, 0.12765))[:, None].cuda()
+        monkeypatch.setenv('EMP_BILINEAR32_X4', '1')
+        a = {k: v.clone() for k, v in model(x, 2, False).items()}
+        monkeypatch.setenv('EMP_BILINEAR32_X4', '0')
+        b = model(x, 2, False)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (prec, k)
