@@ -229,6 +229,19 @@ def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3, precisi
                        'on the 256x256 LDS-DMA tile (csrc/conv16x3p.hip), the separable blocks fused (csrc/sepconv_x3.hip); heads '
                        'within 1e-3 of the fp32 forward in the MAX norm on every one of 8 tiles x 3 weight seeds '
                        '(tests/test_gpu_fp16x3.py); same step as `value`'}
+    if precision == 'fp16x3':      # the reference API's contract (engines.py:300-325: one tile per call) in the default precision
+        one = x[:1]
+        for _ in range(3):
+            step1 = m32(one, 2, interpolate_ins=False, sub=float(sub), mul=float(mul))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            o = m32(one, 2, interpolate_ins=False, sub=float(sub), mul=float(mul))
+            cells, _, _, kmax = e32.instance_cells_int(o['ctr_hmp'], o['offsets'], 1)
+            e32.panoptic_merge_int(logits_to_prob(o['sem_logits']), cells, kmax)
+        torch.cuda.synchronize()
+        res['latency_ms_batch1'] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+        del step1
     if stack3d:      # the 3-D half of the metric in this precision (the same job as the line's `stack3d` block, no CPU leg)
         try:
             j3 = stack3d_line(m32, stack3d, with_cpu=False)

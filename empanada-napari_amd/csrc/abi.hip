@@ -144,8 +144,10 @@ int emp_conv2d_nhwc_f16x3_ex(const float* d_in, int N, int H, int W, int Cin, in
                              int in2_ld, int stride2, const float* d_head_w, const float* d_head_b, int head_c, float* d_head_out,
                              void* stream) {
   EMP_REQUIRE(d_in && d_w && (d_out || d_head_w), "conv2d_f16x3_ex: null pointer");
-  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0 && wmode >= 0 && wmode <= 2,
-              "conv2d_f16x3_ex: bad geometry (wmode 0 fp32 weights, 1 split pairs, 2 pairs + LDS-DMA image)");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0 && wmode >= 0 && (wmode & 3) <= 2 && wmode < 8,
+              "conv2d_f16x3_ex: bad geometry (wmode 0 fp32 weights, 1 split pairs, 2 pairs + LDS-DMA image; + 4: split-K allowed)");
+  const bool ksplit = (wmode & 4) != 0;
+  wmode &= 3;
   hipStream_t s = (hipStream_t)stream;
   Conv32 p{};
   p.in = d_in; p.in_ld = in_ld; p.w = d_w; p.bias = d_bias; p.bias_n = d_bias_n; p.res = d_res; p.res_ld = res_ld;
@@ -177,6 +179,12 @@ int emp_conv2d_nhwc_f16x3_ex(const float* d_in, int N, int H, int W, int Cin, in
       p.wimg = (const half_t*)d;
       rc = launch_x3_weight_image(d_w, (half_t*)d, Cout, (int)Krow, s);
     }
+  }
+  if (!rc && ksplit && !d_head_w && !d_in2) {      // scratch for the launcher's split-K rule (Conv32::kpart)
+    void* d = nullptr;
+    if (hipMalloc(&d, (size_t)X3_KPART_BYTES) != hipSuccess) { cleanup(); set_error("conv2d_f16x3_ex: out of memory"); return EMP_ERR_NOMEM; }
+    tmp.push_back(d);
+    p.kpart = (float*)d; p.kpart_bytes = X3_KPART_BYTES;
   }
   const int64_t MP = (int64_t)N * p.Ho * p.Wo;
   const int tiles = conv16x3_cout_tiles(Cout);

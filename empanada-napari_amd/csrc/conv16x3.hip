@@ -425,7 +425,8 @@ constexpr int XS_SLOT_HALFS = 4 * XS_TILE;
 // hi tile and the lo tile exactly as they lie in LDS, 16 KiB contiguous) by LDS-DMA, three steps deep in a ring of their own --
 // no registers, no split, no LDS stores for half of the operand bytes, and twice the bytes in flight (finding 51: register
 // staging bounded them).  LDS then: pixel slots 2 x [Xh | Xl] + cout slots 3 x [Wh | Wl] = 80 KiB, two workgroups per CU.
-template <int ACT, bool WPAIR, int XS_SLOTS, bool WIMG = false>
+// KSPLIT (round 6, late): blockIdx.y = s walks steps [s * x3_ksteps, ...) of the K loop only and stores raw partial sums (Conv32::kpart)
+template <int ACT, bool WPAIR, int XS_SLOTS, bool WIMG = false, bool KSPLIT = false>
 __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(const Conv32 p) {
   static_assert(!WIMG || XS_SLOTS == 2, "the image variant has two pixel slots");
   extern __shared__ __attribute__((aligned(1024))) char xs_lds[];
@@ -448,7 +449,9 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
   const int HoWo = p.Ho * p.Wo;
   const int M = p.N * HoWo;
   const int K = p.KH * p.KW * p.Cin;
-  const int nsteps = (K + X_BK - 1) / X_BK;
+  const int nsteps_all = (K + X_BK - 1) / X_BK;
+  const int t0 = KSPLIT ? (int)blockIdx.y * p.x3_ksteps : 0;                                  // first step of this workgroup
+  const int nsteps = KSPLIT ? min(p.x3_ksteps, nsteps_all - t0) : nsteps_all;                 // ... and how many it walks
   if (stager) {
     // ---- waves 0-3: global -> registers -> split -> LDS.  Piece i of thread t = row t / 8 + 32 i, FOUR-channel chunk t % 8:
     // eight consecutive lanes read one whole 128-byte line (a row's 32 fp32 channels of the step).  (The four-wave kernel's
@@ -461,7 +464,7 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
     for (int i = 0; i < 4; ++i) {
       const int co = n0 + srow + 32 * i;
       const float* base = WPAIR ? reinterpret_cast<const float*>(p.wpair) : p.w;
-      wrow[i] = co < p.Cout ? base + (size_t)(gco + co) * K + sc4 * 4 : nullptr;
+      wrow[i] = co < p.Cout ? base + (size_t)(gco + co) * K + sc4 * 4 + (size_t)t0 * X_BK : nullptr;
     }
     // TWO register sets: the loads of step k + A + 1 and k + A + 2 are in flight while step k + A is split and stored (the
     // stagers' registers are free -- the allocation is the multipliers' -- and one step of the multipliers is shorter than a
@@ -476,9 +479,16 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
     uint32_t dx[4], dw[4];                      // bytes per step: 128, or 0 on the zero page
     const int csteps = p.Cin / X_BK;            // steps per tap
     int c_left = csteps, g_t = 0, g_ky = 0, g_kx = 0;
+    int c_first = 0;                            // KSPLIT: the channel the first tap of this split starts at
+    if constexpr (KSPLIT) {
+      const int tap0 = t0 / csteps, s_in = t0 - tap0 * csteps;
+      g_ky = tap0 / p.KW; g_kx = tap0 - g_ky * p.KW;
+      c_left = csteps - s_in;
+      c_first = s_in * X_BK;
+    }
     // (the pixel's coordinates are recomputed at every tap change -- KH * KW times per workgroup -- instead of living in
     // registers through the loop)
-    auto set_tap = [&](bool live) {
+    auto set_tap = [&](bool live, int c0 = 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         int sr = srow;
@@ -488,13 +498,13 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
         const int aoy = r / p.Wo, aox = r - aoy * p.Wo;
         const int iy = aoy * p.stride - p.pad + g_ky * p.dil, ix = aox * p.stride - p.pad + g_kx * p.dil;
         const bool ok = live && am < M && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        int sc = sc4 * 4;
+        int sc = sc4 * 4 + c0;
         asm volatile("" : "+v"(sc));
         px[i] = reinterpret_cast<const char*>(ok ? gin + ((size_t)((an * p.H + iy) * p.W + ix) * p.in_ld + sc) : p.zero);
         dx[i] = ok ? X_BK * 4u : 0u;
       }
     };
-    set_tap(true);
+    set_tap(true, c_first);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       pw[i] = reinterpret_cast<const char*>(wrow[i] ? wrow[i] : p.zero);
@@ -557,7 +567,7 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
     __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(WIMG ? p.wimg : nullptr), 0, 0x7fffffff, 0x00020000);
     auto dma_w = [&](int t) {
       const int tc = t < nsteps ? t : nsteps - 1;
-      const int soff0 = (((ntile * nsteps + tc) * 16 + wave * 4) * 512) * 2;      // bytes (launcher: the image is below 2 GiB)
+      const int soff0 = (((ntile * nsteps_all + t0 + tc) * 16 + wave * 4) * 512) * 2;      // bytes (launcher: the image is below 2 GiB)
       half_t* dst = wslot(t % 3) + wave * 4 * 512;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -662,6 +672,21 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
     }
     lds_barrier();
   }
+  if constexpr (KSPLIT) {      // raw partial sums of this K range; ksplit_finish32_kernel does the rest
+    float* const part = p.kpart + (size_t)blockIdx.y * M * p.Cout;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wp + j * 16 + fr;
+      if (m >= M) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = n0 + wc + i * 16 + (lane >> 4) * 4;
+        if (co < p.Cout)
+          *reinterpret_cast<float4*>(part + (size_t)m * p.Cout + co) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    return;
+  }
   // epilogue: the 16-byte form of conv16x3_kernel (the launcher sends everything else to that kernel)
   float4 bi[4];
   bool cok[4];
@@ -701,6 +726,35 @@ inline bool xs_epilogue_ok(const Conv32& p, int gco_step) {
          (!p.res || ((p.res_ld & 3) == 0 && (((uintptr_t)p.res) & 15) == 0));
 }
 
+// out = act(sum over s (ascending) of part[s] + bias + bias_n + res), four couts per thread
+template <int ACT>
+__global__ void __launch_bounds__(256) ksplit_finish32_kernel(const Conv32 p, int64_t total) {
+  const int C4 = p.Cout >> 2, HoWo = p.Ho * p.Wo;
+  const int64_t M = (int64_t)p.N * HoWo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / C4;
+    const int co = (int)(i - m * C4) * 4;
+    float4 t = *reinterpret_cast<const float4*>(p.kpart + (size_t)m * p.Cout + co);
+    for (int sidx = 1; sidx < p.ksplit; ++sidx) {
+      const float4 u = *reinterpret_cast<const float4*>(p.kpart + ((size_t)sidx * M + m) * p.Cout + co);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    if (p.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+      t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+    }
+    if (p.bias_n) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias_n + (size_t)(m / HoWo) * p.Cout + co);
+      t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+    }
+    if (p.res) {
+      const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.res_ld + co);
+      t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+    }
+    store4<ACT>(p, (int)m, co, t);
+  }
+}
+
 template <bool WPAIR, int SLOTS, bool WIMG = false>
 int launch_spec(const Conv32& p, dim3 grid, hipStream_t s) {
   constexpr int LDS = WIMG ? 4 * XS_TILE * 2 : SLOTS * XS_SLOT_HALFS * 2;      // dynamic part (WIMG: + 48 KiB static cout ring)
@@ -710,6 +764,16 @@ int launch_spec(const Conv32& p, dim3 grid, hipStream_t s) {
     EMP_LAUNCH_CHECK();
     return EMP_OK;
   };
+  if (p.ksplit > 1) {
+    if (int rc = go(&conv16x3s_kernel<0, WPAIR, SLOTS, WIMG, true>)) return rc;
+    const int64_t total = (int64_t)p.N * p.Ho * p.Wo * (p.Cout >> 2);
+    const dim3 fg((unsigned)std::min<int64_t>((total + 255) / 256, 4096));
+    if (p.act == 1) hipLaunchKernelGGL(ksplit_finish32_kernel<1>, fg, dim3(256), 0, s, p, total);
+    else if (p.act == 2) hipLaunchKernelGGL(ksplit_finish32_kernel<2>, fg, dim3(256), 0, s, p, total);
+    else hipLaunchKernelGGL(ksplit_finish32_kernel<0>, fg, dim3(256), 0, s, p, total);
+    EMP_LAUNCH_CHECK();
+    return EMP_OK;
+  }
   if (p.act == 1) return go(&conv16x3s_kernel<1, WPAIR, SLOTS, WIMG>);
   if (p.act == 2) return go(&conv16x3s_kernel<2, WPAIR, SLOTS, WIMG>);
   return go(&conv16x3s_kernel<0, WPAIR, SLOTS, WIMG>);
@@ -737,7 +801,7 @@ int launch_pair(Conv32 p, hipStream_t s) {
   const int kk = p.KH * p.KW * p.Cin;
   static const int rk = [] { const char* e = getenv("EMP_X3_RASTER_K"); return e ? atoi(e) : 256; }();
   p.x3_mtx = (nt >= 2 && kk >= rk) ? (p.x3_mt + 7) / 8 : 0;
-  const dim3 grid((unsigned)(p.x3_mtx ? 8 * p.x3_mtx * p.x3_nt : p.x3_mt * p.x3_nt), 1u, (unsigned)G);
+  dim3 grid((unsigned)(p.x3_mtx ? 8 * p.x3_mtx * p.x3_nt : p.x3_mt * p.x3_nt), 1u, (unsigned)G);
   static const int kdb = [] { const char* e = getenv("EMP_X3_KDB"); return e ? atoi(e) : 1024; }();     // K from which the two-buffer pipeline runs (measured: profiles/r05_conv16x3.txt)
   if (p.head_w) {      // fused head: one-buffer variant, ReLU (the separable head blocks: K = the decoder width)
     EMP_REQUIRE(p.head_part && p.head_c >= 1 && p.head_c <= 4 && p.act == 1 && G == 1 && !p.res && !p.bias_n && p.ps_cout == 0,
@@ -758,6 +822,22 @@ int launch_pair(Conv32 p, hipStream_t s) {
   static const int spec = [] { const char* e = getenv("EMP_X3_SPEC"); return e ? atoi(e) : 2; }();      // 0: the four-wave kernel everywhere; 2 / 3: LDS slots of the split-role kernel (A/B; 3 slots = one workgroup per CU measured slower)
   if (db && spec && bn == 128 && p.Cin % X_BK == 0 && xs_epilogue_ok(p, p.Cout)) {      // (its stagers step whole taps: Cin % 32 == 0)
     static const bool wimg_on = [] { const char* e = getenv("EMP_X3_WIMG"); return !(e && e[0] == '0'); }();      // A/B runs
+    // split-K: S workgroups per tile while S * tiles still fit the chip's 256 CUs and every one keeps >= 16 steps (a launch that
+    // fills half the chip or more gains nothing: the finish pass costs what the shorter loop saves)
+    p.ksplit = 0;
+    if (p.kpart && G == 1 && !p.out2 && spec == 2) {
+      const int wgs = (int)grid.x, nsteps = kk / X_BK;
+      static const int cap = [] { const char* e = getenv("EMP_X3_KSPLIT_WGS"); return e ? atoi(e) : 512; }();      // workgroups a split launch may reach: two per CU (A/B: 256 is 1-5 % slower at batches 1-8)
+      int S = std::min(std::min(8, cap / std::max(wgs, 1)), nsteps / 16);
+      if (S >= 2) {
+        const int per = (nsteps + S - 1) / S;
+        S = (nsteps + per - 1) / per;
+        if (S >= 2 && (int64_t)S * M * p.Cout * 4 <= p.kpart_bytes && ((uintptr_t)p.kpart & 15) == 0) {
+          p.ksplit = S; p.x3_ksteps = per;
+          grid.y = (unsigned)S;
+        }
+      }
+    }
     if (p.wimg && wimg_on && G == 1 && spec == 2 && (int64_t)nt * (kk / X_BK) * 16384 < (1ll << 31)) return launch_spec<WPAIR, 2, true>(p, grid, s);
     return spec == 3 ? launch_spec<WPAIR, 3>(p, grid, s) : launch_spec<WPAIR, 2>(p, grid, s);
   }

@@ -125,6 +125,10 @@ struct emp_pdl {
   bool x3_planes = [] { const char* e = getenv("EMP_X3_PLANES"); return !(e && e[0] == '0'); }();
   int x3_planes_min_tiles = [] { const char* e = getenv("EMP_X3_PLANES_MIN_TILES"); return e ? atoi(e) : 128; }();
   bool x3_planes_ready = false;      // set by finalize32: every layer of the region has its packed image
+  // fp16x3 mode, round 6 (late): split-K for the long-K launches that fill less than half the chip (ONE 1024^2 tile: each 3x3 ASPP branch
+  // is 64 workgroups over K = 18 432) -- Conv32::kpart; EMP_X3_KSPLIT=0: never (A/B)
+  bool x3_ksplit = [] { const char* e = getenv("EMP_X3_KSPLIT"); return !(e && e[0] == '0'); }();
+  float* x3_kpart = nullptr;      // X3_KPART_BYTES of scratch, made by finalize32
   bool x3_fuse_stem = [] { const char* e = getenv("EMP_X3_FUSE_STEM"); return !(e && e[0] == '0'); }();      // stem + max-pool as one MFMA launch (A/B)
   bool x3_merge_proj = [] { const char* e = getenv("EMP_X3_MERGE_PROJ"); return !(e && e[0] == '0'); }();      // both decoders' low-level projections as one launch (A/B)
   bool x3_merge_aspp = [] { const char* e = getenv("EMP_X3_MERGE_ASPP"); return !(e && e[0] == '0'); }();      // both decoders' ASPP branches as one launch (A/B)
@@ -1555,6 +1559,12 @@ int finalize32(emp_pdl* n) {
       for (int i = 0; i < K; ++i) w[(size_t)o * ldp + i] = hp.w[(size_t)o * K + i];
     RC32(upload_f32(n, "pr.predictor.w32", w));
   }
+  if (n->precision == 2 && n->x3_ksplit && !n->x3_kpart) {
+    void* d = nullptr;
+    EMP_CHECK_HIP(hipMalloc(&d, (size_t)X3_KPART_BYTES));
+    n->owned.push_back(d);
+    n->x3_kpart = (float*)d;
+  }
   if (n->precision == 2 && n->x3_fuse_sep) {
     // fp16x3 mode, round 6: the separable blocks' weights in the fused kernel's orders (sepconv_x3.hip)
     for (auto& kv : n->w32) {
@@ -1724,6 +1734,7 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
   p.wpair = p.x3 ? w.wp : nullptr;
   p.wimg = (p.x3 && groups <= 1) ? w.wimg : nullptr;
   p.head_w = head_w; p.head_part = head_part; p.head_c = head_c;      // (fp16x3 only: the map `out` is then not written)
+  if (p.x3 && n->x3_ksplit && n->x3_kpart && !head_w && !in2 && !out2) { p.kpart = n->x3_kpart; p.kpart_bytes = X3_KPART_BYTES; }
   if (in2) {      // K-concatenated second source (fp16x3 only: weights packed by pack32_conv3_ds)
     EMP_REQUIRE(p.x3 && w.cin2_16 > 0 && w.cin2_16 <= in2->ld && in2->N == in.N, "%s: second source mismatch", wname.c_str());
     p.in2 = in2->p; p.in2_ld = in2->ld; p.Cin2 = w.cin2_16; p.H2 = in2->H; p.W2 = in2->W; p.stride2 = stride2;

@@ -242,7 +242,10 @@ EMP_API int emp_conv2d_nhwc_f16x3(const float* d_in, int N, int H, int W, int Ci
 /* Round 6 (ABI version 5) -- every variant of the fp16x3 convolution that the network reaches and the entry above cannot
  * express, for op-level tests and tuning (replaces the same nn.Conv2d, resnet.py:109-129 / aspp.py:51-103 / heads.py:12-15):
  *   wmode    : 0 fp32 weights split in the kernel; 1 weights pre-split into fp16 pairs (what emp_pdl_finalize makes);
- *              2 pairs + the split-role kernel's LDS-DMA weight image (long K, Cin % 32 == 0)
+ *              2 pairs + the split-role kernel's LDS-DMA weight image (long K, Cin % 32 == 0);
+ *              + 4: split-K allowed -- a long-K launch of fewer than 128 workgroups (few pixels: ONE 1024^2 tile's ASPP branch) runs
+ *              S <= 8 workgroups per tile over K / S each, fp32 partial sums added in ascending order by a finish pass (what the
+ *              network does at small batches; the result differs from the unsplit one by fp32 summation order only)
  *   d_in2 .. : optional second source K-concatenated behind the first -- a 1x1 convolution of d_in2 (N, H2, W2, in2_ld) at
  *              stride2 summed into the same accumulators (a bottleneck's projection shortcut folded into conv3); d_w rows are
  *              then [KH*KW*Cin | Cin2] long

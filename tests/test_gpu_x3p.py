@@ -203,6 +203,63 @@ def test_round5_long_k_kernels_op_level(case, wmode):
     assert err < 8e-6 * scale * np.sqrt(Cin * k * k / 64.0 + 1.0), err
 
 
+KSPLIT_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, act, res, bias_n, out_fmt | (pixel tiles x cout tiles, steps) -> S x steps per split
+    (1, 16, 16, 256, 256, 3, 1, 1, 1, 1, False, False, 0),     # 2 x 2, 72 -> 4 x 18
+    (1, 20, 20, 160, 200, 3, 1, 2, 2, 0, True, True, 0),       # 4 x 2, 45 -> 2 x 23 | 22: a split starts in the middle of a tap; ragged M, Cout
+    (2, 12, 12, 2048, 256, 3, 1, 4, 4, 1, False, True, 0),     # the ASPP branch: 3 x 2, 576 -> 8 x 72, per-image bias
+    (1, 24, 24, 1024, 512, 1, 1, 0, 1, 2, True, False, 0),     # 1x1, 5 x 4, 32 -> 2 x 16, SiLU + residual
+    (1, 16, 16, 512, 256, 3, 1, 1, 1, 1, False, False, 1),     # hl32 output through the finish pass
+]
+
+
+@pytest.mark.parametrize('wmode', [0, 1, 2])
+@pytest.mark.parametrize('case', KSPLIT_CASES)
+def test_split_k_op_level(case, wmode):
+    """Round 6 (late): long-K launches of few workgroups run S workgroups per tile over K / S each (conv16x3s_kernel<KSPLIT>,
+    raw fp32 partial sums, ksplit_finish32_kernel adds them in ascending order, then bias / bias_n / residual / activation) --
+    wmode | 4.  Against fp64 within the unsplit kernels' bound, and against the unsplit launch within fp32 summation order."""
+    from gpu_common import dev
+    _abi, lib = _lib()
+    N, H, W, Cin, Cout, k, stride, pad, dil, act, res, use_bn, ofmt = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn((N, H, W, Cin), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn((Cout,), generator=g)
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    r = torch.randn((N, Ho, Wo, Cout), generator=g) if res else None
+    bn = torch.randn((N, Cout), generator=g) if use_bn else None
+    ref = _ref(x, w, b, stride, pad, dil, act, r, bn)
+    xd, bd = x.to(dev()), b.to(dev())
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(dev())
+    rd = r.to(dev()) if res else None
+    bnd = bn.to(dev()) if use_bn else None
+    ld = Cout if ofmt else Cout + 8
+    outs = []
+    for split in (4, 0):
+        out = torch.full((N, Ho, Wo, ld), 7.0, device=dev())
+        _abi.check(lib.emp_conv2d_nhwc_f16x3_ex(_abi.ptr(xd), N, H, W, Cin, Cin, _abi.ptr(wd), _abi.ptr(bd), _abi.ptr(bnd) if use_bn else None,
+                                                _abi.ptr(rd) if res else None, Cout, _abi.ptr(out), ld, ofmt, Cout, k, k, stride, pad, dil, act,
+                                                wmode | split, None, 0, 0, 0, 0, 1, None, None, 0, None, _abi.stream_ptr(dev())), 'conv16x3_ex')
+        torch.cuda.synchronize()
+        outs.append(out)
+    if ofmt:
+        f = [torch.zeros((N * Ho * Wo, Cout), device=dev()) for _ in outs]
+        for o, t in zip(outs, f):
+            _abi.check(lib.emp_hl32_to_f32(_abi.ptr(o), _abi.ptr(t), N * Ho * Wo, Cout, Cout, Cout, _abi.stream_ptr(dev())), 'hl32_to_f32')
+        torch.cuda.synchronize()
+        outs = [t.reshape(N, Ho, Wo, Cout) for t in f]
+    else:
+        assert torch.all(outs[0][..., Cout:] == 7.0), 'wrote outside its channel slice'
+    got, unsplit = (o[..., :Cout].cpu().permute(0, 3, 1, 2).double() for o in outs)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 8e-6 * scale * np.sqrt(Cin * k * k / 64.0 + 1.0)
+    d = float((got - unsplit).abs().max())
+    assert d < 4e-6 * scale, d
+    assert d > 0.0, 'the split launch ran unsplit'      # (a different summation order shows in the last bits)
+
+
 @pytest.mark.parametrize('wmode', [0, 1])
 @pytest.mark.parametrize('geom', [(2, 16, 16, 256, 1024, 512, 2), (1, 10, 14, 64, 256, 64, 1), (1, 12, 12, 512, 2048, 1024, 1)])
 def test_round5_second_source_op_level(geom, wmode):
@@ -387,7 +444,8 @@ def test_fused_fp32_stem_equals_the_two_launches(monkeypatch):
 
 @pytest.mark.parametrize('env', [{'EMP_X3_FUSE_DS': '0'}, {'EMP_X3_FUSE_HEAD': '0', 'EMP_X3_FUSE_SEP': '0'}, {'EMP_X3_FUSE_SEP': '0'},
                                  {'EMP_X3_MERGE_ASPP': '0', 'EMP_X3_MERGE_PROJ': '0'}, {'EMP_X3_FUSE_STEM': '0', 'EMP_X3P_KGROUP': '64'},
-                                 {'EMP_X3_SPEC': '0', 'EMP_X3_PLANES': '0'}, {'EMP_X3_WIMG': '0', 'EMP_X3_PLANES': '0'}])
+                                 {'EMP_X3_SPEC': '0', 'EMP_X3_PLANES': '0'}, {'EMP_X3_WIMG': '0', 'EMP_X3_PLANES': '0'},
+                                 {'EMP_X3_PLANES': '0'}, {'EMP_X3_PLANES': '0', 'EMP_X3_KSPLIT': '0'}])      # (small batches: split-K on round 5's kernels / not)
 def test_every_ab_switch_of_the_mode_stays_within_the_gate(env, monkeypatch):
     """the A/B switches of the fp16x3 mode select other kernels / launch groupings for the same arithmetic:
     with the plane region forced on at test size, every combination keeps the heads within 1e-3 (max norm) of the oracle's fp32

@@ -7,7 +7,7 @@ f = glob.glob('/tmp/xt/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # last step: find the last stem kernel
-idx = [i for i, r in enumerate(rows) if 'stem7x7' in r['Kernel_Name'] or 'stem3x3' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'stem' in r['Kernel_Name']]
 start = idx[-1]
 tot = 0
 for r in rows[start:]:
