@@ -72,6 +72,8 @@ PROTOTYPES = {
     'emp_x3p_pack_weights': (c_int, [vp, vp, c_int, c_int, vp]),
     'emp_conv2d_hl32_f16x3': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, c_int, vp, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_int, c_int, c_int, vp]),
+    'emp_conv2d_hl32_f16x3_ksplit': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp, vp, c_int, c_int, vp, c_int, c_int, vp, c_int, c_int,
+                                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, vp, c_i64, vp]),
     'emp_conv1x1_dual_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, c_int, c_int, c_int, c_int, vp, vp, vp,
                                   c_int, c_int, c_int, c_int, vp]),
     'emp_dwconv_nhwc_f16': (c_int, [vp, c_int, c_int, c_int, c_int, c_int, vp, c_int, vp, c_int, vp]),

@@ -243,6 +243,26 @@ int emp_conv2d_hl32_f16x3(const void* d_in, int N, int H, int W, int Cin, int in
   p.x3 = 1;
   return launch_conv16x3p(p, (hipStream_t)stream);
 }
+int emp_conv2d_hl32_f16x3_ksplit(const void* d_in, int N, int H, int W, int Cin, int in_ld, const void* d_wimg, const float* d_bias,
+                                 const float* d_bias_n, const void* d_res, int res_ld, int res_fmt, void* d_out, int out_ld, int out_fmt,
+                                 void* d_out2, int out2_ld, int split2, int Cout, int KH, int KW, int stride, int pad, int dil, int act,
+                                 void* d_scratch, int64_t scratch_bytes, void* stream) {
+  EMP_REQUIRE(d_in && d_wimg && d_out && d_scratch, "conv2d_hl32_f16x3_ksplit: null pointer");
+  EMP_REQUIRE(N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && stride > 0 && dil > 0 && pad >= 0, "conv2d_hl32_f16x3_ksplit: bad geometry");
+  Conv32 p{};
+  p.in = (const float*)d_in; p.in_ld = in_ld; p.in_fmt = 1; p.wimgp = (const half_t*)d_wimg;
+  p.bias = d_bias; p.bias_n = d_bias_n; p.res = (const float*)d_res; p.res_ld = res_ld; p.res_fmt = res_fmt;
+  p.out = (float*)d_out; p.out_ld = out_ld; p.out_fmt = out_fmt;
+  if (d_out2) { p.out2 = (float*)d_out2; p.out2_ld = out2_ld; p.split2 = split2; }
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.dil = dil;
+  p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  EMP_REQUIRE(p.Ho > 0 && p.Wo > 0 && out_ld >= (d_out2 ? split2 : Cout) && (d_res == nullptr || res_ld >= Cout), "conv2d_hl32_f16x3_ksplit: bad output geometry");
+  p.act = act;
+  p.x3 = 1;
+  p.kpart = (float*)d_scratch; p.kpart_bytes = scratch_bytes;
+  return launch_conv16x3p(p, (hipStream_t)stream);
+}
 
 int emp_conv2d_grouped_nhwc_f32(const float* d_in, int N, int H, int W, int groups, int cin_g, int Cin16, int in_ld, const float* d_w,
                                 const float* d_bias, float* d_out, int out_ld, int cout_g, int KH, int KW, int stride, int pad,

@@ -209,11 +209,11 @@ struct Conv32 {
   int x3p_kg;                        // conv16x3p only: the K-walk group wimgp was packed along (0: tap-major)
   // x3 only, optional (round 6, late): split-K for launches that leave most of the chip idle (a 3x3 ASPP branch of ONE 1024^2 tile is 64
   // workgroups walking K = 18 432).  kpart: scratch of kpart_bytes (>= X3_KPART_BYTES covers every launch the rule below splits);
-  // the launcher picks ksplit = S workgroups per tile (blockIdx.y), each over x3_ksteps steps of 32 K, writing raw fp32 partial sums to
+  // the launcher picks ksplit = S in {2, 4, 8} workgroups per tile (split s on the XCDs = s mod S), each over x3_ksteps steps of 32 K, writing raw fp32 partial sums to
   // kpart[(s * M + m) * Cout + co]; ksplit_finish32 adds them in ascending s, then bias / bias_n / residual / activation.
   float* kpart; int64_t kpart_bytes; int ksplit, x3_ksteps;
 };
-constexpr int64_t X3_KPART_BYTES = 32ll << 20;      // S * workgroups <= 512 tiles of 128 x 128 fp32 (the rule stops there)
+constexpr int64_t X3_KPART_BYTES = 64ll << 20;      // S * workgroups <= 512 tiles of 128 x 128 fp32 (conv16x3s) / 256 tiles of 256 x 256 (conv16x3p)
 int launch_conv32(const Conv32& p, hipStream_t s);
 int launch_conv16x3(const Conv32& p, hipStream_t s);      // called by launch_conv32 when p.x3 (its checks have run)
 int launch_split_pairs(const float* w, uint32_t* out, int64_t n, hipStream_t s);

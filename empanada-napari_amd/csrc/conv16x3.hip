@@ -425,7 +425,7 @@ constexpr int XS_SLOT_HALFS = 4 * XS_TILE;
 // hi tile and the lo tile exactly as they lie in LDS, 16 KiB contiguous) by LDS-DMA, three steps deep in a ring of their own --
 // no registers, no split, no LDS stores for half of the operand bytes, and twice the bytes in flight (finding 51: register
 // staging bounded them).  LDS then: pixel slots 2 x [Xh | Xl] + cout slots 3 x [Wh | Wl] = 80 KiB, two workgroups per CU.
-// KSPLIT (round 6, late): blockIdx.y = s walks steps [s * x3_ksteps, ...) of the K loop only and stores raw partial sums (Conv32::kpart)
+// KSPLIT (round 6, late): split s = XCD % S walks steps [s * x3_ksteps, ...) of the K loop only and stores raw partial sums (Conv32::kpart)
 template <int ACT, bool WPAIR, int XS_SLOTS, bool WIMG = false, bool KSPLIT = false>
 __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(const Conv32 p) {
   static_assert(!WIMG || XS_SLOTS == 2, "the image variant has two pixel slots");
@@ -440,8 +440,16 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool stager = wave < 4;
   const int bid = blockIdx.x, xcd = bid & 7, jj = bid >> 3;
-  const int mtile = p.x3_mtx ? xcd * p.x3_mtx + jj / p.x3_nt : bid % p.x3_mt;
-  const int ntile = p.x3_mtx ? jj % p.x3_nt : bid / p.x3_mt;
+  int mtile = p.x3_mtx ? xcd * p.x3_mtx + jj / p.x3_nt : bid % p.x3_mt;
+  int ntile = p.x3_mtx ? jj % p.x3_nt : bid / p.x3_mt;
+  int ksplit_idx = 0;
+  if constexpr (KSPLIT) {      // S in {2, 4, 8}: a split (its K range of the weights, its channel range of the map) lives on 8 / S XCDs
+    const int S = p.ksplit;
+    ksplit_idx = xcd % S;
+    const int tile = jj * (8 / S) + xcd / S;
+    mtile = tile / p.x3_nt;
+    ntile = tile - mtile * p.x3_nt;
+  }
   if (mtile >= p.x3_mt) return;
   const int m0 = mtile * 128, n0 = ntile * 128;
   const int g = blockIdx.z, gco = g * p.Cout;
@@ -450,7 +458,7 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
   const int M = p.N * HoWo;
   const int K = p.KH * p.KW * p.Cin;
   const int nsteps_all = (K + X_BK - 1) / X_BK;
-  const int t0 = KSPLIT ? (int)blockIdx.y * p.x3_ksteps : 0;                                  // first step of this workgroup
+  const int t0 = KSPLIT ? ksplit_idx * p.x3_ksteps : 0;                                       // first step of this workgroup
   const int nsteps = KSPLIT ? min(p.x3_ksteps, nsteps_all - t0) : nsteps_all;                 // ... and how many it walks
   if (stager) {
     // ---- waves 0-3: global -> registers -> split -> LDS.  Piece i of thread t = row t / 8 + 32 i, FOUR-channel chunk t % 8:
@@ -673,7 +681,7 @@ __global__ void __launch_bounds__(512, XS_SLOTS == 2 ? 4 : 2) conv16x3s_kernel(c
     lds_barrier();
   }
   if constexpr (KSPLIT) {      // raw partial sums of this K range; ksplit_finish32_kernel does the rest
-    float* const part = p.kpart + (size_t)blockIdx.y * M * p.Cout;
+    float* const part = p.kpart + (size_t)ksplit_idx * M * p.Cout;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + wp + j * 16 + fr;
@@ -826,15 +834,16 @@ int launch_pair(Conv32 p, hipStream_t s) {
     // fills half the chip or more gains nothing: the finish pass costs what the shorter loop saves)
     p.ksplit = 0;
     if (p.kpart && G == 1 && !p.out2 && spec == 2) {
-      const int wgs = (int)grid.x, nsteps = kk / X_BK;
+      const int nsteps = kk / X_BK;
       static const int cap = [] { const char* e = getenv("EMP_X3_KSPLIT_WGS"); return e ? atoi(e) : 512; }();      // workgroups a split launch may reach: two per CU (A/B: 256 is 1-5 % slower at batches 1-8)
-      int S = std::min(std::min(8, cap / std::max(wgs, 1)), nsteps / 16);
+      const int tiles = p.x3_mt * p.x3_nt;
+      int S = std::min(std::min(8, cap / std::max(tiles, 1)), nsteps / 16);
+      S = S >= 8 ? 8 : (S >= 4 ? 4 : (S >= 2 ? 2 : 0));      // (the kernel's raster: a split per 8 / S XCDs)
       if (S >= 2) {
         const int per = (nsteps + S - 1) / S;
-        S = (nsteps + per - 1) / per;
-        if (S >= 2 && (int64_t)S * M * p.Cout * 4 <= p.kpart_bytes && ((uintptr_t)p.kpart & 15) == 0) {
+        if ((S - 1) * per < nsteps && (int64_t)S * M * p.Cout * 4 <= p.kpart_bytes && ((uintptr_t)p.kpart & 15) == 0) {
           p.ksplit = S; p.x3_ksteps = per;
-          grid.y = (unsigned)S;
+          grid.x = (unsigned)(8 * ((tiles * S + 7) / 8));
         }
       }
     }

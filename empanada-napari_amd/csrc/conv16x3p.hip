@@ -55,6 +55,8 @@ struct X3P {
   int N, H, W, Cin, Cout, KH, KW, stride, pad, dil, Ho, Wo;
   int M, mt, nt, mt_per_xcd;
   int kg;      // K steps (32 channels) per K-walk group and tap: the walk is [group of kg * 32 channels][tap][step]; kg == Cin / 32: tap-major
+  int ksteps, ksplit;  // KSPLIT instantiation: ksplit = S in {2, 4, 8} workgroups per tile, split s walks K steps [s * ksteps, ...) and stores
+               // raw partial sums to out + s * M * Cout floats (ksteps a multiple of kg unless the convolution is pointwise; >= 4 steps in every split)
 };
 
 __device__ __forceinline__ int perm32b(int x) {
@@ -73,7 +75,7 @@ __device__ __forceinline__ float act_p(float x) {
 // lane (fq, fr) owns couts co0 + P * 32 + fq * 8 + [0, 8) of pixel mrow0 + q * 16 + fr (the weight rows are permuted in the
 // image, perm32b): 32 contiguous bytes of an fp32 row, or 16 B of hi and 16 B of lo inside one 32-channel block of an hl32 row
 template <int ACT, int OUTF, int RESF>      // RESF: 0 no residual, 1 fp32 rows, 2 hl32 rows
-__device__ __forceinline__ void x3p_epilogue(const X3P& p, f32x4 (&acc)[4][8], int mrow0, int co0, int fr, int fq, int HoWo) {
+__device__ __forceinline__ void x3p_epilogue(const X3P& p, void* out_base, f32x4 (&acc)[4][8], int mrow0, int co0, int fr, int fq, int HoWo) {
   // Two passes (couts P * 32 + fq * 8 + [0, 8) each).  The residual of FOUR pixel fragments at a time is requested up front --
   // 8 loads in flight per lane, in the K loop's free fragment registers -- instead of one load -> wait -> store round trip per
   // fragment: with one workgroup per CU nothing else hides that latency, and the short-K launches (conv3 of a bottleneck: 8-16 K
@@ -92,7 +94,7 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& p, f32x4 (&acc)[4][8], i
     const bool second = p.out2 && co0 >= p.split;      // (whole 256-cout tiles: wave-uniform)
     const int oc = second ? co - p.split : co;
     const int old_ = second ? p.out2_ld : p.out_ld;
-    void* const obase = second ? p.out2 : p.out;
+    void* const obase = second ? p.out2 : out_base;
     constexpr int QG = 4;      // fragments per group
 #pragma unroll
     for (int qh = 0; qh < 8 / QG; ++qh) {      // (four fragments at a time: 32 registers of residual beside the 128 accumulators)
@@ -163,13 +165,24 @@ __device__ __forceinline__ void x3p_epilogue(const X3P& p, f32x4 (&acc)[4][8], i
   }
 }
 
-template <int ACT, int OUTF, int RESF>
+template <int ACT, int OUTF, int RESF, bool KSPLIT = false>
 __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
   extern __shared__ __attribute__((aligned(1024))) char lds[];
   const int bid = blockIdx.x;
   const int xcd = bid & 7, j = bid >> 3;
-  const int mtile = xcd * p.mt_per_xcd + j / p.nt;      // XCD-aware raster: the cout tiles of a pixel tile side by side on one XCD
-  const int ntile = j % p.nt;
+  int mtile = xcd * p.mt_per_xcd + j / p.nt;      // XCD-aware raster: the cout tiles of a pixel tile side by side on one XCD
+  int ntile = j % p.nt;
+  int ksplit_idx = 0;
+  if constexpr (KSPLIT) {
+    // S in {2, 4, 8} splits: a split's workgroups share its K range of the weight image and its channel range of the map, so a
+    // split lives on 8 / S XCDs -- every XCD's L2 fetches 1 / S of the weights (with the plain raster each of the 8 L2s fetched all
+    // of them: the merged ASPP branch of one tile moved 300 MB instead of 38 and ran at a third of its MFMA rate)
+    const int S = p.ksplit, per = 8 / S;
+    ksplit_idx = xcd % S;
+    const int tile = j * per + xcd / S;
+    mtile = tile / p.nt;
+    ntile = tile - mtile * p.nt;
+  }
   if (mtile >= p.mt) return;
   const int m0 = mtile * 256, n0 = ntile * 256;
 
@@ -179,13 +192,15 @@ __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
   const int HoWo = p.Ho * p.Wo;
   const int KT = p.KH * p.KW;
   const int CB = p.Cin / KS;              // K steps per tap
-  const int KTOT = KT * CB;               // >= 4 (launcher)
+  const int KTOT_ALL = KT * CB;           // >= 4 (launcher)
+  const int t0 = KSPLIT ? ksplit_idx * p.ksteps : 0;                                    // KSPLIT: this workgroup's first K step ...
+  const int KTOT = KSPLIT ? min(p.ksteps, KTOT_ALL - t0) : KTOT_ALL;                    // ... and how many it walks (>= 4, launcher)
   const bool pointwise = (KT == 1) && p.stride == 1 && p.pad == 0;
 
   // ---- weight pieces: buffer form (descriptor + scalar piece offset + one lane-offset register) ----
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.wimg), 0, 0x7fffffff, 0x00020000);
   const int w_voff = l * 16;
-  const int w_tile0 = ntile * KTOT;
+  const int w_tile0 = ntile * KTOT_ALL + t0;
   auto dma_w = [&](int t, int hi) {      // this wave's two pieces (wave, wave + 8) of Wl(t) / Wh(t) into ring slot t & 1
     const int soff = ((w_tile0 + t) * 32 + hi * 16 + wave) * 1024;
     char* dst = lds + (hi ? WH_BASE : WL_BASE) + (t & 1) * WSLOT + wave * 1024;
@@ -209,7 +224,7 @@ __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
     a_inc[i] = 0;
     if (m < p.M) {
       if (pointwise) {
-        a_cur[i] = p.in + (size_t)m * row_halfs + pchunk * 8;
+        a_cur[i] = p.in + (size_t)m * row_halfs + pchunk * 8 + t0 * (2 * KS);
         a_inc[i] = 2 * KS;
       } else {
         const int n = m / HoWo;
@@ -224,6 +239,13 @@ __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
   }
   int x_ky = 0, x_kx = 0, x_cb = 0, x_grp = 0, x_slot = 0;
   const int KG = p.kg;
+  if constexpr (KSPLIT) {      // t0 is a multiple of KG (launcher): the walk [group][tap][step] starts a tap's group
+    const int per = KT * KG;
+    x_grp = t0 / per;
+    const int tap = (t0 - x_grp * per) / KG;
+    x_ky = tap / p.KW;
+    x_kx = tap - x_ky * p.KW;
+  }
   auto x_prep = [&]() {      // address work of the next K step's pixel pieces (in a LOAD phase, out of the MFMAs' way)
     if (x_cb == 0 && !pointwise) {
       const int dy = x_ky * p.dil, dx = x_kx * p.dil;
@@ -413,7 +435,9 @@ __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
     lds_barrier();
   }
   __builtin_amdgcn_sched_barrier(0);      // (no epilogue address arithmetic hoisted into the last K steps: it spilled there)
-  x3p_epilogue<ACT, OUTF, RESF>(p, acc, m0 + grp * 128, n0 + wc * 64, fr, fq, HoWo);
+  void* out_base = p.out;
+  if constexpr (KSPLIT) out_base = reinterpret_cast<float*>(p.out) + (size_t)ksplit_idx * p.M * p.Cout;
+  x3p_epilogue<ACT, OUTF, RESF>(p, out_base, acc, m0 + grp * 128, n0 + wc * 64, fr, fq, HoWo);
 }
 
 // [cout tile of 256][K step][part: 0 = lo, 1 = hi][piece of 16 rows][lane][8 halfs]: the bytes lane l of the wave that stages piece
@@ -501,6 +525,70 @@ __global__ void __launch_bounds__(1024) avgpool_hl32_kernel(const half_t* __rest
     __syncthreads();
   }
   if (wv == 0 && c < C) out[(size_t)n * C + c] = part[0][lane] / (float)HW;
+}
+
+// split-K finish: out = act(sum over s (ascending) of part[s] + bias + bias_n + res), eight couts per thread; c carries the
+// ORIGINAL launch's epilogue operands (p.out = the fp32 / hl32 destination), part = the KSPLIT launch's scratch [S][M][Cout]
+template <int ACT>
+__global__ void __launch_bounds__(256) x3p_finish_kernel(const X3P p, const float* __restrict__ part, int S, int out_fmt, int64_t total) {
+  const int C8 = p.Cout >> 3, HoWo = p.Ho * p.Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / C8;
+    const int co = (int)(i - m * C8) * 8;
+    float v[8];
+    {
+      const float* q = part + (size_t)m * p.Cout + co;
+      const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    for (int sidx = 1; sidx < S; ++sidx) {
+      const float* q = part + ((size_t)sidx * p.M + m) * p.Cout + co;
+      const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    if (p.bias) {
+      const float4 a = *reinterpret_cast<const float4*>(p.bias + co), b = *reinterpret_cast<const float4*>(p.bias + co + 4);
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    if (p.bias_n) {
+      const float* q = p.bias_n + (size_t)(m / HoWo) * p.Cout + co;
+      const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    if (p.res) {
+      if (p.res_fmt) {
+        const half_t* rp = reinterpret_cast<const half_t*>(p.res) + (size_t)m * (2 * p.res_ld) + (co >> 5) * 64 + (co & 31);
+        const f16x8 rh = *reinterpret_cast<const f16x8*>(rp), rl = *reinterpret_cast<const f16x8*>(rp + 32);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rh[r] + (float)rl[r];
+      } else {
+        const float* q = reinterpret_cast<const float*>(p.res) + (size_t)m * p.res_ld + co;
+        const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = act_p<ACT>(v[r]);
+    const bool second = p.out2 && co >= p.split;
+    const int oc = second ? co - p.split : co;
+    const int old_ = second ? p.out2_ld : p.out_ld;
+    void* const obase = second ? p.out2 : p.out;
+    if (out_fmt) {
+      half_t* op = reinterpret_cast<half_t*>(obase) + (size_t)m * (2 * old_) + (oc >> 5) * 64 + (oc & 31);
+      f16x8 h, lo;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        h[r] = (half_t)v[r];
+        lo[r] = (half_t)(v[r] - (float)h[r]);
+      }
+      *reinterpret_cast<f16x8*>(op) = h;
+      *reinterpret_cast<f16x8*>(op + 32) = lo;
+    } else {
+      float* op = reinterpret_cast<float*>(obase) + (size_t)m * old_ + oc;
+      *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
 }
 
 }  // namespace
@@ -597,6 +685,42 @@ int launch_conv16x3p(const Conv32& c, hipStream_t s) {
   EMP_REQUIRE((c.Cin / KS) % p.kg == 0, "conv16x3p: the walk group must divide the channel blocks");
   const int grid = 8 * p.mt_per_xcd * p.nt;
   const int act = c.act;
+  // split-K (Conv32::kpart): a long-K launch of a few pixel tiles -- the merged 3x3 ASPP branches of ONE 1024^2 tile are 32 workgroups
+  // over 576 K steps -- as S workgroups per tile while S * tiles fit the chip (one workgroup per CU), every split a multiple of the
+  // walk group and >= 8 steps; raw partial sums to the scratch, x3p_finish_kernel does the epilogue
+  if (c.kpart) {
+    const int KTOT = c.KH * c.KW * (c.Cin / KS);
+    const bool pointwise = c.KH * c.KW == 1 && c.stride == 1 && c.pad == 0;
+    const int unit = pointwise ? 1 : p.kg;
+    int S = std::min(std::min(8, 256 / std::max(p.mt * p.nt, 1)), KTOT / 8);
+    S = S >= 8 ? 8 : (S >= 4 ? 4 : (S >= 2 ? 2 : 0));      // (the kernel's raster: a split per 8 / S XCDs)
+    while (S >= 2) {
+      const int per = cdiv(cdiv(KTOT, S), unit) * unit;
+      const int last = KTOT - (S - 1) * per;
+      if (per < 8 || last < 4) { S >>= 1; continue; }      // (every split walks >= 4 steps, the last one what is left)
+      break;
+    }
+    if (S >= 2) {
+      const int per = cdiv(cdiv(KTOT, S), unit) * unit;
+      if ((int64_t)S * M * c.Cout * 4 <= c.kpart_bytes && ((uintptr_t)c.kpart % 16) == 0) {
+        X3P q = p;
+        q.bias = nullptr; q.bias_n = nullptr; q.res = nullptr; q.out2 = nullptr; q.split = 0;
+        q.out = c.kpart; q.out_ld = c.Cout;
+        q.ksteps = per; q.ksplit = S;
+        auto kern = &conv16x3p_kernel<0, 0, 0, true>;
+        if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), X3P_LDS)) return rc;
+        hipLaunchKernelGGL(kern, dim3(8 * cdiv(p.mt * p.nt * S, 8)), dim3(512), X3P_LDS, s, q);
+        EMP_LAUNCH_CHECK();
+        const int64_t total = M * (c.Cout / 8);
+        const dim3 fg((unsigned)std::min<int64_t>((total + 255) / 256, 8192));
+        if (act == 1) hipLaunchKernelGGL(x3p_finish_kernel<1>, fg, dim3(256), 0, s, p, c.kpart, S, c.out_fmt, total);
+        else if (act == 2) hipLaunchKernelGGL(x3p_finish_kernel<2>, fg, dim3(256), 0, s, p, c.kpart, S, c.out_fmt, total);
+        else hipLaunchKernelGGL(x3p_finish_kernel<0>, fg, dim3(256), 0, s, p, c.kpart, S, c.out_fmt, total);
+        EMP_LAUNCH_CHECK();
+        return EMP_OK;
+      }
+    }
+  }
   auto go = [&](auto kern) -> int {
     if (int rc = ensure_dyn_lds(reinterpret_cast<const void*>(kern), X3P_LDS)) return rc;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), X3P_LDS, s, p);

@@ -129,6 +129,7 @@ struct emp_pdl {
   // is 64 workgroups over K = 18 432) -- Conv32::kpart; EMP_X3_KSPLIT=0: never (A/B)
   bool x3_ksplit = [] { const char* e = getenv("EMP_X3_KSPLIT"); return !(e && e[0] == '0'); }();
   float* x3_kpart = nullptr;      // X3_KPART_BYTES of scratch, made by finalize32
+  bool x3_small_aspp = [] { const char* e = getenv("EMP_X3_SMALL_ASPP"); return !(e && e[0] == '0'); }();      // below the plane region's threshold the ASPP branches still run merged on the plane kernel, K-split (A/B)
   bool x3_fuse_stem = [] { const char* e = getenv("EMP_X3_FUSE_STEM"); return !(e && e[0] == '0'); }();      // stem + max-pool as one MFMA launch (A/B)
   bool x3_merge_proj = [] { const char* e = getenv("EMP_X3_MERGE_PROJ"); return !(e && e[0] == '0'); }();      // both decoders' low-level projections as one launch (A/B)
   bool x3_merge_aspp = [] { const char* e = getenv("EMP_X3_MERGE_ASPP"); return !(e && e[0] == '0'); }();      // both decoders' ASPP branches as one launch (A/B)
@@ -1734,7 +1735,7 @@ int c32(emp_pdl* n, const std::string& wname, const T32& in, int in_coff, const 
   p.wpair = p.x3 ? w.wp : nullptr;
   p.wimg = (p.x3 && groups <= 1) ? w.wimg : nullptr;
   p.head_w = head_w; p.head_part = head_part; p.head_c = head_c;      // (fp16x3 only: the map `out` is then not written)
-  if (p.x3 && n->x3_ksplit && n->x3_kpart && !head_w && !in2 && !out2) { p.kpart = n->x3_kpart; p.kpart_bytes = X3_KPART_BYTES; }
+  if (p.x3 && n->x3_ksplit && n->x3_kpart && !head_w && !in2 && (in.fmt || !out2)) { p.kpart = n->x3_kpart; p.kpart_bytes = X3_KPART_BYTES; }
   if (in2) {      // K-concatenated second source (fp16x3 only: weights packed by pack32_conv3_ds)
     EMP_REQUIRE(p.x3 && w.cin2_16 > 0 && w.cin2_16 <= in2->ld && in2->N == in.N, "%s: second source mismatch", wname.c_str());
     p.in2 = in2->p; p.in2_ld = in2->ld; p.Cin2 = w.cin2_16; p.H2 = in2->H; p.W2 = in2->W; p.stride2 = stride2;
@@ -2034,6 +2035,23 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
     const char* decs[2] = {"semantic_decoder", "instance_decoder"};
     // plane region: branch i of BOTH decoders as one launch (weights stacked along Cout at finalize, two destinations)
     const bool merged_aspp = p5.fmt && c.ins_decoder && n->w32.count("decoders.aspp.convs.0.0") && n->w32.count("decoders.aspp.convs.3.0");
+    // below the plane region's threshold (small batches; round 6, late): the branches still run merged on the plane kernel -- K-split
+    // (Conv32::kpart: 32 workgroups x 8 splits for ONE 1024^2 tile) -- from an hl32 copy of p5, into fp32 concat buffers
+    bool small_aspp = false;
+    if (!p5.fmt && n->precision == 2 && n->x3_planes_ready && n->x3_ksplit && n->x3_small_aspp && n->x3_kpart && c.ins_decoder &&
+        n->w32.count("decoders.aspp.convs.0.0") && n->w32.count("decoders.aspp.convs.3.0") && p5.C % 32 == 0) {
+      small_aspp = true;
+      RC32(mk("p5.hl32", p5.H, p5.W, p5.C, 1));
+      const T32& ph = A("p5.hl32");
+      RC32(launch_hl32_from_f32(p5.p, reinterpret_cast<half_t*>(ph.p), (int64_t)N * p5.H * p5.W, p5.C, p5.ld, ph.ld, s));
+      for (int d = 0; d < 2; ++d) RC32(mk(std::string(decs[d]) + ".aspp.cat", p5.H, p5.W, 4 * n->aspp_ch, 0));
+      const T32 &c0 = A("semantic_decoder.aspp.cat"), &c1 = A("instance_decoder.aspp.cat");
+      for (int i = 0; i <= 3; ++i) {
+        const int r = i ? c.atrous_rates[i - 1] : 1;
+        RC32(c32(n, "decoders.aspp.convs." + std::to_string(i) + ".0", ph, 0, c0, i * n->aspp_ch, 1, i ? r : 0, r, 1, nullptr, nullptr, s, 0, 1,
+                 nullptr, nullptr, 0, nullptr, 1, &c1, i * n->aspp_ch, n->aspp_ch));
+      }
+    }
     if (merged_aspp) {
       for (int d = 0; d < 2; ++d) RC32(mk(std::string(decs[d]) + ".aspp.cat", p5.H, p5.W, 4 * n->aspp_ch, 1));
       const T32 &c0 = A("semantic_decoder.aspp.cat"), &c1 = A("instance_decoder.aspp.cat");
@@ -2072,7 +2090,7 @@ int run32(emp_pdl* n, const void* img, int dtype, float sub, float mul, int N, i
       RC32(buf32(n, p + ".bias_n", (size_t)N * n->aspp_ch, &bias_n));
       RC32(launch_gemv(pooled, N, p5.C, n->f32w.at(p + ".pool.w"), nullptr, n->aspp_ch, 1, poolfeat, s));
       RC32(launch_gemv(poolfeat, N, n->aspp_ch, n->f32w.at(p + ".projpool.w"), nullptr, n->aspp_ch, 0, bias_n, s));
-      if (!merged_aspp) {
+      if (!merged_aspp && !small_aspp) {
         RC32(mk(p + ".aspp.cat", p5.H, p5.W, 4 * n->aspp_ch, p5.fmt));      // (the projection reads it as it was written; its output is fp32: the up-sampler's input)
         RC32(c32(n, p + ".aspp.convs.0.0", p5, 0, A(p + ".aspp.cat"), 0, 1, 0, 1, 1, nullptr, nullptr, s));
         for (int i = 1; i <= 3; ++i) {

@@ -251,7 +251,9 @@ class Engine2d:
         ``batch`` images per forward; the next batch's upload (pinned staging buffer, copy stream) and the previous
         batch's int32 label maps going back (second copy stream, straight into one pinned result block) overlap the
         current batch's forward + voting + merge + force_connected.  Returns a list of int32 (h,w) arrays (views of
-        that block).  Bit-identical to the per-image calls (batch invariance, DESIGN.md finding 13)."""
+        that block).  On the fp16 engine bit-identical to the per-image calls (batch invariance, DESIGN.md finding 13); in the
+        default fp16x3 precision the kernels a layer runs on depend on the batch (hl32 plane region from 128 pixel tiles, split-K
+        below half the chip), so the float heads of a tile agree between batch sizes to fp32 rounding (~1e-6), not to the bit."""
         from .preprocess import normalize_params
         images = list(images)
         if not images:
@@ -355,7 +357,8 @@ class Engine2d:
         """inference.py:283-318: per tile engine call -> RLE on the GPU -> image frame -> tile consensus -> dense.
         The tile rectangles come from ``tile.Tiler`` (cztile stand-in, parity unpinned).  The tiles have one size, so for
         raw integer images at native scale they go through the engine in batches (``batched``; same label maps as the
-        per-tile calls -- batch invariance) and the dense -> RLE step runs on a whole batch."""
+        per-tile calls on the fp16 engine -- batch invariance; fp16x3: heads to fp32 rounding, see infer_batch) and the dense -> RLE
+        step runs on a whole batch."""
         from .tile import Tiler
         tiler = Tiler(image.shape, tile_size=self.tile_size, overlap_width=min(128, int(self.tile_size * 0.1)))
         self.last_tiler = tiler

@@ -283,6 +283,18 @@ EMP_API int emp_conv2d_hl32_f16x3(const void* d_in, int N, int H, int W, int Cin
                         const void* d_res, int res_ld, int res_fmt,
                         void* d_out, int out_ld, int out_fmt, int Cout,
                         int KH, int KW, int stride, int pad, int dil, int act, void* stream);
+/* The same convolution with split-K allowed (what the network does below the plane region's batch threshold: the merged 3x3 ASPP
+ * branches of ONE 1024^2 tile are 32 workgroups over 576 K steps): with d_scratch of scratch_bytes (S * M * Cout * 4 needed; 64 MiB
+ * covers every launch the rule splits) a launch of fewer than 128 workgroups runs S <= 8 workgroups per tile over K / S each (raw fp32
+ * partial sums), and a finish pass adds them in ascending order, then bias / bias_n / residual / activation -- the unsplit result up to
+ * fp32 summation order.  d_out2 (optional): couts [split2, Cout) go there (split2 % 256 == 0), as the network's merged launches.
+ * Launches the rule does not split run exactly as emp_conv2d_hl32_f16x3.  No allocation, no synchronisation. */
+EMP_API int emp_conv2d_hl32_f16x3_ksplit(const void* d_in, int N, int H, int W, int Cin, int in_ld,
+                        const void* d_wimg, const float* d_bias, const float* d_bias_n,
+                        const void* d_res, int res_ld, int res_fmt,
+                        void* d_out, int out_ld, int out_fmt, void* d_out2, int out2_ld, int split2, int Cout,
+                        int KH, int KW, int stride, int pad, int dil, int act,
+                        void* d_scratch, int64_t scratch_bytes, void* stream);
 
 /* Round 6 -- the depthwise-separable block of the fp16x3 mode as ONE launch (csrc/sepconv_x3.hip): replaces
  * nn.Conv2d(C,C,k,groups=C,padding=k/2,bias=False) -> nn.Conv2d(C,Cout,1) -> folded BatchNorm -> ReLU / SiLU (models/blocks.py:15-33;

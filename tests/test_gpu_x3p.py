@@ -146,6 +146,79 @@ def test_conv16x3p_equals_fp64_and_round5_kernels_bit_for_bit(case):
         assert torch.equal(got, o5), f'{int((got != o5).sum())} of {got.numel()} values differ from the round-5 kernel'
 
 
+X3P_KSPLIT_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, act, res, bias_n, out_fmt, split2 | (tiles, K steps) -> S x steps per split
+    (1, 16, 16, 2048, 512, 3, 1, 4, 4, 1, '', False, 0, 256),     # the merged ASPP branch: 1 x 2, 576 -> 8 x 72, two fp32 destinations
+    (2, 16, 16, 512, 256, 3, 1, 2, 2, 1, 'hl32', False, 1, 0),    # 2 x 1, 144 -> 8 x 18, hl32 residual + hl32 output through the finish pass
+    (1, 20, 20, 1024, 256, 1, 1, 0, 1, 2, 'f32', True, 0, 0),     # pointwise (linear walk, any split boundary): 2 x 1, 32 -> 4 x 8; ragged M
+    (1, 24, 24, 96, 256, 3, 1, 1, 1, 0, '', True, 1, 0),          # 3 x 1, 27 steps (tap-major: whole taps) -> 3 x 9
+]
+
+
+@pytest.mark.parametrize('case', X3P_KSPLIT_CASES)
+def test_conv16x3p_split_k_op_level(case):
+    """Round 6 (late): the plane kernel with a K range per workgroup (conv16x3p_kernel<0, 0, 0, KSPLIT>: raw fp32 partial sums to a
+    scratch; x3p_finish_kernel: ascending sum + bias / bias_n / residual / activation, fp32 or hl32 rows, optional second destination)
+    through emp_conv2d_hl32_f16x3_ksplit: against fp64, and against the unsplit launch within fp32 summation order."""
+    from gpu_common import dev
+    _abi, lib = _lib()
+    N, H, W, Cin, Cout, k, stride, pad, dil, act, res, use_bn, out_fmt, split2 = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn((N, H, W, Cin), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn((Cout,), generator=g)
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    r = torch.randn((N, Ho, Wo, Cout), generator=g) if res else None
+    bn = torch.randn((N, Cout), generator=g) if use_bn else None
+    xd, bd = x.to(dev()), b.to(dev())
+    wd = w.permute(0, 2, 3, 1).reshape(Cout, k * k * Cin).contiguous().to(dev())
+    rd = r.to(dev()) if res else None
+    bnd = bn.to(dev()) if use_bn else None
+    K = k * k * Cin
+    img = torch.zeros((2 * Cout * K,), dtype=torch.float16, device=dev())
+    _abi.check(lib.emp_x3p_pack_weights(_abi.ptr(wd), _abi.ptr(img), Cout, K, _abi.stream_ptr(dev())), 'x3p_pack')
+    xh = _to_hl32(xd)
+    rh = _to_hl32(rd) if res == 'hl32' else rd
+    r_seen = _from_hl32(rh, Cout).reshape(N, Ho, Wo, Cout).cpu() if res == 'hl32' else r
+    M = N * Ho * Wo
+    scratch = torch.zeros((16 << 20,), device=dev())      # 64 MiB
+    c0 = split2 or Cout
+
+    def run(split):
+        if out_fmt:
+            o = torch.full((M, 2 * (c0 + 32)), 7.0, dtype=torch.float16, device=dev())
+            o2 = torch.full((M, 2 * (Cout - c0 + 32)), 7.0, dtype=torch.float16, device=dev())
+            ld, ld2 = c0 + 32, Cout - c0 + 32
+        else:
+            o = torch.full((M, c0 + 8), 7.0, device=dev())
+            o2 = torch.full((M, Cout - c0 + 8), 7.0, device=dev())
+            ld, ld2 = c0 + 8, Cout - c0 + 8
+        _abi.check(lib.emp_conv2d_hl32_f16x3_ksplit(
+            _abi.ptr(xh), N, H, W, Cin, Cin, _abi.ptr(img), _abi.ptr(bd), _abi.ptr(bnd) if use_bn else None, _abi.ptr(rh) if res else None, Cout,
+            1 if res == 'hl32' else 0, _abi.ptr(o), ld, out_fmt, _abi.ptr(o2) if split2 else None, ld2, split2, Cout, k, k, stride, pad, dil, act,
+            _abi.ptr(scratch), scratch.numel() * 4 if split else 0, _abi.stream_ptr(dev())), 'conv16x3p ksplit')
+        torch.cuda.synchronize()
+        parts = []
+        for t, c, l in ((o, c0, ld), (o2, Cout - c0, ld2)):
+            if not c:
+                continue
+            if out_fmt:
+                assert torch.all(t[:, 2 * c:] == 7.0), 'wrote outside its channel slice'
+                parts.append(_from_hl32(t, c, ld=l))
+            else:
+                assert torch.all(t[:, c:] == 7.0), 'wrote outside its channel slice'
+                parts.append(t[:, :c])
+        return torch.cat(parts, 1).reshape(N, Ho, Wo, Cout).cpu()
+
+    got, unsplit = run(True), run(False)      # (scratch_bytes = 0: the rule cannot split -> the plain launch)
+    ref = _ref(x, w, b, stride, pad, dil, act, r_seen, bn).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) < 8e-6 * scale * np.sqrt(K / 64.0 + 1.0) + (2.0 ** -21 * scale if out_fmt else 0.0)
+    d = float((got - unsplit).abs().max())
+    assert 0.0 < d < 4e-6 * scale, d      # another summation order of the same terms (> 0: the split launch really ran)
+
+
 def test_conv16x3p_refuses_what_it_cannot_take():
     from gpu_common import dev
     _abi, lib = _lib()
@@ -445,7 +518,8 @@ def test_fused_fp32_stem_equals_the_two_launches(monkeypatch):
 @pytest.mark.parametrize('env', [{'EMP_X3_FUSE_DS': '0'}, {'EMP_X3_FUSE_HEAD': '0', 'EMP_X3_FUSE_SEP': '0'}, {'EMP_X3_FUSE_SEP': '0'},
                                  {'EMP_X3_MERGE_ASPP': '0', 'EMP_X3_MERGE_PROJ': '0'}, {'EMP_X3_FUSE_STEM': '0', 'EMP_X3P_KGROUP': '64'},
                                  {'EMP_X3_SPEC': '0', 'EMP_X3_PLANES': '0'}, {'EMP_X3_WIMG': '0', 'EMP_X3_PLANES': '0'},
-                                 {'EMP_X3_PLANES': '0'}, {'EMP_X3_PLANES': '0', 'EMP_X3_KSPLIT': '0'}])      # (small batches: split-K on round 5's kernels / not)
+                                 {'EMP_X3_PLANES': '0'}, {'EMP_X3_PLANES': '0', 'EMP_X3_KSPLIT': '0'},      # (small batches: split-K on round 5's kernels / not)
+                                 {'EMP_X3_PLANES_MIN_TILES': '100000'}, {'EMP_X3_PLANES_MIN_TILES': '100000', 'EMP_X3_SMALL_ASPP': '0'}])      # (below the threshold: ASPP merged + K-split on the plane kernel / not)
 def test_every_ab_switch_of_the_mode_stays_within_the_gate(env, monkeypatch):
     """the A/B switches of the fp16x3 mode select other kernels / launch groupings for the same arithmetic:
     with the plane region forced on at test size, every combination keeps the heads within 1e-3 (max norm) of the oracle's fp32

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/xt
-rocprofv3 --kernel-trace --output-format csv -d /tmp/xt -o xt -- python3 $GRAFT_REPO_ROOT/tools/precision_profile.py fp16x3 ${1:-16} 2 ${2:-pdl} > /tmp/xt.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/xt -o xt -- python3 $GRAFT_REPO_ROOT/tools/precision_profile.py ${PREC:-fp16x3} ${1:-16} 2 ${2:-pdl} > /tmp/xt.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/xt/**/*kernel_trace.csv', recursive=True)[0]
