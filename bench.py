@@ -242,6 +242,20 @@ def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3, precisi
         torch.cuda.synchronize()
         res['latency_ms_batch1'] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
         del step1
+        try:      # the API level in the default precision: host uint8 tiles -> int32 numpy label maps (the line's engine2d_tiles_per_s, fp16x3)
+            from empanada_napari_amd.inference import Engine2d
+            mc = {'model': m32, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
+                  'norms': {'mean': 0.57571, 'std': 0.12765}}
+            e2 = Engine2d(mc, label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5, device=dev)
+            imgs = [host_tiles[i % len(host_tiles)] for i in range(batch * 8)]
+            e2.infer_batch(imgs[:2 * batch], batch=batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e2.infer_batch(imgs, batch=batch)
+            res['engine2d_tiles_per_s'] = round(len(imgs) / (time.perf_counter() - t0), 2)
+            del e2
+        except Exception as e:      # noqa: BLE001
+            res['engine2d_tiles_per_s'] = {'error': f'{type(e).__name__}: {e}'}
     if stack3d:      # the 3-D half of the metric in this precision (the same job as the line's `stack3d` block, no CPU leg)
         try:
             j3 = stack3d_line(m32, stack3d, with_cpu=False)
