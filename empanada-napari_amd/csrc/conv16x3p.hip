@@ -56,7 +56,7 @@ struct X3P {
   int M, mt, nt, mt_per_xcd;
   int kg;      // K steps (32 channels) per K-walk group and tap: the walk is [group of kg * 32 channels][tap][step]; kg == Cin / 32: tap-major
   int ksteps, ksplit;  // KSPLIT instantiation: ksplit = S in {2, 4, 8} workgroups per tile, split s walks K steps [s * ksteps, ...) and stores
-               // raw partial sums to out + s * M * Cout floats (ksteps a multiple of kg unless the convolution is pointwise; >= 4 steps in every split)
+               // raw partial sums to out + s * M * Cout floats (>= 4 steps in every split)
 };
 
 __device__ __forceinline__ int perm32b(int x) {
@@ -239,12 +239,25 @@ __global__ void __launch_bounds__(512, 1) conv16x3p_kernel(const X3P p) {
   }
   int x_ky = 0, x_kx = 0, x_cb = 0, x_grp = 0, x_slot = 0;
   const int KG = p.kg;
-  if constexpr (KSPLIT) {      // t0 is a multiple of KG (launcher): the walk [group][tap][step] starts a tap's group
+  if constexpr (KSPLIT) {      // step t0 of the walk [group][tap][step]: its group, tap and step inside the tap's group
     const int per = KT * KG;
     x_grp = t0 / per;
-    const int tap = (t0 - x_grp * per) / KG;
+    const int idx = t0 - x_grp * per;
+    const int tap = idx / KG;
+    x_cb = idx - tap * KG;
     x_ky = tap / p.KW;
     x_kx = tap - x_ky * p.KW;
+    if (x_cb != 0 && !pointwise) {      // the split starts inside a tap's group: x_prep computes addresses at x_cb == 0 only
+      const int dy = x_ky * p.dil, dx = x_kx * p.dil;
+      const int c0 = (x_grp * KG + x_cb) * (2 * KS) + pchunk * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        a_cur[i] = ok ? p.in + ((size_t)(a_pix[i] + iy * p.W + ix) * row_halfs + c0) : p.zero;
+        a_inc[i] = ok ? 2 * KS : 0;
+      }
+    }
   }
   auto x_prep = [&]() {      // address work of the next K step's pixel pieces (in a LOAD phase, out of the MFMAs' way)
     if (x_cb == 0 && !pointwise) {
@@ -686,12 +699,10 @@ int launch_conv16x3p(const Conv32& c, hipStream_t s) {
   const int grid = 8 * p.mt_per_xcd * p.nt;
   const int act = c.act;
   // split-K (Conv32::kpart): a long-K launch of a few pixel tiles -- the merged 3x3 ASPP branches of ONE 1024^2 tile are 32 workgroups
-  // over 576 K steps -- as S workgroups per tile while S * tiles fit the chip (one workgroup per CU), every split a multiple of the
-  // walk group and >= 8 steps; raw partial sums to the scratch, x3p_finish_kernel does the epilogue
+  // over 576 K steps -- as S workgroups per tile while S * tiles fit the chip (one workgroup per CU), every split >= 8 steps; raw partial sums to the scratch, x3p_finish_kernel does the epilogue
   if (c.kpart) {
     const int KTOT = c.KH * c.KW * (c.Cin / KS);
-    const bool pointwise = c.KH * c.KW == 1 && c.stride == 1 && c.pad == 0;
-    const int unit = pointwise ? 1 : p.kg;
+    const int unit = 1;      // (a split may start anywhere in the walk)
     int S = std::min(std::min(8, 256 / std::max(p.mt * p.nt, 1)), KTOT / 8);
     S = S >= 8 ? 8 : (S >= 4 ? 4 : (S >= 2 ? 2 : 0));      // (the kernel's raster: a split per 8 / S XCDs)
     while (S >= 2) {

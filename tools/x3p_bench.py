@@ -79,6 +79,15 @@ def main():
             _abi.check(lib.emp_conv2d_hl32_f16x3(_abi.ptr(xh), B, H, W, Cin, Cin, _abi.ptr(img), _abi.ptr(b), None, _abi.ptr(rh) if res else None,
                                                  Cout, 1, _abi.ptr(outh), Cout, 1, Cout, k_, k_, s, p, d, 1, st), 'x3p')
 
+        scratch = torch.empty((16 << 20,), device=dev) if os.environ.get('X3P_KSPLIT') else None
+
+        def new_split():
+            _abi.check(lib.emp_conv2d_hl32_f16x3_ksplit(_abi.ptr(xh), B, H, W, Cin, Cin, _abi.ptr(img), _abi.ptr(b), None, _abi.ptr(rh) if res else None,
+                                                        Cout, 1, _abi.ptr(outh), Cout, 1, None, 0, 0, Cout, k_, k_, s, p, d, 1, _abi.ptr(scratch),
+                                                        scratch.numel() * 4, st), 'x3p ksplit')
+        if scratch is not None:
+            new = new_split      # noqa: F811  (X3P_KSPLIT=1: the split-K entry; the launcher's rule decides whether a shape splits)
+
         def old():
             _abi.check(lib.emp_conv2d_nhwc_f16x3(_abi.ptr(x), B, H, W, Cin, Cin, _abi.ptr(w), _abi.ptr(b), None, _abi.ptr(r32) if res else None,
                                                  Cout, _abi.ptr(out32), Cout, Cout, k_, k_, s, p, d, 1, 1, 0, st), 'x3')
