@@ -837,8 +837,11 @@ int launch_pair(Conv32 p, hipStream_t s) {
       const int nsteps = kk / X_BK;
       static const int cap = [] { const char* e = getenv("EMP_X3_KSPLIT_WGS"); return e ? atoi(e) : 512; }();      // workgroups a split launch may reach: two per CU (A/B: 256 is 1-5 % slower at batches 1-8)
       const int tiles = p.x3_mt * p.x3_nt;
-      int S = std::min(std::min(8, cap / std::max(tiles, 1)), nsteps / 16);
+      static const int min_per = [] { const char* e = getenv("EMP_X3_KSPLIT_PER"); return e ? std::max(atoi(e), 4) : 16; }();      // steps a split keeps at least (A/B)
+      int S = std::min(std::min(8, cap / std::max(tiles, 1)), nsteps / min_per);
       S = S >= 8 ? 8 : (S >= 4 ? 4 : (S >= 2 ? 2 : 0));      // (the kernel's raster: a split per 8 / S XCDs)
+      static const int min_steps = [] { const char* e = getenv("EMP_X3_KSPLIT_MINSTEPS"); return e ? atoi(e) : 32; }();      // (A/B: 40 and 64 are 3 % slower at one tile per call)
+      if (nsteps < min_steps) S = 0;
       if (S >= 2) {
         const int per = (nsteps + S - 1) / S;
         if ((S - 1) * per < nsteps && (int64_t)S * M * p.Cout * 4 <= p.kpart_bytes && ((uintptr_t)p.kpart & 15) == 0) {

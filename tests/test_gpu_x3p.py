@@ -281,7 +281,7 @@ KSPLIT_CASES = [
     (1, 16, 16, 256, 256, 3, 1, 1, 1, 1, False, False, 0),     # 2 x 2, 72 -> 4 x 18
     (1, 20, 20, 160, 200, 3, 1, 2, 2, 0, True, True, 0),       # 4 x 2, 45 -> 2 x 23 | 22: a split starts in the middle of a tap; ragged M, Cout
     (2, 12, 12, 2048, 256, 3, 1, 4, 4, 1, False, True, 0),     # the ASPP branch: 3 x 2, 576 -> 8 x 72, per-image bias
-    (1, 24, 24, 1024, 512, 1, 1, 0, 1, 2, True, False, 0),     # 1x1, 5 x 4, 32 -> 2 x 16, SiLU + residual
+    (1, 24, 24, 1024, 512, 1, 1, 0, 1, 2, True, False, 0),     # 1x1, 5 x 4, 32 (the shortest K the rule splits) -> 2 x 16, SiLU + residual
     (1, 16, 16, 512, 256, 3, 1, 1, 1, 1, False, False, 1),     # hl32 output through the finish pass
 ]
 
