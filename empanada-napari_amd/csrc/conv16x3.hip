@@ -807,7 +807,7 @@ int launch_pair(Conv32 p, hipStream_t s) {
   p.x3_mt = (int)((M + 127) / 128);
   p.x3_nt = (int)nt;
   const int kk = p.KH * p.KW * p.Cin;
-  static const int rk = [] { const char* e = getenv("EMP_X3_RASTER_K"); return e ? atoi(e) : 256; }();
+  static const int rk = [] { const char* e = getenv("EMP_X3_RASTER_K"); return e ? atoi(e) : 64; }();      // (round 6: 64 instead of 256 -- +0.3-1 % at batch 16, neutral below)
   p.x3_mtx = (nt >= 2 && kk >= rk) ? (p.x3_mt + 7) / 8 : 0;
   dim3 grid((unsigned)(p.x3_mtx ? 8 * p.x3_mtx * p.x3_nt : p.x3_mt * p.x3_nt), 1u, (unsigned)G);
   static const int kdb = [] { const char* e = getenv("EMP_X3_KDB"); return e ? atoi(e) : 1024; }();     // K from which the two-buffer pipeline runs (measured: profiles/r05_conv16x3.txt)
