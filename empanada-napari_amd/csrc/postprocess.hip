@@ -217,10 +217,74 @@ __global__ void __launch_bounds__(256) centers_kernel(const uint32_t* __restrict
 // wins ties; K > 20 reproduces the chunked path's 1e5 initial distance.
 // ---------------------------------------------------------------------------
 constexpr int CTR_TILE = 1024;
+
+// ---- dense scenes (round 6, late): a uniform grid over the centres ----------------------------------------------------
+// The scan below costs pixels x centres: a 4096^2 slice of BASELINE configs[3] with 4 276 objects is 4.5 ms of voting next to a
+// 12 ms forward.  From GRID_MIN centres per image the centres are binned (bins of B x B in the scaled coordinates, B a power of two
+// with ~2+ centres per bin and at most GRID_BINS bins) and a pixel searches the rings of bins around its voted position outwards
+// until the next ring cannot hold a centre at the best distance found.  The RESULT IS THE SCAN'S, bit for bit: the same fp32
+// expressions per candidate, the winner = the lowest index among the candidates of minimal ROUNDED distance below the 1e5
+// start value (the scan's strict '<' in index order), and a ring is skipped only when its exact lower bound on the distance
+// exceeds the best fp32 sum by more than the arithmetic's rounding (a relative 4e-6 against ~3e-7).  Non-finite votes keep id 0
+// as in the scan.  Per image in the work buffer: hdr {log2 B, GH, GW, used} | bin_start[GRID_BINS + 1] | sorted {cy, cx, id, -}[GRID_KMAX].
+constexpr int GRID_MIN = 192, GRID_KMAX = 16384, GRID_BINS = 4096;
+constexpr size_t GRID_HDR_INTS = 4 + GRID_BINS + 4;      // hdr | bin_start (+ pad to 16 B)
+constexpr size_t GRID_IMG_BYTES = GRID_HDR_INTS * 4 + (size_t)GRID_KMAX * 16;
+
+__global__ void __launch_bounds__(1024) ctr_grid_build_kernel(const int32_t* __restrict__ centers, const int32_t* __restrict__ num,
+                                                              int max_centers, int step, int Hs, int Ws, char* __restrict__ gridbuf) {
+  __shared__ int cnt[GRID_BINS];
+  __shared__ uint32_t sh[16];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  int K = num[n];
+  K = K < max_centers ? K : max_centers;
+  int* hdr = reinterpret_cast<int*>(gridbuf + (size_t)n * GRID_IMG_BYTES);
+  if (K < GRID_MIN || K > GRID_KMAX) {
+    if (tid == 0) hdr[3] = 0;
+    return;
+  }
+  int lb = 4;
+  while ((int64_t)((Hs + (1 << lb) - 1) >> lb) * ((Ws + (1 << lb) - 1) >> lb) > GRID_BINS || ((int64_t)K << (2 * lb)) < 2ll * Hs * Ws) ++lb;
+  const int GH = (Hs + (1 << lb) - 1) >> lb, GW = (Ws + (1 << lb) - 1) >> lb, nb = GH * GW;
+  int* start = hdr + 4;
+  float4* sorted = reinterpret_cast<float4*>(hdr + GRID_HDR_INTS);
+  const int32_t* cn = centers + (size_t)n * max_centers * 2;
+  for (int b = tid; b < GRID_BINS; b += 1024) cnt[b] = 0;
+  __syncthreads();
+  for (int k = tid; k < K; k += 1024) atomicAdd(&cnt[((cn[2 * k] * step) >> lb) * GW + ((cn[2 * k + 1] * step) >> lb)], 1);
+  __syncthreads();
+  // exclusive scan over the bins: four consecutive bins per thread, a block scan of the per-thread sums
+  const int b0 = tid * 4;
+  int c[4], tsum = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { c[e] = cnt[b0 + e]; tsum += c[e]; }
+  const int lane = tid & 63, wv = tid >> 6;
+  uint32_t inc = wave_incl_scan((uint32_t)tsum, lane);
+  if (lane == 63) sh[wv] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int e = 0; e < wv; ++e) base += sh[e];
+  int pos = (int)(base + inc) - tsum;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (b0 + e < nb) start[b0 + e] = pos;
+    cnt[b0 + e] = pos;                          // the bin's write cursor
+    pos += c[e];
+  }
+  if (tid == 0) { hdr[0] = lb; hdr[1] = GH; hdr[2] = GW; hdr[3] = 1; start[nb] = K; }
+  __syncthreads();
+  for (int k = tid; k < K; k += 1024) {
+    const int cyi = cn[2 * k] * step, cxi = cn[2 * k + 1] * step;
+    const int at = atomicAdd(&cnt[(cyi >> lb) * GW + (cxi >> lb)], 1);      // (order inside a bin is free: ties go by the stored id)
+    sorted[at] = make_float4((float)cyi, (float)cxi, __int_as_float(k + 1), 0.f);
+  }
+}
+
 __global__ void __launch_bounds__(256) group_pixels_kernel(const float* __restrict__ offsets, int h, int w,
                                                            const int32_t* __restrict__ centers,
                                                            const int32_t* __restrict__ num, int max_centers, int step,
-                                                           int up, int32_t* __restrict__ cells) {
+                                                           int up, int32_t* __restrict__ cells, const char* __restrict__ gridbuf) {
   __shared__ float cy[CTR_TILE], cx[CTR_TILE];
   const int n = blockIdx.y;
   const int hw = h * w;
@@ -234,6 +298,53 @@ __global__ void __launch_bounds__(256) group_pixels_kernel(const float* __restri
     const float* off = offsets + (size_t)n * 2 * hw;
     ly = (float)(y * step) + off[i];
     lx = (float)(x * step) + off[hw + i];
+  }
+  const int* ghdr = gridbuf ? reinterpret_cast<const int*>(gridbuf + (size_t)n * GRID_IMG_BYTES) : nullptr;
+  if (ghdr && ghdr[3]) {      // (block-uniform: one image per blockIdx.y)
+    if (!active) return;
+    int id = 0;
+    if (ly - ly == 0.f && lx - lx == 0.f) {      // finite votes only: a NaN / inf vote matches no centre in the scan either
+      const int lb = ghdr[0], GH = ghdr[1], GW = ghdr[2];
+      const int* start = ghdr + 4;
+      const float4* sorted = reinterpret_cast<const float4*>(ghdr + GRID_HDR_INTS);
+      const int Hs = h * step, Ws = w * step;
+      const int by = (int)floorf(fminf(fmaxf(ly, 0.f), (float)(Hs - 1))) >> lb;
+      const int bx = (int)floorf(fminf(fmaxf(lx, 0.f), (float)(Ws - 1))) >> lb;
+      float best = 1e5f, best_s = 1e10f, best_hi = 1e10f * 1.000004f;
+      auto scan = [&](int a, int b) {
+        for (int t = a; t < b; ++t) {
+          const float4 c = sorted[t];
+          const float dy = c.x - ly, dx = c.y - lx;
+          const float dy2 = dy * dy;
+          const float s2 = __builtin_fmaf(dx, dx, dy2);
+          if (s2 > best_hi) continue;
+          const float d = __builtin_sqrtf(s2);
+          const int idx = __float_as_int(c.z);
+          if (d < best || (d == best && idx < id)) { best = d; best_s = s2; best_hi = s2 * 1.000004f; id = idx; }
+        }
+      };
+      for (int r = 0;; ++r) {
+        const int y0 = by - r, y1 = by + r, x0 = bx - r, x1 = bx + r;
+        if (y0 < 0 && y1 >= GH && x0 < 0 && x1 >= GW) break;      // the ring lies outside the grid: every bin has been seen
+        const int xa = x0 > 0 ? x0 : 0, xb = x1 < GW - 1 ? x1 : GW - 1;
+        if (y0 >= 0) scan(start[y0 * GW + xa], start[y0 * GW + xb + 1]);                 // top row of the ring: contiguous bins
+        if (r > 0 && y1 < GH) scan(start[y1 * GW + xa], start[y1 * GW + xb + 1]);        // bottom row
+        const int ya = y0 + 1 > 0 ? y0 + 1 : 0, yb = y1 - 1 < GH - 1 ? y1 - 1 : GH - 1;
+        for (int yy = ya; yy <= yb; ++yy) {                                              // the two side bins of the inner rows
+          if (x0 >= 0) scan(start[yy * GW + x0], start[yy * GW + x0 + 1]);
+          if (x1 < GW) scan(start[yy * GW + x1], start[yy * GW + x1 + 1]);
+        }
+        // a centre of ring r + 1 or beyond is at least r * B away from the (clamped) vote along one axis
+        const float lbn = (float)(r << lb);
+        if (lbn * lbn * (1.f - 4e-6f) > best_s) break;
+      }
+      (void)best_s;
+    }
+    const int W = w * up;
+    int32_t* o = cells + (size_t)n * hw * up * up + (size_t)(y * up) * W + x * up;
+    for (int dy = 0; dy < up; ++dy)
+      for (int dx = 0; dx < up; ++dx) o[(size_t)dy * W + dx] = id;
+    return;
   }
   float best = (K > 20) ? 1e5f : INFINITY;
   // squared-distance screen (round 5; exact): sqrt is monotone, so a centre whose fp32 sum s = fma(dx,dx,fl(dy*dy)) is
@@ -466,9 +577,12 @@ int emp_median_recursive(const float* d_hist, const float* d_raw, int n_raw, int
   return EMP_OK;
 }
 
-size_t emp_instance_cells_work_bytes(int N, int h, int w) {
-  size_t words = ((size_t)h * w + 31) / 32 + 2;
-  return (size_t)N * words * 4 + 256;
+static inline size_t cells_mask_bytes(int N, int h, int w) {
+  const size_t words = ((size_t)h * w + 31) / 32 + 2;
+  return ((size_t)N * words * 4 + 255) & ~(size_t)255;
+}
+size_t emp_instance_cells_work_bytes(int N, int h, int w) {      // NMS bit mask | per-image centre grid (round 6)
+  return cells_mask_bytes(N, h, w) + (size_t)N * GRID_IMG_BYTES + 256;
 }
 
 int emp_instance_cells(const float* d_ctr_hmp, const float* d_offsets, int N, int h, int w, float nms_threshold,
@@ -486,8 +600,16 @@ int emp_instance_cells(const float* d_ctr_hmp, const float* d_offsets, int N, in
   hipLaunchKernelGGL(centers_kernel, dim3(N), dim3(256), 0, s, mask, words, (hw + 31) / 32, w, d_centers,
                      d_num_centers, max_centers);
   EMP_LAUNCH_CHECK();
+  // dense scenes: bin the centres (one workgroup per image; images below GRID_MIN centres mark their grid unused and take the scan)
+  const char* grid_env = getenv("EMP_VOTE_GRID");      // =0: the scan for every image (A/B; bit-identical)
+  char* gridbuf = nullptr;
+  if (!(grid_env && grid_env[0] == '0') && (int64_t)h * step < (1 << 20) && (int64_t)w * step < (1 << 20)) {
+    gridbuf = (char*)d_work + cells_mask_bytes(N, h, w);
+    hipLaunchKernelGGL(ctr_grid_build_kernel, dim3(N), dim3(1024), 0, s, d_centers, d_num_centers, max_centers, step, h * step, w * step, gridbuf);
+    EMP_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(group_pixels_kernel, dim3(nb, N), dim3(256), 0, s, d_offsets, h, w, d_centers, d_num_centers,
-                     max_centers, step, up, d_cells);
+                     max_centers, step, up, d_cells, gridbuf);
   EMP_LAUNCH_CHECK();
   return EMP_OK;
 }

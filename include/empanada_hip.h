@@ -423,7 +423,12 @@ EMP_API int emp_median_recursive(const float* d_hist, const float* d_raw, int n_
  *   d_centers (N, max_centers, 2) int32 (y,x) in row-major order,
  *   d_num_centers (N) int32 (clamped to max_centers; overflow is reported by
  *   a negative return of emp_instance_cells_check).
- *   d_work: scratch of emp_instance_cells_work_bytes(N,h,w) bytes. */
+ *   d_work: scratch of emp_instance_cells_work_bytes(N,h,w) bytes (the NMS bit mask + a per-image grid over the centres).
+ * Round 6: an image with 192 .. 16 384 centres is voted through a uniform grid over its centres (bins of ~2+ centres, rings of bins
+ * searched outwards from the voted position until the next ring cannot hold a centre at the best distance found) instead of the
+ * scan over every centre per pixel: the scan's cells bit for bit (same fp32 expression per candidate, lowest index among the minima
+ * of the rounded distance, 1e5 start value, non-finite votes -> 0) at pixels x ~tens instead of pixels x centres evaluations
+ * (1024^2 tile, 4 500 centres: 1.56 -> 0.15 ms).  EMP_VOTE_GRID=0 (read per call): the scan for every image. */
 EMP_API size_t emp_instance_cells_work_bytes(int N, int h, int w);
 EMP_API int emp_instance_cells(const float* d_ctr_hmp, const float* d_offsets, int N, int h, int w,
                        float nms_threshold, int nms_kernel, int step, int up,

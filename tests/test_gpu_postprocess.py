@@ -167,3 +167,43 @@ def test_harden_and_get_panoptic_seg_api(golden_dir, i):
     assert torch.equal(a, b) and a.dtype == torch.int64
     want = opp.get_panoptic_seg(opp.harden_seg(opp.logits_to_prob(sem), 0.5)[0], cells.cpu().numpy(), tl, 1000, 64, 0)
     np.testing.assert_array_equal(a.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('h,w,step,dens', [(256, 256, 4, 0.02), (192, 320, 4, 0.2), (512, 384, 1, 0.004), (1024, 1024, 4, 0.004), (96, 96, 1, 0.9)])
+def test_centre_grid_voting_equals_the_scan(h, w, step, dens, monkeypatch):
+    """Round 6 (late): from 192 centres per image the nearest-centre vote searches a uniform grid over the centres ring by ring
+    (ctr_grid_build_kernel + the grid path of group_pixels_kernel, csrc/postprocess.hip) instead of scanning every centre per pixel.
+    It must return the scan's cells bit for bit -- same fp32 expression per candidate, lowest index among the minima of the ROUNDED
+    distance, 1e5 start value -- including exact ties (integer votes: a pixel equidistant from several centres), votes far outside
+    the image, NaN / inf votes and images of a batch below the threshold (which keep the scan).  EMP_VOTE_GRID=0 is the scan."""
+    from gpu_common import dev
+    from empanada_napari_amd.engines import PanopticDeepLabRenderEngine
+    g = torch.Generator().manual_seed(h * 7 + w + step)
+    N = 3
+    ctr = torch.rand((N, 1, h, w), generator=g)
+    keep = torch.rand((N, 1, h, w), generator=g) < dens      # density of candidate peaks
+    ctr = torch.where(keep, ctr, torch.zeros(()))
+    ctr[2] = 0.0
+    ctr[2, 0, ::h // 9 + 1, ::w // 11 + 1] = 0.9      # image 2: <= 99 centres -> below the grid's threshold
+    off = torch.randint(-60, 61, (N, 2, h, w), generator=g).float()      # integer votes: exact ties
+    off[0, :, : h // 4] += torch.randn((2, h // 4, w), generator=g) * 3.0      # ... and generic ones
+    off[1, 0, 5, 7] = float('nan')
+    off[1, 1, 9, 3] = float('inf')
+    off[1, 0, 11, 2] = -float('inf')
+    off[0, :, -3:, :] = 5.0e4      # far outside the image, still below the 1e5 start value
+    off[0, :, -1, :] = 3.0e5       # beyond it: no centre
+    eng = PanopticDeepLabRenderEngine(_Fake({}), [1], label_divisor=1000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                                      coarse_boundaries=(step == 4))
+    eng.MAX_CENTERS = 16384
+    ctr, off = ctr.to(dev()), off.to(dev())
+    monkeypatch.setenv('EMP_VOTE_GRID', '1')
+    a, ca, na, _ = eng.instance_cells_int(ctr, off, 1)
+    a, ca, na = a.clone(), ca.clone(), na.clone()
+    monkeypatch.setenv('EMP_VOTE_GRID', '0')
+    b, cb, nb_, _ = eng.instance_cells_int(ctr, off, 1)
+    torch.cuda.synchronize()
+    num = na.cpu().tolist()
+    assert num == nb_.cpu().tolist() and num[0] >= 192 and num[1] >= 192 and num[2] < 192, num
+    assert torch.equal(ca, cb)
+    assert torch.equal(a, b), f'{int((a != b).sum())} cells differ (centres per image {num})'
+    assert int(a[0].max()) > 100 and int((a[0] == 0).sum()) > 0      # both populated cells and "no centre" cells exist
