@@ -136,7 +136,7 @@ struct emp_pdl {
   // fp16x3 mode, round 6: a separable block (depthwise KxK -> pointwise -> act [-> head 1x1]) as ONE launch (sepconv_x3.hip) once
   // the map has this many 8 x 16 tiles (a persistent workgroup per CU); EMP_X3_FUSE_SEP=0: the depthwise launch + conv16x3 (A/B)
   bool x3_fuse_sep = [] { const char* e = getenv("EMP_X3_FUSE_SEP"); return !(e && e[0] == '0'); }();
-  int x3_sep_min_tiles = [] { const char* e = getenv("EMP_X3_SEP_MIN_TILES"); return e ? atoi(e) : 256; }();
+  int x3_sep_min_tiles = [] { const char* e = getenv("EMP_X3_SEP_MIN_TILES"); return e ? atoi(e) : 1; }();      // (256 until finding 75: fewer launches win at every size measured)
   struct SepX3 { float* dw = nullptr; half_t* pw = nullptr; int C = 0, Cout = 0, ks = 0; };
   std::map<std::string, SepX3> sepx3;      // by the block's name ("... .sepconv" without the .0 / .1)
   bool regnet_grouped = [] { const char* e = getenv("EMP_REGNET_GROUPED"); return !(e && e[0] == '0'); }();

@@ -222,7 +222,7 @@ constexpr int CTR_TILE = 1024;
 // The scan below costs pixels x centres: a 4096^2 slice of BASELINE configs[3] with 4 276 objects is 4.5 ms of voting next to a
 // 12 ms forward.  From GRID_MIN centres per image the centres are binned (bins of B x B in the scaled coordinates, B a power of two
 // with ~2+ centres per bin and at most GRID_BINS bins) and a pixel searches the rings of bins around its voted position outwards
-// until the next ring cannot hold a centre at the best distance found.  The RESULT IS THE SCAN'S, bit for bit: the same fp32
+// until the next ring cannot hold a centre at the best distance found (votes that would walk a quarter of the grid: one pass over all centres).  The RESULT IS THE SCAN'S, bit for bit: the same fp32
 // expressions per candidate, the winner = the lowest index among the candidates of minimal ROUNDED distance below the 1e5
 // start value (the scan's strict '<' in index order), and a ring is skipped only when its exact lower bound on the distance
 // exceeds the best fp32 sum by more than the arithmetic's rounding (a relative 4e-6 against ~3e-7).  Non-finite votes keep id 0
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(1024) ctr_grid_build_kernel(const int32_t* __r
     if (tid == 0) hdr[3] = 0;
     return;
   }
-  int lb = 4;
+  int lb = 2;      // bins of 4 x 4 at the densest (every second cell of a coarse map a centre)
   while ((int64_t)((Hs + (1 << lb) - 1) >> lb) * ((Ws + (1 << lb) - 1) >> lb) > GRID_BINS || ((int64_t)K << (2 * lb)) < 2ll * Hs * Ws) ++lb;
   const int GH = (Hs + (1 << lb) - 1) >> lb, GW = (Ws + (1 << lb) - 1) >> lb, nb = GH * GW;
   int* start = hdr + 4;
@@ -337,6 +337,21 @@ __global__ void __launch_bounds__(256) group_pixels_kernel(const float* __restri
         // a centre of ring r + 1 or beyond is at least r * B away from the (clamped) vote along one axis
         const float lbn = (float)(r << lb);
         if (lbn * lbn * (1.f - 4e-6f) > best_s) break;
+        if (r >= 2) {
+          // a vote far outside the image, or with no centre below 1e5 at all, would walk every ring: once the bins still to visit
+          // (up to the ring the best distance so far calls for; nothing found yet: the rings seen so far) are a quarter of the
+          // grid, ONE pass over every centre is cheaper (the same rule: candidates seen twice change nothing)
+          const int side = 2 * r + 1;
+          int todo = side * side;
+          if (id) {
+            const int need = min(((int)(__builtin_sqrtf(best_s) * 1.00001f) >> lb) + 1, 1 << 12);
+            todo = (2 * need + 1) * (2 * need + 1) - side * side;
+          }
+          if (todo * 4 >= GH * GW) {
+            scan(0, start[GH * GW]);
+            break;
+          }
+        }
       }
       (void)best_s;
     }
