@@ -247,7 +247,7 @@ def fp32_mode_block(cfg, P, host_tiles, sub, mul, dev, batch=4, steps=3, precisi
             mc = {'model': m32, 'thing_list': [1], 'labels': [1], 'class_names': {1: 'mito'}, 'padding_factor': 16,
                   'norms': {'mean': 0.57571, 'std': 0.12765}}
             e2 = Engine2d(mc, label_divisor=10000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5, device=dev)
-            imgs = [host_tiles[i % len(host_tiles)] for i in range(batch * 8)]
+            imgs = [host_tiles[i % len(host_tiles)] for i in range(batch * 16)]      # 16 batches, as the fp16 line: fill and drain amortised
             e2.infer_batch(imgs[:2 * batch], batch=batch)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
