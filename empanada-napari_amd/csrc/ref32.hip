@@ -421,6 +421,71 @@ __global__ void __launch_bounds__(256) point_features32_kernel(const float* __re
   }
 }
 
+// The same sampling with 16 lanes per point and four channels per lane (round 6, late): a wave gathers four points at once, every
+// corner row as 16-byte loads (8 192 points per image whatever its size: at 512^2 slices this kernel was 4 % of the 3-D job).  Per
+// channel the same fmaf chain over the corners 00, 01, 10, 11: bit-identical to point_features32_kernel.  Needs C % 4 == 0, ld % 4 == 0.
+__global__ void __launch_bounds__(256) point_features32v_kernel(const float* __restrict__ feat, int N, int fh, int fw, int C,
+                                                                int feat_ld, const float* __restrict__ coarse, int ncls,
+                                                                const int32_t* __restrict__ idx, int P, int H2, int W2,
+                                                                float* __restrict__ x0, float* __restrict__ x1, int ld) {
+  const int l16 = threadIdx.x & 15;
+  const int64_t pt = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  if (pt >= (int64_t)N * P) return;
+  const int n = (int)(pt / P);
+  const int id = idx[pt];
+  const int iy = id / W2, ix = id - iy * W2;
+  const float w_step = 1.0f / (float)W2, h_step = 1.0f / (float)H2;
+  const float cx = 0.5f * w_step + w_step * (float)ix;
+  const float cy = 0.5f * h_step + h_step * (float)iy;
+  const float gx = 2.0f * cx - 1.0f, gy = 2.0f * cy - 1.0f;
+  const float sx = ((gx + 1.f) * (float)fw - 1.f) * 0.5f;
+  const float sy = ((gy + 1.f) * (float)fh - 1.f) * 0.5f;
+  const float fx0 = floorf(sx), fy0 = floorf(sy);
+  const int xa = (int)fx0, ya = (int)fy0, xb = xa + 1, yb = ya + 1;
+  const float lx = sx - fx0, ly = sy - fy0;
+  const float w00 = (1.f - lx) * (1.f - ly), w01 = lx * (1.f - ly), w10 = (1.f - lx) * ly, w11 = lx * ly;
+  const bool ok00 = xa >= 0 && xa < fw && ya >= 0 && ya < fh;
+  const bool ok01 = xb >= 0 && xb < fw && ya >= 0 && ya < fh;
+  const bool ok10 = xa >= 0 && xa < fw && yb >= 0 && yb < fh;
+  const bool ok11 = xb >= 0 && xb < fw && yb >= 0 && yb < fh;
+  float* r0 = x0 + (size_t)pt * ld;
+  float* r1 = x1 + (size_t)pt * ld;
+  const float* fb = feat + (size_t)n * fh * fw * feat_ld;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = l16 * 4; c < ld; c += 64) {
+    if (c < C) {
+      const float4 a = ok00 ? *reinterpret_cast<const float4*>(fb + ((size_t)ya * fw + xa) * feat_ld + c) : z;
+      const float4 b = ok01 ? *reinterpret_cast<const float4*>(fb + ((size_t)ya * fw + xb) * feat_ld + c) : z;
+      const float4 d = ok10 ? *reinterpret_cast<const float4*>(fb + ((size_t)yb * fw + xa) * feat_ld + c) : z;
+      const float4 e = ok11 ? *reinterpret_cast<const float4*>(fb + ((size_t)yb * fw + xb) * feat_ld + c) : z;
+      float4 v = z;
+      if (ok00) { v.x = fmaf(a.x, w00, v.x); v.y = fmaf(a.y, w00, v.y); v.z = fmaf(a.z, w00, v.z); v.w = fmaf(a.w, w00, v.w); }
+      if (ok01) { v.x = fmaf(b.x, w01, v.x); v.y = fmaf(b.y, w01, v.y); v.z = fmaf(b.z, w01, v.z); v.w = fmaf(b.w, w01, v.w); }
+      if (ok10) { v.x = fmaf(d.x, w10, v.x); v.y = fmaf(d.y, w10, v.y); v.z = fmaf(d.z, w10, v.z); v.w = fmaf(d.w, w10, v.w); }
+      if (ok11) { v.x = fmaf(e.x, w11, v.x); v.y = fmaf(e.y, w11, v.y); v.z = fmaf(e.z, w11, v.z); v.w = fmaf(e.w, w11, v.w); }
+      *reinterpret_cast<float4*>(r0 + c) = v;
+    } else {
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = c + q - C;
+        if (k < ncls) {
+          const float* cb = coarse + ((size_t)n * ncls + k) * fh * fw;
+          float v = 0.f;
+          if (ok00) v = fmaf(cb[ya * fw + xa], w00, v);
+          if (ok01) v = fmaf(cb[ya * fw + xb], w01, v);
+          if (ok10) v = fmaf(cb[yb * fw + xa], w10, v);
+          if (ok11) v = fmaf(cb[yb * fw + xb], w11, v);
+          o[q] = v;
+        }
+      }
+      const float4 v = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(r0 + c) = v;
+      *reinterpret_cast<float4*>(r1 + c) = v;
+    }
+  }
+}
+
 }  // namespace
 
 // RegNet stem (regnet.py:38-49): 3x3 stride-2 conv of the single-channel image + folded BN + ReLU, normalisation and
@@ -603,6 +668,14 @@ int launch_head1x1_f32(const float* in, int N, int P, int K, int in_ld, const fl
 int launch_point_features_f32(const float* feat, int N, int fh, int fw, int C, int feat_ld, const float* coarse, int ncls,
                               const int32_t* idx, int P, int H2, int W2, float* x0, float* x1, int ld, hipStream_t s) {
   const int64_t pts = (int64_t)N * P;
+  const char* v_env = getenv("EMP_PF32_VEC");      // =0: one wave per point, one channel per lane (A/B; bit-identical)
+  if (C % 4 == 0 && ld % 4 == 0 && feat_ld % 4 == 0 && ((uintptr_t)feat % 16) == 0 && ((uintptr_t)x0 % 16) == 0 && ((uintptr_t)x1 % 16) == 0 &&
+      !(v_env && v_env[0] == '0')) {
+    hipLaunchKernelGGL(point_features32v_kernel, dim3((unsigned)((pts * 16 + 255) / 256)), dim3(256), 0, s, feat, N, fh, fw, C, feat_ld, coarse,
+                       ncls, idx, P, H2, W2, x0, x1, ld);
+    EMP_LAUNCH_CHECK();
+    return EMP_OK;
+  }
   hipLaunchKernelGGL(point_features32_kernel, dim3((unsigned)((pts * 64 + 255) / 256)), dim3(256), 0, s, feat, N, fh, fw, C,
                      feat_ld, coarse, ncls, idx, P, H2, W2, x0, x1, ld);
   EMP_LAUNCH_CHECK();

@@ -206,3 +206,24 @@ def test_four_column_bilinear_kernel_is_the_plain_kernels_arithmetic(monkeypatch
         b = model(x, 2, False)
         for k in a:
             assert torch.equal(a[k], b[k]), (prec, k)
+
+
+@pytest.mark.parametrize('arch,ncls', [('pdl', 1), ('bifpn', 4)])
+def test_vector_point_sampling_is_the_scalar_kernels_arithmetic(monkeypatch, arch, ncls):
+    """Round 6 (late): PointRend's point sampling of the fp32 / fp16x3 graph with 16 lanes per point and four channels per lane
+    (point_features32v_kernel) -- per channel the one-channel-per-lane kernel's fmaf chain over the four corners (EMP_PF32_VEC=0),
+    so the refined semantic logits are bit-identical, for one and four classes, in both precisions"""
+    from empanada_napari_amd import synth
+    from empanada_napari_amd.preprocess import normalize
+    from empanada_napari_amd.engines import HipPanopticDeepLab
+    cfg, P, _ = _models(arch, ncls)
+    for prec, size in (('fp32', 256), ('fp16x3', 384)):
+        model = HipPanopticDeepLab(P, cfg, folded=True, precision=prec)
+        x = torch.from_numpy(normalize(synth.em_tiles(2, size, seed=31), 0.57571, 0.12765))[:, None].cuda()
+        monkeypatch.setenv('EMP_PF32_VEC', '1')
+        a = {k: v.clone() for k, v in model(x, 3, False).items()}
+        monkeypatch.setenv('EMP_PF32_VEC', '0')
+        b = model(x, 3, False)
+        assert float(a['sem_logits'].abs().max()) > 0
+        for k in a:
+            assert torch.equal(a[k], b[k]), (prec, k)
