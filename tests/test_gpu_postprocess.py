@@ -207,3 +207,37 @@ def test_centre_grid_voting_equals_the_scan(h, w, step, dens, monkeypatch):
     assert torch.equal(ca, cb)
     assert torch.equal(a, b), f'{int((a != b).sum())} cells differ (centres per image {num})'
     assert int(a[0].max()) > 100 and int((a[0] == 0).sum()) > 0      # both populated cells and "no centre" cells exist
+
+
+def test_centre_grid_voting_random_sweep(monkeypatch):
+    """24 random geometries (40 .. 700 pixels a side, steps 1 / 4, 0.3 % .. 90 % of the cells candidate peaks, one to three images) x four
+    kinds of votes (integer: exact ties; gaussian at 0.5 .. 500 px; none; 3e4 px: mostly outside the 1e5 radius of nothing) -- the grid
+    path's cells equal the scan's bit for bit in every one (60 such configurations were run when the kernel was written)"""
+    from gpu_common import dev
+    from empanada_napari_amd.engines import PanopticDeepLabRenderEngine
+    rng = np.random.default_rng(123)
+    for it in range(24):
+        h, w = int(rng.integers(40, 700)), int(rng.integers(40, 700))
+        step, dens = int(rng.choice([1, 4])), float(rng.choice([0.003, 0.01, 0.05, 0.3, 0.9]))
+        N = int(rng.integers(1, 4))
+        g = torch.Generator().manual_seed(it)
+        ctr = torch.rand((N, 1, h, w), generator=g)
+        ctr = torch.where(torch.rand((N, 1, h, w), generator=g) < dens, ctr, torch.zeros(()))
+        mode = it % 4
+        if mode == 0:
+            off = torch.randint(-40, 41, (N, 2, h, w), generator=g).float()
+        elif mode == 1:
+            off = torch.randn((N, 2, h, w), generator=g) * float(rng.choice([0.5, 5, 50, 500]))
+        elif mode == 2:
+            off = torch.zeros((N, 2, h, w))
+        else:
+            off = torch.randn((N, 2, h, w), generator=g) * 3e4
+        eng = PanopticDeepLabRenderEngine(_Fake({}), [1], label_divisor=1000, nms_threshold=0.1, nms_kernel=3, confidence_thr=0.5,
+                                          coarse_boundaries=(step == 4))
+        eng.MAX_CENTERS = 1 << 17
+        c, o = ctr.to(dev()), off.to(dev())
+        monkeypatch.setenv('EMP_VOTE_GRID', '1')
+        a = eng.instance_cells_int(c, o, 1)[0].clone()
+        monkeypatch.setenv('EMP_VOTE_GRID', '0')
+        b = eng.instance_cells_int(c, o, 1)[0]
+        assert torch.equal(a, b), (it, h, w, step, dens, mode, int((a != b).sum()))
